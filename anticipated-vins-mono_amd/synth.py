@@ -1,0 +1,317 @@
+"""Seeded synthetic EuRoC-shaped inputs for both hot paths.
+
+There is no dataset access in this environment; these generators produce inputs with the
+shape and statistics of the reference's operating point (config/euroc/euroc_config.yaml):
+11 keyframes @ 10 Hz, 200 Hz IMU (20 samples / interval), 150 landmarks, a 75-dim prior,
+and for the selector 500 candidates over a 752x480 pinhole image with a 10-frame horizon.
+Window w is generated from seed 0xA17C0000 + w, selector problem p from 0xF5E10000 + p, so
+a shard of windows is identical no matter which rank generates it.
+"""
+import numpy as np
+
+from . import abi
+from .buffers import FselArrays, WindowArrays
+
+SEED_WINDOW = 0xA17C0000
+SEED_FSEL = 0xF5E10000
+
+# config/euroc/euroc_config.yaml:30-42
+RIC = np.array(
+    [
+        [0.0148655429818, -0.999880929698, 0.00414029679422],
+        [0.999557249008, 0.0149672133247, 0.025715529948],
+        [-0.0257744366974, 0.00375618835797, 0.999660727178],
+    ]
+)
+TIC = np.array([-0.0216401454975, -0.064676986768, 0.00981073058949])
+G_NORM = 9.81007
+ACC_N, GYR_N, ACC_W, GYR_W = 0.08, 0.004, 0.00004, 2.0e-6
+CAM = dict(fx=461.6, fy=460.3, cx=363.0, cy=248.1, k1=-0.2917, k2=0.08228, p1=5.333e-05, p2=-1.578e-04,
+           image_width=752, image_height=480)
+
+
+def _rot_zyx(y, p, r):
+    cy, sy, cp, sp, cr, sr = np.cos(y), np.sin(y), np.cos(p), np.sin(p), np.cos(r), np.sin(r)
+    return np.array(
+        [
+            [cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+            [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+            [-sp, cp * sr, cp * cr],
+        ]
+    )
+
+
+def quat_from_R(R):
+    """(x,y,z,w), w >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        v = np.zeros(3)
+        v[i] = 0.25 * s
+        v[j] = (R[j, i] + R[i, j]) / s
+        v[k] = (R[k, i] + R[i, k]) / s
+        q = np.array([v[0], v[1], v[2], (R[k, j] - R[j, k]) / s])
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def R_from_quat(q):
+    x, y, z, w = q
+    return np.array(
+        [
+            [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+        ]
+    )
+
+
+def _expm_so3(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * K @ K
+
+
+class _Trajectory:
+    """Smooth analytic trajectory: position = line + sinusoids, attitude = ZYX Euler sinusoids."""
+
+    def __init__(self, rng):
+        speed = rng.uniform(0.5, 2.0)
+        hd = rng.uniform(0, 2 * np.pi)
+        self.p0 = rng.normal(0, 2.0, 3)
+        self.v0 = np.array([speed * np.cos(hd), speed * np.sin(hd), rng.normal(0, 0.1)])
+        self.A = rng.uniform(0.05, 0.4, (3, 2)) * np.array([[1.0], [1.0], [0.5]])
+        self.w = rng.uniform(0.8, 3.0, (3, 2))
+        self.ph = rng.uniform(0, 2 * np.pi, (3, 2))
+        self.yaw0 = hd + rng.normal(0, 0.3)
+        self.yaw_rate = rng.uniform(-0.5, 0.5)
+        self.eA = rng.uniform(0.02, 0.12, (3,))  # yaw wobble, pitch, roll amplitudes
+        self.ew = rng.uniform(0.8, 2.5, (3,))
+        self.eph = rng.uniform(0, 2 * np.pi, (3,))
+
+    def pos(self, t):
+        return self.p0 + self.v0 * t + (self.A * np.sin(self.w * t + self.ph)).sum(1)
+
+    def vel(self, t):
+        return self.v0 + (self.A * self.w * np.cos(self.w * t + self.ph)).sum(1)
+
+    def acc(self, t):
+        return -(self.A * self.w**2 * np.sin(self.w * t + self.ph)).sum(1)
+
+    def euler(self, t):
+        s = self.eA * np.sin(self.ew * t + self.eph)
+        return np.array([self.yaw0 + self.yaw_rate * t + s[0], s[1], s[2]])
+
+    def euler_rate(self, t):
+        c = self.eA * self.ew * np.cos(self.ew * t + self.eph)
+        return np.array([self.yaw_rate + c[0], c[1], c[2]])
+
+    def R(self, t):
+        y, p, r = self.euler(t)
+        return _rot_zyx(y, p, r)
+
+    def omega_body(self, t):
+        y, p, r = self.euler(t)
+        yd, pd, rd = self.euler_rate(t)
+        return np.array(
+            [rd - yd * np.sin(p), pd * np.cos(r) + yd * np.sin(r) * np.cos(p), -pd * np.sin(r) + yd * np.cos(r) * np.cos(p)]
+        )
+
+
+def _one_window(wid, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, max_prior, max_pblk, out, b):
+    rng = np.random.Generator(np.random.Philox(key=SEED_WINDOW + wid))
+    tr = _Trajectory(rng)
+    G = np.array([0, 0, G_NORM])
+    nF, ns, dt = abi.NFRAMES, 20, 0.005
+    ba = rng.normal(0, 0.02, 3)
+    bg = rng.normal(0, 0.002, 3)
+    tk = np.arange(nF) * 0.1
+    Rw = [tr.R(t) for t in tk]
+    Pw = [tr.pos(t) for t in tk]
+    Vw = [tr.vel(t) for t in tk]
+    # ---- IMU
+    for j in range(abi.WINDOW_SIZE):
+        out["imu_n"][b, j] = ns
+        out["imu_dt"][b, j, :ns] = dt
+        for s in range(ns + 1):
+            t = tk[j] + s * dt
+            R = tr.R(t)
+            out["imu_acc"][b, j, s] = R.T @ (tr.acc(t) + G) + ba + rng.normal(0, ACC_N, 3)
+            out["imu_gyr"][b, j, s] = tr.omega_body(t) + bg + rng.normal(0, GYR_N, 3)
+    # ---- landmarks and tracks
+    if tracks == "dense":
+        starts = np.zeros(n_feat, np.int64)
+        lens = np.full(n_feat, nF, np.int64)
+    else:
+        starts = np.sort(rng.integers(0, abi.WINDOW_SIZE - 2, n_feat))  # start_frame < WINDOW_SIZE-2
+        lens = np.array([rng.integers(2, nF - s + 1) for s in starts])
+    out["n_feat"][b] = n_feat
+    o = 0
+    sig_px = 1.5 / 460.0
+    for e in range(n_feat):
+        s, L = int(starts[e]), int(lens[e])
+        for _ in range(50):
+            xy = np.array([rng.uniform(-0.7, 0.7), rng.uniform(-0.45, 0.45)])
+            depth = rng.uniform(2.0, 15.0)
+            pc = np.array([xy[0], xy[1], 1.0]) * depth
+            pw = Rw[s] @ (RIC @ pc + TIC) + Pw[s]
+            obs, ok = [], True
+            for f in range(s, s + L):
+                pcf = RIC.T @ (Rw[f].T @ (pw - Pw[f]) - TIC)
+                if pcf[2] < 0.5:
+                    ok = False
+                    break
+                obs.append(pcf[:2] / pcf[2])
+            if ok:
+                break
+        obs = np.array(obs) + rng.normal(0, sig_px, (L, 2))
+        outl = rng.uniform(size=L) < 0.05
+        outl[0] = False
+        obs[outl] += rng.uniform(-0.2, 0.2, (int(outl.sum()), 2))
+        out["feat_start"][b, e] = s
+        out["feat_nobs"][b, e] = L
+        out["feat_obs_begin"][b, e] = o
+        out["obs_xy"][b, o : o + L] = obs
+        out["inv_depth"][b, e] = (1.0 / depth) * (1.0 + rng.normal(0, 0.10))
+        o += L
+    assert o <= max_obs
+    # ---- initial state = ground truth + perturbation
+    ba0 = ba + rng.normal(0, 0.01, 3)
+    bg0 = bg + rng.normal(0, 0.001, 3)
+    for f in range(nF):
+        Rp = Rw[f] @ _expm_so3(rng.normal(0, np.deg2rad(1.0), 3))
+        out["pose"][b, f, :3] = Pw[f] + rng.normal(0, 0.05, 3)
+        out["pose"][b, f, 3:] = quat_from_R(Rp)
+        out["speedbias"][b, f, :3] = Vw[f] + rng.normal(0, 0.05, 3)
+        out["speedbias"][b, f, 3:6] = ba0  # biases are copied forward frame to frame (estimator.cpp:104-108)
+        out["speedbias"][b, f, 6:9] = bg0
+    for j in range(abi.WINDOW_SIZE):
+        out["imu_lin_ba"][b, j] = out["speedbias"][b, j, 3:6]
+        out["imu_lin_bg"][b, j] = out["speedbias"][b, j, 6:9]
+    out["ex_pose"][b, :3] = TIC
+    out["ex_pose"][b, 3:] = quat_from_R(RIC)
+    # ---- prior over pose[0..9], speedbias[0], ex_pose (what MARGIN_OLD leaves, estimator.cpp:904-916)
+    if with_prior:
+        kinds = [abi.BLK_POSE] * 10 + [abi.BLK_SPEEDBIAS, abi.BLK_EXPOSE]
+        frames = list(range(10)) + [0, 0]
+        n = 10 * 6 + 9 + 6
+        wts = np.concatenate([np.tile([10.0] * 3 + [50.0] * 3, 10), [10.0] * 3 + [20.0] * 3 + [200.0] * 3, [100.0] * 3 + [200.0] * 3])
+        J = (np.eye(n) + 0.05 * rng.normal(size=(n, n))) * wts[None, :]
+        out["prior_n"][b] = n
+        out["prior_nblk"][b] = len(kinds)
+        out["prior_blk_kind"][b, : len(kinds)] = kinds
+        out["prior_blk_frame"][b, : len(kinds)] = frames
+        out["prior_J"][b, :n, :n] = J
+        out["prior_r"][b, :n] = rng.normal(0, 0.3, n)
+        for k, (kd, fr) in enumerate(zip(kinds, frames)):
+            if kd == abi.BLK_POSE:
+                x0 = out["pose"][b, fr].copy()
+                x0[:3] += rng.normal(0, 0.01, 3)
+                x0[3:] = quat_from_R(R_from_quat(x0[3:]) @ _expm_so3(rng.normal(0, 0.002, 3)))
+                out["prior_x0"][b, k, :7] = x0
+            elif kd == abi.BLK_SPEEDBIAS:
+                out["prior_x0"][b, k, :9] = out["speedbias"][b, fr] + rng.normal(0, 0.005, 9) * np.array([1] * 3 + [0.2] * 3 + [0.02] * 3)
+            else:
+                out["prior_x0"][b, k, :7] = out["ex_pose"][b]
+
+
+def make_windows(n_windows, first_id=0, tracks="dense", n_feat=150, with_prior=True, max_feat=None, max_obs=None,
+                 max_samp=20, max_prior=96, max_pblk=16) -> WindowArrays:
+    """B synthetic windows [first_id, first_id + n_windows). tracks: 'dense' (K=1500) or 'sparse' (ragged)."""
+    max_feat = max_feat or max(n_feat, 1)
+    max_obs = max_obs or max_feat * abi.NFRAMES
+    B = n_windows
+    out = {
+        "pose": np.zeros((B, abi.NFRAMES, 7)),
+        "speedbias": np.zeros((B, abi.NFRAMES, 9)),
+        "ex_pose": np.zeros((B, 7)),
+        "inv_depth": np.ones((B, max_feat)),
+        "n_feat": np.zeros(B, np.int32),
+        "feat_start": np.zeros((B, max_feat), np.int32),
+        "feat_nobs": np.zeros((B, max_feat), np.int32),
+        "feat_obs_begin": np.zeros((B, max_feat), np.int32),
+        "obs_xy": np.zeros((B, max_obs, 2)),
+        "imu_n": np.zeros((B, abi.WINDOW_SIZE), np.int32),
+        "imu_dt": np.zeros((B, abi.WINDOW_SIZE, max_samp)),
+        "imu_acc": np.zeros((B, abi.WINDOW_SIZE, max_samp + 1, 3)),
+        "imu_gyr": np.zeros((B, abi.WINDOW_SIZE, max_samp + 1, 3)),
+        "imu_lin_ba": np.zeros((B, abi.WINDOW_SIZE, 3)),
+        "imu_lin_bg": np.zeros((B, abi.WINDOW_SIZE, 3)),
+        "prior_n": np.zeros(B, np.int32),
+        "prior_nblk": np.zeros(B, np.int32),
+        "prior_blk_kind": np.zeros((B, max_pblk), np.int32),
+        "prior_blk_frame": np.zeros((B, max_pblk), np.int32),
+        "prior_J": np.zeros((B, max_prior, max_prior)),
+        "prior_r": np.zeros((B, max_prior)),
+        "prior_x0": np.zeros((B, max_pblk, 9)),
+    }
+    for b in range(B):
+        _one_window(first_id + b, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, max_prior, max_pblk, out, b)
+    dims = dict(n_windows=B, max_feat=max_feat, max_obs=max_obs, max_samp=max_samp, max_prior=max_prior, max_pblk=max_pblk)
+    return WindowArrays(dims, out)
+
+
+def tile_windows(base: WindowArrays, n_windows: int) -> WindowArrays:
+    """Repeat a set of generated windows cyclically up to n_windows (bench uses it to fill 4096
+    windows quickly from a few hundred distinct ones; stated in bench output as `distinct`)."""
+    nb = base.n_windows
+    idx = np.arange(n_windows) % nb
+    d = dict(base.dims)
+    d["n_windows"] = n_windows
+    return WindowArrays(d, {k: np.ascontiguousarray(v[idx]) for k, v in base.a.items()})
+
+
+def make_fsel(n_problems, first_id=0, horizon=10, n_cand=500, n_used=0, n_cloud=150, max_features=150,
+              max_cand=None, max_used=None, max_cloud=None) -> FselArrays:
+    H, P = horizon, n_problems
+    max_cand = max_cand or max(n_cand, 1)
+    max_used = max_used or max(n_used, 1)
+    max_cloud = max_cloud or max(n_cloud, 1)
+    a = {
+        "hor_pos": np.zeros((P, H + 1, 3)),
+        "hor_quat": np.zeros((P, H + 1, 4)),
+        "nr_imu": np.full(P, 20, np.int32),
+        "delta_imu": np.full(P, 0.005),
+        "n_cand": np.full(P, n_cand, np.int32),
+        "cand_id": np.zeros((P, max_cand), np.int32),
+        "cand_xy": np.zeros((P, max_cand, 2)),
+        "cand_prob": np.zeros((P, max_cand)),
+        "n_used": np.full(P, n_used, np.int32),
+        "used_id": np.zeros((P, max_used), np.int32),
+        "used_xy": np.zeros((P, max_used, 2)),
+        "n_cloud": np.full(P, n_cloud, np.int32),
+        "cloud_xy": np.zeros((P, max_cloud, 2)),
+        "cloud_depth": np.ones((P, max_cloud)),
+    }
+    for p in range(P):
+        rng = np.random.Generator(np.random.Philox(key=SEED_FSEL + first_id + p))
+        tr = _Trajectory(rng)
+        for h in range(H + 1):
+            t = 0.1 * h
+            a["hor_pos"][p, h] = tr.pos(t)
+            a["hor_quat"][p, h] = quat_from_R(tr.R(t))
+
+        def pix(n):
+            u = rng.uniform(0, CAM["image_width"], n)
+            v = rng.uniform(0, CAM["image_height"], n)
+            return np.stack([(u - CAM["cx"]) / CAM["fx"], (v - CAM["cy"]) / CAM["fy"]], 1)
+
+        ids = 1000 + np.cumsum(rng.integers(1, 4, n_used + n_cand))
+        a["used_id"][p, :n_used] = ids[:n_used]
+        a["used_xy"][p, :n_used] = pix(n_used)
+        a["cand_id"][p, :n_cand] = ids[n_used:]
+        a["cand_xy"][p, :n_cand] = pix(n_cand)
+        a["cand_prob"][p, :n_cand] = rng.uniform(0.05, 1.0, n_cand).astype(np.float32).astype(np.float64)
+        a["cloud_xy"][p, :n_cloud] = pix(n_cloud)
+        a["cloud_depth"][p, :n_cloud] = rng.uniform(2.0, 15.0, n_cloud)
+    dims = dict(n_problems=P, horizon=H, max_cand=max_cand, max_used=max_used, max_cloud=max_cloud, max_features=max_features)
+    sc = dict(acc_var=ACC_N, acc_bias_var=ACC_W, q_ic=quat_from_R(RIC), t_ic=TIC, **CAM)
+    return FselArrays(dims, a, sc)

@@ -1,0 +1,264 @@
+/*
+ * avm.h — C ABI of the MI355X-native hot paths of Anticipated-VINS-Mono.
+ *
+ * The reference has no FFI/plugin interface: both hot paths are C++ member
+ * functions on stateful objects called from one thread
+ * (vins_estimator/src/estimator_node.cpp:340,360).  This header is the boundary
+ * a maintainer would bind instead of
+ *
+ *   HP-A  void Estimator::optimization()                       vins_estimator/src/estimator.h:47
+ *                                                              (body estimator.cpp:661-994)
+ *   HP-B  std::pair<std::vector<int>,std::vector<int>>
+ *         FeatureSelector::select(image_t&, const Header&, int) vins_estimator/src/feature_selector.h:49-50
+ *                                                              (body feature_selector.cpp:74-202)
+ *
+ * Conventions
+ *   - plain pointers + sizes, FP64 everywhere, row-major, no exceptions cross
+ *     the ABI; every function returns AVM_OK (0) or a negative avm_status.
+ *   - all buffers are caller owned.  `mem` says whether the pointers are host
+ *     pointers (the library stages them over PCIe) or device pointers already
+ *     resident in HBM (what bench.py times).
+ *   - one avm_ctx per host thread (re-entrant, no statics — the reference's
+ *     function-local statics at feature_selector.cpp:85,383,424 are NOT
+ *     reproduced); the ctx owns device scratch + one HIP stream.
+ *   - quaternions are stored (x,y,z,w) exactly like para_Pose
+ *     (estimator.cpp:484-488).
+ *
+ * Struct layouts in this header are shared verbatim by the CPU oracle
+ * (oracle/, test infrastructure only) so the same buffers can be handed to both.
+ */
+#ifndef AVM_H_
+#define AVM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVM_WINDOW_SIZE 10               /* parameters.h:14  */
+#define AVM_NFRAMES (AVM_WINDOW_SIZE + 1)
+#define AVM_SIZE_POSE 7                  /* parameters.h:53  */
+#define AVM_SIZE_SPEEDBIAS 9             /* parameters.h:54  */
+#define AVM_MAX_ITER_TRACE 16
+
+typedef enum avm_status {
+  AVM_OK = 0,
+  AVM_ERR_INVALID = -1,     /* bad argument / size */
+  AVM_ERR_UNSUPPORTED = -2, /* option combination not built (documented in DESIGN.md) */
+  AVM_ERR_NO_DEVICE = -3,   /* no HIP device: there is NO CPU fallback */
+  AVM_ERR_HIP = -4,         /* HIP runtime error, see avm_last_error() */
+  AVM_ERR_CAPACITY = -5     /* problem larger than avm_config limits */
+} avm_status;
+
+typedef enum avm_mem { AVM_MEM_HOST = 0, AVM_MEM_DEVICE = 1 } avm_mem;
+
+/* prior block kinds (replaces the pointer-keyed addr_shift map, estimator.cpp:904-916) */
+enum { AVM_BLK_POSE = 0, AVM_BLK_SPEEDBIAS = 1, AVM_BLK_EXPOSE = 2 };
+
+/* marginalization_flag, estimator.h:33-37 */
+enum { AVM_MARGIN_OLD = 0, AVM_MARGIN_SECOND_NEW = 1, AVM_MARGIN_NONE = 2 };
+
+/* termination, mirrors ceres::TerminationType as far as this path can reach it */
+enum {
+  AVM_TERM_NO_CONVERGENCE = 0, /* max_num_iterations reached */
+  AVM_TERM_GRADIENT_TOL = 1,
+  AVM_TERM_PARAMETER_TOL = 2,
+  AVM_TERM_FUNCTION_TOL = 3,
+  AVM_TERM_MIN_RADIUS = 4,
+  AVM_TERM_FAILURE = 5         /* too many invalid steps / linear solver failure */
+};
+
+/* Solver + model options.  Defaults (avm_default_options) are the values the
+ * reference runs with: estimator.cpp:794-806, config/euroc/euroc_config.yaml:54-63,
+ * parameters.cpp:11, estimator.cpp:17, and the Ceres defaults listed in SURVEY.md §5.9. */
+typedef struct avm_options {
+  int32_t max_num_iterations;        /* NUM_ITERATIONS = 8; wall-clock cap is NOT reproduced */
+  int32_t estimate_extrinsic;        /* 0: ex_pose constant (SetParameterBlockConstant, estimator.cpp:677-681) */
+  int32_t estimate_td;               /* 0 only (ProjectionTdFactor is a SURVEY §8 A7 follow-up) */
+  int32_t marginalization_flag;      /* AVM_MARGIN_* */
+  double focal_length;               /* FOCAL_LENGTH 460; sqrt_info = focal/1.5 * I2 (estimator.cpp:17) */
+  double g[3];                       /* G = (0,0,g_norm) parameters.cpp:11,127 */
+  double acc_n, gyr_n, acc_w, gyr_w; /* integration_base.h:21-27 */
+  double cauchy_a;                   /* CauchyLoss(1.0) estimator.cpp:666 */
+  double max_sum_dt;                 /* 10.0: IMU factor skipped above (estimator.cpp:705) */
+  /* Ceres trust-region defaults (not overridden by the reference) */
+  double initial_trust_region_radius; /* 1e4  */
+  double max_trust_region_radius;     /* 1e16 */
+  double min_trust_region_radius;     /* 1e-32 */
+  double min_relative_decrease;       /* 1e-3 */
+  double function_tolerance;          /* 1e-6 */
+  double gradient_tolerance;          /* 1e-10 */
+  double parameter_tolerance;         /* 1e-8 */
+  double min_lm_diagonal;             /* 1e-6 */
+  double max_lm_diagonal;             /* 1e32 */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  int32_t jacobi_scaling;                    /* 1 */
+  double marg_eps;                           /* 1e-8 marginalization_factor.h:70 */
+} avm_options;
+
+/* A batch of independent sliding windows, struct-of-arrays over the window index.
+ * [B] = n_windows.  Strides are the max_* fields so that one batch can hold
+ * ragged windows.  Maps the inputs of Estimator::optimization() (SURVEY §8 A1,A14). */
+typedef struct avm_window_batch {
+  int32_t n_windows;
+  int32_t max_feat;  /* stride of per-feature arrays (>= max n_feat) */
+  int32_t max_obs;   /* stride of per-observation arrays (>= max total observations) */
+  int32_t max_samp;  /* stride of IMU sample arrays (>= max samples per interval) */
+  int32_t max_prior; /* leading dimension of prior_J / prior_r (>= max prior_n) */
+  int32_t max_pblk;  /* stride of prior block tables */
+
+  /* ---- state, in/out: para_Pose / para_SpeedBias / para_Ex_Pose / para_Feature (estimator.h:109-115) */
+  double* pose;      /* [B][11][7]  x y z qx qy qz qw */
+  double* speedbias; /* [B][11][9]  v ba bg */
+  double* ex_pose;   /* [B][7]      tic, qic */
+  double* inv_depth; /* [B][max_feat]  1/estimated_depth, feature_manager.cpp:184-200 */
+
+  /* ---- feature tracks (already filtered by used_num>=2 && start_frame<WINDOW_SIZE-2, estimator.cpp:715) */
+  const int32_t* n_feat;         /* [B] */
+  const int32_t* feat_start;     /* [B][max_feat] start_frame (imu_i); must be non-decreasing in e (std::list order) */
+  const int32_t* feat_nobs;      /* [B][max_feat] feature_per_frame.size(); frames start..start+nobs-1 */
+  const int32_t* feat_obs_begin; /* [B][max_feat] offset of the first observation in obs_xy */
+  const double* obs_xy;          /* [B][max_obs][2] normalized-plane point.x, point.y (z == 1) */
+
+  /* ---- IMU raw samples per interval j=0..9 (pre_integrations[j+1], between frames j and j+1) */
+  const int32_t* imu_n; /* [B][10] number of push_back() samples */
+  const double* imu_dt; /* [B][10][max_samp] */
+  const double* imu_acc; /* [B][10][max_samp+1][3]; row 0 = acc_0 of the constructor (integration_base.h:13) */
+  const double* imu_gyr; /* [B][10][max_samp+1][3] */
+  const double* imu_lin_ba; /* [B][10][3] linearized_ba */
+  const double* imu_lin_bg; /* [B][10][3] linearized_bg */
+
+  /* ---- marginalization prior in (last_marginalization_info), prior_n == 0: none */
+  const int32_t* prior_n;         /* [B] residual dimension n */
+  const int32_t* prior_nblk;      /* [B] number of kept blocks */
+  const int32_t* prior_blk_kind;  /* [B][max_pblk] AVM_BLK_* */
+  const int32_t* prior_blk_frame; /* [B][max_pblk] frame index the block is applied to (already addr_shift'ed) */
+  const double* prior_J;          /* [B][max_prior][max_prior] linearized_jacobians (n x n used) */
+  const double* prior_r;          /* [B][max_prior] linearized_residuals */
+  const double* prior_x0;         /* [B][max_pblk][9] keep_block_data (pose uses 7, speedbias 9) */
+} avm_window_batch;
+
+/* new prior produced by the post-solve marginalization (estimator.cpp:817-990) */
+typedef struct avm_prior_out {
+  int32_t max_prior, max_pblk;
+  int32_t* n;         /* [B] */
+  int32_t* nblk;      /* [B] */
+  int32_t* blk_kind;  /* [B][max_pblk] */
+  int32_t* blk_frame; /* [B][max_pblk] frame index AFTER addr_shift */
+  double* J;          /* [B][max_prior][max_prior] */
+  double* r;          /* [B][max_prior] */
+  double* x0;         /* [B][max_pblk][9] */
+} avm_prior_out;
+
+/* per-window solve report (subset of ceres::Solver::Summary) */
+typedef struct avm_solve_summary {
+  int32_t termination;      /* AVM_TERM_* */
+  int32_t num_iterations;   /* step attempts (iteration 0 not counted) */
+  int32_t num_successful;   /* accepted steps */
+  int32_t accept_mask;      /* bit k set: attempt k+1 accepted */
+  double initial_cost;
+  double final_cost;
+  double cost_trace[AVM_MAX_ITER_TRACE]; /* x_cost after each attempt */
+  double radius_trace[AVM_MAX_ITER_TRACE];
+} avm_solve_summary;
+
+/* One feature-selection problem = the inputs FeatureSelector::select() reads from its
+ * members + estimator.  H is a runtime parameter (state_defs.h:8 fixes 13). */
+typedef struct avm_fsel_batch {
+  int32_t n_problems;
+  int32_t horizon;   /* HORIZON; Omega is 9(H+1) square */
+  int32_t max_cand;  /* stride of candidate arrays */
+  int32_t max_used;  /* stride of already-tracked ("subset") arrays */
+  int32_t max_cloud; /* stride of depth cloud arrays */
+  int32_t max_features; /* maxFeatures_ */
+
+  /* horizon states state_kkH[0..H] (state_defs.h:15-19): pos, vel, ba, quaternion(x,y,z,w) */
+  const double* hor_pos;  /* [P][H+1][3] */
+  const double* hor_quat; /* [P][H+1][4] x y z w */
+  const int32_t* nr_imu;  /* [P] nrImuMeasurements */
+  const double* delta_imu; /* [P] deltaImu */
+  /* IMU noise passed to setParameters (std-devs passed where variances are expected — kept) */
+  double acc_var, acc_bias_var;
+  /* extrinsics + pinhole camera (config/euroc/euroc_config.yaml:11-22,30-42) */
+  double q_ic[4]; /* x y z w */
+  double t_ic[3];
+  double fx, fy, cx, cy, k1, k2, p1, p2;
+  int32_t image_width, image_height;
+
+  /* new candidates (image_new), ascending feature id */
+  const int32_t* n_cand;  /* [P] */
+  const int32_t* cand_id; /* [P][max_cand] */
+  const double* cand_xy;  /* [P][max_cand][2] normalized plane x,y (z==1) */
+  const double* cand_prob; /* [P][max_cand] fPROB channel (float32-rounded upstream) */
+  /* already tracked features present in this frame (subset) */
+  const int32_t* n_used;  /* [P] */
+  const int32_t* used_id; /* [P][max_used] */
+  const double* used_xy;  /* [P][max_used][2] */
+  /* depth cloud of initKDTree(): nip points w.r.t camera k+1 and their depths (feature_selector.cpp:396-419) */
+  const int32_t* n_cloud;   /* [P] */
+  const double* cloud_xy;   /* [P][max_cloud][2] */
+  const double* cloud_depth; /* [P][max_cloud] */
+} avm_fsel_batch;
+
+typedef struct avm_fsel_out {
+  int32_t* n_selected;   /* [P] */
+  int32_t* selected_ids; /* [P][max_features] in selection order (blacklist order) */
+  double* fvalues;       /* [P][max_features] fMax of each round (nullable) */
+} avm_fsel_out;
+
+typedef struct avm_config {
+  int32_t device;       /* HIP device ordinal */
+  int32_t max_windows;  /* capacity of one avm_window_solve_batch call */
+  int32_t max_problems; /* capacity of one avm_fsel_select_batch call */
+  int32_t reserved[5];
+} avm_config;
+
+typedef struct avm_ctx avm_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------- */
+int avm_default_options(avm_options* opt);
+int avm_create(const avm_config* cfg, avm_ctx** out);
+void avm_destroy(avm_ctx* ctx);
+const char* avm_last_error(const avm_ctx* ctx);
+const char* avm_version(void);
+
+/* ---- HP-A: Estimator::optimization() for a batch of independent windows ------ */
+/* solve in place (states updated like double2vector+vector2double leave them),
+ * optionally producing the new prior.  prior_out may be NULL iff
+ * opt->marginalization_flag == AVM_MARGIN_NONE.  summary may be NULL. */
+int avm_window_solve_batch(avm_ctx* ctx, const avm_options* opt, avm_mem mem,
+                           const avm_window_batch* batch, avm_prior_out* prior_out,
+                           avm_solve_summary* summary /* [B], host or device per mem */);
+
+/* A4 only: IntegrationBase for every interval of every window (integration_base.h:13-158).
+ * out_* are [B][10][...]: delta (p3,q4 xyzw,v3 = 10), jacobian 15x15, covariance 15x15, sum_dt. */
+int avm_imu_preintegrate_batch(avm_ctx* ctx, const avm_options* opt, avm_mem mem,
+                               const avm_window_batch* batch, double* out_delta, double* out_jacobian,
+                               double* out_covariance, double* out_sum_dt);
+
+/* A5/A6/A8 only: evaluate every factor once at the current state and return
+ * residuals/Jacobians (local 6-column pose blocks).  Used by the per-factor parity tests.
+ *   proj_r [B][max_obs][2], proj_J [B][max_obs][2][13]  (pose_i 6 | pose_j 6 | inv_depth 1), index = observation slot
+ *   imu_r  [B][10][15],     imu_J  [B][10][15][30]      (pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9)
+ *   prior_res [B][max_prior]
+ * robust loss (Cauchy) correction is applied to proj_* when apply_loss != 0. */
+int avm_window_eval_factors(avm_ctx* ctx, const avm_options* opt, avm_mem mem,
+                            const avm_window_batch* batch, int apply_loss, double* proj_r, double* proj_J,
+                            double* imu_r, double* imu_J, double* prior_res, double* cost /* [B] */);
+
+/* ---- HP-B: FeatureSelector::select() for a batch of independent frames ------- */
+int avm_fsel_select_batch(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, avm_fsel_out* out);
+
+/* B5/B6 only: Omega_kkH (+prior) [P][N][N] and compact Delta_ell position blocks
+ * [P][max_cand][3H][3H] (+ valid flag [P][max_cand]); for parity tests. */
+int avm_fsel_information(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, double* omega,
+                         double* delta_cand, int32_t* cand_valid);
+
+/* ---- timing of the last call on the ctx stream (HIP events), milliseconds ---- */
+int avm_last_kernel_ms(const avm_ctx* ctx, const char* which, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVM_H_ */

@@ -1,0 +1,361 @@
+// oracle/avm_oracle.cpp — TEST INFRASTRUCTURE ONLY. The CPU restatement ("oracle") of the two
+// hot paths, exported with the same POD structs as include/avm.h so tests/, smoke() and
+// bench.py's cpu_baseline leg can hand identical buffers to the oracle and the HIP product.
+// Nothing under anticipated-vins-mono_amd/ may include, link or call this file.
+//
+// PARITY UNPINNED: /root/reference has no tests, fixtures or golden vectors, and cannot be
+// compiled in this image (needs ROS, Ceres, Eigen, OpenCV, Boost).  Ceres and Eigen are
+// un-vendored third-party dependencies; their algorithms are restated from the published
+// sources (see solver.hpp / linalg.hpp headers).  Anchors that do exist are exercised in
+// tests/: the finite-difference convention of ProjectionFactor::check()
+// (projection_factor.cpp:123-225) and the MATLAB transcript of createLinearImuMatrices
+// (support_files/scripts/createMatricesLinearImuFactor.m:17-101, test_ccT.m:24-36).
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+#include "fsel.hpp"
+#include "solver.hpp"
+
+using namespace avmo;
+
+namespace {
+
+void load_window(const avm_options& o, const avm_window_batch& B, int w, Window& W) {
+  for (int f = 0; f < AVM_NFRAMES; f++) {
+    std::memcpy(W.x.pose[f], B.pose + ((size_t)w * AVM_NFRAMES + f) * 7, 7 * sizeof(double));
+    std::memcpy(W.x.sb[f], B.speedbias + ((size_t)w * AVM_NFRAMES + f) * 9, 9 * sizeof(double));
+  }
+  std::memcpy(W.x.ex, B.ex_pose + (size_t)w * 7, 7 * sizeof(double));
+  W.nf = B.n_feat[w];
+  W.x.lam.assign(B.inv_depth + (size_t)w * B.max_feat, B.inv_depth + (size_t)w * B.max_feat + W.nf);
+  W.start.assign(B.feat_start + (size_t)w * B.max_feat, B.feat_start + (size_t)w * B.max_feat + W.nf);
+  W.nobs.assign(B.feat_nobs + (size_t)w * B.max_feat, B.feat_nobs + (size_t)w * B.max_feat + W.nf);
+  W.obs_begin.assign(B.feat_obs_begin + (size_t)w * B.max_feat, B.feat_obs_begin + (size_t)w * B.max_feat + W.nf);
+  W.obs_xy.assign(B.obs_xy + (size_t)w * B.max_obs * 2, B.obs_xy + ((size_t)w + 1) * B.max_obs * 2);
+  ImuNoise nz{o.acc_n, o.gyr_n, o.acc_w, o.gyr_w};
+  W.pre.clear();
+  W.sqrt_info.clear();
+  for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
+    size_t iv = (size_t)w * AVM_WINDOW_SIZE + j;
+    const double* acc = B.imu_acc + iv * (B.max_samp + 1) * 3;
+    const double* gyr = B.imu_gyr + iv * (B.max_samp + 1) * 3;
+    const double* dt = B.imu_dt + iv * B.max_samp;
+    const double* lba = B.imu_lin_ba + iv * 3;
+    const double* lbg = B.imu_lin_bg + iv * 3;
+    PreIntegration p(V3(acc[0], acc[1], acc[2]), V3(gyr[0], gyr[1], gyr[2]), V3(lba[0], lba[1], lba[2]), V3(lbg[0], lbg[1], lbg[2]), nz);
+    int ns = B.imu_n[iv];
+    for (int s = 0; s < ns; s++)
+      p.push_back(dt[s], V3(acc[3 * (s + 1)], acc[3 * (s + 1) + 1], acc[3 * (s + 1) + 2]),
+                  V3(gyr[3 * (s + 1)], gyr[3 * (s + 1) + 1], gyr[3 * (s + 1) + 2]));
+    W.pre.push_back(p);
+    W.sqrt_info.push_back(imu_sqrt_info(p));
+  }
+  W.has_prior = B.prior_n && B.prior_n[w] > 0;
+  if (W.has_prior) {
+    Prior& P = W.prior;
+    P = Prior();
+    P.n = B.prior_n[w];
+    int nb = B.prior_nblk[w];
+    int off = 0;
+    for (int k = 0; k < nb; k++) {
+      int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k];
+      P.blk_kind.push_back(kind);
+      P.blk_frame.push_back(B.prior_blk_frame[(size_t)w * B.max_pblk + k]);
+      P.blk_idx.push_back(off);
+      off += Prior::lsize(kind);
+      const double* x0 = B.prior_x0 + ((size_t)w * B.max_pblk + k) * 9;
+      P.x0.push_back(std::vector<double>(x0, x0 + Prior::gsize(kind)));
+    }
+    P.J = Mat(P.n, P.n);
+    for (int i = 0; i < P.n; i++)
+      for (int j = 0; j < P.n; j++) P.J(i, j) = B.prior_J[((size_t)w * B.max_prior + i) * B.max_prior + j];
+    P.r.assign(B.prior_r + (size_t)w * B.max_prior, B.prior_r + (size_t)w * B.max_prior + P.n);
+  }
+}
+
+void store_state(const avm_window_batch& B, int w, const State& x) {
+  for (int f = 0; f < AVM_NFRAMES; f++) {
+    std::memcpy(B.pose + ((size_t)w * AVM_NFRAMES + f) * 7, x.pose[f], 7 * sizeof(double));
+    std::memcpy(B.speedbias + ((size_t)w * AVM_NFRAMES + f) * 9, x.sb[f], 9 * sizeof(double));
+  }
+  std::memcpy(B.ex_pose + (size_t)w * 7, x.ex, 7 * sizeof(double));
+  for (size_t e = 0; e < x.lam.size(); e++) B.inv_depth[(size_t)w * B.max_feat + e] = x.lam[e];
+}
+
+void store_prior(avm_prior_out& O, int w, const Prior& P) {
+  O.n[w] = P.n;
+  if (P.n < 0) {
+    O.nblk[w] = 0;
+    return;
+  }
+  O.nblk[w] = (int)P.blk_kind.size();
+  for (size_t k = 0; k < P.blk_kind.size(); k++) {
+    O.blk_kind[(size_t)w * O.max_pblk + k] = P.blk_kind[k];
+    O.blk_frame[(size_t)w * O.max_pblk + k] = P.blk_frame[k];
+    double* x0 = O.x0 + ((size_t)w * O.max_pblk + k) * 9;
+    for (int i = 0; i < 9; i++) x0[i] = i < (int)P.x0[k].size() ? P.x0[k][i] : 0.0;
+  }
+  for (int i = 0; i < P.n; i++) {
+    for (int j = 0; j < P.n; j++) O.J[((size_t)w * O.max_prior + i) * O.max_prior + j] = P.J(i, j);
+    O.r[(size_t)w * O.max_prior + i] = P.r[i];
+  }
+}
+
+template <class F>
+void parallel_for(int n, int n_threads, F f) {
+  if (n_threads <= 1) {
+    for (int i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++)
+    th.emplace_back([&]() {
+      for (;;) {
+        int i = next.fetch_add(1);
+        if (i >= n) break;
+        f(i);
+      }
+    });
+  for (auto& t : th) t.join();
+}
+
+void load_fsel(const avm_fsel_batch& B, int p, FselProblem& P) {
+  P.H = B.horizon;
+  P.pos.resize(P.H + 1);
+  P.quat.resize(P.H + 1);
+  for (int h = 0; h <= P.H; h++) {
+    const double* a = B.hor_pos + ((size_t)p * (P.H + 1) + h) * 3;
+    const double* q = B.hor_quat + ((size_t)p * (P.H + 1) + h) * 4;
+    P.pos[h] = V3(a[0], a[1], a[2]);
+    P.quat[h] = Q(q[3], q[0], q[1], q[2]);
+  }
+  P.nrImu = B.nr_imu[p];
+  P.deltaImu = B.delta_imu[p];
+  P.accVar = B.acc_var;
+  P.accBiasVar = B.acc_bias_var;
+  P.q_IC = Q(B.q_ic[3], B.q_ic[0], B.q_ic[1], B.q_ic[2]);
+  P.t_IC = V3(B.t_ic[0], B.t_ic[1], B.t_ic[2]);
+  P.cam = FselCamera{B.fx, B.fy, B.cx, B.cy, B.k1, B.k2, B.p1, B.p2, B.image_width, B.image_height};
+  int nc = B.n_cand[p], nu = B.n_used ? B.n_used[p] : 0, ncl = B.n_cloud ? B.n_cloud[p] : 0;
+  P.cand_id.assign(B.cand_id + (size_t)p * B.max_cand, B.cand_id + (size_t)p * B.max_cand + nc);
+  P.cand_x.resize(nc), P.cand_y.resize(nc), P.cand_p.resize(nc);
+  for (int i = 0; i < nc; i++) {
+    P.cand_x[i] = B.cand_xy[((size_t)p * B.max_cand + i) * 2];
+    P.cand_y[i] = B.cand_xy[((size_t)p * B.max_cand + i) * 2 + 1];
+    P.cand_p[i] = B.cand_prob[(size_t)p * B.max_cand + i];
+  }
+  P.used_id.clear(), P.used_x.clear(), P.used_y.clear();
+  for (int i = 0; i < nu; i++) {
+    P.used_id.push_back(B.used_id[(size_t)p * B.max_used + i]);
+    P.used_x.push_back(B.used_xy[((size_t)p * B.max_used + i) * 2]);
+    P.used_y.push_back(B.used_xy[((size_t)p * B.max_used + i) * 2 + 1]);
+  }
+  P.cloud_x.clear(), P.cloud_y.clear(), P.cloud_d.clear();
+  for (int i = 0; i < ncl; i++) {
+    P.cloud_x.push_back(B.cloud_xy[((size_t)p * B.max_cloud + i) * 2]);
+    P.cloud_y.push_back(B.cloud_xy[((size_t)p * B.max_cloud + i) * 2 + 1]);
+    P.cloud_d.push_back(B.cloud_depth[(size_t)p * B.max_cloud + i]);
+  }
+  P.maxFeatures = B.max_features;
+}
+
+}  // namespace
+
+extern "C" {
+
+int avmo_default_options(avm_options* o) {
+  std::memset(o, 0, sizeof *o);
+  o->max_num_iterations = 8;
+  o->estimate_extrinsic = 0;
+  o->estimate_td = 0;
+  o->marginalization_flag = AVM_MARGIN_OLD;
+  o->focal_length = 460.0;
+  o->g[0] = 0, o->g[1] = 0, o->g[2] = 9.81007;
+  o->acc_n = 0.08, o->gyr_n = 0.004, o->acc_w = 0.00004, o->gyr_w = 2.0e-6;
+  o->cauchy_a = 1.0;
+  o->max_sum_dt = 10.0;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->marg_eps = 1e-8;
+  return 0;
+}
+
+// Estimator::optimization() on host buffers.  n_threads > 1 runs independent windows on
+// std::threads (each solve stays single-threaded like Ceres num_threads=1).
+int avmo_window_solve_batch(const avm_options* opt, const avm_window_batch* batch, avm_prior_out* prior_out,
+                            avm_solve_summary* summary, int n_threads) {
+  parallel_for(batch->n_windows, n_threads, [&](int w) {
+    Window W;
+    load_window(*opt, *batch, w, W);
+    Problem P;
+    P.build(W, *opt);
+    SolveResult R = trust_region_solve(P, W.x);
+    State out;
+    out.lam = R.x.lam;
+    gauge_fix_roundtrip(W.x, R.x, out);
+    if (summary) summary[w] = R.sum;
+    if (opt->marginalization_flag != AVM_MARGIN_NONE && prior_out) {
+      Prior np;
+      marginalize(W, out, *opt, np);
+      store_prior(*prior_out, w, np);
+    }
+    store_state(*batch, w, out);
+  });
+  return 0;
+}
+
+int avmo_imu_preintegrate_batch(const avm_options* opt, const avm_window_batch* batch, double* out_delta, double* out_jacobian,
+                                double* out_covariance, double* out_sum_dt, double* out_sqrt_info) {
+  for (int w = 0; w < batch->n_windows; w++) {
+    Window W;
+    avm_window_batch B = *batch;
+    int32_t zero = 0;
+    (void)zero;
+    load_window(*opt, B, w, W);
+    for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
+      size_t iv = (size_t)w * AVM_WINDOW_SIZE + j;
+      const PreIntegration& p = W.pre[j];
+      double* d = out_delta + iv * 10;
+      d[0] = p.delta_p.x, d[1] = p.delta_p.y, d[2] = p.delta_p.z;
+      d[3] = p.delta_q.x, d[4] = p.delta_q.y, d[5] = p.delta_q.z, d[6] = p.delta_q.w;
+      d[7] = p.delta_v.x, d[8] = p.delta_v.y, d[9] = p.delta_v.z;
+      std::memcpy(out_jacobian + iv * 225, p.jacobian.a.data(), 225 * sizeof(double));
+      std::memcpy(out_covariance + iv * 225, p.covariance.a.data(), 225 * sizeof(double));
+      out_sum_dt[iv] = p.sum_dt;
+      if (out_sqrt_info) std::memcpy(out_sqrt_info + iv * 225, W.sqrt_info[j].a.data(), 225 * sizeof(double));
+    }
+  }
+  return 0;
+}
+
+int avmo_window_eval_factors(const avm_options* opt, const avm_window_batch* batch, int apply_loss, double* proj_r, double* proj_J,
+                             double* imu_r, double* imu_J, double* prior_res, double* cost) {
+  const double sq = opt->focal_length / 1.5;
+  V3 G(opt->g[0], opt->g[1], opt->g[2]);
+  for (int w = 0; w < batch->n_windows; w++) {
+    Window W;
+    load_window(*opt, *batch, w, W);
+    double c = 0;
+    if (W.has_prior) {
+      std::vector<const double*> ps;
+      for (size_t k = 0; k < W.prior.blk_kind.size(); k++) {
+        int kind = W.prior.blk_kind[k], fr = W.prior.blk_frame[k];
+        ps.push_back(kind == AVM_BLK_POSE ? W.x.pose[fr] : (kind == AVM_BLK_SPEEDBIAS ? W.x.sb[fr] : W.x.ex));
+      }
+      std::vector<double> dx, res(W.prior.n);
+      prior_dx(W.prior, ps, dx);
+      prior_residual(W.prior, dx, res.data());
+      for (int i = 0; i < W.prior.n; i++) {
+        if (prior_res) prior_res[(size_t)w * batch->max_prior + i] = res[i];
+        c += 0.5 * res[i] * res[i];
+      }
+    }
+    for (int i = 0; i < AVM_WINDOW_SIZE; i++) {
+      double r[15], j0[105], j1[135], j2[105], j3[135];
+      double* jac[4] = {j0, j1, j2, j3};
+      imu_factor_evaluate(W.pre[i], W.sqrt_info[i], G, W.x.pose[i], W.x.sb[i], W.x.pose[i + 1], W.x.sb[i + 1], r, jac);
+      size_t iv = (size_t)w * AVM_WINDOW_SIZE + i;
+      for (int k = 0; k < 15; k++) {
+        if (imu_r) imu_r[iv * 15 + k] = r[k];
+        if (W.pre[i].sum_dt <= opt->max_sum_dt) c += 0.5 * r[k] * r[k];
+        if (imu_J) {
+          double* row = imu_J + (iv * 15 + k) * 30;
+          for (int cc = 0; cc < 6; cc++) row[cc] = j0[k * 7 + cc], row[15 + cc] = j2[k * 7 + cc];
+          for (int cc = 0; cc < 9; cc++) row[6 + cc] = j1[k * 9 + cc], row[21 + cc] = j3[k * 9 + cc];
+        }
+      }
+    }
+    for (int e = 0; e < W.nf; e++) {
+      int s0 = W.obs_begin[e];
+      V3 pts_i(W.obs_xy[2 * s0], W.obs_xy[2 * s0 + 1], 1.0);
+      for (int t = 1; t < W.nobs[e]; t++) {
+        int slot = s0 + t;
+        V3 pts_j(W.obs_xy[2 * slot], W.obs_xy[2 * slot + 1], 1.0);
+        double r[2], j0[14], j1[14], j2[14], j3[2];
+        double* jac[4] = {j0, j1, j2, j3};
+        projection_factor_evaluate(pts_i, pts_j, sq, W.x.pose[W.start[e]], W.x.pose[W.start[e] + t], W.x.ex, W.x.lam[e], r, jac);
+        double J[26];
+        for (int k = 0; k < 2; k++) {
+          for (int cc = 0; cc < 6; cc++) J[k * 13 + cc] = j0[k * 7 + cc], J[k * 13 + 6 + cc] = j1[k * 7 + cc];
+          J[k * 13 + 12] = j3[k];
+        }
+        double sn = r[0] * r[0] + r[1] * r[1], rho[3];
+        cauchy_loss(opt->cauchy_a, sn, rho);
+        c += 0.5 * rho[0];
+        if (apply_loss) {
+          Corrector corr(sn, rho);
+          corr.correctJacobian(2, 13, r, J);
+          corr.correctResiduals(2, r);
+        }
+        size_t o = (size_t)w * batch->max_obs + slot;
+        if (proj_r) proj_r[o * 2] = r[0], proj_r[o * 2 + 1] = r[1];
+        if (proj_J) std::memcpy(proj_J + o * 26, J, sizeof J);
+      }
+    }
+    if (cost) cost[w] = c;
+  }
+  return 0;
+}
+
+int avmo_fsel_select_batch(const avm_fsel_batch* batch, avm_fsel_out* out, int n_threads, int64_t* n_logdet) {
+  std::atomic<long> total(0);
+  parallel_for(batch->n_problems, n_threads, [&](int p) {
+    FselProblem P;
+    load_fsel(*batch, p, P);
+    FselResult R = fsel_select(P);
+    out->n_selected[p] = (int)R.selected.size();
+    for (size_t i = 0; i < R.selected.size(); i++) {
+      out->selected_ids[(size_t)p * batch->max_features + i] = R.selected[i];
+      if (out->fvalues) out->fvalues[(size_t)p * batch->max_features + i] = R.fvalues[i];
+    }
+    total += R.n_logdet;
+  });
+  if (n_logdet) *n_logdet = total;
+  return 0;
+}
+
+int avmo_fsel_information(const avm_fsel_batch* batch, double* omega, double* delta_cand, int32_t* cand_valid) {
+  const int H = batch->horizon, N = 9 * (H + 1), H3 = 3 * H;
+  for (int p = 0; p < batch->n_problems; p++) {
+    FselProblem P;
+    load_fsel(*batch, p, P);
+    Mat Om = calcInfoFromRobotMotion(P);
+    if (omega) std::memcpy(omega + (size_t)p * N * N, Om.a.data(), sizeof(double) * N * N);
+    std::map<int, Mat> D = calcInfoFromFeatures(P, P.cand_id, P.cand_x, P.cand_y);
+    for (size_t c = 0; c < P.cand_id.size(); c++) {
+      auto it = D.find(P.cand_id[c]);
+      if (cand_valid) cand_valid[(size_t)p * batch->max_cand + c] = it != D.end();
+      if (!delta_cand) continue;
+      double* dst = delta_cand + ((size_t)p * batch->max_cand + c) * H3 * H3;
+      for (int i = 0; i < H3; i++)
+        for (int j = 0; j < H3; j++)
+          dst[i * H3 + j] = it == D.end() ? 0.0 : it->second(9 * (1 + i / 3) + i % 3, 9 * (1 + j / 3) + j % 3);
+    }
+  }
+  return 0;
+}
+
+// symmetric eigen-solver exported for unit tests against numpy
+int avmo_eig_sym(int n, const double* A, double* w, double* V) {
+  Mat M(n, n);
+  std::memcpy(M.a.data(), A, sizeof(double) * n * n);
+  std::vector<double> d;
+  Mat VV;
+  eig_sym(M, d, VV);
+  std::memcpy(w, d.data(), sizeof(double) * n);
+  std::memcpy(V, VV.a.data(), sizeof(double) * n * n);
+  return 0;
+}
+
+}  // extern "C"
