@@ -1,0 +1,369 @@
+// avm_api.hip — the C ABI of include/avm.h on top of the gfx950 kernels.
+// Host language is C++ (the reference's host code is C++: vins_estimator/src/estimator.cpp,
+// feature_selector.cpp).  No torch types, no exceptions across the boundary.  There is no CPU
+// fallback: without a HIP device avm_create() fails with AVM_ERR_NO_DEVICE.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace avm;
+
+struct avm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int n_slots = 0;
+  // device buffers owned by the ctx
+  double* scratch = nullptr;
+  int32_t* iscratch = nullptr;
+  double *pre_delta = nullptr, *pre_jac = nullptr, *pre_cov = nullptr, *pre_sqrt = nullptr, *pre_sum = nullptr;
+  size_t pre_cap = 0;  // windows
+  avm_solve_summary* d_summary = nullptr;
+  size_t summary_cap = 0;
+  // staging pool for AVM_MEM_HOST calls: name -> (ptr, bytes)
+  std::map<std::string, std::pair<void*, size_t>> pool;
+  hipEvent_t ev[8];
+  std::map<std::string, float> last_ms;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e__ = (call);                                                               \
+    if (e__ != hipSuccess) {                                                               \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+      return AVM_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+int fail(avm_ctx* c, int code, const char* msg) {
+  c->err = msg;
+  return code;
+}
+
+void* pool_get(avm_ctx* c, const std::string& name, size_t bytes) {
+  auto& e = c->pool[name];
+  if (e.second < bytes || e.first == nullptr) {
+    if (e.first) (void)hipFree(e.first);
+    e.first = nullptr;
+    if (hipMalloc(&e.first, bytes ? bytes : 8) != hipSuccess) return nullptr;
+    e.second = bytes;
+  }
+  return e.first;
+}
+
+template <class T>
+int stage_in(avm_ctx* c, const char* name, const T* host, size_t count, const T** dev) {
+  if (!host || count == 0) {
+    *dev = nullptr;
+    return AVM_OK;
+  }
+  void* d = pool_get(c, name, count * sizeof(T));
+  if (!d) return fail(c, AVM_ERR_HIP, "hipMalloc failed (staging)");
+  HIPCHK(c, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  *dev = static_cast<const T*>(d);
+  return AVM_OK;
+}
+
+int ensure_window_buffers(avm_ctx* c, int n_windows) {
+  if (!c->scratch) {
+    HIPCHK(c, hipMalloc(&c->scratch, sizeof(double) * Scratch::TOTAL * c->n_slots));
+    HIPCHK(c, hipMalloc(&c->iscratch, sizeof(int32_t) * MAXOBS * c->n_slots));
+    HIPCHK(c, hipMemsetAsync(c->scratch, 0, sizeof(double) * Scratch::TOTAL * c->n_slots, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->iscratch, 0, sizeof(int32_t) * MAXOBS * c->n_slots, c->stream));
+  }
+  if ((size_t)n_windows > c->pre_cap) {
+    for (double** p : {&c->pre_delta, &c->pre_jac, &c->pre_cov, &c->pre_sqrt, &c->pre_sum})
+      if (*p) (void)hipFree(*p), *p = nullptr;
+    const size_t iv = (size_t)n_windows * 10;
+    HIPCHK(c, hipMalloc(&c->pre_delta, sizeof(double) * iv * 10));
+    HIPCHK(c, hipMalloc(&c->pre_jac, sizeof(double) * iv * 225));
+    HIPCHK(c, hipMalloc(&c->pre_cov, sizeof(double) * iv * 225));
+    HIPCHK(c, hipMalloc(&c->pre_sqrt, sizeof(double) * iv * 225));
+    HIPCHK(c, hipMalloc(&c->pre_sum, sizeof(double) * iv));
+    c->pre_cap = n_windows;
+  }
+  return AVM_OK;
+}
+
+int check_window_batch(avm_ctx* c, const avm_options* opt, const avm_window_batch* b) {
+  if (!opt || !b || b->n_windows < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (opt->estimate_extrinsic) return fail(c, AVM_ERR_UNSUPPORTED, "estimate_extrinsic != 0 is not built (ex_pose is held constant)");
+  if (opt->estimate_td) return fail(c, AVM_ERR_UNSUPPORTED, "estimate_td != 0 is not built (ProjectionTdFactor)");
+  if (b->max_feat > MAXE) return fail(c, AVM_ERR_CAPACITY, "max_feat > 150");
+  if (b->max_obs > MAXOBS) return fail(c, AVM_ERR_CAPACITY, "max_obs > 1650");
+  if (b->max_prior > MAXPRIOR || b->max_pblk > MAXPBLK) return fail(c, AVM_ERR_CAPACITY, "prior larger than 96 / 16 blocks");
+  if (opt->max_num_iterations > AVM_MAX_ITER_TRACE) return fail(c, AVM_ERR_CAPACITY, "max_num_iterations > 16");
+  return AVM_OK;
+}
+
+// copy a host batch to the device; out = batch with device pointers
+int stage_window_batch(avm_ctx* c, const avm_window_batch* h, avm_window_batch* d) {
+  *d = *h;
+  const size_t B = h->n_windows;
+  int rc;
+#define ST(field, type, count)                                                       \
+  if ((rc = stage_in<type>(c, "w_" #field, h->field, (count), (const type**)&d->field)) != AVM_OK) return rc;
+  ST(pose, double, B * 77)
+  ST(speedbias, double, B * 99)
+  ST(ex_pose, double, B * 7)
+  ST(inv_depth, double, B * h->max_feat)
+  ST(n_feat, int32_t, B)
+  ST(feat_start, int32_t, B * h->max_feat)
+  ST(feat_nobs, int32_t, B * h->max_feat)
+  ST(feat_obs_begin, int32_t, B * h->max_feat)
+  ST(obs_xy, double, B * h->max_obs * 2)
+  ST(imu_n, int32_t, B * 10)
+  ST(imu_dt, double, B * 10 * h->max_samp)
+  ST(imu_acc, double, B * 10 * (h->max_samp + 1) * 3)
+  ST(imu_gyr, double, B * 10 * (h->max_samp + 1) * 3)
+  ST(imu_lin_ba, double, B * 30)
+  ST(imu_lin_bg, double, B * 30)
+  ST(prior_n, int32_t, B)
+  ST(prior_nblk, int32_t, B)
+  ST(prior_blk_kind, int32_t, B * h->max_pblk)
+  ST(prior_blk_frame, int32_t, B * h->max_pblk)
+  ST(prior_J, double, B * h->max_prior * h->max_prior)
+  ST(prior_r, double, B * h->max_prior)
+  ST(prior_x0, double, B * h->max_pblk * 9)
+#undef ST
+  return AVM_OK;
+}
+
+int run_preint(avm_ctx* c, const avm_options* opt, const avm_window_batch* d) {
+  PreintArgs pa;
+  pa.n_windows = d->n_windows, pa.max_samp = d->max_samp;
+  pa.imu_n = d->imu_n, pa.imu_dt = d->imu_dt, pa.imu_acc = d->imu_acc, pa.imu_gyr = d->imu_gyr;
+  pa.imu_lin_ba = d->imu_lin_ba, pa.imu_lin_bg = d->imu_lin_bg;
+  pa.acc_n = opt->acc_n, pa.gyr_n = opt->gyr_n, pa.acc_w = opt->acc_w, pa.gyr_w = opt->gyr_w;
+  pa.out_delta = c->pre_delta, pa.out_jacobian = c->pre_jac, pa.out_covariance = c->pre_cov, pa.out_sum_dt = c->pre_sum,
+  pa.out_sqrt_info = c->pre_sqrt;
+  launch_preint(pa, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return AVM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* avm_version(void) { return "avm-mi355x 0.1 (gfx950, fp64)"; }
+
+int avm_default_options(avm_options* o) {
+  if (!o) return AVM_ERR_INVALID;
+  std::memset(o, 0, sizeof *o);
+  o->max_num_iterations = 8;  // config/euroc/euroc_config.yaml:55
+  o->estimate_extrinsic = 0;
+  o->estimate_td = 0;
+  o->marginalization_flag = AVM_MARGIN_OLD;
+  o->focal_length = 460.0;  // parameters.h:13
+  o->g[0] = 0, o->g[1] = 0, o->g[2] = 9.81007;
+  o->acc_n = 0.08, o->gyr_n = 0.004, o->acc_w = 0.00004, o->gyr_w = 2.0e-6;
+  o->cauchy_a = 1.0;
+  o->max_sum_dt = 10.0;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->marg_eps = 1e-8;
+  return AVM_OK;
+}
+
+int avm_create(const avm_config* cfg, avm_ctx** out) {
+  if (!out) return AVM_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AVM_ERR_NO_DEVICE;
+  const int dev = cfg ? cfg->device : 0;
+  if (dev < 0 || dev >= ndev) return AVM_ERR_INVALID;
+  if (hipSetDevice(dev) != hipSuccess) return AVM_ERR_HIP;
+  avm_ctx* c = new avm_ctx();
+  c->device = dev;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return AVM_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    delete c;
+    return AVM_ERR_HIP;
+  }
+  // one resident 512-thread workgroup per CU (the solve kernel takes ~158 KiB of the 160 KiB LDS)
+  c->n_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  for (auto& e : c->ev) (void)hipEventCreate(&e);
+  *out = c;
+  return AVM_OK;
+}
+
+void avm_destroy(avm_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->pool)
+    if (kv.second.first) (void)hipFree(kv.second.first);
+  for (void* p : {(void*)c->scratch, (void*)c->iscratch, (void*)c->pre_delta, (void*)c->pre_jac, (void*)c->pre_cov, (void*)c->pre_sqrt,
+                  (void*)c->pre_sum, (void*)c->d_summary})
+    if (p) (void)hipFree(p);
+  for (auto& e : c->ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* avm_last_error(const avm_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int avm_last_kernel_ms(const avm_ctx* c, const char* which, float* ms) {
+  if (!c || !which || !ms) return AVM_ERR_INVALID;
+  auto it = c->last_ms.find(which);
+  if (it == c->last_ms.end()) return AVM_ERR_INVALID;
+  *ms = it->second;
+  return AVM_OK;
+}
+
+int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* batch, avm_prior_out* prior_out,
+                           avm_solve_summary* summary) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  int rc = check_window_batch(c, opt, batch);
+  if (rc != AVM_OK) return rc;
+  if (opt->marginalization_flag != AVM_MARGIN_NONE) {
+    if (!prior_out) return fail(c, AVM_ERR_INVALID, "prior_out is NULL but marginalization_flag != AVM_MARGIN_NONE");
+    return fail(c, AVM_ERR_UNSUPPORTED, "post-solve marginalization kernel not built yet: use AVM_MARGIN_NONE");
+  }
+  if (batch->n_windows == 0) return AVM_OK;
+  if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
+  avm_window_batch d;
+  avm_solve_summary* d_sum = nullptr;
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = stage_window_batch(c, batch, &d)) != AVM_OK) return rc;
+    if (summary) {
+      d_sum = static_cast<avm_solve_summary*>(pool_get(c, "w_summary", sizeof(avm_solve_summary) * batch->n_windows));
+      if (!d_sum) return fail(c, AVM_ERR_HIP, "hipMalloc failed (summary)");
+    }
+  } else {
+    d = *batch;
+    d_sum = summary;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if ((rc = run_preint(c, opt, &d)) != AVM_OK) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  SolveArgs sa;
+  sa.b = d, sa.opt = *opt;
+  sa.pre_delta = c->pre_delta, sa.pre_jac = c->pre_jac, sa.pre_sqrt = c->pre_sqrt, sa.pre_sum_dt = c->pre_sum;
+  sa.scratch = c->scratch, sa.iscratch = c->iscratch, sa.summary = d_sum, sa.n_slots = c->n_slots;
+  HIPCHK(c, launch_window_solve(sa, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (mem == AVM_MEM_HOST) {
+    const size_t B = batch->n_windows;
+    HIPCHK(c, hipMemcpyAsync(batch->pose, d.pose, sizeof(double) * B * 77, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(batch->speedbias, d.speedbias, sizeof(double) * B * 99, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(batch->ex_pose, d.ex_pose, sizeof(double) * B * 7, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(batch->inv_depth, d.inv_depth, sizeof(double) * B * batch->max_feat, hipMemcpyDeviceToHost, c->stream));
+    if (summary) HIPCHK(c, hipMemcpyAsync(summary, d_sum, sizeof(avm_solve_summary) * B, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->last_ms["preint"] = ms;
+  if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->last_ms["window_solve"] = ms;
+  return AVM_OK;
+}
+
+int avm_imu_preintegrate_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* batch, double* out_delta,
+                               double* out_jacobian, double* out_covariance, double* out_sum_dt) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  int rc = check_window_batch(c, opt, batch);
+  if (rc != AVM_OK) return rc;
+  if (batch->n_windows == 0) return AVM_OK;
+  if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
+  avm_window_batch d;
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = stage_window_batch(c, batch, &d)) != AVM_OK) return rc;
+  } else {
+    d = *batch;
+  }
+  if ((rc = run_preint(c, opt, &d)) != AVM_OK) return rc;
+  const size_t iv = (size_t)batch->n_windows * 10;
+  const hipMemcpyKind kind = mem == AVM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (out_delta) HIPCHK(c, hipMemcpyAsync(out_delta, c->pre_delta, sizeof(double) * iv * 10, kind, c->stream));
+  if (out_jacobian) HIPCHK(c, hipMemcpyAsync(out_jacobian, c->pre_jac, sizeof(double) * iv * 225, kind, c->stream));
+  if (out_covariance) HIPCHK(c, hipMemcpyAsync(out_covariance, c->pre_cov, sizeof(double) * iv * 225, kind, c->stream));
+  if (out_sum_dt) HIPCHK(c, hipMemcpyAsync(out_sum_dt, c->pre_sum, sizeof(double) * iv, kind, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
+}
+
+// test hook (not in avm.h): sqrt_info of the last pre-integration, [B][10][15][15]
+int avm_debug_copy_sqrt_info(avm_ctx* c, int n_windows, double* host_out) {
+  if (!c || !c->pre_sqrt) return AVM_ERR_INVALID;
+  HIPCHK(c, hipMemcpy(host_out, c->pre_sqrt, sizeof(double) * (size_t)n_windows * 2250, hipMemcpyDeviceToHost));
+  return AVM_OK;
+}
+
+int avm_window_eval_factors(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* batch, int apply_loss,
+                            double* proj_r, double* proj_J, double* imu_r, double* imu_J, double* prior_res, double* cost) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  int rc = check_window_batch(c, opt, batch);
+  if (rc != AVM_OK) return rc;
+  if (batch->n_windows == 0) return AVM_OK;
+  if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
+  avm_window_batch d;
+  const size_t B = batch->n_windows;
+  EvalArgs ea;
+  struct Out {
+    double** dst;
+    double* host;
+    size_t n;
+    const char* name;
+  };
+  Out outs[6] = {{&ea.proj_r, proj_r, B * batch->max_obs * 2, "e_pr"},   {&ea.proj_J, proj_J, B * batch->max_obs * 26, "e_pJ"},
+                 {&ea.imu_r, imu_r, B * 150, "e_ir"},                      {&ea.imu_J, imu_J, B * 4500, "e_iJ"},
+                 {&ea.prior_res, prior_res, B * batch->max_prior, "e_pres"}, {&ea.cost, cost, B, "e_cost"}};
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = stage_window_batch(c, batch, &d)) != AVM_OK) return rc;
+    for (auto& o : outs) {
+      *o.dst = nullptr;
+      if (o.host) {
+        *o.dst = static_cast<double*>(pool_get(c, o.name, o.n * sizeof(double)));
+        if (!*o.dst) return fail(c, AVM_ERR_HIP, "hipMalloc failed (eval out)");
+        HIPCHK(c, hipMemsetAsync(*o.dst, 0, o.n * sizeof(double), c->stream));
+      }
+    }
+  } else {
+    d = *batch;
+    for (auto& o : outs) *o.dst = o.host;
+  }
+  if ((rc = run_preint(c, opt, &d)) != AVM_OK) return rc;
+  ea.b = d, ea.opt = *opt, ea.apply_loss = apply_loss;
+  ea.pre_delta = c->pre_delta, ea.pre_jac = c->pre_jac, ea.pre_sqrt = c->pre_sqrt, ea.pre_sum_dt = c->pre_sum;
+  HIPCHK(c, launch_eval_factors(ea, c->stream));
+  if (mem == AVM_MEM_HOST)
+    for (auto& o : outs)
+      if (o.host) HIPCHK(c, hipMemcpyAsync(o.host, *o.dst, o.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
+}
+
+int avm_fsel_select_batch(avm_ctx* c, avm_mem, const avm_fsel_batch*, avm_fsel_out*) {
+  if (!c) return AVM_ERR_INVALID;
+  return fail(c, AVM_ERR_UNSUPPORTED, "feature selector kernels not built yet");
+}
+
+int avm_fsel_information(avm_ctx* c, avm_mem, const avm_fsel_batch*, double*, double*, int32_t*) {
+  if (!c) return AVM_ERR_INVALID;
+  return fail(c, AVM_ERR_UNSUPPORTED, "feature selector kernels not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// kernels.hpp — argument blocks shared by the host C-ABI layer (avm_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/avm.h"
+
+namespace avm {
+
+// compile-time problem limits of the window-solve kernel (WINDOW_SIZE = 10 => 11 frames)
+constexpr int NFR = AVM_NFRAMES;       // 11
+constexpr int NPOSE = NFR * 6;         // 66 pose columns (local)
+constexpr int NF = NFR * 15;           // 165 f-block columns: poses first, then speed-bias
+constexpr int SB0 = NPOSE;             // column of speedbias[0]
+constexpr int MAXE = 150;              // inverse depths (e-blocks)
+constexpr int NCOL = NF + MAXE;        // 315
+constexpr int MAXOBS = MAXE * NFR;     // 1650 observation slots
+constexpr int MAXPRIOR = 96;           // prior residual dimension limit
+constexpr int MAXPBLK = 16;
+
+struct PreintArgs {
+  int n_windows, max_samp;
+  const int32_t* imu_n;
+  const double *imu_dt, *imu_acc, *imu_gyr, *imu_lin_ba, *imu_lin_bg;
+  double acc_n, gyr_n, acc_w, gyr_w;
+  double *out_delta, *out_jacobian, *out_covariance, *out_sum_dt, *out_sqrt_info;
+};
+
+// per-slot global scratch layout (doubles), one slot per resident workgroup
+struct Scratch {
+  static constexpr size_t JF = 0;                              // [28][MAXOBS] per-observation-slot factor rows
+  static constexpr size_t FA = JF + 28 * (size_t)MAXOBS;       // [35][MAXE] per-feature aggregates
+  static constexpr size_t W = FA + 35 * (size_t)MAXE;          // [MAXE][NPOSE] E^T F
+  static constexpr size_t IJ = W + (size_t)MAXE * NPOSE;       // [10][15][31] IMU residual + Jacobian
+  static constexpr size_t HP = IJ + 10 * 15 * 31;              // [MAXPRIOR][MAXPRIOR] J0^T J0
+  static constexpr size_t TOTAL = HP + (size_t)MAXPRIOR * MAXPRIOR;
+};
+
+struct SolveArgs {
+  avm_window_batch b;  // device pointers
+  avm_options opt;
+  const double *pre_delta, *pre_jac, *pre_sqrt, *pre_sum_dt;  // [B][10][...]
+  double* scratch;                                            // [n_slots][Scratch::TOTAL]
+  int32_t* iscratch;                                          // [n_slots][MAXOBS] observation slot -> feature
+  avm_solve_summary* summary;                                 // [B] or null
+  int n_slots;
+};
+
+struct EvalArgs {
+  avm_window_batch b;
+  avm_options opt;
+  const double *pre_delta, *pre_jac, *pre_sqrt, *pre_sum_dt;
+  int apply_loss;
+  double *proj_r, *proj_J, *imu_r, *imu_J, *prior_res, *cost;
+};
+
+void launch_preint(const PreintArgs& a, hipStream_t stream);
+hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
+hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
+int window_solve_lds_bytes();
+
+}  // namespace avm

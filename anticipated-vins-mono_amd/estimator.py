@@ -1,0 +1,69 @@
+"""Host-side mirror of the reference's Estimator::optimization() call surface
+(vins_estimator/src/estimator.h:47, estimator.cpp:661-994) over the C ABI.
+
+The reference method takes no arguments and works on member arrays (para_Pose,
+para_SpeedBias, para_Ex_Pose, para_Feature, pre_integrations, f_manager.feature,
+last_marginalization_info).  Here those members live in a WindowArrays batch (host numpy or
+HBM-resident torch tensors); optimization() solves all B windows in place and hands back the
+new prior, exactly like the reference leaves last_marginalization_info behind.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, buffers
+from .lib import Context
+
+
+class Estimator:
+    def __init__(self, ctx: Context = None, options: abi.Options = None, device: int = 0):
+        self.ctx = ctx or Context(device)
+        self.options = options or abi.default_options()
+        self.last_summary = None
+        self.last_marginalization_info = None  # PriorOutArrays after a MARGIN_OLD / SECOND_NEW solve
+
+    # the reference's name
+    def optimization(self, windows: buffers.WindowArrays, want_summary: bool = True):
+        L = self.ctx._L
+        B = windows.n_windows
+        s = windows.struct()
+        dev = "cuda:%d" % self.ctx.device if windows.on_device else None
+        summ = buffers.summary_alloc(B, dev) if want_summary else None
+        prior = None
+        if self.options.marginalization_flag != abi.MARGIN_NONE:
+            prior = buffers.PriorOutArrays.alloc(B, windows.dims["max_prior"], windows.dims["max_pblk"], dev)
+        po = prior.struct() if prior is not None else None
+        rc = L.avm_window_solve_batch(self.ctx.h, C.byref(self.options), windows.mem, C.byref(s),
+                                      C.byref(po) if po is not None else None,
+                                      buffers.summary_ptr(summ) if summ is not None else None)
+        self.ctx.check(rc, "avm_window_solve_batch")
+        self.last_summary = summ
+        self.last_marginalization_info = prior
+        return summ
+
+    def preintegrate(self, windows: buffers.WindowArrays):
+        """IntegrationBase for every interval: returns delta [B,10,10], jacobian, covariance [B,10,15,15], sum_dt [B,10]."""
+        assert not windows.on_device
+        B = windows.n_windows
+        d, j, cv, sd = np.zeros((B, 10, 10)), np.zeros((B, 10, 15, 15)), np.zeros((B, 10, 15, 15)), np.zeros((B, 10))
+        s = windows.struct()
+        rc = self.ctx._L.avm_imu_preintegrate_batch(self.ctx.h, C.byref(self.options), windows.mem, C.byref(s),
+                                                    abi.dptr(d), abi.dptr(j), abi.dptr(cv), abi.dptr(sd))
+        self.ctx.check(rc, "avm_imu_preintegrate_batch")
+        return d, j, cv, sd
+
+    def sqrt_info(self, n_windows: int):
+        out = np.zeros((n_windows, 10, 15, 15))
+        self.ctx.check(self.ctx._L.avm_debug_copy_sqrt_info(self.ctx.h, n_windows, abi.dptr(out)), "avm_debug_copy_sqrt_info")
+        return out
+
+    def eval_factors(self, windows: buffers.WindowArrays, apply_loss: bool = False):
+        assert not windows.on_device
+        B, mo, mp = windows.n_windows, windows.dims["max_obs"], windows.dims["max_prior"]
+        out = dict(proj_r=np.zeros((B, mo, 2)), proj_J=np.zeros((B, mo, 2, 13)), imu_r=np.zeros((B, 10, 15)),
+                   imu_J=np.zeros((B, 10, 15, 30)), prior_res=np.zeros((B, mp)), cost=np.zeros(B))
+        s = windows.struct()
+        rc = self.ctx._L.avm_window_eval_factors(self.ctx.h, C.byref(self.options), windows.mem, C.byref(s), int(apply_loss),
+                                                 *[abi.dptr(out[k]) for k in ("proj_r", "proj_J", "imu_r", "imu_J", "prior_res", "cost")])
+        self.ctx.check(rc, "avm_window_eval_factors")
+        return out

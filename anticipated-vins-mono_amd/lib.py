@@ -1,0 +1,95 @@
+"""Loader for the product library libavm_hip.so (HIP/gfx950).  No fallback: a missing library
+or a missing GPU raises, it never silently routes to CPU code."""
+import ctypes as C
+import os
+import subprocess
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libavm_hip.so")
+_lib = None
+
+
+class AvmError(RuntimeError):
+    pass
+
+
+def build(force: bool = False):
+    """Compile csrc/*.hip for gfx950 with hipcc (works without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise AvmError(
+                f"{_LIB_PATH} is missing: build it with __graft_entry__.build() "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        L = C.CDLL(_LIB_PATH)
+        vp = C.c_void_p
+        L.avm_version.restype = C.c_char_p
+        L.avm_last_error.restype = C.c_char_p
+        L.avm_last_error.argtypes = [vp]
+        L.avm_default_options.argtypes = [C.POINTER(abi.Options)]
+        L.avm_create.argtypes = [C.POINTER(abi.Config), C.POINTER(vp)]
+        L.avm_destroy.argtypes = [vp]
+        L.avm_destroy.restype = None
+        L.avm_last_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
+        L.avm_window_solve_batch.argtypes = [vp, C.POINTER(abi.Options), C.c_int, C.POINTER(abi.WindowBatch),
+                                             C.POINTER(abi.PriorOut), C.POINTER(abi.SolveSummary)]
+        L.avm_imu_preintegrate_batch.argtypes = [vp, C.POINTER(abi.Options), C.c_int, C.POINTER(abi.WindowBatch)] + [abi.c_dp] * 4
+        L.avm_window_eval_factors.argtypes = [vp, C.POINTER(abi.Options), C.c_int, C.POINTER(abi.WindowBatch), C.c_int] + [abi.c_dp] * 6
+        L.avm_fsel_select_batch.argtypes = [vp, C.c_int, C.POINTER(abi.FselBatch), C.POINTER(abi.FselOut)]
+        L.avm_fsel_information.argtypes = [vp, C.c_int, C.POINTER(abi.FselBatch), abi.c_dp, abi.c_dp, abi.c_ip]
+        L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
+        _lib = L
+    return _lib
+
+
+EXPORTS = [
+    "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
+    "avm_window_solve_batch", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
+    "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms",
+]
+
+
+class Context:
+    """avm_ctx: one per host thread, owns device scratch and one HIP stream."""
+
+    def __init__(self, device: int = 0):
+        self._L = lib()
+        cfg = abi.Config()
+        cfg.device = device
+        h = C.c_void_p()
+        rc = self._L.avm_create(C.byref(cfg), C.byref(h))
+        if rc != abi.AVM_OK:
+            raise AvmError(f"avm_create failed with status {rc} (no HIP device? there is no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.avm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int, what: str):
+        if rc != abi.AVM_OK:
+            raise AvmError(f"{what} failed: status {rc}: {self._L.avm_last_error(self.h).decode()}")
+
+    def kernel_ms(self, which: str) -> float:
+        ms = C.c_float(0)
+        self.check(self._L.avm_last_kernel_ms(self.h, which.encode(), C.byref(ms)), "avm_last_kernel_ms")
+        return ms.value

@@ -46,3 +46,27 @@ def fsel_select(fsel, out, n_threads=1):
     rc = lib().avmo_fsel_select_batch(C.byref(s), C.byref(o), int(n_threads), C.byref(n))
     assert rc == 0
     return n.value
+
+
+def preintegrate(opt, win):
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    B = win.n_windows
+    d, j, cv, sd, sq = np.zeros((B, 10, 10)), np.zeros((B, 10, 15, 15)), np.zeros((B, 10, 15, 15)), np.zeros((B, 10)), np.zeros((B, 10, 15, 15))
+    s = win.struct()
+    rc = lib().avmo_imu_preintegrate_batch(C.byref(opt), C.byref(s), abi.dptr(d), abi.dptr(j), abi.dptr(cv), abi.dptr(sd), abi.dptr(sq))
+    assert rc == 0
+    return d, j, cv, sd, sq
+
+
+def eval_factors(opt, win, apply_loss=False):
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    B, mo, mp = win.n_windows, win.dims["max_obs"], win.dims["max_prior"]
+    out = dict(proj_r=np.zeros((B, mo, 2)), proj_J=np.zeros((B, mo, 2, 13)), imu_r=np.zeros((B, 10, 15)),
+               imu_J=np.zeros((B, 10, 15, 30)), prior_res=np.zeros((B, mp)), cost=np.zeros(B))
+    s = win.struct()
+    rc = lib().avmo_window_eval_factors(C.byref(opt), C.byref(s), int(apply_loss),
+                                        *[abi.dptr(out[k]) for k in ("proj_r", "proj_J", "imu_r", "imu_J", "prior_res", "cost")])
+    assert rc == 0
+    return out
