@@ -3,6 +3,7 @@
 // feature_selector.cpp).  No torch types, no exceptions across the boundary.  There is no CPU
 // fallback: without a HIP device avm_create() fails with AVM_ERR_NO_DEVICE.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -23,6 +24,7 @@ struct avm_ctx {
   double *pre_delta = nullptr, *pre_jac = nullptr, *pre_cov = nullptr, *pre_sqrt = nullptr, *pre_sum = nullptr;
   size_t pre_cap = 0;  // windows
   avm_solve_summary* d_summary = nullptr;
+  long long* prof = nullptr;  // [n_slots][32], enabled by AVM_PROFILE=1
   size_t summary_cap = 0;
   // staging pool for AVM_MEM_HOST calls: name -> (ptr, bytes)
   std::map<std::string, std::pair<void*, size_t>> pool;
@@ -203,6 +205,8 @@ int avm_create(const avm_config* cfg, avm_ctx** out) {
   // one resident 512-thread workgroup per CU (the solve kernel takes ~158 KiB of the 160 KiB LDS)
   c->n_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  if (const char* pe = getenv("AVM_PROFILE"))
+    if (pe[0] == '1') (void)hipMalloc(&c->prof, sizeof(long long) * 32 * c->n_slots);
   *out = c;
   return AVM_OK;
 }
@@ -262,6 +266,8 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   sa.b = d, sa.opt = *opt;
   sa.pre_delta = c->pre_delta, sa.pre_jac = c->pre_jac, sa.pre_sqrt = c->pre_sqrt, sa.pre_sum_dt = c->pre_sum;
   sa.scratch = c->scratch, sa.iscratch = c->iscratch, sa.summary = d_sum, sa.n_slots = c->n_slots;
+  sa.prof = c->prof;
+  if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * 32 * c->n_slots, c->stream));
   HIPCHK(c, launch_window_solve(sa, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (mem == AVM_MEM_HOST) {
@@ -302,6 +308,25 @@ int avm_imu_preintegrate_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, 
   if (out_sum_dt) HIPCHK(c, hipMemcpyAsync(out_sum_dt, c->pre_sum, sizeof(double) * iv, kind, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return AVM_OK;
+}
+
+// debug hook (not in avm.h): per-phase shader clocks of the last solve, summed over slots, [32]
+int avm_debug_copy_profile(avm_ctx* c, long long* host_out) {
+  if (!c || !c->prof) return AVM_ERR_INVALID;
+  std::vector<long long> h((size_t)32 * c->n_slots);
+  HIPCHK(c, hipMemcpy(h.data(), c->prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 32; k++) host_out[k] = 0;
+  for (int s = 0; s < c->n_slots; s++)
+    for (int k = 0; k < 32; k++) host_out[k] += h[(size_t)s * 32 + k];
+  return AVM_OK;
+}
+
+// test hook (not in avm.h): sizeof of every ABI struct, for the ctypes mirror check
+int avm_debug_struct_sizes(int* out) {
+  out[0] = (int)sizeof(avm_options), out[1] = (int)sizeof(avm_window_batch), out[2] = (int)sizeof(avm_prior_out);
+  out[3] = (int)sizeof(avm_solve_summary), out[4] = (int)sizeof(avm_fsel_batch), out[5] = (int)sizeof(avm_fsel_out);
+  out[6] = (int)sizeof(avm_config);
+  return 7;
 }
 
 // test hook (not in avm.h): sqrt_info of the last pre-integration, [B][10][15][15]
@@ -356,14 +381,128 @@ int avm_window_eval_factors(avm_ctx* c, const avm_options* opt, avm_mem mem, con
   return AVM_OK;
 }
 
-int avm_fsel_select_batch(avm_ctx* c, avm_mem, const avm_fsel_batch*, avm_fsel_out*) {
-  if (!c) return AVM_ERR_INVALID;
-  return fail(c, AVM_ERR_UNSUPPORTED, "feature selector kernels not built yet");
+namespace {
+
+int check_fsel(avm_ctx* c, const avm_fsel_batch* b) {
+  if (!b || b->n_problems < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (!fsel_horizon_supported(b->horizon)) return fail(c, AVM_ERR_UNSUPPORTED, "horizon must be one of 2,3,5,10,13");
+  if (b->max_cand <= 0 || b->max_features < 0) return fail(c, AVM_ERR_INVALID, "bad max_cand / max_features");
+  return AVM_OK;
 }
 
-int avm_fsel_information(avm_ctx* c, avm_mem, const avm_fsel_batch*, double*, double*, int32_t*) {
+int stage_fsel(avm_ctx* c, const avm_fsel_batch* h, avm_fsel_batch* d) {
+  *d = *h;
+  const size_t P = h->n_problems, H1 = h->horizon + 1;
+  int rc;
+#define ST(field, type, count) \
+  if ((rc = stage_in<type>(c, "f_" #field, h->field, (count), (const type**)&d->field)) != AVM_OK) return rc;
+  ST(hor_pos, double, P * H1 * 3)
+  ST(hor_quat, double, P * H1 * 4)
+  ST(nr_imu, int32_t, P)
+  ST(delta_imu, double, P)
+  ST(n_cand, int32_t, P)
+  ST(cand_id, int32_t, P * h->max_cand)
+  ST(cand_xy, double, P * h->max_cand * 2)
+  ST(cand_prob, double, P * h->max_cand)
+  ST(n_used, int32_t, P)
+  ST(used_id, int32_t, P * h->max_used)
+  ST(used_xy, double, P * h->max_used * 2)
+  ST(n_cloud, int32_t, P)
+  ST(cloud_xy, double, P * h->max_cloud * 2)
+  ST(cloud_depth, double, P * h->max_cloud)
+#undef ST
+  return AVM_OK;
+}
+
+int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
+  const size_t P = b->n_problems, T = 3 * (size_t)b->horizon, mc = b->max_cand, mu = b->max_used > 0 ? b->max_used : 1;
+#define GET(field, type, count)                                                             \
+  w->field = static_cast<type*>(pool_get(c, "fw_" #field, sizeof(type) * (count)));          \
+  if (!w->field) return fail(c, AVM_ERR_HIP, "hipMalloc failed (selector work buffer)");
+  GET(C, double, P * T * T)
+  GET(dpp, double, P * T)
+  GET(consts, double, P * 4)
+  GET(delta, double, P * mc * T * T)
+  GET(delta_u, double, P * mu * T * T)
+  GET(fval, double, P * mc)
+  GET(ub, double, P * mc)
+  GET(valid, int32_t, P * mc)
+  GET(valid_u, int32_t, P * mu)
+  GET(black, int32_t, P * mc)
+  GET(nsel, int32_t, P)
+  GET(done, int32_t, P)
+#undef GET
+  return AVM_OK;
+}
+
+}  // namespace
+
+int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, avm_fsel_out* out) {
   if (!c) return AVM_ERR_INVALID;
-  return fail(c, AVM_ERR_UNSUPPORTED, "feature selector kernels not built yet");
+  (void)hipSetDevice(c->device);
+  int rc = check_fsel(c, batch);
+  if (rc != AVM_OK) return rc;
+  if (!out || !out->n_selected || !out->selected_ids) return fail(c, AVM_ERR_INVALID, "null output");
+  if (batch->n_problems == 0) return AVM_OK;
+  avm_fsel_batch d;
+  avm_fsel_out dout;
+  const size_t P = batch->n_problems, mf = batch->max_features;
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = stage_fsel(c, batch, &d)) != AVM_OK) return rc;
+    dout.n_selected = static_cast<int32_t*>(pool_get(c, "fo_n", sizeof(int32_t) * P));
+    dout.selected_ids = static_cast<int32_t*>(pool_get(c, "fo_ids", sizeof(int32_t) * P * (mf ? mf : 1)));
+    dout.fvalues = out->fvalues ? static_cast<double*>(pool_get(c, "fo_fv", sizeof(double) * P * (mf ? mf : 1))) : nullptr;
+    if (!dout.n_selected || !dout.selected_ids) return fail(c, AVM_ERR_HIP, "hipMalloc failed (selector out)");
+  } else {
+    d = *batch;
+    dout = *out;
+  }
+  FselBuffers w;
+  if ((rc = fsel_buffers(c, &d, &w)) != AVM_OK) return rc;
+  HIPCHK(c, hipMemsetAsync(dout.n_selected, 0, sizeof(int32_t) * P, c->stream));
+  HIPCHK(c, hipMemsetAsync(dout.selected_ids, 0xff, sizeof(int32_t) * P * mf, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  if (mem == AVM_MEM_HOST) {
+    HIPCHK(c, hipMemcpyAsync(out->n_selected, dout.n_selected, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out->selected_ids, dout.selected_ids, sizeof(int32_t) * P * mf, hipMemcpyDeviceToHost, c->stream));
+    if (out->fvalues) HIPCHK(c, hipMemcpyAsync(out->fvalues, dout.fvalues, sizeof(double) * P * mf, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->last_ms["fsel_select"] = ms;
+  return AVM_OK;
+}
+
+int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, double* omega, double* delta_cand, int32_t* cand_valid) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  int rc = check_fsel(c, batch);
+  if (rc != AVM_OK) return rc;
+  if (batch->n_problems == 0) return AVM_OK;
+  avm_fsel_batch d;
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = stage_fsel(c, batch, &d)) != AVM_OK) return rc;
+  } else {
+    d = *batch;
+  }
+  FselBuffers w;
+  if ((rc = fsel_buffers(c, &d, &w)) != AVM_OK) return rc;
+  const size_t P = batch->n_problems, N = 9 * ((size_t)batch->horizon + 1), T = 3 * (size_t)batch->horizon, mc = batch->max_cand;
+  double* d_om = nullptr;
+  if (omega) {
+    d_om = mem == AVM_MEM_HOST ? static_cast<double*>(pool_get(c, "fi_om", sizeof(double) * P * N * N)) : omega;
+    if (!d_om) return fail(c, AVM_ERR_HIP, "hipMalloc failed (omega)");
+  }
+  avm_fsel_out none{nullptr, nullptr, nullptr};
+  HIPCHK(c, launch_fsel(d, w, none, d_om, false, c->stream));
+  const hipMemcpyKind kind = mem == AVM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (omega && mem == AVM_MEM_HOST) HIPCHK(c, hipMemcpyAsync(omega, d_om, sizeof(double) * P * N * N, kind, c->stream));
+  if (delta_cand) HIPCHK(c, hipMemcpyAsync(delta_cand, w.delta, sizeof(double) * P * mc * T * T, kind, c->stream));
+  if (cand_valid) HIPCHK(c, hipMemcpyAsync(cand_valid, w.valid, sizeof(int32_t) * P * mc, kind, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
 }
 
 }  // extern "C"

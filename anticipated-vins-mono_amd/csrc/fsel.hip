@@ -1,0 +1,484 @@
+// fsel.hip — FeatureSelector::select() (initialized branch) for a batch of frames on gfx950.
+//
+// reference: vins_estimator/src/feature_selector.cpp
+//   calcInfoFromRobotMotion :463-527, createLinearImuMatrices :531-598, addOmegaPrior :602-609,
+//   calcInfoFromFeatures :239-365 (+ inFOV :369-376, findNNDepth :437-459, PinholeCamera
+//   spaceToPlane/distortion camera_model/src/camera_models/PinholeCamera.cc:520-542,646-662),
+//   selectInformativeFeatures :613-686, sortedlogDetUB :690-728, Utility::logdet utility.h:144-167.
+//
+// MI355X mapping.  Delta_ell only touches the 3H position rows of horizon states 1..H
+// (feature_selector.cpp:349-355), while Omega's other 6H+9 rows never change during a
+// select() call.  So the Cholesky pivots of those rows are hoisted: setup eliminates them once
+// per frame (partial Cholesky in LDS) leaving C0 = Omega_pp - Omega_pn Omega_nn^-1 Omega_np and
+// logdet(Omega_nn); every candidate evaluation logdet(Omega + OmegaS + p*Delta) is then
+// logdet(Omega_nn) + logdet(C + p*Delta_pp) with a 3H x 3H factorisation held entirely in the
+// registers of one wavefront (lane = matrix row; two candidates per wave when 3H <= 32).
+// This is the same Cholesky with the constant leading pivots factored once — the same kind of
+// hoist as IMUFactor's sqrt_info.  All FP64; selection order is deterministic.
+#include <cfloat>
+
+#include "devmath.hpp"
+#include "kernels.hpp"
+
+namespace avm {
+
+namespace {
+
+constexpr int FS_NT = 256;
+
+struct FselDev {
+  avm_fsel_batch b;  // device pointers
+  // work buffers
+  double* C;        // [P][T*T] current reduced position information (C0 + used + OmegaS)
+  double* dpp;      // [P][T]   un-reduced diagonal of the position rows (for the Hadamard bound)
+  double* consts;   // [P][4]   ld_nn, Kn
+  double* delta;    // [P][max_cand][T*T]
+  double* delta_u;  // [P][max_used][T*T]
+  int32_t* valid;   // [P][max_cand] 1 = triangulable (numVisible > 1)
+  int32_t* valid_u; // [P][max_used]
+  int32_t* black;   // [P][max_cand]
+  double* fval;     // [P][max_cand]
+  double* ub;       // [P][max_cand]
+  int32_t* nsel;    // [P] number selected so far
+  int32_t* done;    // [P] 1 when a round found no winner (state is then frozen)
+  double* omega_out;  // optional [P][N*N] (tests)
+  avm_fsel_out out;
+};
+
+AVM_DEV quat slerp_eigen(quat a, double t, quat b) {
+  const double one = 1.0 - DBL_EPSILON;
+  const double d = a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z;
+  const double ad = fabs(d);
+  double s0, s1;
+  if (ad >= one) {
+    s0 = 1.0 - t;
+    s1 = t;
+  } else {
+    const double th = acos(ad), st = sin(th);
+    s0 = sin((1.0 - t) * th) / st;
+    s1 = sin(t * th) / st;
+  }
+  if (d < 0) s1 = -s1;
+  return quat{s0 * a.w + s1 * b.w, s0 * a.x + s1 * b.x, s0 * a.y + s1 * b.y, s0 * a.z + s1 * b.z};
+}
+
+// Delta_ell position blocks of one feature (calcInfoFromFeatures), written as dense T x T.
+// cam[h] (h = 1..H): t_WC (3), R of q_WC^-1 (9), R of (q_WC * q_IC)^-1 (9)  => 21 doubles per h
+AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* out /*T*T*/) {
+  const int T = 3 * H;
+  // findNNDepth: exact 1-NN, first strictly smaller distance wins
+  double dep = 1.0;
+  const int ncl = b.n_cloud ? b.n_cloud[p] : 0;
+  if (ncl > 0) {
+    const double* cxy = b.cloud_xy + (size_t)p * b.max_cloud * 2;
+    int best = 0;
+    double bd = DBL_MAX;
+    for (int i = 0; i < ncl; i++) {
+      const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
+      const double d = dx * dx + dy * dy;
+      if (d < bd) bd = d, best = i;
+    }
+    dep = b.cloud_depth[(size_t)p * b.max_cloud + best];
+  }
+  const double nrm = sqrt(fx_ * fx_ + fy_ * fy_ + 1.0);
+  const v3 fn = mk3(fx_ / nrm, fy_ / nrm, 1.0 / nrm);  // feature.normalized()
+  const v3 feat = dep * fn;
+  // pell = t_WC_k1 + q_WC_k1 * feature  (R of q_WC^-1 is the transpose of R(q_WC) for unit quaternions; the
+  // oracle rotates with the quaternion itself; cam[1] block stores R(q_WC) too at +21*H.. see setup)
+  const double* c1 = cam + 1 * 30;
+  const v3 pell = mk3(c1[0], c1[1], c1[2]) + Rmul(c1 + 21, feat);
+  int numVisible = 1;
+  double Ch[13 * 6];  // symmetric 3x3 per h: xx xy xz yy yz zz
+  for (int i = 0; i < H * 6; i++) Ch[i] = 0.0;
+  double E[6] = {0, 0, 0, 0, 0, 0};
+  auto addC = [&](int hidx, v3 u, const double* Rinv2) {
+    // Bh = skew(u) * Rinv2 ; C = Bh^T Bh
+    double S[9], Bm[9];
+    skew9(u, S);
+    mat3mul(S, Rinv2, Bm);
+    double* C = Ch + hidx * 6;
+    C[0] = Bm[0] * Bm[0] + Bm[3] * Bm[3] + Bm[6] * Bm[6];
+    C[1] = Bm[0] * Bm[1] + Bm[3] * Bm[4] + Bm[6] * Bm[7];
+    C[2] = Bm[0] * Bm[2] + Bm[3] * Bm[5] + Bm[6] * Bm[8];
+    C[3] = Bm[1] * Bm[1] + Bm[4] * Bm[4] + Bm[7] * Bm[7];
+    C[4] = Bm[1] * Bm[2] + Bm[4] * Bm[5] + Bm[7] * Bm[8];
+    C[5] = Bm[2] * Bm[2] + Bm[5] * Bm[5] + Bm[8] * Bm[8];
+    for (int k = 0; k < 6; k++) E[k] += C[k];
+  };
+  for (int h = 2; h <= H; ++h) {
+    const double* ch = cam + h * 30;
+    const v3 tw = mk3(ch[0], ch[1], ch[2]);
+    v3 ue = Rmul(ch + 3, pell - tw);  // q_WC_h^-1 * (pell - t_WC_h)
+    const double n = sqrt(dot(ue, ue));
+    ue = mk3(ue.x / n, ue.y / n, ue.z / n);
+    // PinholeCamera::spaceToPlane with radial-tangential distortion
+    const double xu = ue.x / ue.z, yu = ue.y / ue.z;
+    const double mx2 = xu * xu, my2 = yu * yu, mxy = xu * yu, rho2 = mx2 + my2;
+    const double rad = b.k1 * rho2 + b.k2 * rho2 * rho2;
+    const double dxx = xu * rad + 2.0 * b.p1 * mxy + b.p2 * (rho2 + 2.0 * mx2);
+    const double dyy = yu * rad + 2.0 * b.p2 * mxy + b.p1 * (rho2 + 2.0 * my2);
+    const double pu = b.fx * (xu + dxx) + b.cx, pv = b.fy * (yu + dyy) + b.cy;
+    const int iu = (int)round(pu), ivv = (int)round(pv);  // std::round: half away from zero
+    if (!((0 <= iu && iu < b.image_width) && (0 <= ivv && ivv < b.image_height))) continue;
+    addC(h - 1, ue, ch + 12);
+    ++numVisible;
+  }
+  if (numVisible == 1) return false;
+  addC(0, fn, c1 + 12);
+  // W = EtE^-1 (cofactors / det)
+  const double a00 = E[0], a01 = E[1], a02 = E[2], a11 = E[3], a12 = E[4], a22 = E[5];
+  double Wm[9];
+  {
+    const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c10 = a12 * a02 - a01 * a22, c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12;
+    const double c20 = a01 * a12 - a11 * a02, c21 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    const double det = a00 * c00 + a01 * c10 + a02 * c20;
+    const double id = 1.0 / det;
+    Wm[0] = id * c00, Wm[1] = id * c01, Wm[2] = id * c02, Wm[3] = id * c10, Wm[4] = id * c11, Wm[5] = id * c12, Wm[6] = id * c20,
+    Wm[7] = id * c21, Wm[8] = id * c22;
+  }
+  auto full = [&](int hidx, double* M) {
+    const double* C = Ch + hidx * 6;
+    M[0] = C[0], M[1] = C[1], M[2] = C[2], M[3] = C[1], M[4] = C[3], M[5] = C[4], M[6] = C[2], M[7] = C[4], M[8] = C[5];
+  };
+  for (int j = 1; j <= H; ++j) {
+    double Cj[9];
+    full(j - 1, Cj);
+    for (int i = j; i <= H; ++i) {
+      double Ci[9], CW[9], D[9];
+      full(i - 1, Ci);
+      mat3mul(Ci, Wm, CW);
+      // Dij = Ci * W * Cj^T
+      for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) D[a * 3 + c] = CW[a * 3] * Cj[c * 3] + CW[a * 3 + 1] * Cj[c * 3 + 1] + CW[a * 3 + 2] * Cj[c * 3 + 2];
+      for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) {
+          const int r = 3 * (i - 1) + a, q = 3 * (j - 1) + c;
+          if (i == j) {
+            out[r * T + q] = Ci[a * 3 + c] - D[a * 3 + c];
+          } else {
+            out[r * T + q] = -D[a * 3 + c];
+            out[q * T + r] = -D[a * 3 + c];
+          }
+        }
+    }
+  }
+  return true;
+}
+
+// ---- setup: Omega, partial Cholesky of the non-position rows, Delta of every feature ------
+__global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  const avm_fsel_batch& b = A.b;
+  const int p = blockIdx.x, t = threadIdx.x;
+  const int H = b.horizon, N = 9 * (H + 1), T = 3 * H;
+  double* Om = lds;                 // N*N
+  double* Wh = Om + N * N;          // [H+1][81] Omega_h (h>=1)
+  double* Ah = Wh + (H + 1) * 81;   // [H+1][81] Ablk_h
+  double* Th = Ah + (H + 1) * 81;   // [H+1][81] At*Omega
+  double* B1 = Th + (H + 1) * 81;   // [H+1][81] At*Omega*A
+  double* cam = B1 + (H + 1) * 81;  // [H+1][30]
+  double* col = cam + (H + 1) * 30; // N
+  double* red = col + N;            // 64
+  int* isp = reinterpret_cast<int*>(red + 64);  // N: position-row flag
+  const double* hp = b.hor_pos + (size_t)p * (H + 1) * 3;
+  const double* hq = b.hor_quat + (size_t)p * (H + 1) * 4;
+  const quat qic{b.q_ic[3], b.q_ic[0], b.q_ic[1], b.q_ic[2]};
+  for (int i = t; i < N * N; i += FS_NT) Om[i] = 0.0;
+  for (int i = t; i < N; i += FS_NT) isp[i] = (i >= 9 && (i % 9) < 3) ? 1 : 0;
+  // per consecutive pair: createLinearImuMatrices
+  if (t >= 1 && t <= H) {
+    const int h = t;
+    const quat Qi{hq[(h - 1) * 4 + 3], hq[(h - 1) * 4], hq[(h - 1) * 4 + 1], hq[(h - 1) * 4 + 2]};
+    const quat Qj{hq[h * 4 + 3], hq[h * 4], hq[h * 4 + 1], hq[h * 4 + 2]};
+    const double nr = (double)b.nr_imu[p], dI = b.delta_imu[p];
+    double Nij[9], Mij[9];
+    for (int k = 0; k < 9; k++) Nij[k] = 0, Mij[k] = 0;
+    double c11 = 0, c12 = 0;
+    for (int i = 0; i < nr; ++i) {
+      const quat q = slerp_eigen(Qi, i / nr, Qj);
+      double R[9];
+      q2R(q, R);
+      const double jkh = (nr - i - 0.5);
+      for (int k = 0; k < 9; k++) Nij[k] += jkh * R[k], Mij[k] += R[k];
+      c11 += jkh * jkh;
+      c12 += jkh;
+    }
+    const double d2 = dI * dI, d3 = d2 * dI, d4 = d3 * dI;
+    const double ca = 1.0 * nr * c11 * d4 * b.acc_var, cb = 1.0 * c12 * d3 * b.acc_var, cd = 1.0 * nr * d2 * b.acc_var,
+                 cc = 1.0 * nr * b.acc_bias_var;
+    // inverse of [[ca I, cb I, 0],[cb I, cd I, 0],[0,0,cc I]]
+    const double det = ca * cd - cb * cb;
+    double* W = Wh + h * 81;
+    double* Am = Ah + h * 81;
+    for (int k = 0; k < 81; k++) W[k] = 0, Am[k] = 0;
+    for (int i = 0; i < 3; i++) {
+      W[i * 9 + i] = cd / det, W[i * 9 + 3 + i] = -cb / det, W[(3 + i) * 9 + i] = -cb / det, W[(3 + i) * 9 + 3 + i] = ca / det;
+      W[(6 + i) * 9 + 6 + i] = 1.0 / cc;
+    }
+    for (int i = 0; i < 9; i++) Am[i * 9 + i] = -1.0;
+    for (int i = 0; i < 3; i++) Am[i * 9 + 3 + i] = -1.0 * nr * dI;
+    for (int a = 0; a < 3; a++)
+      for (int c = 0; c < 3; c++) Am[a * 9 + 6 + c] = Nij[a * 3 + c] * d2, Am[(3 + a) * 9 + 6 + c] = Mij[a * 3 + c] * dI;
+  }
+  // camera frames for calcInfoFromFeatures
+  if (t >= 64 && t <= 64 + H) {
+    const int h = t - 64;
+    const quat q{hq[h * 4 + 3], hq[h * 4], hq[h * 4 + 1], hq[h * 4 + 2]};
+    const v3 tw = mk3(hp[h * 3], hp[h * 3 + 1], hp[h * 3 + 2]) + qrot(q, mk3(b.t_ic[0], b.t_ic[1], b.t_ic[2]));
+    const quat qwc = qmul(q, qic);
+    double* c = cam + h * 30;
+    c[0] = tw.x, c[1] = tw.y, c[2] = tw.z;
+    q2R(qinv(qwc), c + 3);                 // q_WC^-1
+    q2R(qinv(qmul(qwc, qic)), c + 12);     // (q_WC * q_IC)^-1 : q_IC twice, bug-compatible (:304,:321)
+    q2R(qwc, c + 21);                      // q_WC (frame k+1 back-projection)
+  }
+  __syncthreads();
+  for (int idx = t; idx < H * 81; idx += FS_NT) {  // Th = A^T W
+    const int h = 1 + idx / 81, i = (idx % 81) / 9, j = idx % 9;
+    double s = 0;
+    for (int k = 0; k < 9; k++) s += Ah[h * 81 + k * 9 + i] * Wh[h * 81 + k * 9 + j];
+    Th[h * 81 + i * 9 + j] = s;
+  }
+  __syncthreads();
+  for (int idx = t; idx < H * 81; idx += FS_NT) {  // B1 = Th A
+    const int h = 1 + idx / 81, i = (idx % 81) / 9, j = idx % 9;
+    double s = 0;
+    for (int k = 0; k < 9; k++) s += Th[h * 81 + i * 9 + k] * Ah[h * 81 + k * 9 + j];
+    B1[h * 81 + i * 9 + j] = s;
+  }
+  __syncthreads();
+  // assemble Omega: diagonal block d = Omega_d (pair d) + At*Omega*A (pair d+1) [+ I for d == 0]
+  for (int idx = t; idx < (H + 1) * 81; idx += FS_NT) {
+    const int d = idx / 81, i = (idx % 81) / 9, j = idx % 9;
+    double s = 0;
+    if (d >= 1) s += Wh[d * 81 + i * 9 + j];
+    if (d < H) s += B1[(d + 1) * 81 + i * 9 + j];
+    if (d == 0 && i == j) s += 1.0;
+    Om[(d * 9 + i) * N + d * 9 + j] = s;
+  }
+  for (int idx = t; idx < H * 81; idx += FS_NT) {
+    const int h = 1 + idx / 81, i = (idx % 81) / 9, j = idx % 9;
+    const double v = Th[h * 81 + i * 9 + j];
+    Om[((h - 1) * 9 + i) * N + h * 9 + j] = v;  // At*Omega
+    Om[(h * 9 + j) * N + (h - 1) * 9 + i] = v;  // its transpose
+  }
+  __syncthreads();
+  if (A.omega_out)
+    for (int i = t; i < N * N; i += FS_NT) A.omega_out[(size_t)p * N * N + i] = Om[i];
+  // constants of the Hadamard bound + original position diagonal
+  double kn = 0;
+  for (int i = t; i < N; i += FS_NT)
+    if (!isp[i]) kn += log(Om[i * N + i]);
+  kn = block_sum<FS_NT>(kn, red);
+  if (t < T) A.dpp[(size_t)p * T + t] = Om[(9 * (1 + t / 3) + t % 3) * (N + 1)];
+  __syncthreads();
+  // partial right-looking Cholesky over the non-position rows (ascending order)
+  double ld = 0;
+  for (int k = 0; k < N; k++) {
+    if (isp[k]) continue;
+    const double d = sqrt(Om[k * N + k]);
+    ld += log(d);
+    for (int i = t; i < N; i += FS_NT) col[i] = (i > k || isp[i]) && i != k ? Om[i * N + k] / d : 0.0;
+    __syncthreads();
+    for (int idx = t; idx < N * N; idx += FS_NT) {
+      const int i = idx / N, j = idx % N;
+      const double li = col[i], lj = col[j];
+      if (li != 0.0 && lj != 0.0) Om[idx] -= li * lj;
+    }
+    __syncthreads();
+  }
+  double* C = A.C + (size_t)p * T * T;
+  for (int idx = t; idx < T * T; idx += FS_NT) {
+    const int i = idx / T, j = idx % T;
+    C[idx] = Om[(9 * (1 + i / 3) + i % 3) * N + 9 * (1 + j / 3) + j % 3];
+  }
+  if (t == 0) {
+    A.consts[(size_t)p * 4] = 2.0 * ld;
+    A.consts[(size_t)p * 4 + 1] = kn;
+    A.nsel[p] = 0;
+    A.done[p] = 0;
+  }
+  // Delta of candidates and of the already-used subset
+  const int nc = b.n_cand[p], nu = b.n_used ? b.n_used[p] : 0;
+  for (int f = t; f < nc + nu; f += FS_NT) {
+    const bool isu = f >= nc;
+    const int k = isu ? f - nc : f;
+    const double* xy = isu ? b.used_xy + ((size_t)p * b.max_used + k) * 2 : b.cand_xy + ((size_t)p * b.max_cand + k) * 2;
+    double* out = isu ? A.delta_u + ((size_t)p * b.max_used + k) * T * T : A.delta + ((size_t)p * b.max_cand + k) * T * T;
+    for (int i = 0; i < T * T; i++) out[i] = 0.0;
+    const bool ok = feature_delta(b, p, cam, xy[0], xy[1], H, out);
+    if (isu)
+      A.valid_u[(size_t)p * b.max_used + k] = ok;
+    else
+      A.valid[(size_t)p * b.max_cand + k] = ok, A.black[(size_t)p * b.max_cand + k] = 0;
+  }
+  __syncthreads();
+  // Omega += sum of Delta_used (ascending id order = input order)
+  for (int idx = t; idx < T * T; idx += FS_NT) {
+    double s = C[idx], dd = 0;
+    for (int u = 0; u < nu; u++)
+      if (A.valid_u[(size_t)p * b.max_used + u]) {
+        const double v = A.delta_u[((size_t)p * b.max_used + u) * T * T + idx];
+        s += v;
+        dd += v;
+      }
+    C[idx] = s;
+    if (idx / T == idx % T) A.dpp[(size_t)p * T + idx / T] += dd;
+  }
+}
+
+// ---- one greedy round: f_l = logdet(Omega + OmegaS + p_l Delta_l) for every live candidate ----
+template <int T>
+__global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int round) {
+  constexpr int PER_WAVE = (T <= 32) ? 2 : 1;
+  constexpr int HALF = (T <= 32) ? 32 : 64;
+  const avm_fsel_batch& b = A.b;
+  const int p = blockIdx.y;
+  const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
+  if (round >= kappa || A.done[p]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = lane / HALF, row = lane % HALF;
+  const int l = (blockIdx.x * (FS_NT / 64) + wv) * PER_WAVE + sub;
+  const int nc = b.n_cand[p];
+  const bool live = l < nc && A.valid[(size_t)p * b.max_cand + l] && !A.black[(size_t)p * b.max_cand + l];
+  // whole (half-)wave idle?
+  if (__ballot(live) == 0) return;
+  const double pr = live ? b.cand_prob[(size_t)p * b.max_cand + l] : 0.0;
+  const double* C = A.C + (size_t)p * T * T;
+  const double* D = A.delta + ((size_t)p * b.max_cand + (live ? l : 0)) * T * T;
+  const int r = row < T ? row : T - 1;
+  double Ar[T];
+#pragma unroll
+  for (int k = 0; k < T; k++) Ar[k] = C[r * T + k] + pr * D[r * T + k];
+  // Hadamard upper bound (sortedlogDetUB): sum of log of the diagonal of Omega + OmegaS + p Delta
+  double ubt = (row < T) ? log(A.dpp[(size_t)p * T + r] + pr * D[r * T + r]) : 0.0;
+#pragma unroll
+  for (int o = HALF / 2; o > 0; o >>= 1) ubt += __shfl_xor(ubt, o, 64);
+  // in-register Cholesky, lane = row
+  double ld = 0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    const double djj = __shfl(Ar[j], j, HALF);
+    if (!(djj > 0.0)) bad = true;
+    const double d = sqrt(djj);
+    ld += log(d);
+    const double lij = Ar[j] / d;
+#pragma unroll
+    for (int k = j + 1; k < T; k++) {
+      const double lkj = __shfl(lij, k, HALF);
+      Ar[k] -= lij * lkj;
+    }
+  }
+  if (live && row == 0) {
+    const double f = bad ? __builtin_nan("") : (A.consts[(size_t)p * 4] + 2.0 * ld);
+    A.fval[(size_t)p * b.max_cand + l] = f;
+    A.ub[(size_t)p * b.max_cand + l] = A.consts[(size_t)p * 4 + 1] + ubt;
+  }
+}
+
+// ---- pick the round's winner and fold it into OmegaS ------------------------------------------
+__global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) {
+  __shared__ double s_f[FS_NT / 64], s_u[FS_NT / 64];
+  __shared__ int s_i[FS_NT / 64];
+  __shared__ int s_win;
+  const avm_fsel_batch& b = A.b;
+  const int p = blockIdx.x, t = threadIdx.x;
+  const int T = 3 * b.horizon;
+  const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
+  if (round >= kappa || A.done[p]) return;
+  const int nc = b.n_cand[p];
+  // lexicographic max of (fValue, ub, id) over live candidates with fValue > fMax0 = -1.0 (NaN never wins)
+  double bf = -1.0, bu = -DBL_MAX;
+  int bi = -1;
+  for (int l = t; l < nc; l += FS_NT) {
+    if (!A.valid[(size_t)p * b.max_cand + l] || A.black[(size_t)p * b.max_cand + l]) continue;
+    const double f = A.fval[(size_t)p * b.max_cand + l], u = A.ub[(size_t)p * b.max_cand + l];
+    if (!(f > -1.0)) continue;
+    if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
+  }
+  auto better = [](double f, double u, int i, double f2, double u2, int i2) {
+    if (i2 < 0) return false;
+    if (i < 0) return true;
+    return f2 > f || (f2 == f && (u2 > u || (u2 == u && i2 > i)));
+  };
+  for (int o = 32; o > 0; o >>= 1) {
+    const double f2 = __shfl_xor(bf, o, 64), u2 = __shfl_xor(bu, o, 64);
+    const int i2 = __shfl_xor(bi, o, 64);
+    if (better(bf, bu, bi, f2, u2, i2)) bf = f2, bu = u2, bi = i2;
+  }
+  if ((t & 63) == 0) s_f[t >> 6] = bf, s_u[t >> 6] = bu, s_i[t >> 6] = bi;
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < FS_NT / 64; w++)
+      if (better(bf, bu, bi, s_f[w], s_u[w], s_i[w])) bf = s_f[w], bu = s_u[w], bi = s_i[w];
+    s_win = bi;
+    if (bi >= 0) {
+      const int k = A.nsel[p];
+      A.out.selected_ids[(size_t)p * b.max_features + k] = b.cand_id[(size_t)p * b.max_cand + bi];
+      if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + k] = bf;
+      A.nsel[p] = k + 1;
+      A.out.n_selected[p] = k + 1;
+      A.black[(size_t)p * b.max_cand + bi] = 1;
+    } else {
+      A.done[p] = 1;  // lMax == -1: nothing is added; later rounds would repeat the same state
+    }
+  }
+  __syncthreads();
+  const int win = s_win;
+  if (win < 0) return;
+  const double pr = b.cand_prob[(size_t)p * b.max_cand + win];
+  const double* D = A.delta + ((size_t)p * b.max_cand + win) * T * T;
+  double* C = A.C + (size_t)p * T * T;
+  for (int idx = t; idx < T * T; idx += FS_NT) {
+    C[idx] += pr * D[idx];
+    if (idx / T == idx % T) A.dpp[(size_t)p * T + idx / T] += pr * D[idx];
+  }
+}
+
+}  // namespace
+
+struct FselWork {
+  FselDev d;
+};
+
+size_t fsel_setup_lds_bytes(int H) {
+  const int N = 9 * (H + 1);
+  return sizeof(double) * ((size_t)N * N + 4 * (H + 1) * 81 + (H + 1) * 30 + N + 64) + sizeof(int) * N + 16;
+}
+
+// Launches setup (+ optional rounds).  All pointers in `d` are device pointers.
+hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
+                       hipStream_t stream) {
+  FselDev d;
+  d.b = b;
+  d.C = w.C, d.dpp = w.dpp, d.consts = w.consts, d.delta = w.delta, d.delta_u = w.delta_u, d.valid = w.valid, d.valid_u = w.valid_u;
+  d.black = w.black, d.fval = w.fval, d.ub = w.ub, d.nsel = w.nsel, d.done = w.done, d.omega_out = omega_out, d.out = out;
+  const int H = b.horizon, T = 3 * H;
+  const size_t lds = fsel_setup_lds_bytes(H);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fsel_setup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems), dim3(FS_NT), lds, stream, d);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (!run_rounds) return hipSuccess;
+  const int per_block = (FS_NT / 64) * (T <= 32 ? 2 : 1);
+  const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
+  for (int r = 0; r < b.max_features; r++) {
+    switch (T) {
+      case 6: hipLaunchKernelGGL(fsel_round_kernel<6>, grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 9: hipLaunchKernelGGL(fsel_round_kernel<9>, grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 15: hipLaunchKernelGGL(fsel_round_kernel<15>, grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 30: hipLaunchKernelGGL(fsel_round_kernel<30>, grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 39: hipLaunchKernelGGL(fsel_round_kernel<39>, grid, dim3(FS_NT), 0, stream, d, r); break;
+      default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(fsel_pick_kernel, dim3(b.n_problems), dim3(FS_NT), 0, stream, d, r);
+  }
+  return hipGetLastError();
+}
+
+bool fsel_horizon_supported(int H) { return H == 2 || H == 3 || H == 5 || H == 10 || H == 13; }
+
+}  // namespace avm

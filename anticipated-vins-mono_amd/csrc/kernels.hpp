@@ -43,6 +43,7 @@ struct SolveArgs {
   int32_t* iscratch;                                          // [n_slots][MAXOBS] observation slot -> feature
   avm_solve_summary* summary;                                 // [B] or null
   int n_slots;
+  long long* prof;  // optional [n_slots][32] per-phase shader-clock accumulators (debug)
 };
 
 struct EvalArgs {
@@ -53,7 +54,16 @@ struct EvalArgs {
   double *proj_r, *proj_J, *imu_r, *imu_J, *prior_res, *cost;
 };
 
+// device work buffers of the feature selector (owned by the ctx)
+struct FselBuffers {
+  double *C, *dpp, *consts, *delta, *delta_u, *fval, *ub;
+  int32_t *valid, *valid_u, *black, *nsel, *done;
+};
+
 void launch_preint(const PreintArgs& a, hipStream_t stream);
+hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
+                       hipStream_t stream);
+bool fsel_horizon_supported(int H);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 int window_solve_lds_bytes();

@@ -27,6 +27,9 @@ namespace avm {
 
 namespace {
 
+#define PROF_T0() long long pt__ = clock64()
+#define PROF(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pt__; pt__ = n__; } } while (0)
+
 constexpr int NT = 512;          // threads per workgroup (8 wavefronts)
 constexpr int SROWS = 13778;     // padded packed lower triangle of a 165x165 matrix
 constexpr int VEC = 320;         // padded NCOL
@@ -246,6 +249,7 @@ AVM_DEV void prior_block_dx(int kind, const double* xb, const double* x0, double
 }
 
 struct WinCtx {
+  long long* prof;
   double* lds;
   int* ids;
   double* sc;   // global scratch slot
@@ -345,6 +349,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   double* lds = c.lds;
   const int t = threadIdx.x;
   const double* xs = lds + L_X;
+  PROF_T0();
   build_frames(lds, xs, 0);
   for (int i = t; i < 10 * 465; i += NT) lds[L_S + i] = 0.0;
   __syncthreads();
@@ -374,6 +379,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
     JF[27 * MAXOBS + s] = Je[1];
   }
   __syncthreads();
+  PROF(c, 0);
   // E2: IJ = sqrt_info * raw  (residual col 0 + 30 Jacobian cols), sqrt_info upper triangular
   double* IJ = c.sc + Scratch::IJ;
   for (int idx = t; idx < 10 * 465; idx += NT) {
@@ -384,6 +390,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
     IJ[idx] = s;
     if (cc == 0) acc += 0.5 * s * s;
   }
+  PROF(c, 1);
   // E1b: per-feature aggregates over the start pose (H_aa, w_a, h_e, g_a, g_e)
   double* FA = c.sc + Scratch::FA;
   for (int idx = t; idx < c.nf * 35; idx += NT) {
@@ -412,6 +419,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
     }
     FA[q * MAXE + e] = s;
   }
+  PROF(c, 2);
   // prior residual (uses L_DXP/L_RP; includes syncs)
   if (c.pn > 0) {
     prior_residual_dev(c, xs);
@@ -419,6 +427,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   } else {
     __syncthreads();
   }
+  PROF(c, 3);
   // zero S and g
   for (int i = t; i < SROWS; i += NT) lds[L_S + i] = 0.0;
   for (int i = t; i < VEC; i += NT) lds[L_G + i] = 0.0;
@@ -453,6 +462,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
     }
     lds[L_S + roff(i) + j] = s;
   }
+  PROF(c, 4);
   // E4(B): pose gradient
   if (t < NPOSE) {
     const int b = t / 6, ci = t % 6;
@@ -467,6 +477,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
     }
     lds[L_G + t] = s;
   }
+  PROF(c, 5);
   // E4(C): W rows (E^T F) ; E4(D): E^T E and feature gradient
   double* W = c.sc + Scratch::W;
   for (int idx = t; idx < c.nf * NPOSE; idx += NT) {
@@ -486,6 +497,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
     lds[L_G + NF + t] = FA[34 * MAXE + t];
   }
   __syncthreads();
+  PROF(c, 6);
   // E4(F): IMU J^T J and J^T r, even then odd factors
   for (int par = 0; par < 2; par++) {
     for (int idx = t; idx < 5 * 495; idx += NT) {
@@ -511,6 +523,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
     }
     __syncthreads();
   }
+  PROF(c, 7);
   // E4(G): prior  H += Hp (mapped), g += J0^T r_p
   if (c.pn > 0) {
     const double* HP = c.sc + Scratch::HP;
@@ -533,6 +546,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   }
   const double cost = block_sum<NT>(acc, lds + L_RED);
   __syncthreads();
+  PROF(c, 8);
   return cost;
 }
 
@@ -734,6 +748,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
     c.osf = A.iscratch + (size_t)blockIdx.x * MAXOBS;
     c.w = w;
+    c.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
     c.nf = B.n_feat[w];
     c.obs = B.obs_xy + (size_t)w * B.max_obs * 2;
     c.pdelta = A.pre_delta + (size_t)w * 100, c.pjac = A.pre_jac + (size_t)w * 2250, c.psqrt = A.pre_sqrt + (size_t)w * 2250;
@@ -746,6 +761,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     c.pr = B.prior_r + (size_t)w * B.max_prior;
     c.px0 = B.prior_x0 + (size_t)w * B.max_pblk * 9;
     __syncthreads();
+    PROF_T0();
     // ---------------- load ----------------
     for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
     for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
@@ -803,6 +819,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     }
     __syncthreads();
 
+    PROF(c, 9);
     // ---------------- TrustRegionMinimizer ----------------
     if (t < 32) lds[L_SUM + t] = 0.0;
     int n_successful = 0, accept_mask = 0;
@@ -824,7 +841,9 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     };
     // evaluate + scaling + gradient max norm at lds[L_X]
     auto evaluate_x = [&]() {
+      { PROF_T0(); (void)pt__; }
       x_cost = eval_jac(c, o);
+      PROF_T0();
       // Jacobi scaling from the column norms of the first Jacobian (diag of unscaled H)
       if (first) {
         if (o.jacobi_scaling) {
@@ -861,6 +880,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       if (t < c.nf) lds[L_HEE + t] *= scl[NF + t] * scl[NF + t];
       for (int i = t; i < NF + c.nf; i += NT) lds[L_G + i] *= scl[i];
       __syncthreads();
+      PROF(c, 10);
     };
 
     x_norm = amb_norm(lds + L_X);
@@ -914,6 +934,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
             evaluate_x();
             rebuilt = true;
           }
+          PROF_T0();
           // Schur complement on the inverse depths: S_pp -= W^T (hee + mu D_e^2)^-1 W ; rhs
           if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
           for (int i = t; i < NF; i += NT) lds[L_Y + i] = lds[L_G + i];
@@ -957,13 +978,16 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
             if (ei[q] >= 0) lds[L_S + roff(ei[q]) + ej[q]] -= accS[q];
           if (t < NPOSE) lds[L_Y + t] -= accR;
           __syncthreads();
+          PROF(c, 11);
           const bool ok = cholesky_lds(lds);
+          PROF(c, 12);
           if (!ok) {
             mu *= mu_inc;
             rebuilt = false;
             continue;
           }
           chol_solve_lds(lds, L_Y);
+          PROF(c, 13);
           // back substitution y_e = (g_e - W_e y_p) / (hee + mu D_e^2): one wavefront per feature
           {
             const int lane = t & 63, wv = t >> 6;
@@ -978,6 +1002,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
             }
           }
           __syncthreads();
+          PROF(c, 14);
           double bad = 0;
           for (int i = t; i < NF + c.nf; i += NT)
             if (!isfinite(lds[L_Y + i])) bad = 1;
@@ -1062,11 +1087,13 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
         continue;
       }
       // candidate
+      PROF_T0();
       state_plus(lds);
       __syncthreads();
       build_frames(lds, lds + L_XC, 1);
       __syncthreads();
       const double cand_cost = eval_cost(c, o, lds + L_XC, 1);
+      PROF(c, 15);
       double d2 = 0;
       for (int i = t; i < 176 + c.nf; i += NT) {
         const double d = lds[L_X + i] - lds[L_XC + i];
@@ -1157,6 +1184,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
         B.inv_depth[(size_t)w * B.max_feat + e] = 1.0 / (1.0 / lds[L_X + XLAM + e]);
       }
     }
+    if (c.prof && t == 0) c.prof[31] += 1;
     if (t == 0 && A.summary) {
       avm_solve_summary* so = A.summary + w;
       so->termination = termination;

@@ -1,0 +1,66 @@
+"""Host-side mirror of FeatureSelector::select() (vins_estimator/src/feature_selector.h:49-50,
+feature_selector.cpp:74-202) over the C ABI.
+
+The reference mutates `image` in place and returns {trackedFeatures_, selectedIds}; the host
+bookkeeping around the scoring loop (splitOnFeatureId :208-219, the tracked list :108-120,192-196)
+is plain index work and stays on the host, the information matrices and the greedy logdet
+scoring run on the GPU through avm_fsel_select_batch.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, buffers
+from .lib import Context
+
+
+class FeatureSelector:
+    def __init__(self, ctx: Context = None, device: int = 0):
+        self.ctx = ctx or Context(device)
+        self.trackedFeatures_ = []  # feature_selector.h:93
+        self.lastFeatureId_ = 0
+
+    def select_batch(self, problems: buffers.FselArrays, want_fvalues: bool = True):
+        """Greedy selection for P independent frames. Returns (n_selected[P], ids[P, max_features], fvalues)."""
+        P, mf = problems.n_problems, problems.dims["max_features"]
+        dev = "cuda:%d" % self.ctx.device if problems.on_device else None
+        out = buffers.FselOutArrays.alloc(P, mf, dev)
+        if not want_fvalues:
+            out.a["fvalues"] = None
+        s, o = problems.struct(), out.struct()
+        rc = self.ctx._L.avm_fsel_select_batch(self.ctx.h, problems.mem, C.byref(s), C.byref(o))
+        self.ctx.check(rc, "avm_fsel_select_batch")
+        return out
+
+    def information(self, problems: buffers.FselArrays):
+        """Omega_kkH (+prior) [P,N,N], compact Delta_ell [P,max_cand,3H,3H], valid [P,max_cand] (host arrays)."""
+        assert not problems.on_device
+        P, H, mc = problems.n_problems, problems.dims["horizon"], problems.dims["max_cand"]
+        N, T = 9 * (H + 1), 3 * H
+        om, dl, va = np.zeros((P, N, N)), np.zeros((P, mc, T, T)), np.zeros((P, mc), np.int32)
+        s = problems.struct()
+        rc = self.ctx._L.avm_fsel_information(self.ctx.h, problems.mem, C.byref(s), abi.dptr(om), abi.dptr(dl), abi.iptr(va))
+        self.ctx.check(rc, "avm_fsel_information")
+        return om, dl, va
+
+    def select(self, image: dict, problem_builder, header_stamp=None, nrImuMeasurements=None):
+        """Single-frame convenience with the reference's bookkeeping: `image` maps feature id ->
+        8-vector (x y 1 u v vx vy prob); `problem_builder(new_ids, used_ids)` returns a 1-problem
+        FselArrays for those ids.  Returns (trackedFeatures_, selectedIds) and mutates `image`."""
+        ids = sorted(image)
+        new_ids = [i for i in ids if i > self.lastFeatureId_]  # splitOnFeatureId
+        old = {i: image[i] for i in ids if i <= self.lastFeatureId_}
+        if new_ids:
+            self.lastFeatureId_ = new_ids[-1]
+        used_ids = [f for f in self.trackedFeatures_ if f in old]
+        prob = problem_builder(new_ids, used_ids)
+        out = self.select_batch(prob).to_host()
+        n = int(out.a["n_selected"][0])
+        selected = [int(v) for v in out.a["selected_ids"][0, :n]]
+        subset = {f: old[f] for f in used_ids}
+        for f in selected:
+            subset[f] = image[f]
+        image.clear()
+        image.update(subset)
+        self.trackedFeatures_.extend(selected)
+        return list(self.trackedFeatures_), selected

@@ -70,3 +70,15 @@ def eval_factors(opt, win, apply_loss=False):
                                         *[abi.dptr(out[k]) for k in ("proj_r", "proj_J", "imu_r", "imu_J", "prior_res", "cost")])
     assert rc == 0
     return out
+
+
+def fsel_information(fsel):
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    P, H, mc = fsel.n_problems, fsel.dims["horizon"], fsel.dims["max_cand"]
+    N, T = 9 * (H + 1), 3 * H
+    om, dl, va = np.zeros((P, N, N)), np.zeros((P, mc, T, T)), np.zeros((P, mc), np.int32)
+    s = fsel.struct()
+    rc = lib().avmo_fsel_information(C.byref(s), abi.dptr(om), abi.dptr(dl), abi.iptr(va))
+    assert rc == 0
+    return om, dl, va

@@ -1,0 +1,27 @@
+"""Per-phase shader-clock profile of the window-solve kernel (AVM_PROFILE=1)."""
+import importlib, sys, os, ctypes as C
+os.environ["AVM_PROFILE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+pkg = "anticipated-vins-mono_amd"
+synth = importlib.import_module(pkg + ".synth"); abi = importlib.import_module(pkg + ".abi")
+est_m = importlib.import_module(pkg + ".estimator")
+NAMES = ["E1 proj+imu raw", "E2 sqrtinfo*raw", "E1b feat aggr", "prior resid", "zero+E4A pose-pose", "E4B g_pose", "E4CD W,hee", "E4F imu JtJ",
+         "E4G prior + cost", "load+Hp", "scale/gmax", "schur", "cholesky", "tri solve", "backsub", "cand eval"]
+nw = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+tracks = sys.argv[2] if len(sys.argv) > 2 else "dense"
+opt = abi.default_options(); opt.marginalization_flag = abi.MARGIN_NONE
+E = est_m.Estimator(options=opt)
+base = synth.make_windows(min(nw, 32), tracks=tracks)
+w = synth.tile_windows(base, nw)
+E.optimization(w.copy())
+E.optimization(w.copy())
+ms = E.ctx.kernel_ms("window_solve")
+prof = (C.c_longlong * 32)()
+E.ctx._L.avm_debug_copy_profile.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+E.ctx.check(E.ctx._L.avm_debug_copy_profile(E.ctx.h, prof), "prof")
+tot = sum(prof[:16]); n = prof[31]
+print(f"windows {nw} tracks {tracks}: kernel {ms:.3f} ms, {nw/ms*1e3:.0f} solves/s; per-window cycles total {tot/n:.0f}")
+for k, nm in enumerate(NAMES):
+    print(f"  {nm:22s} {prof[k]/n:12.0f} cyc/window  {100*prof[k]/tot:5.1f}%")
