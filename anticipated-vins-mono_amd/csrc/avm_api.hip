@@ -75,9 +75,9 @@ int stage_in(avm_ctx* c, const char* name, const T* host, size_t count, const T*
 int ensure_window_buffers(avm_ctx* c, int n_windows) {
   if (!c->scratch) {
     HIPCHK(c, hipMalloc(&c->scratch, sizeof(double) * Scratch::TOTAL * c->n_slots));
-    HIPCHK(c, hipMalloc(&c->iscratch, sizeof(int32_t) * MAXOBS * c->n_slots));
+    HIPCHK(c, hipMalloc(&c->iscratch, sizeof(int32_t) * ISCRATCH * c->n_slots));
     HIPCHK(c, hipMemsetAsync(c->scratch, 0, sizeof(double) * Scratch::TOTAL * c->n_slots, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->iscratch, 0, sizeof(int32_t) * MAXOBS * c->n_slots, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->iscratch, 0, sizeof(int32_t) * ISCRATCH * c->n_slots, c->stream));
   }
   if ((size_t)n_windows > c->pre_cap) {
     for (double** p : {&c->pre_delta, &c->pre_jac, &c->pre_cov, &c->pre_sqrt, &c->pre_sum})

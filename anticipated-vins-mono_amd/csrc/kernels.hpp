@@ -25,22 +25,23 @@ struct PreintArgs {
   double *out_delta, *out_jacobian, *out_covariance, *out_sum_dt, *out_sqrt_info;
 };
 
-// per-slot global scratch layout (doubles), one slot per resident workgroup
+// per-slot global scratch layout (doubles), one slot per resident workgroup (stays L2 resident)
 struct Scratch {
-  static constexpr size_t JF = 0;                              // [28][MAXOBS] per-observation-slot factor rows
-  static constexpr size_t FA = JF + 28 * (size_t)MAXOBS;       // [35][MAXE] per-feature aggregates
-  static constexpr size_t W = FA + 35 * (size_t)MAXE;          // [MAXE][NPOSE] E^T F
-  static constexpr size_t IJ = W + (size_t)MAXE * NPOSE;       // [10][15][31] IMU residual + Jacobian
-  static constexpr size_t HP = IJ + 10 * 15 * 31;              // [MAXPRIOR][MAXPRIOR] J0^T J0
+  static constexpr size_t PF = 0;                               // [8][MAXOBS] per-factor Ji^T Je (6), Je^T Je, Je^T r
+  static constexpr size_t PART = PF + 8 * (size_t)MAXOBS;       // [11][11][27] sum_b Ji^T Ji (21) and Ji^T r (6) per (frame b, start a)
+  static constexpr size_t IJRAW = PART + 3272;                  // [10][15][31] IMU residual + Jacobian before sqrt_info
+  static constexpr size_t W = IJRAW + 4656;                     // [MAXE][NPOSE] E^T F
+  static constexpr size_t HP = W + (size_t)MAXE * NPOSE;        // [MAXPRIOR][MAXPRIOR] J0^T J0
   static constexpr size_t TOTAL = HP + (size_t)MAXPRIOR * MAXPRIOR;
 };
+constexpr int ISCRATCH = MAXOBS + NFR * MAXE;  // ints per slot: observation slot -> feature, then cov[11][150]
 
 struct SolveArgs {
   avm_window_batch b;  // device pointers
   avm_options opt;
   const double *pre_delta, *pre_jac, *pre_sqrt, *pre_sum_dt;  // [B][10][...]
   double* scratch;                                            // [n_slots][Scratch::TOTAL]
-  int32_t* iscratch;                                          // [n_slots][MAXOBS] observation slot -> feature
+  int32_t* iscratch;                                          // [n_slots][ISCRATCH]
   avm_solve_summary* summary;                                 // [B] or null
   int n_slots;
   long long* prof;  // optional [n_slots][32] per-phase shader-clock accumulators (debug)

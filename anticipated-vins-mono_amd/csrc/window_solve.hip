@@ -35,32 +35,50 @@ constexpr int SROWS = 13778;     // padded packed lower triangle of a 165x165 ma
 constexpr int VEC = 320;         // padded NCOL
 constexpr int XN = 328;          // pose 77 | speedbias 99 | inv depth 150 (+2 pad)
 constexpr int XSB = 77, XLAM = 176;
-constexpr int WCH = 40;          // features per Schur staging chunk
 
-// LDS carve (offsets in doubles)
+// LDS carve (offsets in doubles).  Everything between L_S + SPP (end of the pose-pose rows of S) and
+// L_G is dead while the projection factors are being assembled, so that range doubles as the per-wave
+// staging area of the MFMA X^T X products (ASM_WAVES x XSTG doubles).
+constexpr int SPP = 2244;          // roff(66): packed rows 0..65 = pose-pose block
+constexpr int WCH = 32;            // features per Schur staging chunk (x 80 padded columns)
+constexpr int WLD = 80;
+constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r | start-frame tag
+constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows
+constexpr int ASM_WAVES = 7;       // wavefronts assembling projection factors (the 8th does the IMU factors)
 constexpr int L_S = 0;
-constexpr int L_G = L_S + SROWS;   // scaled gradient g (f | e)
-constexpr int L_Y = L_G + VEC;     // Gauss-Newton solution y of (H + mu D^2) y = g
-constexpr int L_DG = L_Y + VEC;    // g / D
+constexpr int L_Y = L_S + SROWS;   // Gauss-Newton solution y of (H + mu D^2) y = g
+constexpr int L_ST = L_Y + VEC;    // trust region step (scaled space)
+constexpr int L_XC = L_ST + VEC;   // candidate state
+constexpr int L_WCH = L_XC + XN;   // Schur staging [32][80]
+constexpr int L_G = L_WCH + WCH * WLD;  // scaled gradient g (f | e)
+constexpr int L_DG = L_G + VEC;    // g / D
 constexpr int L_DD = L_DG + VEC;   // D
 constexpr int L_SC = L_DD + VEC;   // Jacobi scaling
-constexpr int L_ST = L_SC + VEC;   // trust region step (scaled space)
-constexpr int L_X = L_ST + VEC;
-constexpr int L_XC = L_X + XN;
-constexpr int L_FR = L_XC + XN;    // [2][198]: R (11x9) then A = ric^T R^T (11x9)
+constexpr int L_X = L_SC + VEC;
+constexpr int L_FR = L_X + XN;     // [2][198]: R (11x9) then A = ric^T R^T (11x9)
 constexpr int L_RIC = L_FR + 396;  // ric 9, tic 3, current ex_pose 7 (+1 pad)
 constexpr int L_HEE = L_RIC + 20;  // E^T E (150) padded
 constexpr int L_DXP = L_HEE + 152;
 constexpr int L_RP = L_DXP + MAXPRIOR;
 constexpr int L_RED = L_RP + MAXPRIOR;
-constexpr int L_WCH = L_RED + 64;
-constexpr int L_INT = L_WCH + WCH * NPOSE;  // int region (as doubles): 360 doubles = 720 ints
+constexpr int L_INT = L_RED + 32;  // int region (as doubles): 360 doubles = 720 ints
 constexpr int L_SUM = L_INT + 360;  // cost_trace[16], radius_trace[16]
 constexpr int L_END = L_SUM + 32;
 static_assert(L_END * 8 <= 163840, "LDS budget exceeded");
+static_assert(L_S + SPP + ASM_WAVES * XSTG <= L_G, "assembly staging overlaps live data");
+static_assert(L_Y + 5 * 465 + 8 + 5 * 225 <= L_G, "IMU staging overlaps live data");
 // int carve (offsets in ints from L_INT)
-constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 546, I_PBLK = 560 /* kind,frame,off x16 */, I_FAIL = 620, I_END = 624;
+constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 546, I_PBLK = 560 /* kind,frame,off x16 */, I_FAIL = 620,
+              I_NCOV = 624 /* [11] factors observed in frame b */, I_FRW = 636 /* [11] assembling wave of frame b */,
+              I_PMASK = 648 /* [11] start frames flushed by frame b */, I_END = 660;
 static_assert(I_END <= 720, "int carve");
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+AVM_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 AVM_DEV int roff(int i) {
   const int q = i >> 1;
@@ -254,6 +272,7 @@ struct WinCtx {
   int* ids;
   double* sc;   // global scratch slot
   int32_t* osf; // observation slot -> feature
+  int32_t* cov; // [11][150] features observed in frame b, in feature order
   int w, nf, nobs_tot, pn, pnblk;
   const double* obs;   // [max_obs][2]
   const double *pdelta, *pjac, *psqrt, *psum;  // this window's 10 intervals
@@ -344,82 +363,175 @@ AVM_DEV double eval_cost(const WinCtx& c, const avm_options& o, const double* xs
   return block_sum<NT>(acc, lds + L_RED);
 }
 
+// All projection factors observed in frame b, by one wavefront (lane = factor, 64 at a time).
+// Each lane evaluates its factor, then the 2 x 13 rows [Jj | Ji | r] of the 64 factors are staged in LDS
+// and X^T X is accumulated with v_mfma_f64_16x16x4: one 16x16 product gives Jj^T Jj (block b,b),
+// Jj^T Ji (block b,a), Ji^T Ji (goes to block a,a), Jj^T r and Ji^T r at once — the cross-lane reduction
+// is done by the matrix core.  Features are sorted by start frame, so factors with the same start frame a
+// are consecutive; the B operand is masked per a-run to keep the (b,a)/(a,a) blocks separate.
+// Blocks (b,b), (b,a) and g_b belong to this frame only and are written straight into LDS; the (a,a)
+// contributions go to PART[b][a] in the scratch slot and are summed in a fixed order afterwards.
+AVM_DEV double frame_task(const WinCtx& c, const avm_options& o, int b, double* stage) {
+  double* lds = c.lds;
+  const int lane = threadIdx.x & 63;
+  const int ncov = c.ids[I_NCOV + b];
+  const int32_t* cov = c.cov + b * MAXE;
+  Frames fr{lds + L_FR, lds + L_FR + 99};
+  const double* xs = lds + L_X;
+  const double sqi = o.focal_length / 1.5;
+  double* W = c.sc + Scratch::W;
+  double* PF = c.sc + Scratch::PF;
+  double* PART = c.sc + Scratch::PART + (size_t)b * NFR * 27;
+  d4 Dtot = {0, 0, 0, 0}, Drun = {0, 0, 0, 0};
+  int a_run = -1, pmask = 0;
+  double cost = 0;
+  const int drow = lane >> 4, dcol = lane & 15;
+  auto flush = [&]() {
+    if (a_run < 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = drow + 4 * r;
+      const double v = Drun[r];
+      if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + 6 * a_run + (dcol - 6)] = v;  // Jj^T Ji
+      if (row >= 6 && row < 12) {
+        const int i = row - 6;
+        if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[a_run * 27 + i * (i + 1) / 2 + (dcol - 6)] = v;  // Ji^T Ji (lower)
+        if (dcol == 12) PART[a_run * 27 + 21 + i] = v;                                                    // Ji^T r
+      }
+    }
+    pmask |= 1 << a_run;
+    Dtot += Drun;
+    Drun = d4{0, 0, 0, 0};
+  };
+  for (int chunk0 = 0; chunk0 < ncov; chunk0 += 64) {
+    const int idx = chunk0 + lane;
+    const bool act = idx < ncov;
+    const int e = act ? cov[idx] : 0;
+    const int fa = c.ids[I_FSTART + e];
+    const int s0 = c.ids[I_FOBS + e];
+    const int s = s0 + (b - fa);
+    double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 12; k++) Ji[k] = 0, Jj[k] = 0;
+    if (act) {
+      cost += proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1],
+                              xs[XLAM + e], fa, b, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        W[(size_t)e * NPOSE + 6 * b + k] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
+        PF[k * MAXOBS + s] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+      }
+      PF[6 * MAXOBS + s] = Je[0] * Je[0] + Je[1] * Je[1];
+      PF[7 * MAXOBS + s] = Je[0] * r[0] + Je[1] * r[1];
+    }
+    const double tag = act ? (double)fa : -1.0;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+      double* row = stage + (2 * lane + rr) * XLD;
+#pragma unroll
+      for (int k = 0; k < 6; k++) row[k] = Jj[rr * 6 + k], row[6 + k] = Ji[rr * 6 + k];
+      row[12] = r[rr];
+      row[13] = tag;
+    }
+    wave_lds_sync();
+    const int nact = min(64, ncov - chunk0);
+    int l = 0;
+    while (l < nact) {
+      const int a_cur = __shfl(fa, l, 64);
+      const int cnt = __popcll(__ballot(act && fa == a_cur));
+      const int l_end = l + cnt;
+      if (a_cur != a_run) {
+        flush();
+        a_run = a_cur;
+      }
+      const double ta = (double)a_cur;
+      for (int m = (2 * l) >> 2; m < ((2 * l_end + 3) >> 2); m++) {
+        const double* row = stage + (4 * m + drow) * XLD;
+        const double v = dcol < 13 ? row[dcol] : 0.0;
+        const double bop = (row[13] == ta) ? v : 0.0;
+        Drun = __builtin_amdgcn_mfma_f64_16x16x4f64(v, bop, Drun, 0, 0, 0);
+      }
+      l = l_end;
+    }
+    wave_lds_sync();
+  }
+  flush();
+  // block (b,b) lower triangle and g_b
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = drow + 4 * r;
+    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r];
+    if (row < 6 && dcol == 12) lds[L_G + 6 * b + row] = Dtot[r];
+  }
+  if (lane == 0) c.ids[I_PMASK + b] = pmask;
+  return cost;
+}
+
 // Full evaluation at lds[L_X]: fills S (unscaled H_ff), W, hee, g (unscaled) and returns the cost.
 AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   double* lds = c.lds;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const double* xs = lds + L_X;
   PROF_T0();
   build_frames(lds, xs, 0);
-  for (int i = t; i < 10 * 465; i += NT) lds[L_S + i] = 0.0;
+  for (int i = t; i < SPP; i += NT) lds[L_S + i] = 0.0;
+  for (int i = t; i < VEC; i += NT) lds[L_G + i] = 0.0;
+  if (t < NFR) c.ids[I_PMASK + t] = 0;
+  double* IJR = c.sc + Scratch::IJRAW;
+  for (int i = t; i < 10 * 465; i += NT) IJR[i] = 0.0;
   __syncthreads();
   Frames fr{lds + L_FR, lds + L_FR + 99};
-  const double sqi = o.focal_length / 1.5;
   double acc = 0;
-  double* JF = c.sc + Scratch::JF;
-  // E1: IMU raw (last wave, 10 lanes) || projection factors (everyone, strided)
-  if (t >= NT - 64 && t < NT - 64 + 10) {
-    const int i = t - (NT - 64);
+  // ---- phase A: projection factors (waves 0..6, one frame at a time) || IMU raw Jacobians (wave 7)
+  if (wv < ASM_WAVES) {
+    double* stage = lds + L_S + SPP + wv * XSTG;
+    for (int b = 1; b < NFR; b++)
+      if (c.ids[I_FRW + b] == wv) acc += frame_task(c, o, b, stage);
+  } else if (lane < 10) {
+    const int i = lane;
     if (c.psum[i] <= o.max_sum_dt)
-      imu_raw<true>(xs, fr.R, o, c.pdelta + i * 10, c.pjac + i * 225, c.psum[i], c.lba + i * 3, c.lbg + i * 3, i, lds + L_S + i * 465);
-  }
-  for (int s = t; s < c.nobs_tot; s += NT) {
-    const int e = c.osf[s];
-    const int s0 = c.ids[I_FOBS + e];
-    if (s == s0) continue;
-    const int fa = c.ids[I_FSTART + e], fb = fa + (s - s0);
-    double r[2], Ji[12], Jj[12], Je[2];
-    acc += proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1],
-                           xs[XLAM + e], fa, fb, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
-    JF[0 * MAXOBS + s] = r[0];
-    JF[1 * MAXOBS + s] = r[1];
-#pragma unroll
-    for (int k = 0; k < 12; k++) JF[(2 + k) * MAXOBS + s] = Ji[k], JF[(14 + k) * MAXOBS + s] = Jj[k];
-    JF[26 * MAXOBS + s] = Je[0];
-    JF[27 * MAXOBS + s] = Je[1];
+      imu_raw<true>(xs, fr.R, o, c.pdelta + i * 10, c.pjac + i * 225, c.psum[i], c.lba + i * 3, c.lbg + i * 3, i, IJR + i * 465);
   }
   __syncthreads();
   PROF(c, 0);
-  // E2: IJ = sqrt_info * raw  (residual col 0 + 30 Jacobian cols), sqrt_info upper triangular
-  double* IJ = c.sc + Scratch::IJ;
-  for (int idx = t; idx < 10 * 465; idx += NT) {
-    const int i = idx / 465, rc = idx % 465, r = rc / 31, cc = rc % 31;
-    double s = 0;
-    if (c.psum[i] <= o.max_sum_dt)
-      for (int k = r; k < 15; k++) s += c.psqrt[i * 225 + r * 15 + k] * lds[L_S + i * 465 + k * 31 + cc];
-    IJ[idx] = s;
-    if (cc == 0) acc += 0.5 * s * s;
+  // ---- phase B: per-feature sums over the start pose, diagonal blocks, pose gradient
+  {
+    double* W = c.sc + Scratch::W;
+    const double* PF = c.sc + Scratch::PF;
+    for (int idx = t; idx < c.nf * NFR; idx += NT) {
+      const int e = idx / NFR, f = idx % NFR;
+      const int a = c.ids[I_FSTART + e], no = c.ids[I_FNOBS + e], s0 = c.ids[I_FOBS + e];
+      if (f == a) {
+        double sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 1; k < no; k++)
+#pragma unroll
+          for (int q = 0; q < 8; q++) sacc[q] += PF[q * MAXOBS + s0 + k];
+#pragma unroll
+        for (int q = 0; q < 6; q++) W[(size_t)e * NPOSE + 6 * a + q] = sacc[q];
+        lds[L_HEE + e] = sacc[6];
+        lds[L_G + NF + e] = sacc[7];
+      } else if (!(f > a && f < a + no)) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) W[(size_t)e * NPOSE + 6 * f + q] = 0.0;
+      }
+    }
+    const double* PART = c.sc + Scratch::PART;
+    if (t < NFR * 27) {
+      const int f = t / 27, q = t % 27;
+      double sacc = 0;
+      for (int b = f + 1; b < NFR; b++)
+        if (c.ids[I_PMASK + b] & (1 << f)) sacc += PART[((size_t)b * NFR + f) * 27 + q];
+      if (q < 21) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= q) i++;
+        const int j = q - i * (i + 1) / 2;
+        lds[L_S + roff(6 * f + i) + 6 * f + j] += sacc;
+      } else {
+        lds[L_G + 6 * f + (q - 21)] += sacc;
+      }
+    }
   }
   PROF(c, 1);
-  // E1b: per-feature aggregates over the start pose (H_aa, w_a, h_e, g_a, g_e)
-  double* FA = c.sc + Scratch::FA;
-  for (int idx = t; idx < c.nf * 35; idx += NT) {
-    const int e = idx / 35, q = idx % 35;
-    const int s0 = c.ids[I_FOBS + e], no = c.ids[I_FNOBS + e];
-    int ra, rb;  // JF rows (first residual row); second row = +6 for Ji, +1 for Je/r
-    int stride_a, stride_b;
-    if (q < 21) {
-      int ci = 0;
-      while ((ci + 1) * (ci + 2) / 2 <= q) ci++;
-      const int cj = q - ci * (ci + 1) / 2;
-      ra = 2 + ci, rb = 2 + cj, stride_a = 6, stride_b = 6;
-    } else if (q < 27) {
-      ra = 2 + (q - 21), rb = 26, stride_a = 6, stride_b = 1;
-    } else if (q == 27) {
-      ra = 26, rb = 26, stride_a = 1, stride_b = 1;
-    } else if (q < 34) {
-      ra = 2 + (q - 28), rb = 0, stride_a = 6, stride_b = 1;
-    } else {
-      ra = 26, rb = 0, stride_a = 1, stride_b = 1;
-    }
-    double s = 0;
-    for (int k = 1; k < no; k++) {
-      const int sl = s0 + k;
-      s += JF[ra * MAXOBS + sl] * JF[rb * MAXOBS + sl] + JF[(ra + stride_a) * MAXOBS + sl] * JF[(rb + stride_b) * MAXOBS + sl];
-    }
-    FA[q * MAXE + e] = s;
-  }
-  PROF(c, 2);
   // prior residual (uses L_DXP/L_RP; includes syncs)
   if (c.pn > 0) {
     prior_residual_dev(c, xs);
@@ -427,104 +539,56 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   } else {
     __syncthreads();
   }
+  PROF(c, 2);
+  // rows 66.. of S (the staging area is dead now)
+  for (int i = SPP + t; i < SROWS; i += NT) lds[L_S + i] = 0.0;
+  __syncthreads();
   PROF(c, 3);
-  // zero S and g
-  for (int i = t; i < SROWS; i += NT) lds[L_S + i] = 0.0;
-  for (int i = t; i < VEC; i += NT) lds[L_G + i] = 0.0;
-  __syncthreads();
-  // E4(A): pose-pose lower-triangular entries
-  const int* fs = c.ids + I_FS;
-  for (int idx = t; idx < NPOSE * (NPOSE + 1) / 2; idx += NT) {
-    int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= idx) i++;
-    while (i * (i + 1) / 2 > idx) i--;
-    const int j = idx - i * (i + 1) / 2;
-    const int b = i / 6, ci = i % 6, a = j / 6, cj = j % 6;
-    double s = 0;
-    if (a < b) {
-      const int d = b - a;
-      for (int e = fs[a]; e < fs[a + 1]; e++) {
-        if (c.ids[I_FNOBS + e] > d) {
-          const int sl = c.ids[I_FOBS + e] + d;
-          s += JF[(14 + ci) * MAXOBS + sl] * JF[(2 + cj) * MAXOBS + sl] + JF[(20 + ci) * MAXOBS + sl] * JF[(8 + cj) * MAXOBS + sl];
-        }
-      }
-    } else {
-      const int q = ci * (ci + 1) / 2 + cj;
-      for (int e = fs[a]; e < fs[a + 1]; e++) s += FA[q * MAXE + e];
-      for (int e = 0; e < fs[a]; e++) {
-        const int d = a - c.ids[I_FSTART + e];
-        if (c.ids[I_FNOBS + e] > d) {
-          const int sl = c.ids[I_FOBS + e] + d;
-          s += JF[(14 + ci) * MAXOBS + sl] * JF[(14 + cj) * MAXOBS + sl] + JF[(20 + ci) * MAXOBS + sl] * JF[(20 + cj) * MAXOBS + sl];
-        }
-      }
-    }
-    lds[L_S + roff(i) + j] = s;
-  }
-  PROF(c, 4);
-  // E4(B): pose gradient
-  if (t < NPOSE) {
-    const int b = t / 6, ci = t % 6;
-    double s = 0;
-    for (int e = fs[b]; e < fs[b + 1]; e++) s += FA[(28 + ci) * MAXE + e];
-    for (int e = 0; e < fs[b]; e++) {
-      const int d = b - c.ids[I_FSTART + e];
-      if (c.ids[I_FNOBS + e] > d) {
-        const int sl = c.ids[I_FOBS + e] + d;
-        s += JF[(14 + ci) * MAXOBS + sl] * JF[sl] + JF[(20 + ci) * MAXOBS + sl] * JF[MAXOBS + sl];
-      }
-    }
-    lds[L_G + t] = s;
-  }
-  PROF(c, 5);
-  // E4(C): W rows (E^T F) ; E4(D): E^T E and feature gradient
-  double* W = c.sc + Scratch::W;
-  for (int idx = t; idx < c.nf * NPOSE; idx += NT) {
-    const int e = idx / NPOSE, cc = idx % NPOSE, bb = cc / 6, ck = cc % 6;
-    const int a = c.ids[I_FSTART + e], d = bb - a;
-    double s = 0;
-    if (d == 0)
-      s = FA[(21 + ck) * MAXE + e];
-    else if (d > 0 && d < c.ids[I_FNOBS + e]) {
-      const int sl = c.ids[I_FOBS + e] + d;
-      s = JF[(14 + ck) * MAXOBS + sl] * JF[26 * MAXOBS + sl] + JF[(20 + ck) * MAXOBS + sl] * JF[27 * MAXOBS + sl];
-    }
-    W[idx] = s;
-  }
-  if (t < c.nf) {
-    lds[L_HEE + t] = FA[27 * MAXE + t];
-    lds[L_G + NF + t] = FA[34 * MAXE + t];
-  }
-  __syncthreads();
-  PROF(c, 6);
-  // E4(F): IMU J^T J and J^T r, even then odd factors
+  // ---- phase D: IMU factors, even then odd: IJ = sqrt_info * raw into LDS, then J^T J / J^T r
+  double* IJ5 = lds + L_Y;            // [5][15][31]
+  double* SQ5 = lds + L_Y + 5 * 465 + 3;  // [5][225], 8-byte aligned is enough
   for (int par = 0; par < 2; par++) {
+    for (int idx = t; idx < 5 * 225; idx += NT) SQ5[idx] = c.psqrt[(2 * (idx / 225) + par) * 225 + idx % 225];
+    __syncthreads();
+    for (int idx = t; idx < 5 * 465; idx += NT) {
+      const int ii = idx / 465, i = 2 * ii + par, rc = idx % 465, r = rc / 31, cc = rc % 31;
+      double sacc = 0;
+      if (c.psum[i] <= o.max_sum_dt) {
+        const double* raw = IJR + i * 465 + cc;
+#pragma unroll 5
+        for (int k = r; k < 15; k++) sacc += SQ5[ii * 225 + r * 15 + k] * raw[k * 31];
+      }
+      IJ5[idx] = sacc;
+      if (cc == 0) acc += 0.5 * sacc * sacc;
+    }
+    __syncthreads();
     for (int idx = t; idx < 5 * 495; idx += NT) {
-      const int i = 2 * (idx / 495) + par, q = idx % 495;
+      const int ii = idx / 495, i = 2 * ii + par, q = idx % 495;
       if (c.psum[i] > o.max_sum_dt) continue;
-      const double* Jm = IJ + i * 465;
+      const double* Jm = IJ5 + ii * 465;
       if (q < 465) {
         int p = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
         while ((p + 1) * (p + 2) / 2 <= q) p++;
         while (p * (p + 1) / 2 > q) p--;
         const int qq = q - p * (p + 1) / 2;
-        double s = 0;
-        for (int r = 0; r < 15; r++) s += Jm[r * 31 + 1 + p] * Jm[r * 31 + 1 + qq];
+        double sacc = 0;
+#pragma unroll
+        for (int r = 0; r < 15; r++) sacc += Jm[r * 31 + 1 + p] * Jm[r * 31 + 1 + qq];
         const int ip = imu_col(i, p), iq = imu_col(i, qq);
         const int hi = max(ip, iq), lo = min(ip, iq);
-        lds[L_S + roff(hi) + lo] += s;
+        lds[L_S + roff(hi) + lo] += sacc;
       } else {
         const int p = q - 465;
-        double s = 0;
-        for (int r = 0; r < 15; r++) s += Jm[r * 31 + 1 + p] * Jm[r * 31];
-        lds[L_G + imu_col(i, p)] += s;
+        double sacc = 0;
+#pragma unroll
+        for (int r = 0; r < 15; r++) sacc += Jm[r * 31 + 1 + p] * Jm[r * 31];
+        lds[L_G + imu_col(i, p)] += sacc;
       }
     }
     __syncthreads();
   }
   PROF(c, 7);
-  // E4(G): prior  H += Hp (mapped), g += J0^T r_p
+  // ---- phase E: prior  H += Hp (mapped), g += J0^T r_p
   if (c.pn > 0) {
     const double* HP = c.sc + Scratch::HP;
     const int* pidx = c.ids + I_PIDX;
@@ -538,10 +602,18 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
       const int hi = max(ip, iq), lo = min(ip, iq);
       lds[L_S + roff(hi) + lo] += HP[p * MAXPRIOR + q];
     }
-    if (t < c.pn && pidx[t] >= 0) {
-      double s = 0;
-      for (int i = 0; i < c.pn; i++) s += c.pJ[(size_t)i * c.ldp + t] * lds[L_RP + i];
-      lds[L_G + pidx[t]] += s;
+    // g += J0^T r_p : 4 lanes per column, each a quarter of the rows
+    {
+      const int col = t >> 2, part = t & 3;
+      double sacc = 0;
+      if (col < c.pn && pidx[col] >= 0) {
+        const int q4 = (c.pn + 3) >> 2;
+        const int i1 = min(c.pn, (part + 1) * q4);
+        for (int i = part * q4; i < i1; i++) sacc += c.pJ[(size_t)i * c.ldp + col] * lds[L_RP + i];
+      }
+      sacc += __shfl_xor(sacc, 1, 64);
+      sacc += __shfl_xor(sacc, 2, 64);
+      if (col < c.pn && part == 0 && pidx[col] >= 0) lds[L_G + pidx[col]] += sacc;
     }
   }
   const double cost = block_sum<NT>(acc, lds + L_RED);
@@ -550,39 +622,50 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   return cost;
 }
 
-// || J' u ||^2 with J' the Jacobi-scaled Jacobian, u in lds[L_ST] (scaled space); JF/IJ valid for L_X
+// || J' u ||^2 with J' the Jacobi-scaled Jacobian, u in lds[L_ST] (scaled space), at state lds[L_X].
+// Only needed when the Gauss-Newton step leaves the trust region (Cauchy point), so the factors are
+// simply re-evaluated here instead of keeping their Jacobians around.
 AVM_DEV double jac_times_vec_sq(const WinCtx& c, const avm_options& o) {
   double* lds = c.lds;
   const int t = threadIdx.x;
   const double* u = lds + L_ST;
   const double* scl = lds + L_SC;
-  const double* JF = c.sc + Scratch::JF;
-  const double* IJ = c.sc + Scratch::IJ;
+  const double* xs = lds + L_X;
+  Frames fr{lds + L_FR, lds + L_FR + 99};
+  const double sqi = o.focal_length / 1.5;
   double acc = 0;
   for (int s = t; s < c.nobs_tot; s += NT) {
     const int e = c.osf[s];
     const int s0 = c.ids[I_FOBS + e];
     if (s == s0) continue;
     const int fa = c.ids[I_FSTART + e], fb = fa + (s - s0);
+    double r[2], Ji[12], Jj[12], Je[2];
+    proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1], xs[XLAM + e],
+                    fa, fb, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
     double y0 = 0, y1 = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const double va = u[fa * 6 + k] * scl[fa * 6 + k], vb = u[fb * 6 + k] * scl[fb * 6 + k];
-      y0 += JF[(2 + k) * MAXOBS + s] * va + JF[(14 + k) * MAXOBS + s] * vb;
-      y1 += JF[(8 + k) * MAXOBS + s] * va + JF[(20 + k) * MAXOBS + s] * vb;
+      y0 += Ji[k] * va + Jj[k] * vb;
+      y1 += Ji[6 + k] * va + Jj[6 + k] * vb;
     }
     const double ve = u[NF + e] * scl[NF + e];
-    y0 += JF[26 * MAXOBS + s] * ve;
-    y1 += JF[27 * MAXOBS + s] * ve;
+    y0 += Je[0] * ve;
+    y1 += Je[1] * ve;
     acc += y0 * y0 + y1 * y1;
   }
-  if (t < 150) {
+  if (t < 150) {  // IMU: y = sqrt_info * (raw_J * v), raw Jacobians of the last eval_jac are still in the scratch slot
     const int i = t / 15, r = t % 15;
     if (c.psum[i] <= o.max_sum_dt) {
+      const double* IJR = c.sc + Scratch::IJRAW + i * 465;
       double y = 0;
-      for (int p = 0; p < 30; p++) {
-        const int col = imu_col(i, p);
-        y += IJ[i * 465 + r * 31 + 1 + p] * (u[col] * scl[col]);
+      for (int k = r; k < 15; k++) {
+        double rv = 0;
+        for (int p = 0; p < 30; p++) {
+          const int col = imu_col(i, p);
+          rv += IJR[k * 31 + 1 + p] * (u[col] * scl[col]);
+        }
+        y += c.psqrt[i * 225 + r * 15 + k] * rv;
       }
       acc += y * y;
     }
@@ -598,64 +681,105 @@ AVM_DEV double jac_times_vec_sq(const WinCtx& c, const avm_options& o) {
   return block_sum<NT>(acc, lds + L_RED);
 }
 
+AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
+
 // In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
+// Right-looking, 16-column panels:
+//   (1) the 16x16 diagonal block is factored in the registers of wavefront 0 (lane = row, pivots
+//       broadcast with v_readlane), reciprocal pivots go to lds[L_ST] for the later solves;
+//   (2) the rows below are solved against that triangle, one thread per row;
+//   (3) the trailing matrix is updated tile by tile with v_mfma_f64_16x16x4 (K = 16 -> 4 MFMAs per tile).
 AVM_DEV bool cholesky_lds(double* lds) {
   double* S = lds + L_S;
-  const int t = threadIdx.x;
-  constexpr int NB = 8;
+  double* dinv = lds + L_ST;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  constexpr int NB = 16;
+  constexpr int NPAN = (NF + NB - 1) / NB;  // 11
   volatile int& s_fail = reinterpret_cast<int*>(lds + L_INT)[I_FAIL];
   if (t == 0) s_fail = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < NF; c0 += NB) {
-    const int nb = min(NB, NF - c0);
-    // (1) panel update with the already factored columns [0, c0)
-    if (c0 > 0) {
-      for (int idx = t; idx < (NF - c0) * nb; idx += NT) {
-        const int i = c0 + idx / nb, j = c0 + idx % nb;
-        if (i < j) continue;
-        const double* ri = S + roff(i);
-        const double* rj = S + roff(j);
-        double s = 0;
-        for (int l = 0; l < c0; l++) s += ri[l] * rj[l];
-        S[roff(i) + j] -= s;
-      }
-    }
-    __syncthreads();
-    // (2) factor the nb x nb diagonal block with one wavefront (lane r = row c0 + r)
-    if (t < 64) {
-      for (int jj = 0; jj < nb; jj++) {
-        const int j = c0 + jj;
-        if (t == jj) {
-          double v = S[roff(j) + j];
-          for (int l = c0; l < j; l++) v -= S[roff(j) + l] * S[roff(j) + l];
-          if (!(v > 0.0)) s_fail = 1;
-          S[roff(j) + j] = sqrt(v);
+  for (int p = 0; p < NPAN; p++) {
+    const int c0 = p * NB, nb = min(NB, NF - c0);
+    // (1) diagonal block
+    if (wv == 0) {
+      const int r = lane;
+      double a[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) a[k] = (r < nb && k <= r) ? S[roff(c0 + r) + c0 + k] : (k == r ? 1.0 : 0.0);
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const double djj = readlane_d(a[j], j);
+        if (j < nb && !(djj > 0.0)) bad = true;
+        const double d = sqrt(djj);
+        const double inv = 1.0 / d;
+        const double lij = (r == j) ? d : a[j] * inv;
+        a[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < NB; k++) {
+          const double lkj = readlane_d(lij, k);
+          a[k] -= lij * lkj;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (t > jj && t < nb) {
-          const int i = c0 + t;
-          double v = S[roff(i) + j];
-          for (int l = c0; l < j; l++) v -= S[roff(i) + l] * S[roff(j) + l];
-          S[roff(i) + j] = v / S[roff(j) + j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (r == j && j < nb) dinv[c0 + j] = inv;
       }
+      if (r < nb) {
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+          if (k <= r) S[roff(c0 + r) + c0 + k] = a[k];
+      }
+      if (bad && lane == 0) s_fail = 1;
     }
     __syncthreads();
     if (s_fail) return false;
-    // (3) panel solve: rows below the diagonal block
+    if (c0 + nb >= NF) break;
+    // (2) panel solve: x_j = (A[i][c0+j] - sum_{l<j} x_l L[c0+j][c0+l]) / L[c0+j][c0+j]
     for (int i = c0 + nb + t; i < NF; i += NT) {
-      double* ri = S + roff(i);
-      for (int jj = 0; jj < nb; jj++) {
-        const int j = c0 + jj;
-        const double* rj = S + roff(j);
-        double v = ri[j];
-        for (int l = c0; l < j; l++) v -= ri[l] * rj[l];
-        ri[j] = v / rj[j];
+      double* ri = S + roff(i) + c0;
+      double x[NB];
+#pragma unroll
+      for (int j = 0; j < NB; j++) x[j] = ri[j];
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const double* lj = S + roff(c0 + j) + c0;
+        double v = x[j];
+#pragma unroll
+        for (int l = 0; l < j; l++) v -= x[l] * lj[l];
+        x[j] = v * dinv[c0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < NB; j++) ri[j] = x[j];
+    }
+    __syncthreads();
+    // (3) trailing update on the matrix cores
+    {
+      const int nt = NPAN - 1 - p;           // tile rows/cols left: tile indices p+1 .. NPAN-1
+      const int ntile = nt * (nt + 1) / 2;
+      for (int tile = wv; tile < ntile; tile += NT / 64) {
+        int a_ = 0;
+        while ((a_ + 1) * (a_ + 2) / 2 <= tile) a_++;
+        const int ti = p + 1 + a_, tj = p + 1 + (tile - a_ * (a_ + 1) / 2);
+        const int ri = NB * ti + (lane & 15), rj = NB * tj + (lane & 15);
+        const double* pa = S + roff(min(ri, NF - 1)) + c0 + (lane >> 4);
+        const double* pb = S + roff(min(rj, NF - 1)) + c0 + (lane >> 4);
+        const bool va = ri < NF, vb = rj < NF;
+        d4 D = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < NB / 4; m++) {
+          const double aop = va ? pa[4 * m] : 0.0;
+          const double bop = vb ? pb[4 * m] : 0.0;
+          D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+        }
+        const int gj = NB * tj + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = NB * ti + (lane >> 4) + 4 * r;
+          if (gi < NF && gj <= gi) S[roff(gi) + gj] -= D[r];
+        }
       }
     }
     __syncthreads();
@@ -663,44 +787,65 @@ AVM_DEV bool cholesky_lds(double* lds) {
   return true;
 }
 
-// Solve L L^T z = b in place on lds[vec..vec+NF) with the factor in lds[L_S]
+// Solve L L^T z = b in place on lds[vec..vec+NF) with the factor in lds[L_S] and 1/L_jj in lds[L_ST].
+// Blocks of 16: the triangle is solved by 16 lanes of wavefront 0 (values exchanged with v_readlane),
+// then every thread applies the finished block to one remaining row.
 AVM_DEV void chol_solve_lds(double* lds, int vec) {
   double* S = lds + L_S;
+  const double* dinv = lds + L_ST;
   double* b = lds + vec;
-  const int t = threadIdx.x;
-  constexpr int NB = 8;
-  // forward
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  constexpr int NB = 16;
+  // forward: L z = b
   for (int c0 = 0; c0 < NF; c0 += NB) {
     const int nb = min(NB, NF - c0);
-    if (t == 0) {
-      for (int jj = 0; jj < nb; jj++) {
-        const int j = c0 + jj;
-        double v = b[j];
-        for (int l = c0; l < j; l++) v -= S[roff(j) + l] * b[l];
-        b[j] = v / S[roff(j) + j];
+    if (wv == 0) {
+      const int r = lane;
+      double row[NB];
+#pragma unroll
+      for (int l = 0; l < NB; l++) row[l] = (r < nb && l < r) ? S[roff(c0 + r) + c0 + l] : 0.0;
+      double bv = r < nb ? b[c0 + r] : 0.0;
+      const double di = r < nb ? dinv[c0 + r] : 1.0;
+#pragma unroll
+      for (int jj = 0; jj < NB; jj++) {
+        const double zj = readlane_d(bv * di, jj);
+        if (r > jj) bv -= row[jj] * zj;
+        if (r == jj) bv = zj;
       }
+      if (r < nb) b[c0 + r] = bv;
     }
     __syncthreads();
     for (int i = c0 + nb + t; i < NF; i += NT) {
+      const double* ri = S + roff(i) + c0;
       double v = b[i];
-      for (int l = c0; l < c0 + nb; l++) v -= S[roff(i) + l] * b[l];
+#pragma unroll
+      for (int l = 0; l < NB; l++) v -= ri[l] * b[c0 + l];
       b[i] = v;
     }
     __syncthreads();
   }
-  // backward
-  for (int c1 = NF; c1 > 0; c1 -= NB) {
-    const int c0 = max(0, c1 - NB);
-    if (t == 0) {
-      for (int j = c1 - 1; j >= c0; j--) {
-        double v = b[j];
-        for (int i = j + 1; i < c1; i++) v -= S[roff(i) + j] * b[i];
-        b[j] = v / S[roff(j) + j];
+  // backward: L^T x = z
+  for (int c1 = NF; c1 > 0; c1 = ((c1 - 1) / NB) * NB) {
+    const int c0 = ((c1 - 1) / NB) * NB, nb = c1 - c0;
+    if (wv == 0) {
+      const int r = lane;  // lane r owns x_{c0+r}; needs column r of the block triangle: L[c0+i][c0+r], i > r
+      double colv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; i++) colv[i] = (i > r && i < nb) ? S[roff(c0 + i) + c0 + r] : 0.0;
+      double bv = r < nb ? b[c0 + r] : 0.0;
+      const double di = r < nb ? dinv[c0 + r] : 1.0;
+#pragma unroll
+      for (int jj = NB - 1; jj >= 0; jj--) {
+        const double xj = readlane_d(bv * di, jj);
+        if (r < jj) bv -= colv[jj] * xj;
+        if (r == jj) bv = xj;
       }
+      if (r < nb) b[c0 + r] = bv;
     }
     __syncthreads();
     for (int j = t; j < c0; j += NT) {
       double v = b[j];
+#pragma unroll 4
       for (int i = c0; i < c1; i++) v -= S[roff(i) + j] * b[i];
       b[j] = v;
     }
@@ -746,7 +891,8 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     WinCtx c;
     c.lds = lds, c.ids = ids;
     c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
-    c.osf = A.iscratch + (size_t)blockIdx.x * MAXOBS;
+    c.osf = A.iscratch + (size_t)blockIdx.x * ISCRATCH;
+    c.cov = c.osf + MAXOBS;
     c.w = w;
     c.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
     c.nf = B.n_feat[w];
@@ -805,6 +951,33 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       int tot = 0;
       if (c.nf > 0) tot = B.feat_obs_begin[(size_t)w * B.max_feat + c.nf - 1] + B.feat_nobs[(size_t)w * B.max_feat + c.nf - 1];
       c.nobs_tot = tot;
+    }
+    if (t >= 1 && t < NFR) {  // features observed in frame t (as imu_j), in feature order
+      int n = 0;
+      for (int e = 0; e < c.nf; e++) {
+        const int a = ids[I_FSTART + e];
+        if (a < t && t < a + ids[I_FNOBS + e]) c.cov[t * MAXE + n++] = e;
+      }
+      ids[I_NCOV + t] = n;
+    }
+    if (t == 0) ids[I_NCOV] = 0;
+    __syncthreads();
+    if (t == 0) {  // longest-processing-time assignment of the 10 frames to the assembling wavefronts
+      int load[ASM_WAVES];
+      for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
+      int done = 0;
+      ids[I_FRW] = -1;
+      for (int k = 1; k < NFR; k++) {
+        int bb = -1, bn = -1;
+        for (int f = 1; f < NFR; f++)
+          if (!(done & (1 << f)) && ids[I_NCOV + f] > bn) bn = ids[I_NCOV + f], bb = f;
+        int bw = 0;
+        for (int q = 1; q < ASM_WAVES; q++)
+          if (load[q] < load[bw]) bw = q;
+        ids[I_FRW + bb] = bw;
+        load[bw] += ((bn + 63) / 64) * 64 + 8;
+        done |= 1 << bb;
+      }
     }
     __syncthreads();
     // Hp = J0^T J0 (constant during the solve: hoisted out of the per-iteration J^T J)
@@ -941,41 +1114,58 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
           __syncthreads();
           const double* W = c.sc + Scratch::W;
           // 1/(hee + mu D_e^2) per feature (L_ST is dead here)
-          if (t < c.nf) lds[L_ST + t] = 1.0 / (lds[L_HEE + t] + mu * lds[L_DD + NF + t] * lds[L_DD + NF + t]);
-          double accS[5];
-          int ei[5], ej[5];
-          for (int q = 0; q < 5; q++) {
-            accS[q] = 0;
-            const int idx = t + q * NT;
-            int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-            while ((i + 1) * (i + 2) / 2 <= idx) i++;
-            while (i * (i + 1) / 2 > idx) i--;
-            ei[q] = idx < NPOSE * (NPOSE + 1) / 2 ? i : -1;
-            ej[q] = idx - i * (i + 1) / 2;
+          if (t < MAXE) lds[L_ST + t] = t < c.nf ? 1.0 / (lds[L_HEE + t] + mu * lds[L_DD + NF + t] * lds[L_DD + NF + t]) : 0.0;
+          // S_pp -= (W diag(1/he))^T W as 16x16 tiles on the matrix cores: 5x5 tile grid over the 66 (padded 80)
+          // pose columns, the 15 lower tiles spread over the 8 wavefronts, K = features in chunks of 32
+          const int wv = t >> 6, lane = t & 63;
+          int tti[2], ttj[2];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const int tile = wv + 8 * q;  // 0..14 valid
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+            tti[q] = tile < 15 ? ti : -1;
+            ttj[q] = tile - ti * (ti + 1) / 2;
           }
+          d4 Dt[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
           double accR = 0;
           for (int e0 = 0; e0 < c.nf; e0 += WCH) {
             const int ne = min(WCH, c.nf - e0);
             __syncthreads();
-            for (int idx = t; idx < ne * NPOSE; idx += NT) lds[L_WCH + idx] = W[(size_t)e0 * NPOSE + idx];
+            for (int idx = t; idx < WCH * WLD; idx += NT) {
+              const int e = idx / WLD, cc = idx % WLD;
+              lds[L_WCH + idx] = (e < ne && cc < NPOSE) ? W[(size_t)(e0 + e) * NPOSE + cc] : 0.0;
+            }
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 5; q++) {
-              if (ei[q] >= 0) {
-                double s = 0;
-                for (int e = 0; e < ne; e++) s += (lds[L_WCH + e * NPOSE + ei[q]] * lds[L_ST + e0 + e]) * lds[L_WCH + e * NPOSE + ej[q]];
-                accS[q] += s;
+            for (int q = 0; q < 2; q++) {
+              if (tti[q] >= 0) {
+#pragma unroll
+                for (int m = 0; m < WCH / 4; m++) {
+                  const int er = 4 * m + (lane >> 4);
+                  const double* row = lds + L_WCH + er * WLD;
+                  const double aop = er < ne ? row[16 * tti[q] + (lane & 15)] * lds[L_ST + e0 + er] : 0.0;
+                  const double bop = row[16 * ttj[q] + (lane & 15)];
+                  Dt[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, Dt[q], 0, 0, 0);
+                }
               }
             }
             if (t < NPOSE) {
-              double s = 0;
-              for (int e = 0; e < ne; e++) s += (lds[L_WCH + e * NPOSE + t] * lds[L_ST + e0 + e]) * lds[L_G + NF + e0 + e];
-              accR += s;
+              double sacc = 0;
+              for (int e = 0; e < ne; e++) sacc += (lds[L_WCH + e * WLD + t] * lds[L_ST + e0 + e]) * lds[L_G + NF + e0 + e];
+              accR += sacc;
             }
           }
 #pragma unroll
-          for (int q = 0; q < 5; q++)
-            if (ei[q] >= 0) lds[L_S + roff(ei[q]) + ej[q]] -= accS[q];
+          for (int q = 0; q < 2; q++) {
+            if (tti[q] >= 0) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const int gi = 16 * tti[q] + (lane >> 4) + 4 * r, gj = 16 * ttj[q] + (lane & 15);
+                if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= Dt[q][r];
+              }
+            }
+          }
           if (t < NPOSE) lds[L_Y + t] -= accR;
           __syncthreads();
           PROF(c, 11);

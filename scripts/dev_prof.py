@@ -7,8 +7,7 @@ import numpy as np
 pkg = "anticipated-vins-mono_amd"
 synth = importlib.import_module(pkg + ".synth"); abi = importlib.import_module(pkg + ".abi")
 est_m = importlib.import_module(pkg + ".estimator")
-NAMES = ["E1 proj+imu raw", "E2 sqrtinfo*raw", "E1b feat aggr", "prior resid", "zero+E4A pose-pose", "E4B g_pose", "E4CD W,hee", "E4F imu JtJ",
-         "E4G prior + cost", "load+Hp", "scale/gmax", "schur", "cholesky", "tri solve", "backsub", "cand eval"]
+NAMES = ["A: frames(MFMA)+imu raw", "B: feat sums+diag", "prior resid", "zero S rows", "-", "-", "-", "D: imu sqrt+JtJ", "E: prior + cost", "load+Hp", "scale/gmax", "schur(MFMA)", "cholesky", "tri solve", "backsub", "cand eval"]
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 tracks = sys.argv[2] if len(sys.argv) > 2 else "dense"
 opt = abi.default_options(); opt.marginalization_flag = abi.MARGIN_NONE
