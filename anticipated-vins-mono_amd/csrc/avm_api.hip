@@ -241,9 +241,10 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   (void)hipSetDevice(c->device);
   int rc = check_window_batch(c, opt, batch);
   if (rc != AVM_OK) return rc;
-  if (opt->marginalization_flag != AVM_MARGIN_NONE) {
-    if (!prior_out) return fail(c, AVM_ERR_INVALID, "prior_out is NULL but marginalization_flag != AVM_MARGIN_NONE");
-    return fail(c, AVM_ERR_UNSUPPORTED, "post-solve marginalization kernel not built yet: use AVM_MARGIN_NONE");
+  const bool marg = opt->marginalization_flag != AVM_MARGIN_NONE;
+  if (marg) {
+    if (!prior_out || !prior_out->n || !prior_out->J) return fail(c, AVM_ERR_INVALID, "prior_out is NULL but marginalization_flag != AVM_MARGIN_NONE");
+    if (prior_out->max_prior > MAXPRIOR || prior_out->max_prior < 1 || prior_out->max_pblk < 1) return fail(c, AVM_ERR_CAPACITY, "prior_out dims");
   }
   if (batch->n_windows == 0) return AVM_OK;
   if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
@@ -270,6 +271,37 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * 32 * c->n_slots, c->stream));
   HIPCHK(c, launch_window_solve(sa, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  avm_prior_out dpo;
+  if (marg) {
+    const size_t B = batch->n_windows, mp = prior_out->max_prior, mb = prior_out->max_pblk;
+    dpo = *prior_out;
+    if (mem == AVM_MEM_HOST) {
+      dpo.n = static_cast<int32_t*>(pool_get(c, "po_n", sizeof(int32_t) * B));
+      dpo.nblk = static_cast<int32_t*>(pool_get(c, "po_nblk", sizeof(int32_t) * B));
+      dpo.blk_kind = static_cast<int32_t*>(pool_get(c, "po_kind", sizeof(int32_t) * B * mb));
+      dpo.blk_frame = static_cast<int32_t*>(pool_get(c, "po_frame", sizeof(int32_t) * B * mb));
+      dpo.J = static_cast<double*>(pool_get(c, "po_J", sizeof(double) * B * mp * mp));
+      dpo.r = static_cast<double*>(pool_get(c, "po_r", sizeof(double) * B * mp));
+      dpo.x0 = static_cast<double*>(pool_get(c, "po_x0", sizeof(double) * B * mb * 9));
+      if (!dpo.n || !dpo.nblk || !dpo.blk_kind || !dpo.blk_frame || !dpo.J || !dpo.r || !dpo.x0) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior out)");
+      HIPCHK(c, hipMemsetAsync(dpo.J, 0, sizeof(double) * B * mp * mp, c->stream));
+      HIPCHK(c, hipMemsetAsync(dpo.r, 0, sizeof(double) * B * mp, c->stream));
+      HIPCHK(c, hipMemsetAsync(dpo.x0, 0, sizeof(double) * B * mb * 9, c->stream));
+      HIPCHK(c, hipMemsetAsync(dpo.blk_kind, 0, sizeof(int32_t) * B * mb, c->stream));
+      HIPCHK(c, hipMemsetAsync(dpo.blk_frame, 0, sizeof(int32_t) * B * mb, c->stream));
+    }
+    HIPCHK(c, launch_marginalize(sa, dpo, c->stream));
+    if (mem == AVM_MEM_HOST) {
+      HIPCHK(c, hipMemcpyAsync(prior_out->n, dpo.n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(prior_out->nblk, dpo.nblk, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(prior_out->blk_kind, dpo.blk_kind, sizeof(int32_t) * B * mb, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(prior_out->blk_frame, dpo.blk_frame, sizeof(int32_t) * B * mb, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(prior_out->J, dpo.J, sizeof(double) * B * mp * mp, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(prior_out->r, dpo.r, sizeof(double) * B * mp, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(prior_out->x0, dpo.x0, sizeof(double) * B * mb * 9, hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   if (mem == AVM_MEM_HOST) {
     const size_t B = batch->n_windows;
     HIPCHK(c, hipMemcpyAsync(batch->pose, d.pose, sizeof(double) * B * 77, hipMemcpyDeviceToHost, c->stream));
@@ -282,6 +314,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->last_ms["preint"] = ms;
   if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->last_ms["window_solve"] = ms;
+  if (hipEventElapsedTime(&ms, c->ev[2], c->ev[5]) == hipSuccess) c->last_ms["marginalize"] = ms;
   return AVM_OK;
 }
 

@@ -27,11 +27,11 @@ struct PreintArgs {
 
 // per-slot global scratch layout (doubles), one slot per resident workgroup (stays L2 resident)
 struct Scratch {
-  static constexpr size_t PF = 0;                               // [8][MAXOBS] per-factor Ji^T Je (6), Je^T Je, Je^T r
-  static constexpr size_t PART = PF + 8 * (size_t)MAXOBS;       // [11][11][27] sum_b Ji^T Ji (21) and Ji^T r (6) per (frame b, start a)
+  static constexpr size_t PF = 0;                               // [14][MAXOBS] per-factor Ji^T Je (6), Je^T Je, Je^T r, Jex^T Je (6, marginalization)
+  static constexpr size_t PART = PF + 14 * (size_t)MAXOBS;       // [11][11][27] sum_b Ji^T Ji (21) and Ji^T r (6) per (frame b, start a)
   static constexpr size_t IJRAW = PART + 3272;                  // [10][15][31] IMU residual + Jacobian before sqrt_info
-  static constexpr size_t W = IJRAW + 4656;                     // [MAXE][NPOSE] E^T F
-  static constexpr size_t HP = W + (size_t)MAXE * NPOSE;        // [MAXPRIOR][MAXPRIOR] J0^T J0
+  static constexpr size_t W = IJRAW + 4656;                     // [MAXE][NPOSE] E^T F ([MAXE][72] in the marginalization kernel)
+  static constexpr size_t HP = W + (size_t)MAXE * 72;        // [MAXPRIOR][MAXPRIOR] J0^T J0
   static constexpr size_t TOTAL = HP + (size_t)MAXPRIOR * MAXPRIOR;
 };
 constexpr int ISCRATCH = MAXOBS + NFR * MAXE;  // ints per slot: observation slot -> feature, then cov[11][150]
@@ -67,6 +67,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
 bool fsel_horizon_supported(int H);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
+hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipStream_t stream);
 int window_solve_lds_bytes();
 
 }  // namespace avm

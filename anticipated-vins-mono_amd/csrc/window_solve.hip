@@ -95,7 +95,7 @@ struct Frames {
 template <bool WANT_J>
 AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const double* tic, double pix, double piy, double pjx,
                          double pjy, double lam, int fa, int fb, double sqi, double cauchy_a, bool apply_loss, double* r,
-                         double* Ji, double* Jj, double* Je) {
+                         double* Ji, double* Jj, double* Je, double* Jex = nullptr) {
   const double* Ra = fr.R + fa * 9;
   const double* Rb = fr.R + fb * 9;
   const v3 Pa = mk3(x[fa * 7], x[fa * 7 + 1], x[fa * 7 + 2]);
@@ -148,6 +148,16 @@ AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const do
       Jj[rr * 6 + 0] = -m.x, Jj[rr * 6 + 1] = -m.y, Jj[rr * 6 + 2] = -m.z;
       Jj[rr * 6 + 3] = cj.x, Jj[rr * 6 + 4] = cj.y, Jj[rr * 6 + 5] = cj.z;
       Je[rr] = dot(mr, u) * il2;
+      if (Jex) {
+        // jaco_ex (projection_factor.cpp:97-107): left = ric^T (Rj^T Ri - I); right = -tmp_r [pc_i]x + [tmp_r pc_i]x + [q]x,
+        // and tmp_r pc_i + q is the point in camera j, so the two skew terms collapse to [pc_j]x
+        const v3 mrr = mk3(mr.x * ric[0] + mr.y * ric[3] + mr.z * ric[6], mr.x * ric[1] + mr.y * ric[4] + mr.z * ric[7],
+                           mr.x * ric[2] + mr.y * ric[5] + mr.z * ric[8]);  // (reduce ric^T Rj^T Ri ric) row
+        const v3 rho = mk3(srho * red[rr * 3], srho * red[rr * 3 + 1], srho * red[rr * 3 + 2]);
+        const v3 ex_r = cross(pci, mrr) + cross(rho, pcj);
+        Jex[rr * 6 + 0] = mr.x - n.x, Jex[rr * 6 + 1] = mr.y - n.y, Jex[rr * 6 + 2] = mr.z - n.z;
+        Jex[rr * 6 + 3] = ex_r.x, Jex[rr * 6 + 4] = ex_r.y, Jex[rr * 6 + 5] = ex_r.z;
+      }
     }
   }
   return 0.5 * rho0;
@@ -1389,6 +1399,564 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
   }
 }
 
+// =====================================================================================
+// Post-solve marginalization: MarginalizationInfo::addResidualBlockInfo / preMarginalize /
+// marginalize / getParameterBlocks (vins_estimator/src/factor/marginalization_factor.cpp:89-319)
+// as driven by Estimator::optimization() (estimator.cpp:817-990), one workgroup per window.
+//
+// Variable layout of the joint system: poses 0..65 | speed-bias 66..164 | ex_pose 165..170 (171 dims,
+// packed lower triangle in LDS).  Factors: old prior, IMU factor 0, every projection factor of the
+// features that start in frame 0 (with their ex_pose Jacobians) — assembled with the same MFMA X^T X
+// scheme as the solve (X row = Jj | Ji | r | Jex).  The inverse depths of those features are
+// eliminated first as scalar pivots (they are mutually independent; identical to the reference's joint
+// eigen-pseudo-inverse of Amm whenever no eigenvalue is clamped), then pose0/speedbias0 through the
+// eigen-decomposition of their 15x15 block with the reference's 1e-8 clamp, and the kept block is
+// square-rooted through a second eigen-decomposition (parallel cyclic Jacobi in LDS).
+// Deterministic block order (the reference's is address-hash order): kept = poses by frame,
+// speed-bias by frame, ex_pose.
+namespace mg {
+constexpr int MNF = 171, MEX0 = 165, MROWS = 14792;  // roff(171)
+constexpr int MXLD = 24;                              // Jj 0-5 | Ji 6-11 | r 12 | tag 13 | 0 0 | Jex 16-21 | 0 0
+constexpr int MXSTG = 128 * MXLD;
+constexpr int MASM = 3;                               // assembling wavefronts (staging must stay below row 165)
+constexpr int M_G = MROWS;                            // b over the 171 variables (176)
+constexpr int M_GE = M_G + 176;                       // g_e (152)
+constexpr int M_WCH = M_GE + 152;                     // [24][80] Schur staging / IMU factor rows
+constexpr int MWCH = 24;
+static_assert(M_WCH + MWCH * WLD <= L_G, "marg layout");
+static_assert(SPP + MASM * MXSTG <= 13778, "marg staging must not reach the ex_pose rows");
+constexpr int PARTW = 126;  // aa 21 | g_a 6 | ex.pose0 36 | ex.ex 21 | g_ex 6 | ex.pose_b 36
+}  // namespace mg
+
+// column of the joint system for W column c (0..71): poses, then ex_pose
+AVM_DEV int mg_col(int c) { return c < NPOSE ? c : mg::MEX0 + (c - NPOSE); }
+
+AVM_DEV void marg_frame_task(const WinCtx& c, const avm_options& o, int b, double* stage) {
+  using namespace mg;
+  double* lds = c.lds;
+  const int lane = threadIdx.x & 63;
+  const int ncov = c.ids[I_NCOV + b];
+  const int32_t* cov = c.cov + b * MAXE;
+  Frames fr{lds + L_FR, lds + L_FR + 99};
+  const double* xs = lds + L_X;
+  const double sqi = o.focal_length / 1.5;
+  double* W = c.sc + Scratch::W;       // [MAXE][72] here
+  double* PF = c.sc + Scratch::PF;     // 8 rows here + 6 more in IJRAW's tail (see MPF2)
+  double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;  // [6][MAXOBS] Jex^T Je
+  double* PART = c.sc + Scratch::PART + (size_t)b * PARTW;
+  d4 D00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, D11 = {0, 0, 0, 0};
+  const int drow = lane >> 4, dcol = lane & 15;
+  for (int chunk0 = 0; chunk0 < ncov; chunk0 += 64) {
+    const int idx = chunk0 + lane;
+    const bool act = idx < ncov;
+    const int e = act ? cov[idx] : 0;
+    const int s0 = c.ids[I_FOBS + e];
+    const int s = s0 + b;
+    double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0}, Jx[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) Ji[k] = 0, Jj[k] = 0, Jx[k] = 0;
+    if (act) {
+      proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1], xs[XLAM + e], 0, b,
+                      sqi, o.cauchy_a, true, r, Ji, Jj, Je, Jx);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        W[(size_t)e * 72 + 6 * b + k] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
+        PF[k * MAXOBS + s] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+        PF2[k * MAXOBS + s] = Jx[k] * Je[0] + Jx[6 + k] * Je[1];
+      }
+      PF[6 * MAXOBS + s] = Je[0] * Je[0] + Je[1] * Je[1];
+      PF[7 * MAXOBS + s] = Je[0] * r[0] + Je[1] * r[1];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+      double* row = stage + (2 * lane + rr) * MXLD;
+#pragma unroll
+      for (int k = 0; k < 6; k++) row[k] = Jj[rr * 6 + k], row[6 + k] = Ji[rr * 6 + k], row[16 + k] = Jx[rr * 6 + k];
+      row[12] = r[rr];
+      row[13] = 0.0, row[14] = 0.0, row[15] = 0.0, row[22] = 0.0, row[23] = 0.0;
+    }
+    wave_lds_sync();
+    const int nact = min(64, ncov - chunk0);
+    for (int m = 0; m < ((2 * nact + 3) >> 2); m++) {
+      const double* row = stage + (4 * m + drow) * MXLD;
+      const double v0 = row[dcol], v1 = row[16 + dcol];
+      D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, D00, 0, 0, 0);
+      D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v0, D10, 0, 0, 0);
+      D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, D11, 0, 0, 0);
+    }
+    wave_lds_sync();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = drow + 4 * r;
+    // D00: rows/cols over [Jj | Ji | r]
+    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = D00[r];                   // (b,b)
+    if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + (dcol - 6)] = D00[r];          // (b,0)
+    if (row < 6 && dcol == 12) lds[M_G + 6 * b + row] = D00[r];                                         // g_b
+    if (row >= 6 && row < 12) {
+      const int i = row - 6;
+      if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[i * (i + 1) / 2 + (dcol - 6)] = D00[r];         // (0,0)
+      if (dcol == 12) PART[21 + i] = D00[r];                                                            // g_0
+    }
+    // D10: rows = Jex, cols = [Jj | Ji | r]
+    if (row < 6) {
+      if (dcol < 6) PART[90 + row * 6 + dcol] = D10[r];                       // (ex, pose b)
+      if (dcol >= 6 && dcol < 12) PART[27 + row * 6 + (dcol - 6)] = D10[r];   // (ex, pose 0)
+      if (dcol == 12) PART[84 + row] = D10[r];                                // g_ex
+      if (dcol <= row) PART[63 + row * (row + 1) / 2 + dcol] = D11[r];        // (ex, ex)
+    }
+  }
+}
+
+// Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, leading dimension ld) in LDS.
+// On return the diagonal of A holds the eigenvalues and the columns of V the eigenvectors (A0 = V diag V^T).
+// Round-robin pairing: n/2 disjoint rotations per step, applied as a row pass then a column pass.
+template <int NTH>
+AVM_DEV void jacobi_eig_lds(double* A, double* V, int n, int ld, double* rot /*4 * 64*/, double* red) {
+  const int t = threadIdx.x;
+  const int ne = (n + 1) & ~1, np = ne >> 1;
+  for (int i = t; i < n * n; i += NTH) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 16; sweep++) {
+    // converged when every |a_pq| <= 1e-15 sqrt(a_pp a_qq) (relative criterion: keeps the small eigenvalues
+    // accurate, which matters for the 1e-8 clamp next to eigenvalues of 1e12)
+    double off = 0;
+    for (int i = t; i < n * n; i += NTH) {
+      const int r = i / n, q = i % n;
+      if (r == q) continue;
+      const double v = fabs(A[r * ld + q]);
+      const double sc = sqrt(fabs(A[r * ld + r]) * fabs(A[q * ld + q]));
+      off = fmax(off, sc > 0.0 ? v / sc : (v > 0.0 ? 1.0 : 0.0));
+    }
+    off = block_max<NTH>(off, red);
+    if (off <= 1e-15) break;
+    for (int step = 0; step < ne - 1; step++) {
+      if (t < np) {
+        int a = t == 0 ? ne - 1 : (step + t) % (ne - 1);
+        int b = t == 0 ? step : (step - t + (ne - 1)) % (ne - 1);
+        const int pI = min(a, b), qI = max(a, b);
+        double cs = 1.0, sn = 0.0;
+        if (qI < n) {
+          const double apq = A[pI * ld + qI];
+          if (fabs(apq) > 1e-300) {
+            const double tau = (A[qI * ld + qI] - A[pI * ld + pI]) / (2.0 * apq);
+            const double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            cs = 1.0 / sqrt(1.0 + tt * tt);
+            sn = tt * cs;
+          }
+        }
+        rot[t * 4] = (double)pI, rot[t * 4 + 1] = (double)qI, rot[t * 4 + 2] = cs, rot[t * 4 + 3] = sn;
+      }
+      __syncthreads();
+      for (int idx = t; idx < np * n; idx += NTH) {  // rows p,q <- J^T rows
+        const int k = idx / n, j = idx % n;
+        const int pI = (int)rot[k * 4], qI = (int)rot[k * 4 + 1];
+        if (qI >= n) continue;
+        const double cs = rot[k * 4 + 2], sn = rot[k * 4 + 3];
+        const double x = A[pI * ld + j], y = A[qI * ld + j];
+        A[pI * ld + j] = cs * x - sn * y;
+        A[qI * ld + j] = sn * x + cs * y;
+      }
+      __syncthreads();
+      for (int idx = t; idx < np * n; idx += NTH) {  // columns p,q <- columns J ; same for V
+        const int k = idx / n, i = idx % n;
+        const int pI = (int)rot[k * 4], qI = (int)rot[k * 4 + 1];
+        if (qI >= n) continue;
+        const double cs = rot[k * 4 + 2], sn = rot[k * 4 + 3];
+        double x = A[i * ld + pI], y = A[i * ld + qI];
+        A[i * ld + pI] = cs * x - sn * y;
+        A[i * ld + qI] = sn * x + cs * y;
+        x = V[i * ld + pI], y = V[i * ld + qI];
+        V[i * ld + pI] = cs * x - sn * y;
+        V[i * ld + qI] = sn * x + cs * y;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO) {
+  using namespace mg;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const avm_options& o = A.opt;
+  const avm_window_batch& B = A.b;
+  const int flag = o.marginalization_flag;
+  for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
+    WinCtx c;
+    c.lds = lds, c.ids = ids, c.prof = nullptr;
+    c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
+    c.osf = A.iscratch + (size_t)blockIdx.x * ISCRATCH;
+    c.cov = c.osf + MAXOBS;
+    c.w = w;
+    c.nf = B.n_feat[w];
+    c.obs = B.obs_xy + (size_t)w * B.max_obs * 2;
+    c.pdelta = A.pre_delta + (size_t)w * 100, c.pjac = A.pre_jac + (size_t)w * 2250, c.psqrt = A.pre_sqrt + (size_t)w * 2250;
+    c.psum = A.pre_sum_dt + (size_t)w * 10;
+    c.lba = B.imu_lin_ba + (size_t)w * 30, c.lbg = B.imu_lin_bg + (size_t)w * 30;
+    c.pn = B.prior_n ? B.prior_n[w] : 0;
+    c.pnblk = c.pn > 0 ? B.prior_nblk[w] : 0;
+    c.ldp = B.max_prior;
+    c.pJ = B.prior_J + (size_t)w * B.max_prior * B.max_prior;
+    c.pr = B.prior_r + (size_t)w * B.max_prior;
+    c.px0 = B.prior_x0 + (size_t)w * B.max_pblk * 9;
+    c.nobs_tot = 0;
+    __syncthreads();
+    // ---- load the post-solve state and tables
+    for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
+    for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
+    for (int i = t; i < MAXE; i += NT) lds[L_X + XLAM + i] = i < c.nf ? B.inv_depth[(size_t)w * B.max_feat + i] : 1.0;
+    for (int i = t; i < MAXPRIOR; i += NT) lds[L_DXP + i] = 0.0, lds[L_RP + i] = 0.0;
+    for (int i = t; i < MROWS + 176 + 152; i += NT) lds[i] = 0.0;  // S, b, g_e
+    for (int i = t; i < 152; i += NT) lds[L_HEE + i] = 0.0;
+    if (t < c.nf) {
+      ids[I_FSTART + t] = B.feat_start[(size_t)w * B.max_feat + t];
+      ids[I_FNOBS + t] = B.feat_nobs[(size_t)w * B.max_feat + t];
+      ids[I_FOBS + t] = B.feat_obs_begin[(size_t)w * B.max_feat + t];
+    }
+    if (t < 7) lds[L_RIC + 12 + t] = B.ex_pose[(size_t)w * 7 + t];
+    if (t == 0) {
+      const double* ex = B.ex_pose + (size_t)w * 7;
+      double R[9];
+      q2R(quat{ex[6], ex[3], ex[4], ex[5]}, R);
+      for (int k = 0; k < 9; k++) lds[L_RIC + k] = R[k];
+      for (int k = 0; k < 3; k++) lds[L_RIC + 9 + k] = ex[k];
+      int off = 0;
+      for (int k = 0; k < c.pnblk; k++) {
+        const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
+        ids[I_PBLK + k * 3] = kind, ids[I_PBLK + k * 3 + 1] = fr, ids[I_PBLK + k * 3 + 2] = off;
+        const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
+        for (int q = 0; q < n; q++) ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q : MEX0 + q);
+        off += n;
+      }
+    }
+    __syncthreads();
+    // does the prior take part?  MARGIN_SECOND_NEW needs pose[WINDOW_SIZE-1] in it (estimator.cpp:926-927)
+    bool use_prior = c.pn > 0;
+    bool has9 = false;
+    for (int k = 0; k < c.pnblk; k++)
+      if (ids[I_PBLK + k * 3] == AVM_BLK_POSE && ids[I_PBLK + k * 3 + 1] == AVM_WINDOW_SIZE - 1) has9 = true;
+    if (flag == AVM_MARGIN_SECOND_NEW && !(use_prior && has9)) {
+      if (t == 0) PO.n[w] = -1, PO.nblk[w] = 0;  // nothing to do: the caller keeps the old prior
+      continue;
+    }
+    const bool imu0 = flag == AVM_MARGIN_OLD && c.psum[0] < o.max_sum_dt;  // estimator.cpp:841
+    if (flag == AVM_MARGIN_OLD) {
+      if (t >= 1 && t < NFR) {  // start-frame-0 features observed in frame t
+        int n = 0;
+        for (int e = 0; e < c.nf; e++)
+          if (ids[I_FSTART + e] == 0 && t < ids[I_FNOBS + e]) c.cov[t * MAXE + n++] = e;
+        ids[I_NCOV + t] = n;
+      }
+    } else if (t < NFR) {
+      ids[I_NCOV + t] = 0;
+    }
+    if (t == 0) ids[I_NCOV] = 0;
+    build_frames(lds, lds + L_X, 0);
+    double* IJR = c.sc + Scratch::IJRAW;
+    for (int i = t; i < 465; i += NT) IJR[i] = 0.0;
+    __syncthreads();
+    int nf0 = 0;  // features starting at frame 0 (they come first)
+    for (int e = 0; e < c.nf; e++) nf0 += ids[I_FSTART + e] == 0 ? 1 : 0;
+    // ---- phase A: projection factors of the start-0 features || IMU factor 0
+    if (wv < MASM) {
+      double* stage = lds + L_S + SPP + wv * MXSTG;
+      for (int b = 1 + wv; b < NFR; b += MASM) marg_frame_task(c, o, b, stage);
+    } else if (wv == 7 && lane == 0 && imu0) {
+      imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
+    }
+    __syncthreads();
+    // ---- phase B: per-feature sums, PART gather
+    {
+      double* W = c.sc + Scratch::W;
+      const double* PF = c.sc + Scratch::PF;
+      const double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;
+      for (int idx = t; idx < nf0 * 12; idx += NT) {
+        const int e = idx / 12, f = idx % 12;  // f == 11 : ex_pose column block
+        const int no = ids[I_FNOBS + e], s0 = ids[I_FOBS + e];
+        if (f == 0 || f == 11) {
+          const double* P = f == 0 ? PF : PF2;
+          double sacc[6] = {0, 0, 0, 0, 0, 0};
+          for (int k = 1; k < no; k++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) sacc[q] += P[q * MAXOBS + s0 + k];
+#pragma unroll
+          for (int q = 0; q < 6; q++) W[(size_t)e * 72 + 6 * f + q] = sacc[q];
+          if (f == 0) {
+            double he = 0, ge = 0;
+            for (int k = 1; k < no; k++) he += PF[6 * MAXOBS + s0 + k], ge += PF[7 * MAXOBS + s0 + k];
+            lds[L_HEE + e] = he;
+            lds[M_GE + e] = ge;
+          }
+        } else if (f >= no) {
+#pragma unroll
+          for (int q = 0; q < 6; q++) W[(size_t)e * 72 + 6 * f + q] = 0.0;
+        }
+      }
+    }
+    __syncthreads();  // staging dead: rows >= 66 can be cleared, then the PART sums land (incl. the ex_pose rows)
+    for (int i = SPP + t; i < MROWS; i += NT) lds[L_S + i] = 0.0;
+    __syncthreads();
+    if (flag == AVM_MARGIN_OLD && t < PARTW) {
+      const double* PART = c.sc + Scratch::PART;
+      const int q = t;
+      if (q < 90) {
+        double sacc = 0;
+        for (int b = 1; b < NFR; b++)
+          if (ids[I_NCOV + b] > 0) sacc += PART[(size_t)b * PARTW + q];
+        if (q < 21) {
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= q) i++;
+          lds[L_S + roff(i) + (q - i * (i + 1) / 2)] = sacc;
+        } else if (q < 27) {
+          lds[M_G + (q - 21)] = sacc;
+        } else if (q < 63) {
+          lds[L_S + roff(MEX0 + (q - 27) / 6) + (q - 27) % 6] = sacc;
+        } else if (q < 84) {
+          const int k = q - 63;
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= k) i++;
+          lds[L_S + roff(MEX0 + i) + MEX0 + (k - i * (i + 1) / 2)] = sacc;
+        } else {
+          lds[M_G + MEX0 + (q - 84)] = sacc;
+        }
+      } else {
+        const int k = q - 90;
+        for (int b = 1; b < NFR; b++)
+          if (ids[I_NCOV + b] > 0) lds[L_S + roff(MEX0 + k / 6) + 6 * b + k % 6] = PART[(size_t)b * PARTW + q];
+      }
+    }
+    __syncthreads();
+    // ---- phase D: IMU factor 0
+    if (imu0) {
+      double* IJ = lds + M_WCH;
+      for (int idx = t; idx < 465; idx += NT) {
+        const int r = idx / 31, cc = idx % 31;
+        double sacc = 0;
+        for (int k = r; k < 15; k++) sacc += c.psqrt[r * 15 + k] * IJR[k * 31 + cc];
+        IJ[idx] = sacc;
+      }
+      __syncthreads();
+      for (int q = t; q < 495; q += NT) {
+        if (q < 465) {
+          int p = 0;
+          while ((p + 1) * (p + 2) / 2 <= q) p++;
+          const int qq = q - p * (p + 1) / 2;
+          double sacc = 0;
+          for (int r = 0; r < 15; r++) sacc += IJ[r * 31 + 1 + p] * IJ[r * 31 + 1 + qq];
+          const int ip = imu_col(0, p), iq = imu_col(0, qq);
+          lds[L_S + roff(max(ip, iq)) + min(ip, iq)] += sacc;
+        } else {
+          const int p = q - 465;
+          double sacc = 0;
+          for (int r = 0; r < 15; r++) sacc += IJ[r * 31 + 1 + p] * IJ[r * 31];
+          lds[M_G + imu_col(0, p)] += sacc;
+        }
+      }
+      __syncthreads();
+    }
+    // ---- phase E: old prior (MarginalizationFactor at the current state)
+    if (use_prior) {
+      prior_residual_dev(c, lds + L_X);
+      const int* pidx = ids + I_PIDX;
+      for (int idx = t; idx < c.pn * (c.pn + 1) / 2; idx += NT) {
+        int pp = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while ((pp + 1) * (pp + 2) / 2 <= idx) pp++;
+        while (pp * (pp + 1) / 2 > idx) pp--;
+        const int q = idx - pp * (pp + 1) / 2;
+        double sacc = 0;
+        for (int i = 0; i < c.pn; i++) sacc += c.pJ[(size_t)i * c.ldp + pp] * c.pJ[(size_t)i * c.ldp + q];
+        const int ip = pidx[pp], iq = pidx[q];
+        lds[L_S + roff(max(ip, iq)) + min(ip, iq)] += sacc;
+      }
+      if (t < c.pn) {
+        double sacc = 0;
+        for (int i = 0; i < c.pn; i++) sacc += c.pJ[(size_t)i * c.ldp + t] * lds[L_RP + i];
+        lds[M_G + pidx[t]] += sacc;
+      }
+    }
+    __syncthreads();
+    // ---- phase F: eliminate the start-0 inverse depths (scalar pivots)
+    if (flag == AVM_MARGIN_OLD && nf0 > 0) {
+      const double* W = c.sc + Scratch::W;
+      if (t < MAXE) lds[L_HEE + t] = (t < nf0 && lds[L_HEE + t] > o.marg_eps) ? 1.0 / lds[L_HEE + t] : 0.0;  // 1 / E^T E in place
+      int ei[6], ej[6];
+      double accS[6];
+      for (int q = 0; q < 6; q++) {
+        accS[q] = 0;
+        const int idx = t + q * NT;
+        int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= idx) i++;
+        while (i * (i + 1) / 2 > idx) i--;
+        ei[q] = idx < 72 * 73 / 2 ? i : -1;
+        ej[q] = idx - i * (i + 1) / 2;
+      }
+      double accR = 0;
+      for (int e0 = 0; e0 < nf0; e0 += MWCH) {
+        const int ne = min(MWCH, nf0 - e0);
+        __syncthreads();
+        for (int idx = t; idx < ne * 72; idx += NT) lds[M_WCH + (idx / 72) * WLD + idx % 72] = W[(size_t)(e0 + idx / 72) * 72 + idx % 72];
+        __syncthreads();
+        for (int q = 0; q < 6; q++)
+          if (ei[q] >= 0) {
+            double sacc = 0;
+            for (int e = 0; e < ne; e++) sacc += (lds[M_WCH + e * WLD + ei[q]] * lds[L_HEE + e0 + e]) * lds[M_WCH + e * WLD + ej[q]];
+            accS[q] += sacc;
+          }
+        if (t < 72) {
+          double sacc = 0;
+          for (int e = 0; e < ne; e++) sacc += (lds[M_WCH + e * WLD + t] * lds[L_HEE + e0 + e]) * lds[M_GE + e0 + e];
+          accR += sacc;
+        }
+      }
+      __syncthreads();
+      for (int q = 0; q < 6; q++)
+        if (ei[q] >= 0) {
+          const int gi = mg_col(ei[q]), gj = mg_col(ej[q]);
+          lds[L_S + roff(max(gi, gj)) + min(gi, gj)] -= accS[q];
+        }
+      if (t < 72) lds[M_G + mg_col(t)] -= accR;
+    }
+    __syncthreads();
+    // ---- phase G: dropped / kept variable lists (ints at I_FSTART.. are dead now)
+    int* midx = ids + 0;       // [<=16]
+    int* kidx = ids + 16;      // [<=96]
+    int* kblk = ids + 120;     // [<=16] id of kept block k : pose f -> f, speedbias f -> 11+f, ex -> 22
+    int* cnts = ids + 140;     // m, n, nblk
+    __syncthreads();
+    if (t == 0) {
+      int present = 0;  // bit id
+      for (int k = 0; k < c.pnblk; k++) {
+        const int kind = ids[I_PBLK + k * 3], fr = ids[I_PBLK + k * 3 + 1];
+        present |= 1 << (kind == AVM_BLK_POSE ? fr : (kind == AVM_BLK_SPEEDBIAS ? 11 + fr : 22));
+      }
+      if (!use_prior) present = 0;
+      int m = 0, n = 0, nb = 0;
+      if (flag == AVM_MARGIN_OLD) {
+        if (imu0) present |= (1 << 0) | (1 << 11) | (1 << 1) | (1 << 12);
+        if (nf0 > 0) present |= (1 << 0) | (1 << 22);
+        for (int b = 1; b < NFR; b++)
+          if (ids[I_NCOV + b] > 0) present |= 1 << b;
+        for (int q = 0; q < 6; q++) midx[m++] = q;
+        for (int q = 0; q < 9; q++) midx[m++] = SB0 + q;
+        present &= ~((1 << 0) | (1 << 11));
+      } else {
+        for (int q = 0; q < 6; q++) midx[m++] = 6 * (AVM_WINDOW_SIZE - 1) + q;
+        present &= ~(1 << (AVM_WINDOW_SIZE - 1));
+      }
+      for (int id = 0; id < 23; id++) {
+        if (!(present & (1 << id))) continue;
+        const int base = id < 11 ? 6 * id : (id < 22 ? SB0 + 9 * (id - 11) : MEX0);
+        const int sz = (id >= 11 && id < 22) ? 9 : 6;
+        if (n + sz > MAXPRIOR || nb >= MAXPBLK) break;
+        kblk[nb++] = id;
+        for (int q = 0; q < sz; q++) kidx[n++] = base + q;
+      }
+      cnts[0] = m, cnts[1] = n, cnts[2] = nb;
+    }
+    __syncthreads();
+    const int m = cnts[0], n = cnts[1], nblk = cnts[2];
+    // extract Amm (16x16 at EA), Arm (n x 16 at EB), Arr (n x n), b before the packed matrix is overwritten
+    auto Sget = [&](int i, int j) { return lds[L_S + roff(max(i, j)) + min(i, j)]; };
+    double* EA = lds + M_WCH;            // Amm 16 x 16, then its eigenvectors next to it
+    double* EV = EA + 256;               // 16 x 16
+    double* EB = EV + 256;               // Arm : n x 16   (n <= 96 -> 1536)  (M_WCH region holds 1920+; spills into the dead L_G.. vectors)
+    double* ROT = lds + L_HEE;           // 4 * 64 rotation records (hee / dxp / rp are dead by now: 344 doubles)
+    double* BV = lds + L_FR + 198;       // b_m (16), b_r (96): the candidate-state frame slot is unused here
+    for (int idx = t; idx < 16 * 16; idx += NT) {
+      const int i = idx / 16, j = idx % 16;
+      EA[idx] = (i < m && j < m) ? 0.5 * (Sget(midx[i], midx[j]) + Sget(midx[j], midx[i])) : (i == j ? 1.0 : 0.0);
+    }
+    for (int idx = t; idx < n * 16; idx += NT) {
+      const int i = idx / 16, j = idx % 16;
+      EB[idx] = j < m ? Sget(kidx[i], midx[j]) : 0.0;
+    }
+    if (t < 16) BV[t] = t < m ? lds[M_G + midx[t]] : 0.0;
+    if (t >= 64 && t < 64 + n) BV[16 + t - 64] = lds[M_G + kidx[t - 64]];
+    __syncthreads();
+    // Arr into registers-free staging: it has to move from packed-171 to dense n x n at offset 0; go through global scratch
+    double* GA = c.sc + Scratch::HP;  // n x n dense (<= 96 x 96)
+    for (int idx = t; idx < n * n; idx += NT) GA[idx] = Sget(kidx[idx / n], kidx[idx % n]);
+    __syncthreads();
+    jacobi_eig_lds<NT>(EA, EV, 16, 16, ROT, lds + L_RED);
+    // Amm^+ = V diag(1/lambda > eps) V^T  -> EA (reuse) ; T = Arm Amm^+ ; A' = Arr - T Amr ; b' = br - T bm
+    {
+      double lam_inv[16];
+      for (int k = 0; k < 16; k++) lam_inv[k] = (k < m && EA[k * 16 + k] > o.marg_eps) ? 1.0 / EA[k * 16 + k] : 0.0;
+      __syncthreads();
+      if (t < 256) {
+        const int i = t / 16, j = t % 16;
+        double sacc = 0;
+        for (int k = 0; k < 16; k++) sacc += EV[i * 16 + k] * lam_inv[k] * EV[j * 16 + k];
+        EA[t] = (i < m && j < m) ? sacc : 0.0;
+      }
+      __syncthreads();
+    }
+    double* Ad = lds;                 // A' dense n x n, ld = n
+    double* Vd = lds + n * n;         // eigenvectors (2 n^2 <= 18432 doubles stays below the live state at L_X)
+    double* GT = c.sc + Scratch::W;   // T = Arm Amm^+ : n x 16, in the scratch slot
+    for (int idx = t; idx < n * 16; idx += NT) {
+      const int i = idx / 16, j = idx % 16;
+      double sacc = 0;
+      for (int k = 0; k < 16; k++) sacc += EB[i * 16 + k] * EA[k * 16 + j];
+      GT[idx] = sacc;
+    }
+    __syncthreads();
+    for (int idx = t; idx < n * n; idx += NT) {
+      const int i = idx / n, j = idx % n;
+      double sacc = 0;
+      for (int k = 0; k < 16; k++) sacc += GT[i * 16 + k] * EB[j * 16 + k];
+      GA[idx] -= sacc;
+    }
+    if (t < n) {
+      double sacc = 0;
+      for (int k = 0; k < 16; k++) sacc += GT[t * 16 + k] * BV[k];
+      BV[16 + t] -= sacc;
+    }
+    __syncthreads();
+    for (int idx = t; idx < n * n; idx += NT) Ad[idx] = GA[idx];
+    __syncthreads();
+    jacobi_eig_lds<NT>(Ad, Vd, n, n, ROT, lds + L_RED);
+    // linearized_jacobians = diag(sqrt(S)) V^T ; linearized_residuals = diag(1/sqrt(S)) V^T b
+    {
+      double* oJ = PO.J + (size_t)w * PO.max_prior * PO.max_prior;
+      double* orr = PO.r + (size_t)w * PO.max_prior;
+      for (int idx = t; idx < n * n; idx += NT) {
+        const int k = idx / n, j = idx % n;
+        const double ev = Ad[k * n + k];
+        oJ[(size_t)k * PO.max_prior + j] = (ev > o.marg_eps ? sqrt(ev) : 0.0) * Vd[j * n + k];
+      }
+      if (t < n) {
+        const double ev = Ad[t * n + t];
+        double vb = 0;
+        for (int j = 0; j < n; j++) vb += Vd[j * n + t] * BV[16 + j];
+        orr[t] = (ev > o.marg_eps ? sqrt(1.0 / ev) : 0.0) * vb;
+      }
+      if (t < nblk) {
+        const int id = kblk[t];
+        const int kind = id < 11 ? AVM_BLK_POSE : (id < 22 ? AVM_BLK_SPEEDBIAS : AVM_BLK_EXPOSE);
+        int fr = id < 11 ? id : (id < 22 ? id - 11 : 0);
+        if (kind != AVM_BLK_EXPOSE) {
+          if (flag == AVM_MARGIN_OLD)
+            fr -= 1;  // addr_shift, estimator.cpp:904-909
+          else if (fr == AVM_WINDOW_SIZE)
+            fr -= 1;  // estimator.cpp:965-969
+        }
+        PO.blk_kind[(size_t)w * PO.max_pblk + t] = kind;
+        PO.blk_frame[(size_t)w * PO.max_pblk + t] = fr;
+        double* x0 = PO.x0 + ((size_t)w * PO.max_pblk + t) * 9;
+        const double* src = kind == AVM_BLK_POSE ? lds + L_X + id * 7 : (kind == AVM_BLK_SPEEDBIAS ? lds + L_X + XSB + (id - 11) * 9 : lds + L_RIC + 12);
+        const int gs = kind == AVM_BLK_SPEEDBIAS ? 9 : 7;
+        for (int q = 0; q < 9; q++) x0[q] = q < gs ? src[q] : 0.0;
+      }
+      if (t == 0) PO.n[w] = n, PO.nblk[w] = nblk;
+    }
+    __syncthreads();
+  }
+}
+
 // Per-factor evaluation at the input state (no solve): parity-test surface for A5/A6/A8.
 __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1495,6 +2063,18 @@ hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+
+hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(marginalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 8);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = a.b.n_windows < a.n_slots ? a.b.n_windows : a.n_slots;
+  hipLaunchKernelGGL(marginalize_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a, po);
+  return hipGetLastError();
+}
 
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream) {
   static bool attr_set = false;

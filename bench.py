@@ -203,7 +203,7 @@ def main():
         import oracle_py
 
         cores = os.cpu_count() or 1
-        nsamp = min(base.n_windows, max(cores, 16))
+        nsamp = min(W, max(2 * cores, 32))
         sample = host.slice(0, nsamp).copy()
         o2 = abi.default_options()
         o2.marginalization_flag = opt.marginalization_flag
