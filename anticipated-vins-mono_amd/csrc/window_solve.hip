@@ -27,6 +27,7 @@ namespace avm {
 
 namespace {
 
+#define AVM_NOINL __device__ __noinline__
 #define PROF_T0() long long pt__ = clock64()
 #define PROF(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pt__; pt__ = n__; } } while (0)
 
@@ -371,6 +372,33 @@ AVM_DEV double eval_cost(const WinCtx& c, const avm_options& o, const double* xs
     if (t < c.pn) acc += 0.5 * lds[L_RP + t] * lds[L_RP + t];
   }
   return block_sum<NT>(acc, lds + L_RED);
+}
+
+// HP[p][q] = sum_i J0[i][p] J0[i][q] (lower tiles; mirrored) on the matrix cores: 16x16 tiles, K = prior rows.
+AVM_DEV void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ntl = (pn + 15) >> 4;
+  for (int tile = wv; tile < ntl * (ntl + 1) / 2; tile += NT / 64) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int ca = 16 * ti + (lane & 15), cb = 16 * tj + (lane & 15);
+    d4 D = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < pn; k0 += 4) {
+      const int r = k0 + (lane >> 4);
+      const double aop = (r < pn && ca < pn) ? pJ[(size_t)r * ldp + ca] : 0.0;
+      const double bop = (r < pn && cb < pn) ? pJ[(size_t)r * ldp + cb] : 0.0;
+      D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int gi = 16 * ti + (lane >> 4) + 4 * r, gj = 16 * tj + (lane & 15);
+      if (gi < pn && gj < pn) {
+        HP[gi * MAXPRIOR + gj] = D[r];
+        HP[gj * MAXPRIOR + gi] = D[r];
+      }
+    }
+  }
 }
 
 // All projection factors observed in frame b, by one wavefront (lane = factor, 64 at a time).
@@ -991,15 +1019,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     }
     __syncthreads();
     // Hp = J0^T J0 (constant during the solve: hoisted out of the per-iteration J^T J)
-    if (c.pn > 0) {
-      double* HP = c.sc + Scratch::HP;
-      for (int idx = t; idx < c.pn * c.pn; idx += NT) {
-        const int p = idx / c.pn, q = idx % c.pn;
-        double s = 0;
-        for (int i = 0; i < c.pn; i++) s += c.pJ[(size_t)i * c.ldp + p] * c.pJ[(size_t)i * c.ldp + q];
-        HP[p * MAXPRIOR + q] = s;
-      }
-    }
+    if (c.pn > 0) prior_jtj_mfma(c.pJ, c.ldp, c.pn, c.sc + Scratch::HP);
     __syncthreads();
 
     PROF(c, 9);
@@ -1510,34 +1530,61 @@ AVM_DEV void marg_frame_task(const WinCtx& c, const avm_options& o, int b, doubl
 
 // Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, leading dimension ld) in LDS.
 // On return the diagonal of A holds the eigenvalues and the columns of V the eigenvectors (A0 = V diag V^T).
-// Round-robin pairing: n/2 disjoint rotations per step, applied as a row pass then a column pass.
+// Round-robin pairing: n/2 disjoint rotations per step.  A <- J^T A J is applied as independent 2x2 blocks
+// (rows of pair k1, columns of pair k2, only k1 >= k2, mirrored), V <- V J in the same pass: two barriers per step.
+// rot: 4 doubles per pair (c, s) + ints (p, q) packed behind them; needs 6 * 64 doubles.
 template <int NTH>
-AVM_DEV void jacobi_eig_lds(double* A, double* V, int n, int ld, double* rot /*4 * 64*/, double* red) {
+AVM_DEV int jacobi_eig_lds(double* A, double* V, int n, int ld, double* rot, double* red) {
   const int t = threadIdx.x;
   const int ne = (n + 1) & ~1, np = ne >> 1;
+  double* rcs = rot;                                   // [np][2]
+  int* rpq = reinterpret_cast<int*>(rot + 2 * 64);     // [np][2]
   for (int i = t; i < n * n; i += NTH) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
+  // static work assignment: blocks (k1 >= k2) then V items (pair k, row i)
+  constexpr int MAXIT = 9;
+  const int nblk = np * (np + 1) / 2, nitem = nblk + np * n;
+  short ia[MAXIT], ib[MAXIT];
+  int nmine = 0;
+#pragma unroll
+  for (int u = 0; u < MAXIT; u++) {
+    const int idx = t + u * NTH;
+    ia[u] = 0, ib[u] = 0;
+    if (idx >= nitem) continue;
+    nmine = u + 1;
+    if (idx < nblk) {
+      int k1 = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+      while ((k1 + 1) * (k1 + 2) / 2 <= idx) k1++;
+      while (k1 * (k1 + 1) / 2 > idx) k1--;
+      ia[u] = (short)k1, ib[u] = (short)(idx - k1 * (k1 + 1) / 2);
+    } else {
+      const int j = idx - nblk;
+      ia[u] = (short)(-1 - j / n), ib[u] = (short)(j % n);
+    }
+  }
   __syncthreads();
-  for (int sweep = 0; sweep < 16; sweep++) {
-    // converged when every |a_pq| <= 1e-15 sqrt(a_pp a_qq) (relative criterion: keeps the small eigenvalues
+  int sweeps = 0;
+  for (int sweep = 0; sweep < 20; sweep++) {
+    // converged when every |a_pq| <= tol sqrt(a_pp a_qq) (relative criterion: keeps the small eigenvalues
     // accurate, which matters for the 1e-8 clamp next to eigenvalues of 1e12)
     double off = 0;
     for (int i = t; i < n * n; i += NTH) {
       const int r = i / n, q = i % n;
-      if (r == q) continue;
+      if (r <= q) continue;
       const double v = fabs(A[r * ld + q]);
       const double sc = sqrt(fabs(A[r * ld + r]) * fabs(A[q * ld + q]));
       off = fmax(off, sc > 0.0 ? v / sc : (v > 0.0 ? 1.0 : 0.0));
     }
     off = block_max<NTH>(off, red);
     if (off <= 1e-15) break;
+    sweeps++;
     for (int step = 0; step < ne - 1; step++) {
       if (t < np) {
-        int a = t == 0 ? ne - 1 : (step + t) % (ne - 1);
-        int b = t == 0 ? step : (step - t + (ne - 1)) % (ne - 1);
+        const int a = t == 0 ? ne - 1 : (step + t) % (ne - 1);
+        const int b = t == 0 ? step : (step - t + (ne - 1)) % (ne - 1);
         const int pI = min(a, b), qI = max(a, b);
         double cs = 1.0, sn = 0.0;
         if (qI < n) {
-          const double apq = A[pI * ld + qI];
+          const double apq = A[qI * ld + pI];
           if (fabs(apq) > 1e-300) {
             const double tau = (A[qI * ld + qI] - A[pI * ld + pI]) / (2.0 * apq);
             const double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
@@ -1545,34 +1592,50 @@ AVM_DEV void jacobi_eig_lds(double* A, double* V, int n, int ld, double* rot /*4
             sn = tt * cs;
           }
         }
-        rot[t * 4] = (double)pI, rot[t * 4 + 1] = (double)qI, rot[t * 4 + 2] = cs, rot[t * 4 + 3] = sn;
+        rcs[t * 2] = cs, rcs[t * 2 + 1] = sn;
+        rpq[t * 2] = pI, rpq[t * 2 + 1] = qI;
       }
       __syncthreads();
-      for (int idx = t; idx < np * n; idx += NTH) {  // rows p,q <- J^T rows
-        const int k = idx / n, j = idx % n;
-        const int pI = (int)rot[k * 4], qI = (int)rot[k * 4 + 1];
-        if (qI >= n) continue;
-        const double cs = rot[k * 4 + 2], sn = rot[k * 4 + 3];
-        const double x = A[pI * ld + j], y = A[qI * ld + j];
-        A[pI * ld + j] = cs * x - sn * y;
-        A[qI * ld + j] = sn * x + cs * y;
-      }
-      __syncthreads();
-      for (int idx = t; idx < np * n; idx += NTH) {  // columns p,q <- columns J ; same for V
-        const int k = idx / n, i = idx % n;
-        const int pI = (int)rot[k * 4], qI = (int)rot[k * 4 + 1];
-        if (qI >= n) continue;
-        const double cs = rot[k * 4 + 2], sn = rot[k * 4 + 3];
-        double x = A[i * ld + pI], y = A[i * ld + qI];
-        A[i * ld + pI] = cs * x - sn * y;
-        A[i * ld + qI] = sn * x + cs * y;
-        x = V[i * ld + pI], y = V[i * ld + qI];
-        V[i * ld + pI] = cs * x - sn * y;
-        V[i * ld + qI] = sn * x + cs * y;
+#pragma unroll
+      for (int it = 0; it < MAXIT; it++) {
+        if (it >= nmine) continue;
+        if (ia[it] >= 0) {
+          const int k1 = ia[it], k2 = ib[it];
+          const int p1 = rpq[k1 * 2], q1 = rpq[k1 * 2 + 1], p2 = rpq[k2 * 2], q2 = rpq[k2 * 2 + 1];
+          const double c1 = rcs[k1 * 2], s1 = rcs[k1 * 2 + 1], c2 = rcs[k2 * 2], s2 = rcs[k2 * 2 + 1];
+          const bool r1 = q1 < n, r2 = q2 < n;  // a dummy partner (odd n) leaves its line untouched (c = 1, s = 0)
+          // read the block from the lower triangle (A is kept symmetric: both triangles are written)
+          const double a00 = A[p1 * ld + p2], a01 = r2 ? A[p1 * ld + q2] : 0.0;
+          const double a10 = r1 ? A[q1 * ld + p2] : 0.0, a11 = (r1 && r2) ? A[q1 * ld + q2] : 0.0;
+          const double b00 = c1 * a00 - s1 * a10, b01 = c1 * a01 - s1 * a11;
+          const double b10 = s1 * a00 + c1 * a10, b11 = s1 * a01 + c1 * a11;
+          const double n00 = c2 * b00 - s2 * b01, n01 = s2 * b00 + c2 * b01;
+          const double n10 = c2 * b10 - s2 * b11, n11 = s2 * b10 + c2 * b11;
+          A[p1 * ld + p2] = n00;
+          if (r2) A[p1 * ld + q2] = n01;
+          if (r1) A[q1 * ld + p2] = n10;
+          if (r1 && r2) A[q1 * ld + q2] = n11;
+          if (k1 != k2) {  // mirror
+            A[p2 * ld + p1] = n00;
+            if (r2) A[q2 * ld + p1] = n01;
+            if (r1) A[p2 * ld + q1] = n10;
+            if (r1 && r2) A[q2 * ld + q1] = n11;
+          }
+        } else {
+          const int k = -1 - ia[it], i = ib[it];
+          const int pI = rpq[k * 2], qI = rpq[k * 2 + 1];
+          if (qI < n) {
+            const double cs = rcs[k * 2], sn = rcs[k * 2 + 1];
+            const double x = V[i * ld + pI], y = V[i * ld + qI];
+            V[i * ld + pI] = cs * x - sn * y;
+            V[i * ld + qI] = sn * x + cs * y;
+          }
+        }
       }
       __syncthreads();
     }
   }
+  return sweeps;
 }
 
 __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO) {
@@ -1586,7 +1649,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
   const int flag = o.marginalization_flag;
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
     WinCtx c;
-    c.lds = lds, c.ids = ids, c.prof = nullptr;
+    c.lds = lds, c.ids = ids, c.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
     c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
     c.osf = A.iscratch + (size_t)blockIdx.x * ISCRATCH;
     c.cov = c.osf + MAXOBS;
@@ -1604,6 +1667,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     c.px0 = B.prior_x0 + (size_t)w * B.max_pblk * 9;
     c.nobs_tot = 0;
     __syncthreads();
+    PROF_T0();
     // ---- load the post-solve state and tables
     for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
     for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
@@ -1660,6 +1724,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     __syncthreads();
     int nf0 = 0;  // features starting at frame 0 (they come first)
     for (int e = 0; e < c.nf; e++) nf0 += ids[I_FSTART + e] == 0 ? 1 : 0;
+    PROF(c, 16);
     // ---- phase A: projection factors of the start-0 features || IMU factor 0
     if (wv < MASM) {
       double* stage = lds + L_S + SPP + wv * MXSTG;
@@ -1668,6 +1733,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
     }
     __syncthreads();
+    PROF(c, 17);
     // ---- phase B: per-feature sums, PART gather
     {
       double* W = c.sc + Scratch::W;
@@ -1729,6 +1795,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       }
     }
     __syncthreads();
+    PROF(c, 18);
     // ---- phase D: IMU factor 0
     if (imu0) {
       double* IJ = lds + M_WCH;
@@ -1757,19 +1824,21 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       }
       __syncthreads();
     }
+    PROF(c, 19);
     // ---- phase E: old prior (MarginalizationFactor at the current state)
     if (use_prior) {
       prior_residual_dev(c, lds + L_X);
       const int* pidx = ids + I_PIDX;
+      double* HPm = c.sc + Scratch::HP;
+      prior_jtj_mfma(c.pJ, c.ldp, c.pn, HPm);
+      __syncthreads();
       for (int idx = t; idx < c.pn * (c.pn + 1) / 2; idx += NT) {
         int pp = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
         while ((pp + 1) * (pp + 2) / 2 <= idx) pp++;
         while (pp * (pp + 1) / 2 > idx) pp--;
         const int q = idx - pp * (pp + 1) / 2;
-        double sacc = 0;
-        for (int i = 0; i < c.pn; i++) sacc += c.pJ[(size_t)i * c.ldp + pp] * c.pJ[(size_t)i * c.ldp + q];
         const int ip = pidx[pp], iq = pidx[q];
-        lds[L_S + roff(max(ip, iq)) + min(ip, iq)] += sacc;
+        lds[L_S + roff(max(ip, iq)) + min(ip, iq)] += HPm[pp * MAXPRIOR + q];
       }
       if (t < c.pn) {
         double sacc = 0;
@@ -1778,6 +1847,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       }
     }
     __syncthreads();
+    PROF(c, 20);
     // ---- phase F: eliminate the start-0 inverse depths (scalar pivots)
     if (flag == AVM_MARGIN_OLD && nf0 > 0) {
       const double* W = c.sc + Scratch::W;
@@ -1820,6 +1890,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       if (t < 72) lds[M_G + mg_col(t)] -= accR;
     }
     __syncthreads();
+    PROF(c, 21);
     // ---- phase G: dropped / kept variable lists (ints at I_FSTART.. are dead now)
     int* midx = ids + 0;       // [<=16]
     int* kidx = ids + 16;      // [<=96]
@@ -1863,7 +1934,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     double* EA = lds + M_WCH;            // Amm 16 x 16, then its eigenvectors next to it
     double* EV = EA + 256;               // 16 x 16
     double* EB = EV + 256;               // Arm : n x 16   (n <= 96 -> 1536)  (M_WCH region holds 1920+; spills into the dead L_G.. vectors)
-    double* ROT = lds + L_HEE;           // 4 * 64 rotation records (hee / dxp / rp are dead by now: 344 doubles)
+    double* ROT = lds + L_HEE;           // rotation records (hee / dxp / rp are dead by now: 344 doubles >= 4 * 64 + ints)
     double* BV = lds + L_FR + 198;       // b_m (16), b_r (96): the candidate-state frame slot is unused here
     for (int idx = t; idx < 16 * 16; idx += NT) {
       const int i = idx / 16, j = idx % 16;
@@ -1880,7 +1951,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     double* GA = c.sc + Scratch::HP;  // n x n dense (<= 96 x 96)
     for (int idx = t; idx < n * n; idx += NT) GA[idx] = Sget(kidx[idx / n], kidx[idx % n]);
     __syncthreads();
+    PROF(c, 22);
     jacobi_eig_lds<NT>(EA, EV, 16, 16, ROT, lds + L_RED);
+    PROF(c, 23);
     // Amm^+ = V diag(1/lambda > eps) V^T  -> EA (reuse) ; T = Arm Amm^+ ; A' = Arr - T Amr ; b' = br - T bm
     {
       double lam_inv[16];
@@ -1918,7 +1991,10 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     __syncthreads();
     for (int idx = t; idx < n * n; idx += NT) Ad[idx] = GA[idx];
     __syncthreads();
-    jacobi_eig_lds<NT>(Ad, Vd, n, n, ROT, lds + L_RED);
+    PROF(c, 24);
+    const int nsweep = jacobi_eig_lds<NT>(Ad, Vd, n, n, ROT, lds + L_RED);
+    PROF(c, 25);
+    if (c.prof && t == 0) c.prof[29] += nsweep;
     // linearized_jacobians = diag(sqrt(S)) V^T ; linearized_residuals = diag(1/sqrt(S)) V^T b
     {
       double* oJ = PO.J + (size_t)w * PO.max_prior * PO.max_prior;
@@ -1954,6 +2030,8 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       if (t == 0) PO.n[w] = n, PO.nblk[w] = nblk;
     }
     __syncthreads();
+    PROF(c, 26);
+    if (c.prof && t == 0) c.prof[30] += 1;
   }
 }
 

@@ -10,7 +10,8 @@ est_m = importlib.import_module(pkg + ".estimator")
 NAMES = ["A: frames(MFMA)+imu raw", "B: feat sums+diag", "prior resid", "zero S rows", "-", "-", "-", "D: imu sqrt+JtJ", "E: prior + cost", "load+Hp", "scale/gmax", "schur(MFMA)", "cholesky", "tri solve", "backsub", "cand eval"]
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 tracks = sys.argv[2] if len(sys.argv) > 2 else "dense"
-opt = abi.default_options(); opt.marginalization_flag = abi.MARGIN_NONE
+opt = abi.default_options()
+if len(sys.argv) > 3 and sys.argv[3] == "nomarg": opt.marginalization_flag = abi.MARGIN_NONE
 E = est_m.Estimator(options=opt)
 base = synth.make_windows(min(nw, 32), tracks=tracks)
 w = synth.tile_windows(base, nw)
@@ -24,3 +25,8 @@ tot = sum(prof[:16]); n = prof[31]
 print(f"windows {nw} tracks {tracks}: kernel {ms:.3f} ms, {nw/ms*1e3:.0f} solves/s; per-window cycles total {tot/n:.0f}")
 for k, nm in enumerate(NAMES):
     print(f"  {nm:22s} {prof[k]/n:12.0f} cyc/window  {100*prof[k]/tot:5.1f}%")
+MN = ["load", "A: frames+imu0", "B: feat sums/PART", "D: imu0 JtJ", "E: prior", "F: feature schur", "G+extract", "eig16", "pinv+schur15", "eig n", "write out"]
+if prof[30]:
+    mt = sum(prof[16:27]); print(f"marginalize: kernel {E.ctx.kernel_ms('marginalize'):.3f} ms; per-window cycles {mt/prof[30]:.0f}")
+    print('  jacobi sweeps per window', prof[29]/prof[30])
+    for k, nm in enumerate(MN): print(f"  {nm:22s} {prof[16+k]/prof[30]:12.0f} cyc/window  {100*prof[16+k]/mt:5.1f}%")

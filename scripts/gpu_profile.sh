@@ -1,0 +1,16 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for profiles/ (run on the GPU box through gpurun).
+# Counter passes are separate runs with --kernel-trace only (no sys/hip/hsa trace domains).
+set -x
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$1
+mkdir -p $OUT
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fsel-problems 4"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- $CMD > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- $CMD > /dev/null 2> $OUT/pmc_write.log
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY -d $OUT/pmc_sq -o run -- $CMD > /dev/null 2> $OUT/pmc_sq.log
+python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.log
+find $OUT -name "*.csv" | head -50
+ls -la $OUT/*
