@@ -25,14 +25,20 @@
 
 namespace avm {
 
+extern __shared__ __attribute__((aligned(16))) char avm_smem[];
+
 namespace {
+
+// the workgroup's dynamic LDS, always reached through the shared symbol (never through a generic pointer that
+// crosses a function boundary), so the compiler keeps ds_* addressing inside outlined functions
+AVM_DEV double* LDS() { return reinterpret_cast<double*>(avm_smem); }
 
 #define AVM_NOINL __device__ __noinline__
 #define PROF_T0() long long pt__ = clock64()
 #define PROF(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pt__; pt__ = n__; } } while (0)
 
 constexpr int NT = 512;          // threads per workgroup (8 wavefronts)
-constexpr int SROWS = 13778;     // padded packed lower triangle of a 165x165 matrix
+constexpr int SROWS = 13944;     // padded packed lower triangle of a 165x165 matrix + one augmented row (the RHS): roff(166)
 constexpr int VEC = 320;         // padded NCOL
 constexpr int XN = 328;          // pose 77 | speedbias 99 | inv depth 150 (+2 pad)
 constexpr int XSB = 77, XLAM = 176;
@@ -45,6 +51,7 @@ constexpr int WCH = 32;            // features per Schur staging chunk (x 80 pad
 constexpr int WLD = 80;
 constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r | start-frame tag
 constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows
+constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diagonal block); trailing tiles stay 16x16
 constexpr int ASM_WAVES = 7;       // wavefronts assembling projection factors (the 8th does the IMU factors)
 constexpr int L_S = 0;
 constexpr int L_Y = L_S + SROWS;   // Gauss-Newton solution y of (H + mu D^2) y = g
@@ -279,8 +286,6 @@ AVM_DEV void prior_block_dx(int kind, const double* xb, const double* x0, double
 
 struct WinCtx {
   long long* prof;
-  double* lds;
-  int* ids;
   double* sc;   // global scratch slot
   int32_t* osf; // observation slot -> feature
   int32_t* cov; // [11][150] features observed in frame b, in feature order
@@ -293,7 +298,9 @@ struct WinCtx {
 };
 
 // frames: R_f and A_f = ric^T R_f^T for state vector xs into frame slot `which`
-AVM_DEV void build_frames(double* lds, const double* xs, int which) {
+AVM_DEV void build_frames(int xs_off, int which) {
+  double* lds = LDS();
+  const double* xs = lds + xs_off;
   const int t = threadIdx.x;
   double* R = lds + L_FR + which * 198;
   double* A = R + 99;
@@ -309,11 +316,14 @@ AVM_DEV void build_frames(double* lds, const double* xs, int which) {
 }
 
 // prior residual r_p = r0 + J0 * dx(xs) into lds[L_RP]; returns (to all threads) nothing; needs syncs by caller
-AVM_DEV void prior_residual_dev(const WinCtx& c, const double* xs) {
-  double* lds = c.lds;
+AVM_NOINL void prior_residual_dev(const WinCtx& c, int xs_off) {
+  double* lds = LDS();
+  const double* xs = lds + xs_off;
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  (void)ids;
   const int t = threadIdx.x;
   if (t < c.pnblk) {
-    const int kind = c.ids[I_PBLK + t * 3], fr = c.ids[I_PBLK + t * 3 + 1], off = c.ids[I_PBLK + t * 3 + 2];
+    const int kind = ids[I_PBLK + t * 3], fr = ids[I_PBLK + t * 3 + 1], off = ids[I_PBLK + t * 3 + 2];
     // ex_pose is constant in the solve; its current value sits behind ric/tic
     const double* xb = kind == AVM_BLK_POSE ? xs + fr * 7 : (kind == AVM_BLK_SPEEDBIAS ? xs + XSB + fr * 9 : lds + L_RIC + 12);
     double dx[9];
@@ -335,8 +345,11 @@ AVM_DEV void prior_residual_dev(const WinCtx& c, const double* xs) {
 }
 
 // residual-only cost at state xs (frames slot `which` must be built). Uses lds[L_S..] as IMU staging.
-AVM_DEV double eval_cost(const WinCtx& c, const avm_options& o, const double* xs, int which) {
-  double* lds = c.lds;
+AVM_NOINL double eval_cost(const WinCtx& c, const avm_options& o, int xs_off, int which) {
+  double* lds = LDS();
+  const double* xs = lds + xs_off;
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  (void)ids;
   const int t = threadIdx.x;
   Frames fr{lds + L_FR + which * 198, lds + L_FR + which * 198 + 99};
   const double sqi = o.focal_length / 1.5;
@@ -351,9 +364,9 @@ AVM_DEV double eval_cost(const WinCtx& c, const avm_options& o, const double* xs
   }
   for (int s = t; s < c.nobs_tot; s += NT) {
     const int e = c.osf[s];
-    const int s0 = c.ids[I_FOBS + e];
+    const int s0 = ids[I_FOBS + e];
     if (s == s0) continue;
-    const int fa = c.ids[I_FSTART + e], fb = fa + (s - s0);
+    const int fa = ids[I_FSTART + e], fb = fa + (s - s0);
     double r[2];
     acc += proj_eval<false>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1],
                             xs[XLAM + e], fa, fb, sqi, o.cauchy_a, true, r, nullptr, nullptr, nullptr);
@@ -368,14 +381,14 @@ AVM_DEV double eval_cost(const WinCtx& c, const avm_options& o, const double* xs
     }
   }
   if (c.pn > 0) {
-    prior_residual_dev(c, xs);
+    prior_residual_dev(c, xs_off);
     if (t < c.pn) acc += 0.5 * lds[L_RP + t] * lds[L_RP + t];
   }
   return block_sum<NT>(acc, lds + L_RED);
 }
 
 // HP[p][q] = sum_i J0[i][p] J0[i][q] (lower tiles; mirrored) on the matrix cores: 16x16 tiles, K = prior rows.
-AVM_DEV void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
+AVM_NOINL void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int ntl = (pn + 15) >> 4;
   for (int tile = wv; tile < ntl * (ntl + 1) / 2; tile += NT / 64) {
@@ -409,10 +422,13 @@ AVM_DEV void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
 // are consecutive; the B operand is masked per a-run to keep the (b,a)/(a,a) blocks separate.
 // Blocks (b,b), (b,a) and g_b belong to this frame only and are written straight into LDS; the (a,a)
 // contributions go to PART[b][a] in the scratch slot and are summed in a fixed order afterwards.
-AVM_DEV double frame_task(const WinCtx& c, const avm_options& o, int b, double* stage) {
-  double* lds = c.lds;
+AVM_NOINL double frame_task(const WinCtx& c, const avm_options& o, int b, int stage_off) {
+  double* lds = LDS();
+  double* stage = lds + stage_off;
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  (void)ids;
   const int lane = threadIdx.x & 63;
-  const int ncov = c.ids[I_NCOV + b];
+  const int ncov = ids[I_NCOV + b];
   const int32_t* cov = c.cov + b * MAXE;
   Frames fr{lds + L_FR, lds + L_FR + 99};
   const double* xs = lds + L_X;
@@ -445,8 +461,8 @@ AVM_DEV double frame_task(const WinCtx& c, const avm_options& o, int b, double* 
     const int idx = chunk0 + lane;
     const bool act = idx < ncov;
     const int e = act ? cov[idx] : 0;
-    const int fa = c.ids[I_FSTART + e];
-    const int s0 = c.ids[I_FOBS + e];
+    const int fa = ids[I_FSTART + e];
+    const int s0 = ids[I_FOBS + e];
     const int s = s0 + (b - fa);
     double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0};
 #pragma unroll
@@ -501,20 +517,23 @@ AVM_DEV double frame_task(const WinCtx& c, const avm_options& o, int b, double* 
     if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r];
     if (row < 6 && dcol == 12) lds[L_G + 6 * b + row] = Dtot[r];
   }
-  if (lane == 0) c.ids[I_PMASK + b] = pmask;
+  if (lane == 0) ids[I_PMASK + b] = pmask;
   return cost;
 }
 
 // Full evaluation at lds[L_X]: fills S (unscaled H_ff), W, hee, g (unscaled) and returns the cost.
-AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
-  double* lds = c.lds;
+AVM_NOINL double eval_jac(const WinCtx& c, const avm_options& o) {
+  double* lds = LDS();
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  (void)ids;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const double* xs = lds + L_X;
+  constexpr int xs_off = L_X;
   PROF_T0();
-  build_frames(lds, xs, 0);
+  build_frames(L_X, 0);
   for (int i = t; i < SPP; i += NT) lds[L_S + i] = 0.0;
   for (int i = t; i < VEC; i += NT) lds[L_G + i] = 0.0;
-  if (t < NFR) c.ids[I_PMASK + t] = 0;
+  if (t < NFR) ids[I_PMASK + t] = 0;
   double* IJR = c.sc + Scratch::IJRAW;
   for (int i = t; i < 10 * 465; i += NT) IJR[i] = 0.0;
   __syncthreads();
@@ -522,9 +541,8 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   double acc = 0;
   // ---- phase A: projection factors (waves 0..6, one frame at a time) || IMU raw Jacobians (wave 7)
   if (wv < ASM_WAVES) {
-    double* stage = lds + L_S + SPP + wv * XSTG;
     for (int b = 1; b < NFR; b++)
-      if (c.ids[I_FRW + b] == wv) acc += frame_task(c, o, b, stage);
+      if (ids[I_FRW + b] == wv) acc += frame_task(c, o, b, L_S + SPP + wv * XSTG);
   } else if (lane < 10) {
     const int i = lane;
     if (c.psum[i] <= o.max_sum_dt)
@@ -536,19 +554,27 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   {
     double* W = c.sc + Scratch::W;
     const double* PF = c.sc + Scratch::PF;
+    // sums over the feature's own factors: one thread per (feature, quantity); zero the uncovered W blocks
+    for (int idx = t; idx < c.nf * 8; idx += NT) {
+      const int e = idx >> 3, q = idx & 7;
+      const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e], s0 = ids[I_FOBS + e];
+      const double* P = PF + q * MAXOBS + s0;
+      double s0a = 0, s1a = 0;
+      int k = 1;
+      for (; k + 1 < no; k += 2) s0a += P[k], s1a += P[k + 1];
+      if (k < no) s0a += P[k];
+      const double sacc = s0a + s1a;
+      if (q < 6)
+        W[(size_t)e * NPOSE + 6 * a + q] = sacc;
+      else if (q == 6)
+        lds[L_HEE + e] = sacc;
+      else
+        lds[L_G + NF + e] = sacc;
+    }
     for (int idx = t; idx < c.nf * NFR; idx += NT) {
-      const int e = idx / NFR, f = idx % NFR;
-      const int a = c.ids[I_FSTART + e], no = c.ids[I_FNOBS + e], s0 = c.ids[I_FOBS + e];
-      if (f == a) {
-        double sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 1; k < no; k++)
-#pragma unroll
-          for (int q = 0; q < 8; q++) sacc[q] += PF[q * MAXOBS + s0 + k];
-#pragma unroll
-        for (int q = 0; q < 6; q++) W[(size_t)e * NPOSE + 6 * a + q] = sacc[q];
-        lds[L_HEE + e] = sacc[6];
-        lds[L_G + NF + e] = sacc[7];
-      } else if (!(f > a && f < a + no)) {
+      const int e = idx / NFR, f = idx - e * NFR;
+      const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
+      if (f < a || f >= a + no) {
 #pragma unroll
         for (int q = 0; q < 6; q++) W[(size_t)e * NPOSE + 6 * f + q] = 0.0;
       }
@@ -558,7 +584,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
       const int f = t / 27, q = t % 27;
       double sacc = 0;
       for (int b = f + 1; b < NFR; b++)
-        if (c.ids[I_PMASK + b] & (1 << f)) sacc += PART[((size_t)b * NFR + f) * 27 + q];
+        if (ids[I_PMASK + b] & (1 << f)) sacc += PART[((size_t)b * NFR + f) * 27 + q];
       if (q < 21) {
         int i = 0;
         while ((i + 1) * (i + 2) / 2 <= q) i++;
@@ -572,7 +598,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   PROF(c, 1);
   // prior residual (uses L_DXP/L_RP; includes syncs)
   if (c.pn > 0) {
-    prior_residual_dev(c, xs);
+    prior_residual_dev(c, xs_off);
     if (t < c.pn) acc += 0.5 * lds[L_RP + t] * lds[L_RP + t];
   } else {
     __syncthreads();
@@ -629,7 +655,7 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
   // ---- phase E: prior  H += Hp (mapped), g += J0^T r_p
   if (c.pn > 0) {
     const double* HP = c.sc + Scratch::HP;
-    const int* pidx = c.ids + I_PIDX;
+    const int* pidx = ids + I_PIDX;
     for (int idx = t; idx < c.pn * (c.pn + 1) / 2; idx += NT) {
       int p = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
       while ((p + 1) * (p + 2) / 2 <= idx) p++;
@@ -663,8 +689,10 @@ AVM_DEV double eval_jac(const WinCtx& c, const avm_options& o) {
 // || J' u ||^2 with J' the Jacobi-scaled Jacobian, u in lds[L_ST] (scaled space), at state lds[L_X].
 // Only needed when the Gauss-Newton step leaves the trust region (Cauchy point), so the factors are
 // simply re-evaluated here instead of keeping their Jacobians around.
-AVM_DEV double jac_times_vec_sq(const WinCtx& c, const avm_options& o) {
-  double* lds = c.lds;
+AVM_NOINL double jac_times_vec_sq(const WinCtx& c, const avm_options& o) {
+  double* lds = LDS();
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  (void)ids;
   const int t = threadIdx.x;
   const double* u = lds + L_ST;
   const double* scl = lds + L_SC;
@@ -674,9 +702,9 @@ AVM_DEV double jac_times_vec_sq(const WinCtx& c, const avm_options& o) {
   double acc = 0;
   for (int s = t; s < c.nobs_tot; s += NT) {
     const int e = c.osf[s];
-    const int s0 = c.ids[I_FOBS + e];
+    const int s0 = ids[I_FOBS + e];
     if (s == s0) continue;
-    const int fa = c.ids[I_FSTART + e], fb = fa + (s - s0);
+    const int fa = ids[I_FSTART + e], fb = fa + (s - s0);
     double r[2], Ji[12], Jj[12], Je[2];
     proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1], xs[XLAM + e],
                     fa, fb, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
@@ -710,7 +738,7 @@ AVM_DEV double jac_times_vec_sq(const WinCtx& c, const avm_options& o) {
   }
   if (c.pn > 0 && t >= 192 && t < 192 + c.pn) {
     const int i = t - 192;
-    const int* pidx = c.ids + I_PIDX;
+    const int* pidx = ids + I_PIDX;
     double y = 0;
     for (int k = 0; k < c.pn; k++)
       if (pidx[k] >= 0) y += c.pJ[(size_t)i * c.ldp + k] * (u[pidx[k]] * scl[pidx[k]]);
@@ -726,143 +754,225 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
+// two independent tiles at once (same panel): interleaved by the compiler
+AVM_DEV void chol_trailing_tile2(int c0, int c1, int ti0, int tj0, int ti1, int tj1) {
+  constexpr int NR = NF + 1;
+  double* S = LDS() + L_S;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int ra0 = 16 * ti0 + lr, rb0 = 16 * tj0 + lr, ra1 = 16 * ti1 + lr, rb1 = 16 * tj1 + lr;
+  const double* pa0 = S + roff(min(ra0, NR - 1)) + c0 + lk;
+  const double* pb0 = S + roff(min(rb0, NF - 1)) + c0 + lk;
+  const double* pa1 = S + roff(min(ra1, NR - 1)) + c0 + lk;
+  const double* pb1 = S + roff(min(rb1, NF - 1)) + c0 + lk;
+  const bool va0 = ra0 < NR && ra0 >= c1, vb0 = rb0 < NF && rb0 >= c1, va1 = ra1 < NR && ra1 >= c1, vb1 = rb1 < NF && rb1 >= c1;
+  double x0[CNB / 4], y0[CNB / 4], x1[CNB / 4], y1[CNB / 4];
+#pragma unroll
+  for (int m = 0; m < CNB / 4; m++) {
+    x0[m] = va0 ? pa0[4 * m] : 0.0, y0[m] = vb0 ? pb0[4 * m] : 0.0;
+    x1[m] = va1 ? pa1[4 * m] : 0.0, y1[m] = vb1 ? pb1[4 * m] : 0.0;
+  }
+  // pre-load the destination entries so the read latency hides under the MFMAs
+  double d0[4], d1[4];
+  int o0[4], o1[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi0 = 16 * ti0 + lk + 4 * r, gj0 = 16 * tj0 + lr, gi1 = 16 * ti1 + lk + 4 * r, gj1 = 16 * tj1 + lr;
+    o0[r] = (gi0 < NR && gi0 >= c1 && gj0 < NF && gj0 >= c1 && gj0 <= gi0) ? roff(gi0) + gj0 : -1;
+    o1[r] = (gi1 < NR && gi1 >= c1 && gj1 < NF && gj1 >= c1 && gj1 <= gi1) ? roff(gi1) + gj1 : -1;
+    d0[r] = o0[r] >= 0 ? S[o0[r]] : 0.0;
+    d1[r] = o1[r] >= 0 ? S[o1[r]] : 0.0;
+  }
+  d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < CNB / 4; m++) {
+    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[m], y0[m], D0, 0, 0, 0);
+    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[m], y1[m], D1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (o0[r] >= 0) S[o0[r]] = d0[r] - D0[r];
+    if (o1[r] >= 0) S[o1[r]] = d1[r] - D1[r];
+  }
+}
+
 // In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
+// The right-hand side rides along as row NF of the packed storage, so the forward substitution
+// L z = b happens as part of the panel solves / trailing updates (z ends up in that row).
 // Right-looking, 16-column panels:
 //   (1) the 16x16 diagonal block is factored in the registers of wavefront 0 (lane = row, pivots
-//       broadcast with v_readlane), reciprocal pivots go to lds[L_ST] for the later solves;
-//   (2) the rows below are solved against that triangle, one thread per row;
+//       broadcast with v_readlane, one rsqrt per pivot), reciprocal pivots go to lds[L_ST];
+//   (2) the rows below (and the RHS row) are solved against that triangle, one thread per row;
 //   (3) the trailing matrix is updated tile by tile with v_mfma_f64_16x16x4 (K = 16 -> 4 MFMAs per tile).
-AVM_DEV bool cholesky_lds(double* lds) {
+// raw v_rsq_f64 + two Newton steps (the library rsqrt spends ~3x as long in range handling we do not need:
+// pivots of an SPD matrix are normal positive numbers)
+AVM_DEV double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  return y;
+}
+
+// factor the nb x nb diagonal block at c0 in the registers of the calling wavefront (lane = row)
+AVM_NOINL void chol_diag_block(int c0, int nb) {
+  constexpr int NB = CNB;
+  double* S = LDS() + L_S;
+  double* dinv = LDS() + L_ST;
+  const int r = threadIdx.x & 63;
+  __builtin_amdgcn_s_setprio(3);  // this wavefront is the critical path of the factorization: win issue arbitration
+  double a[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) a[k] = (r < nb && k <= r) ? S[roff(c0 + r) + c0 + k] : (k == r ? 1.0 : 0.0);
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const double djj = readlane_d(a[j], j);
+    if (j < nb && !(djj > 0.0)) bad = true;
+    const double inv = fast_rsqrt(djj);
+    const double lij = (r == j) ? djj * inv : a[j] * inv;
+    a[j] = lij;
+#pragma unroll
+    for (int k = j + 1; k < NB; k++) {
+      const double lkj = readlane_d(lij, k);
+      a[k] -= lij * lkj;
+    }
+    if (r == j && j < nb) dinv[c0 + j] = inv;
+  }
+  if (r < nb) {
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+      if (k <= r) S[roff(c0 + r) + c0 + k] = a[k];
+  }
+  if (bad && r == 0) reinterpret_cast<int*>(LDS() + L_INT)[I_FAIL] = 1;
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// one 16x16 tile (ti, tj) of the trailing update with panel columns [c0, c0+CNB); only entries at or
+// beyond row/column c1 (the first trailing index) are touched
+AVM_DEV void chol_trailing_tile(int c0, int c1, int ti, int tj) {
+  constexpr int NR = NF + 1;
+  double* S = LDS() + L_S;
+  const int lane = threadIdx.x & 63;
+  const int ri = 16 * ti + (lane & 15), rj = 16 * tj + (lane & 15);
+  const double* pa = S + roff(min(ri, NR - 1)) + c0 + (lane >> 4);
+  const double* pb = S + roff(min(rj, NF - 1)) + c0 + (lane >> 4);
+  const bool va = ri < NR && ri >= c1, vb = rj < NF && rj >= c1;
+  d4 D = {0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < CNB / 4; m++) {
+    const double aop = va ? pa[4 * m] : 0.0;
+    const double bop = vb ? pb[4 * m] : 0.0;
+    D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+  }
+  const int gj = 16 * tj + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi = 16 * ti + (lane >> 4) + 4 * r;
+    if (gi < NR && gi >= c1 && gj < NF && gj >= c1 && gj <= gi) S[roff(gi) + gj] -= D[r];
+  }
+}
+
+// In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
+// The right-hand side rides along as row NF of the packed storage, so the forward substitution
+// L z = b happens as part of the panel solves / trailing updates (z ends up in that row).
+// Right-looking, 8-column panels, with look-ahead:
+//   per panel:  (a) rows below the diagonal block (and the RHS row) are solved against its triangle,
+//                   one thread per row;
+//               (b) trailing update in 16x16 tiles on v_mfma_f64_16x16x4 (K = 8 -> 2 MFMAs per tile);
+//                   wavefront 0 takes the tile holding the next diagonal block first and immediately
+//                   factors that block in its registers (lane = row, pivots broadcast with v_readlane,
+//                   v_rsq_f64 + Newton) while the other wavefronts finish the remaining tiles.
+AVM_NOINL bool cholesky_lds(long long* prof) {
+  struct { long long* prof; } c{prof};
+  double* lds = LDS();
   double* S = lds + L_S;
   double* dinv = lds + L_ST;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  constexpr int NB = 16;
-  constexpr int NPAN = (NF + NB - 1) / NB;  // 11
-  volatile int& s_fail = reinterpret_cast<int*>(lds + L_INT)[I_FAIL];
-  if (t == 0) s_fail = 0;
+  const int t = threadIdx.x, wv = t >> 6;
+  constexpr int NB = CNB;
+  constexpr int NR = NF + 1;  // rows incl. the augmented RHS row
+  int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
+  if (t == 0) *s_fail = 0;
   __syncthreads();
-  for (int p = 0; p < NPAN; p++) {
-    const int c0 = p * NB, nb = min(NB, NF - c0);
-    // (1) diagonal block
-    if (wv == 0) {
-      const int r = lane;
-      double a[NB];
-#pragma unroll
-      for (int k = 0; k < NB; k++) a[k] = (r < nb && k <= r) ? S[roff(c0 + r) + c0 + k] : (k == r ? 1.0 : 0.0);
-      bool bad = false;
-#pragma unroll
-      for (int j = 0; j < NB; j++) {
-        const double djj = readlane_d(a[j], j);
-        if (j < nb && !(djj > 0.0)) bad = true;
-        const double d = sqrt(djj);
-        const double inv = 1.0 / d;
-        const double lij = (r == j) ? d : a[j] * inv;
-        a[j] = lij;
-#pragma unroll
-        for (int k = j + 1; k < NB; k++) {
-          const double lkj = readlane_d(lij, k);
-          a[k] -= lij * lkj;
-        }
-        if (r == j && j < nb) dinv[c0 + j] = inv;
-      }
-      if (r < nb) {
-#pragma unroll
-        for (int k = 0; k < NB; k++)
-          if (k <= r) S[roff(c0 + r) + c0 + k] = a[k];
-      }
-      if (bad && lane == 0) s_fail = 1;
-    }
-    __syncthreads();
-    if (s_fail) return false;
-    if (c0 + nb >= NF) break;
-    // (2) panel solve: x_j = (A[i][c0+j] - sum_{l<j} x_l L[c0+j][c0+l]) / L[c0+j][c0+j]
-    for (int i = c0 + nb + t; i < NF; i += NT) {
+  PROF_T0();
+  if (wv == 0) chol_diag_block(0, NB);
+  __syncthreads();
+  PROF(c, 4);
+  for (int c0 = 0; c0 < NF; c0 += NB) {
+    const int nb = min(NB, NF - c0), c1 = c0 + nb;
+    if (*s_fail) return false;
+    // (a) panel solve: x_j = (A[i][c0+j] - sum_{l<j} x_l L[c0+j][c0+l]) / L[c0+j][c0+j] ; rows below + the RHS row
+    for (int i = c1 + t; i < NR; i += NT) {
       double* ri = S + roff(i) + c0;
       double x[NB];
 #pragma unroll
-      for (int j = 0; j < NB; j++) x[j] = ri[j];
+      for (int j = 0; j < NB; j++) x[j] = j < nb ? ri[j] : 0.0;
 #pragma unroll
       for (int j = 0; j < NB; j++) {
-        const double* lj = S + roff(c0 + j) + c0;
-        double v = x[j];
+        if (j < nb) {
+          const double* lj = S + roff(c0 + j) + c0;
+          double v = x[j];
 #pragma unroll
-        for (int l = 0; l < j; l++) v -= x[l] * lj[l];
-        x[j] = v * dinv[c0 + j];
+          for (int l = 0; l < j; l++) v -= x[l] * lj[l];
+          x[j] = v * dinv[c0 + j];
+        }
       }
 #pragma unroll
-      for (int j = 0; j < NB; j++) ri[j] = x[j];
+      for (int j = 0; j < NB; j++)
+        if (j < nb) ri[j] = x[j];
     }
     __syncthreads();
-    // (3) trailing update on the matrix cores
+    PROF(c, 5);
+    if (c1 >= NF) break;
+    // (b) trailing update + look-ahead factorization of the next diagonal block
     {
-      const int nt = NPAN - 1 - p;           // tile rows/cols left: tile indices p+1 .. NPAN-1
+      const int tm = c1 >> 4;            // first tile row/col with trailing entries
+      const int nt = 11 - tm;            // tile indices tm .. 10 (row 165 = RHS lives in tile row 10)
       const int ntile = nt * (nt + 1) / 2;
-      for (int tile = wv; tile < ntile; tile += NT / 64) {
-        int a_ = 0;
-        while ((a_ + 1) * (a_ + 2) / 2 <= tile) a_++;
-        const int ti = p + 1 + a_, tj = p + 1 + (tile - a_ * (a_ + 1) / 2);
-        const int ri = NB * ti + (lane & 15), rj = NB * tj + (lane & 15);
-        const double* pa = S + roff(min(ri, NF - 1)) + c0 + (lane >> 4);
-        const double* pb = S + roff(min(rj, NF - 1)) + c0 + (lane >> 4);
-        const bool va = ri < NF, vb = rj < NF;
-        d4 D = {0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < NB / 4; m++) {
-          const double aop = va ? pa[4 * m] : 0.0;
-          const double bop = vb ? pb[4 * m] : 0.0;
-          D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
+      if (wv == 0) {
+        const long long q0 = clock64();
+        chol_trailing_tile(c0, c1, tm, tm);
+        wave_lds_sync();
+        chol_diag_block(c1, min(NB, NF - c1));
+        if (c.prof && t == 0) c.prof[28] += clock64() - q0;
+      } else {
+        const long long q0 = clock64();
+        // tiles 1 .. ntile-1 over wavefronts 1..7 (tile 0 = (tm,tm) belongs to wavefront 0), two tiles in flight
+        // per wavefront so the LDS latencies and the MFMA chains of the pair overlap
+        constexpr int NW = NT / 64 - 1;
+        for (int tile = wv; tile < ntile; tile += 2 * NW) {
+          int a0 = 0;
+          while ((a0 + 1) * (a0 + 2) / 2 <= tile) a0++;
+          const int b0 = tile - a0 * (a0 + 1) / 2;
+          const int tile1 = tile + NW;
+          if (tile1 < ntile) {
+            int a1 = a0;
+            while ((a1 + 1) * (a1 + 2) / 2 <= tile1) a1++;
+            const int b1 = tile1 - a1 * (a1 + 1) / 2;
+            chol_trailing_tile2(c0, c1, tm + a0, tm + b0, tm + a1, tm + b1);
+          } else {
+            chol_trailing_tile(c0, c1, tm + a0, tm + b0);
+          }
         }
-        const int gj = NB * tj + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int gi = NB * ti + (lane >> 4) + 4 * r;
-          if (gi < NF && gj <= gi) S[roff(gi) + gj] -= D[r];
-        }
+        if (c.prof && t == 64) c.prof[27] += clock64() - q0;
       }
     }
     __syncthreads();
+    PROF(c, 6);
   }
   return true;
 }
 
-// Solve L L^T z = b in place on lds[vec..vec+NF) with the factor in lds[L_S] and 1/L_jj in lds[L_ST].
-// Blocks of 16: the triangle is solved by 16 lanes of wavefront 0 (values exchanged with v_readlane),
-// then every thread applies the finished block to one remaining row.
-AVM_DEV void chol_solve_lds(double* lds, int vec) {
+// Backward substitution L^T x = z with z in the augmented row of lds[L_S] (left there by cholesky_lds),
+// result to lds[vec..vec+NF).  Blocks of 16: the triangle is solved by 16 lanes of wavefront 0
+// (values exchanged with v_readlane), then every thread applies the finished block to one remaining row.
+AVM_NOINL void chol_solve_lds(int vec) {
+  double* lds = LDS();
   double* S = lds + L_S;
   const double* dinv = lds + L_ST;
   double* b = lds + vec;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   constexpr int NB = 16;
-  // forward: L z = b
-  for (int c0 = 0; c0 < NF; c0 += NB) {
-    const int nb = min(NB, NF - c0);
-    if (wv == 0) {
-      const int r = lane;
-      double row[NB];
-#pragma unroll
-      for (int l = 0; l < NB; l++) row[l] = (r < nb && l < r) ? S[roff(c0 + r) + c0 + l] : 0.0;
-      double bv = r < nb ? b[c0 + r] : 0.0;
-      const double di = r < nb ? dinv[c0 + r] : 1.0;
-#pragma unroll
-      for (int jj = 0; jj < NB; jj++) {
-        const double zj = readlane_d(bv * di, jj);
-        if (r > jj) bv -= row[jj] * zj;
-        if (r == jj) bv = zj;
-      }
-      if (r < nb) b[c0 + r] = bv;
-    }
-    __syncthreads();
-    for (int i = c0 + nb + t; i < NF; i += NT) {
-      const double* ri = S + roff(i) + c0;
-      double v = b[i];
-#pragma unroll
-      for (int l = 0; l < NB; l++) v -= ri[l] * b[c0 + l];
-      b[i] = v;
-    }
-    __syncthreads();
-  }
-  // backward: L^T x = z
+  for (int i = t; i < NF; i += NT) b[i] = S[roff(NF) + i];
+  __syncthreads();
   for (int c1 = NF; c1 > 0; c1 = ((c1 - 1) / NB) * NB) {
     const int c0 = ((c1 - 1) / NB) * NB, nb = c1 - c0;
     if (wv == 0) {
@@ -891,8 +1001,121 @@ AVM_DEV void chol_solve_lds(double* lds, int vec) {
   }
 }
 
+// Schur complement on the inverse depths, then the right-hand side into the augmented row:
+//   S_pp -= W^T (hee + mu D_e^2)^-1 W ,  rhs = g_f - W^T (hee + mu D_e^2)^-1 g_e
+AVM_NOINL void schur_reduce(const WinCtx& c, double mu) {
+  double* lds = LDS();
+  const int t = threadIdx.x;
+    // Schur complement on the inverse depths: S_pp -= W^T (hee + mu D_e^2)^-1 W ; rhs
+    if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
+    for (int i = t; i < NF; i += NT) lds[L_S + roff(NF) + i] = lds[L_G + i];  // RHS rides along as row NF
+    __syncthreads();
+    const double* W = c.sc + Scratch::W;
+    // 1/(hee + mu D_e^2) per feature (L_ST is dead here)
+    if (t < MAXE) lds[L_ST + t] = t < c.nf ? 1.0 / (lds[L_HEE + t] + mu * lds[L_DD + NF + t] * lds[L_DD + NF + t]) : 0.0;
+    // S_pp -= (W diag(1/he))^T W as 16x16 tiles on the matrix cores: 5x5 tile grid over the 66 (padded 80)
+    // pose columns, the 15 lower tiles spread over the 8 wavefronts, K = features in chunks of 32
+    const int wv = t >> 6, lane = t & 63;
+    int tti[2], ttj[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int tile = wv + 8 * q;  // 0..14 valid
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+      tti[q] = tile < 15 ? ti : -1;
+      ttj[q] = tile - ti * (ti + 1) / 2;
+    }
+    d4 Dt[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    double accR = 0;
+    for (int e0 = 0; e0 < c.nf; e0 += WCH) {
+      const int ne = min(WCH, c.nf - e0);
+      __syncthreads();
+      for (int idx = t; idx < WCH * WLD; idx += NT) {
+        const int e = idx / WLD, cc = idx % WLD;
+        lds[L_WCH + idx] = (e < ne && cc < NPOSE) ? W[(size_t)(e0 + e) * NPOSE + cc] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (tti[q] >= 0) {
+#pragma unroll
+          for (int m = 0; m < WCH / 4; m++) {
+            const int er = 4 * m + (lane >> 4);
+            const double* row = lds + L_WCH + er * WLD;
+            const double aop = er < ne ? row[16 * tti[q] + (lane & 15)] * lds[L_ST + e0 + er] : 0.0;
+            const double bop = row[16 * ttj[q] + (lane & 15)];
+            Dt[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, Dt[q], 0, 0, 0);
+          }
+        }
+      }
+      if (t < NPOSE) {
+        double sacc = 0;
+        for (int e = 0; e < ne; e++) sacc += (lds[L_WCH + e * WLD + t] * lds[L_ST + e0 + e]) * lds[L_G + NF + e0 + e];
+        accR += sacc;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (tti[q] >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = 16 * tti[q] + (lane >> 4) + 4 * r, gj = 16 * ttj[q] + (lane & 15);
+          if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= Dt[q][r];
+        }
+      }
+    }
+    if (t < NPOSE) lds[L_S + roff(NF) + t] -= accR;
+    __syncthreads();
+}
+
+// back substitution y_e = (g_e - W_e y_p) / (hee + mu D_e^2): one wavefront per feature; returns 1 if y is not finite
+AVM_NOINL double back_substitute(const WinCtx& c, double mu) {
+  double* lds = LDS();
+  const int t = threadIdx.x;
+  const double* W = c.sc + Scratch::W;
+  const int lane = t & 63, wv = t >> 6;
+  for (int e = wv; e < c.nf; e += NT / 64) {
+    double s = W[(size_t)e * NPOSE + lane] * lds[L_Y + lane];
+    if (lane < NPOSE - 64) s += W[(size_t)e * NPOSE + 64 + lane] * lds[L_Y + 64 + lane];
+    s = wave_sum(s);
+    if (lane == 0) {
+      const double he = lds[L_HEE + e] + mu * lds[L_DD + NF + e] * lds[L_DD + NF + e];
+      lds[L_Y + NF + e] = (lds[L_G + NF + e] - s) / he;
+    }
+  }
+  __syncthreads();
+  double bad = 0;
+  for (int i = t; i < NF + c.nf; i += NT)
+    if (!isfinite(lds[L_Y + i])) bad = 1;
+  return block_max<NT>(bad, lds + L_RED);
+}
+
+// Jacobi column scaling of the assembled system: H' = S H S, W', hee', g'
+AVM_NOINL void scale_system(const WinCtx& c) {
+  double* lds = LDS();
+  const int t = threadIdx.x;
+  const double* scl = lds + L_SC;
+  for (int i2 = t; i2 < NF * 4; i2 += NT) {  // 4 lanes per row, interleaved columns
+    const int i = i2 >> 2, part = i2 & 3;
+    double* ri = lds + L_S + roff(i);
+    const double si = scl[i];
+    for (int j = part; j <= i; j += 4) ri[j] *= si * scl[j];
+  }
+  double* W = c.sc + Scratch::W;
+  for (int e = t >> 6; e < c.nf; e += NT / 64) {  // one wavefront per W row
+    const double se = scl[NF + e];
+    const int lane = t & 63;
+    W[(size_t)e * NPOSE + lane] *= se * scl[lane];
+    if (lane < NPOSE - 64) W[(size_t)e * NPOSE + 64 + lane] *= se * scl[64 + lane];
+  }
+  if (t < c.nf) lds[L_HEE + t] *= scl[NF + t] * scl[NF + t];
+  for (int i = t; i < NF + c.nf; i += NT) lds[L_G + i] *= scl[i];
+  __syncthreads();
+}
+
 // Evaluator::Plus : xc = x (+) (step * scale)
-AVM_DEV void state_plus(double* lds) {
+AVM_DEV void state_plus() {
+  double* lds = LDS();
   const int t = threadIdx.x;
   const double* x = lds + L_X;
   double* xc = lds + L_XC;
@@ -918,8 +1141,7 @@ AVM_DEV void state_plus(double* lds) {
 }  // namespace
 
 __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* lds = reinterpret_cast<double*>(smem_raw);
+  double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
   const avm_options& o = A.opt;
@@ -927,7 +1149,6 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
 
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
     WinCtx c;
-    c.lds = lds, c.ids = ids;
     c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
     c.osf = A.iscratch + (size_t)blockIdx.x * ISCRATCH;
     c.cov = c.osf + MAXOBS;
@@ -1071,18 +1292,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       }
       gradient_max_norm = block_max<NT>(gm, lds + L_RED);
       __syncthreads();
-      // scale: H' = S H S, W' , hee', g'
-      const double* scl = lds + L_SC;
-      for (int i = t; i < NF; i += NT) {
-        double* ri = lds + L_S + roff(i);
-        const double si = scl[i];
-        for (int j = 0; j <= i; j++) ri[j] *= si * scl[j];
-      }
-      double* W = c.sc + Scratch::W;
-      for (int idx = t; idx < c.nf * NPOSE; idx += NT) W[idx] *= scl[NF + idx / NPOSE] * scl[idx % NPOSE];
-      if (t < c.nf) lds[L_HEE + t] *= scl[NF + t] * scl[NF + t];
-      for (int i = t; i < NF + c.nf; i += NT) lds[L_G + i] *= scl[i];
-      __syncthreads();
+      scale_system(c);
       PROF(c, 10);
     };
 
@@ -1138,95 +1348,20 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
             rebuilt = true;
           }
           PROF_T0();
-          // Schur complement on the inverse depths: S_pp -= W^T (hee + mu D_e^2)^-1 W ; rhs
-          if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
-          for (int i = t; i < NF; i += NT) lds[L_Y + i] = lds[L_G + i];
-          __syncthreads();
-          const double* W = c.sc + Scratch::W;
-          // 1/(hee + mu D_e^2) per feature (L_ST is dead here)
-          if (t < MAXE) lds[L_ST + t] = t < c.nf ? 1.0 / (lds[L_HEE + t] + mu * lds[L_DD + NF + t] * lds[L_DD + NF + t]) : 0.0;
-          // S_pp -= (W diag(1/he))^T W as 16x16 tiles on the matrix cores: 5x5 tile grid over the 66 (padded 80)
-          // pose columns, the 15 lower tiles spread over the 8 wavefronts, K = features in chunks of 32
-          const int wv = t >> 6, lane = t & 63;
-          int tti[2], ttj[2];
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-            const int tile = wv + 8 * q;  // 0..14 valid
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
-            tti[q] = tile < 15 ? ti : -1;
-            ttj[q] = tile - ti * (ti + 1) / 2;
-          }
-          d4 Dt[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-          double accR = 0;
-          for (int e0 = 0; e0 < c.nf; e0 += WCH) {
-            const int ne = min(WCH, c.nf - e0);
-            __syncthreads();
-            for (int idx = t; idx < WCH * WLD; idx += NT) {
-              const int e = idx / WLD, cc = idx % WLD;
-              lds[L_WCH + idx] = (e < ne && cc < NPOSE) ? W[(size_t)(e0 + e) * NPOSE + cc] : 0.0;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-              if (tti[q] >= 0) {
-#pragma unroll
-                for (int m = 0; m < WCH / 4; m++) {
-                  const int er = 4 * m + (lane >> 4);
-                  const double* row = lds + L_WCH + er * WLD;
-                  const double aop = er < ne ? row[16 * tti[q] + (lane & 15)] * lds[L_ST + e0 + er] : 0.0;
-                  const double bop = row[16 * ttj[q] + (lane & 15)];
-                  Dt[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, Dt[q], 0, 0, 0);
-                }
-              }
-            }
-            if (t < NPOSE) {
-              double sacc = 0;
-              for (int e = 0; e < ne; e++) sacc += (lds[L_WCH + e * WLD + t] * lds[L_ST + e0 + e]) * lds[L_G + NF + e0 + e];
-              accR += sacc;
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-            if (tti[q] >= 0) {
-#pragma unroll
-              for (int r = 0; r < 4; r++) {
-                const int gi = 16 * tti[q] + (lane >> 4) + 4 * r, gj = 16 * ttj[q] + (lane & 15);
-                if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= Dt[q][r];
-              }
-            }
-          }
-          if (t < NPOSE) lds[L_Y + t] -= accR;
-          __syncthreads();
+          schur_reduce(c, mu);
           PROF(c, 11);
-          const bool ok = cholesky_lds(lds);
+          const bool ok = cholesky_lds(c.prof);
           PROF(c, 12);
           if (!ok) {
             mu *= mu_inc;
             rebuilt = false;
             continue;
           }
-          chol_solve_lds(lds, L_Y);
+          chol_solve_lds(L_Y);
           PROF(c, 13);
-          // back substitution y_e = (g_e - W_e y_p) / (hee + mu D_e^2): one wavefront per feature
-          {
-            const int lane = t & 63, wv = t >> 6;
-            for (int e = wv; e < c.nf; e += NT / 64) {
-              double s = W[(size_t)e * NPOSE + lane] * lds[L_Y + lane];
-              if (lane < NPOSE - 64) s += W[(size_t)e * NPOSE + 64 + lane] * lds[L_Y + 64 + lane];
-              s = wave_sum(s);
-              if (lane == 0) {
-                const double he = lds[L_HEE + e] + mu * lds[L_DD + NF + e] * lds[L_DD + NF + e];
-                lds[L_Y + NF + e] = (lds[L_G + NF + e] - s) / he;
-              }
-            }
-          }
-          __syncthreads();
+          const double bad_y = back_substitute(c, mu);
           PROF(c, 14);
-          double bad = 0;
-          for (int i = t; i < NF + c.nf; i += NT)
-            if (!isfinite(lds[L_Y + i])) bad = 1;
-          if (block_max<NT>(bad, lds + L_RED) > 0) {
+          if (bad_y > 0) {
             mu *= mu_inc;
             rebuilt = false;
             continue;
@@ -1308,11 +1443,11 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       }
       // candidate
       PROF_T0();
-      state_plus(lds);
+      state_plus();
       __syncthreads();
-      build_frames(lds, lds + L_XC, 1);
+      build_frames(L_XC, 1);
       __syncthreads();
-      const double cand_cost = eval_cost(c, o, lds + L_XC, 1);
+      const double cand_cost = eval_cost(c, o, L_XC, 1);
       PROF(c, 15);
       double d2 = 0;
       for (int i = t; i < 176 + c.nf; i += NT) {
@@ -1444,18 +1579,21 @@ constexpr int M_GE = M_G + 176;                       // g_e (152)
 constexpr int M_WCH = M_GE + 152;                     // [24][80] Schur staging / IMU factor rows
 constexpr int MWCH = 24;
 static_assert(M_WCH + MWCH * WLD <= L_G, "marg layout");
-static_assert(SPP + MASM * MXSTG <= 13778, "marg staging must not reach the ex_pose rows");
+static_assert(SPP + MASM * MXSTG <= 13778, "marg staging must not reach the ex_pose rows (roff(165))");
 constexpr int PARTW = 126;  // aa 21 | g_a 6 | ex.pose0 36 | ex.ex 21 | g_ex 6 | ex.pose_b 36
 }  // namespace mg
 
 // column of the joint system for W column c (0..71): poses, then ex_pose
 AVM_DEV int mg_col(int c) { return c < NPOSE ? c : mg::MEX0 + (c - NPOSE); }
 
-AVM_DEV void marg_frame_task(const WinCtx& c, const avm_options& o, int b, double* stage) {
+AVM_NOINL void marg_frame_task(const WinCtx& c, const avm_options& o, int b, int stage_off) {
   using namespace mg;
-  double* lds = c.lds;
+  double* lds = LDS();
+  double* stage = lds + stage_off;
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  (void)ids;
   const int lane = threadIdx.x & 63;
-  const int ncov = c.ids[I_NCOV + b];
+  const int ncov = ids[I_NCOV + b];
   const int32_t* cov = c.cov + b * MAXE;
   Frames fr{lds + L_FR, lds + L_FR + 99};
   const double* xs = lds + L_X;
@@ -1470,7 +1608,7 @@ AVM_DEV void marg_frame_task(const WinCtx& c, const avm_options& o, int b, doubl
     const int idx = chunk0 + lane;
     const bool act = idx < ncov;
     const int e = act ? cov[idx] : 0;
-    const int s0 = c.ids[I_FOBS + e];
+    const int s0 = ids[I_FOBS + e];
     const int s = s0 + b;
     double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0}, Jx[12];
 #pragma unroll
@@ -1529,39 +1667,43 @@ AVM_DEV void marg_frame_task(const WinCtx& c, const avm_options& o, int b, doubl
 }
 
 // Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, leading dimension ld) in LDS.
-// On return the diagonal of A holds the eigenvalues and the columns of V the eigenvectors (A0 = V diag V^T).
+// Only the LOWER triangle of A is read and written.  On return the diagonal of A holds the eigenvalues and
+// the columns of V the eigenvectors (A0 = V diag V^T).
 // Round-robin pairing: n/2 disjoint rotations per step.  A <- J^T A J is applied as independent 2x2 blocks
-// (rows of pair k1, columns of pair k2, only k1 >= k2, mirrored), V <- V J in the same pass: two barriers per step.
-// rot: 4 doubles per pair (c, s) + ints (p, q) packed behind them; needs 6 * 64 doubles.
+// (rows of pair k1, columns of pair k2, k1 >= k2); V <- V J with threads grouped by pair so the rotation is
+// loaded once for several rows.  The step is LDS-instruction bound, so every access is kept to the minimum:
+// rotation table read as double2 / int2, no mirrored writes.  Two barriers per step.
 template <int NTH>
-AVM_DEV int jacobi_eig_lds(double* A, double* V, int n, int ld, double* rot, double* red) {
+AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
+  double* A = LDS() + A_off;
+  double* V = LDS() + V_off;
+  double2* rcs = reinterpret_cast<double2*>(LDS() + rot_off);        // [np] (c, s)
+  int2* rpq = reinterpret_cast<int2*>(LDS() + rot_off + 2 * 64);     // [np] (p, q), p < q
+  double* red = LDS() + L_RED;
   const int t = threadIdx.x;
   const int ne = (n + 1) & ~1, np = ne >> 1;
-  double* rcs = rot;                                   // [np][2]
-  int* rpq = reinterpret_cast<int*>(rot + 2 * 64);     // [np][2]
   for (int i = t; i < n * n; i += NTH) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
-  // static work assignment: blocks (k1 >= k2) then V items (pair k, row i)
-  constexpr int MAXIT = 9;
-  const int nblk = np * (np + 1) / 2, nitem = nblk + np * n;
-  short ia[MAXIT], ib[MAXIT];
-  int nmine = 0;
+  // static work assignment
+  //  - blocks (k1 >= k2): up to MAXB per thread
+  //  - V: thread -> pair kv = t / tpp, rows (t % tpp) + tpp * m
+  constexpr int MAXB = 3, MAXR = 8;
+  const int nblk = np * (np + 1) / 2;
+  short bk1[MAXB], bk2[MAXB];
 #pragma unroll
-  for (int u = 0; u < MAXIT; u++) {
+  for (int u = 0; u < MAXB; u++) {
     const int idx = t + u * NTH;
-    ia[u] = 0, ib[u] = 0;
-    if (idx >= nitem) continue;
-    nmine = u + 1;
+    bk1[u] = -1, bk2[u] = 0;
     if (idx < nblk) {
       int k1 = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
       while ((k1 + 1) * (k1 + 2) / 2 <= idx) k1++;
       while (k1 * (k1 + 1) / 2 > idx) k1--;
-      ia[u] = (short)k1, ib[u] = (short)(idx - k1 * (k1 + 1) / 2);
-    } else {
-      const int j = idx - nblk;
-      ia[u] = (short)(-1 - j / n), ib[u] = (short)(j % n);
+      bk1[u] = (short)k1, bk2[u] = (short)(idx - k1 * (k1 + 1) / 2);
     }
   }
+  const int tpp = max(1, NTH / np);          // threads per pair for the V update
+  const int kv = t / tpp, rv0 = t % tpp;     // pair and first row of this thread (kv >= np: idle)
   __syncthreads();
+  auto Lw = [&](int i, int j) -> double& { return A[max(i, j) * ld + min(i, j)]; };
   int sweeps = 0;
   for (int sweep = 0; sweep < 20; sweep++) {
     // converged when every |a_pq| <= tol sqrt(a_pp a_qq) (relative criterion: keeps the small eigenvalues
@@ -1588,47 +1730,55 @@ AVM_DEV int jacobi_eig_lds(double* A, double* V, int n, int ld, double* rot, dou
           if (fabs(apq) > 1e-300) {
             const double tau = (A[qI * ld + qI] - A[pI * ld + pI]) / (2.0 * apq);
             const double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-            cs = 1.0 / sqrt(1.0 + tt * tt);
+            cs = fast_rsqrt(1.0 + tt * tt);
             sn = tt * cs;
           }
         }
-        rcs[t * 2] = cs, rcs[t * 2 + 1] = sn;
-        rpq[t * 2] = pI, rpq[t * 2 + 1] = qI;
+        rcs[t] = double2{cs, sn};
+        rpq[t] = int2{pI, qI};
       }
       __syncthreads();
 #pragma unroll
-      for (int it = 0; it < MAXIT; it++) {
-        if (it >= nmine) continue;
-        if (ia[it] >= 0) {
-          const int k1 = ia[it], k2 = ib[it];
-          const int p1 = rpq[k1 * 2], q1 = rpq[k1 * 2 + 1], p2 = rpq[k2 * 2], q2 = rpq[k2 * 2 + 1];
-          const double c1 = rcs[k1 * 2], s1 = rcs[k1 * 2 + 1], c2 = rcs[k2 * 2], s2 = rcs[k2 * 2 + 1];
-          const bool r1 = q1 < n, r2 = q2 < n;  // a dummy partner (odd n) leaves its line untouched (c = 1, s = 0)
-          // read the block from the lower triangle (A is kept symmetric: both triangles are written)
-          const double a00 = A[p1 * ld + p2], a01 = r2 ? A[p1 * ld + q2] : 0.0;
-          const double a10 = r1 ? A[q1 * ld + p2] : 0.0, a11 = (r1 && r2) ? A[q1 * ld + q2] : 0.0;
+      for (int u = 0; u < MAXB; u++) {
+        if (bk1[u] < 0) continue;
+        const int k1 = bk1[u], k2 = bk2[u];
+        const int2 pq1 = rpq[k1], pq2 = rpq[k2];
+        const double2 r1v = rcs[k1], r2v = rcs[k2];
+        const int p1 = pq1.x, q1 = pq1.y, p2 = pq2.x, q2 = pq2.y;
+        const double c1 = r1v.x, s1 = r1v.y, c2 = r2v.x, s2 = r2v.y;
+        const bool r1 = q1 < n, r2 = q2 < n;  // a dummy partner (odd n) leaves its line untouched (c = 1, s = 0)
+        if (k1 != k2) {
+          double& e00 = Lw(p1, p2);
+          const double a00 = e00, a01 = r2 ? Lw(p1, q2) : 0.0, a10 = r1 ? Lw(q1, p2) : 0.0, a11 = (r1 && r2) ? Lw(q1, q2) : 0.0;
           const double b00 = c1 * a00 - s1 * a10, b01 = c1 * a01 - s1 * a11;
           const double b10 = s1 * a00 + c1 * a10, b11 = s1 * a01 + c1 * a11;
-          const double n00 = c2 * b00 - s2 * b01, n01 = s2 * b00 + c2 * b01;
-          const double n10 = c2 * b10 - s2 * b11, n11 = s2 * b10 + c2 * b11;
-          A[p1 * ld + p2] = n00;
-          if (r2) A[p1 * ld + q2] = n01;
-          if (r1) A[q1 * ld + p2] = n10;
-          if (r1 && r2) A[q1 * ld + q2] = n11;
-          if (k1 != k2) {  // mirror
-            A[p2 * ld + p1] = n00;
-            if (r2) A[q2 * ld + p1] = n01;
-            if (r1) A[p2 * ld + q1] = n10;
-            if (r1 && r2) A[q2 * ld + q1] = n11;
-          }
+          e00 = c2 * b00 - s2 * b01;
+          if (r2) Lw(p1, q2) = s2 * b00 + c2 * b01;
+          if (r1) Lw(q1, p2) = c2 * b10 - s2 * b11;
+          if (r1 && r2) Lw(q1, q2) = s2 * b10 + c2 * b11;
         } else {
-          const int k = -1 - ia[it], i = ib[it];
-          const int pI = rpq[k * 2], qI = rpq[k * 2 + 1];
-          if (qI < n) {
-            const double cs = rcs[k * 2], sn = rcs[k * 2 + 1];
-            const double x = V[i * ld + pI], y = V[i * ld + qI];
-            V[i * ld + pI] = cs * x - sn * y;
-            V[i * ld + qI] = sn * x + cs * y;
+          // diagonal block of the pair itself: [app apq; apq aqq] -> diag(app - t apq, aqq + t apq)
+          const double app = A[p1 * ld + p1];
+          if (r1) {
+            const double aqq = A[q1 * ld + q1], apq = A[q1 * ld + p1];
+            A[p1 * ld + p1] = c1 * c1 * app - 2.0 * c1 * s1 * apq + s1 * s1 * aqq;
+            A[q1 * ld + q1] = s1 * s1 * app + 2.0 * c1 * s1 * apq + c1 * c1 * aqq;
+            A[q1 * ld + p1] = (c1 * c1 - s1 * s1) * apq + c1 * s1 * (app - aqq);
+          }
+        }
+      }
+      if (kv < np) {
+        const int2 pq = rpq[kv];
+        if (pq.y < n) {
+          const double2 cs2 = rcs[kv];
+#pragma unroll
+          for (int m = 0; m < MAXR; m++) {
+            const int i = rv0 + tpp * m;
+            if (i < n) {
+              const double x = V[i * ld + pq.x], y = V[i * ld + pq.y];
+              V[i * ld + pq.x] = cs2.x * x - cs2.y * y;
+              V[i * ld + pq.y] = cs2.y * x + cs2.x * y;
+            }
           }
         }
       }
@@ -1640,8 +1790,7 @@ AVM_DEV int jacobi_eig_lds(double* A, double* V, int n, int ld, double* rot, dou
 
 __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO) {
   using namespace mg;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* lds = reinterpret_cast<double*>(smem_raw);
+  double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const avm_options& o = A.opt;
@@ -1649,7 +1798,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
   const int flag = o.marginalization_flag;
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
     WinCtx c;
-    c.lds = lds, c.ids = ids, c.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
+    c.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
     c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
     c.osf = A.iscratch + (size_t)blockIdx.x * ISCRATCH;
     c.cov = c.osf + MAXOBS;
@@ -1718,7 +1867,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       ids[I_NCOV + t] = 0;
     }
     if (t == 0) ids[I_NCOV] = 0;
-    build_frames(lds, lds + L_X, 0);
+    build_frames(L_X, 0);
     double* IJR = c.sc + Scratch::IJRAW;
     for (int i = t; i < 465; i += NT) IJR[i] = 0.0;
     __syncthreads();
@@ -1727,8 +1876,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     PROF(c, 16);
     // ---- phase A: projection factors of the start-0 features || IMU factor 0
     if (wv < MASM) {
-      double* stage = lds + L_S + SPP + wv * MXSTG;
-      for (int b = 1 + wv; b < NFR; b += MASM) marg_frame_task(c, o, b, stage);
+      for (int b = 1 + wv; b < NFR; b += MASM) marg_frame_task(c, o, b, L_S + SPP + wv * MXSTG);
     } else if (wv == 7 && lane == 0 && imu0) {
       imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
     }
@@ -1827,7 +1975,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     PROF(c, 19);
     // ---- phase E: old prior (MarginalizationFactor at the current state)
     if (use_prior) {
-      prior_residual_dev(c, lds + L_X);
+      prior_residual_dev(c, L_X);
       const int* pidx = ids + I_PIDX;
       double* HPm = c.sc + Scratch::HP;
       prior_jtj_mfma(c.pJ, c.ldp, c.pn, HPm);
@@ -1952,7 +2100,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     for (int idx = t; idx < n * n; idx += NT) GA[idx] = Sget(kidx[idx / n], kidx[idx % n]);
     __syncthreads();
     PROF(c, 22);
-    jacobi_eig_lds<NT>(EA, EV, 16, 16, ROT, lds + L_RED);
+    jacobi_eig_lds<NT>(M_WCH, M_WCH + 256, 16, 16, L_HEE);
     PROF(c, 23);
     // Amm^+ = V diag(1/lambda > eps) V^T  -> EA (reuse) ; T = Arm Amm^+ ; A' = Arr - T Amr ; b' = br - T bm
     {
@@ -1992,7 +2140,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     for (int idx = t; idx < n * n; idx += NT) Ad[idx] = GA[idx];
     __syncthreads();
     PROF(c, 24);
-    const int nsweep = jacobi_eig_lds<NT>(Ad, Vd, n, n, ROT, lds + L_RED);
+    const int nsweep = jacobi_eig_lds<NT>(0, n * n, n, n, L_HEE);
     PROF(c, 25);
     if (c.prof && t == 0) c.prof[29] += nsweep;
     // linearized_jacobians = diag(sqrt(S)) V^T ; linearized_residuals = diag(1/sqrt(S)) V^T b
@@ -2037,15 +2185,14 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
 
 // Per-factor evaluation at the input state (no solve): parity-test surface for A5/A6/A8.
 __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* lds = reinterpret_cast<double*>(smem_raw);
+  double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
   const avm_options& o = A.opt;
   const avm_window_batch& B = A.b;
   const int w = blockIdx.x;
   WinCtx c;
-  c.lds = lds, c.ids = ids, c.sc = nullptr, c.osf = nullptr, c.w = w;
+  c.sc = nullptr, c.osf = nullptr, c.w = w;
   c.nf = B.n_feat[w];
   c.obs = B.obs_xy + (size_t)w * B.max_obs * 2;
   c.pdelta = A.pre_delta + (size_t)w * 100, c.pjac = A.pre_jac + (size_t)w * 2250, c.psqrt = A.pre_sqrt + (size_t)w * 2250;
@@ -2077,7 +2224,7 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
     }
   }
   __syncthreads();
-  build_frames(lds, lds + L_X, 0);
+  build_frames(L_X, 0);
   __syncthreads();
   Frames fr{lds + L_FR, lds + L_FR + 99};
   const double sqi = o.focal_length / 1.5;
@@ -2117,7 +2264,7 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
     }
   }
   if (c.pn > 0) {
-    prior_residual_dev(c, lds + L_X);
+    prior_residual_dev(c, L_X);
     if (t < c.pn) {
       acc += 0.5 * lds[L_RP + t] * lds[L_RP + t];
       if (A.prior_res) A.prior_res[(size_t)w * B.max_prior + t] = lds[L_RP + t];

@@ -7,7 +7,7 @@ import numpy as np
 pkg = "anticipated-vins-mono_amd"
 synth = importlib.import_module(pkg + ".synth"); abi = importlib.import_module(pkg + ".abi")
 est_m = importlib.import_module(pkg + ".estimator")
-NAMES = ["A: frames(MFMA)+imu raw", "B: feat sums+diag", "prior resid", "zero S rows", "-", "-", "-", "D: imu sqrt+JtJ", "E: prior + cost", "load+Hp", "scale/gmax", "schur(MFMA)", "cholesky", "tri solve", "backsub", "cand eval"]
+NAMES = ["A: frames(MFMA)+imu raw", "B: feat sums+diag", "prior resid", "zero S rows", "  chol: diag block", "  chol: panel solve", "  chol: trailing MFMA", "D: imu sqrt+JtJ", "E: prior + cost", "load+Hp", "scale/gmax", "schur(MFMA)", "cholesky", "tri solve", "backsub", "cand eval"]
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 tracks = sys.argv[2] if len(sys.argv) > 2 else "dense"
 opt = abi.default_options()
@@ -21,10 +21,11 @@ ms = E.ctx.kernel_ms("window_solve")
 prof = (C.c_longlong * 32)()
 E.ctx._L.avm_debug_copy_profile.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 E.ctx.check(E.ctx._L.avm_debug_copy_profile(E.ctx.h, prof), "prof")
-tot = sum(prof[:16]); n = prof[31]
+tot = sum(prof[:4]) + sum(prof[7:16]); n = prof[31]
 print(f"windows {nw} tracks {tracks}: kernel {ms:.3f} ms, {nw/ms*1e3:.0f} solves/s; per-window cycles total {tot/n:.0f}")
 for k, nm in enumerate(NAMES):
     print(f"  {nm:22s} {prof[k]/n:12.0f} cyc/window  {100*prof[k]/tot:5.1f}%")
+print(f'  chol lookahead: wave0 (tile+diag) {prof[28]/n:.0f} cyc/window ; wave1 (tiles) {prof[27]/n:.0f} cyc/window')
 MN = ["load", "A: frames+imu0", "B: feat sums/PART", "D: imu0 JtJ", "E: prior", "F: feature schur", "G+extract", "eig16", "pinv+schur15", "eig n", "write out"]
 if prof[30]:
     mt = sum(prof[16:27]); print(f"marginalize: kernel {E.ctx.kernel_ms('marginalize'):.3f} ms; per-window cycles {mt/prof[30]:.0f}")
