@@ -1,7 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/ (run on the GPU box through gpurun).
 # Counter passes are separate runs with --kernel-trace only (no sys/hip/hsa trace domains).
-set -x
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$1
@@ -12,5 +11,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- $CMD > /de
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- $CMD > /dev/null 2> $OUT/pmc_write.log
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY -d $OUT/pmc_sq -o run -- $CMD > /dev/null 2> $OUT/pmc_sq.log
 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.log
-find $OUT -name "*.csv" | head -50
-ls -la $OUT/*
+python scripts/dev_prof.py 256 dense > $OUT/phase_breakdown_dense.txt 2>&1
+python scripts/dev_prof.py 256 sparse > $OUT/phase_breakdown_sparse.txt 2>&1
+tail -1 $OUT/bench.json | cut -c1-400
