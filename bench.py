@@ -130,6 +130,12 @@ def main():
         flops = flop_model(n_fac, n_feat, s)
         k_ms = float(np.mean(kernel_ms))
         achieved = flops / (k_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+        if os.path.exists(tp) and W == 4096 and args.tracks == "dense" and opt.marginalization_flag == abi.MARGIN_OLD:
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/gpu_profile.sh), per launch
+            tj = json.load(open(tp))["window_solve_kernel"]
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01b_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes"
         alg_bytes = W * (44.0 * n_fac + 23.0e3 + 45.6e3 + 3.0e3 + 2.6e3)  # ~140 KB / solve at K=1500
         result = {
             "metric": "sliding-window solves/sec (10 KF, 150 feats)",
@@ -160,7 +166,8 @@ def main():
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "window_solve_kernel",
                 "kernel_ms": k_ms,
                 "flops_per_launch": flops,
@@ -203,7 +210,7 @@ def main():
         import oracle_py
 
         cores = os.cpu_count() or 1
-        nsamp = min(W, max(2 * cores, 32))
+        nsamp = min(W, max(8 * cores, 64))
         sample = host.slice(0, nsamp).copy()
         o2 = abi.default_options()
         o2.marginalization_flag = opt.marginalization_flag
