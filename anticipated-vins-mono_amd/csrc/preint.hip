@@ -14,11 +14,17 @@ namespace avm {
 namespace {
 constexpr int PW = 4;  // waves per block
 
+// every wavefront integrates its own interval: only wave-level ordering of its LDS traffic is needed
+AVM_DEV void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct PreLds {
   double J[225], P[225], F[225], T[225], V[270];
   double m[72];  // Rd, Rr, Ra0, Ra1, IRw (I - Rw*dt), T1=Rd*Ra0, T2=Rr*Ra1, T3=T2*IRw
-  double A[225], Inv[225];
-  double piv[16];
+  double piv[16];  // (the Gauss-Jordan work matrices of the sqrt_info phase alias F and T, which are dead by then)
 };
 }  // namespace
 
@@ -31,12 +37,8 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
   const bool live = iv < (long)a.n_windows * 10;
   const long ivc = live ? iv : 0;
   const int ns = live ? a.imu_n[ivc] : 0;
-  // block-uniform max trip count so that every __syncthreads is executed by all threads
-  __shared__ int s_ns[PW];
-  if (lane == 0) s_ns[wv] = ns;
-  __syncthreads();
-  int nmax = 0;
-  for (int i = 0; i < PW; i++) nmax = max(nmax, s_ns[i]);
+  if (!live) return;  // no block-level barriers below
+  const int nmax = ns;
 
   const double* acc = a.imu_acc + ivc * (a.max_samp + 1) * 3;
   const double* gyr = a.imu_gyr + ivc * (a.max_samp + 1) * 3;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
   v3 acc0 = mk3(acc[0], acc[1], acc[2]), gyr0 = mk3(gyr[0], gyr[1], gyr[2]);
   double sum_dt = 0;
   const double an2 = a.acc_n * a.acc_n, gn2 = a.gyr_n * a.gyr_n, aw2 = a.acc_w * a.acc_w, gw2 = a.gyr_w * a.gyr_w;
-  __syncthreads();
+  wsync();
 
   for (int s = 0; s < nmax; s++) {
     const bool act = s < ns;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
     }
     for (int i = lane; i < 225; i += 64) L.F[i] = (i / 15 == i % 15) ? 1.0 : 0.0;
     for (int i = lane; i < 270; i += 64) L.V[i] = 0.0;
-    __syncthreads();
+    wsync();
     if (act && lane < 9) {
       const int r = lane / 3, c = lane % 3;
       const double Rd = L.m[lane], Rr = L.m[9 + lane], T1 = L.m[45 + lane], T2 = L.m[54 + lane], T3 = L.m[63 + lane];
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
       L.V[(9 + r) * 18 + 12 + c] = I * dt;
       L.V[(12 + r) * 18 + 15 + c] = I * dt;
     }
-    __syncthreads();
+    wsync();
     // T = F*J ; then J = T.  (jacobian = F * jacobian)
     double o[4];
     for (int q = 0; q < 4; q++) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
         o[q] = sacc;
       }
     }
-    __syncthreads();
+    wsync();
     if (act)
       for (int q = 0; q < 4; q++) {
         const int i = lane + 64 * q;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
         L.T[i] = sacc;
       }
     }
-    __syncthreads();
+    wsync();
     // P = T*F^T + V*Q*V^T
     for (int q = 0; q < 4; q++) {
       const int i = lane + 64 * q;
@@ -173,85 +175,87 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
         L.P[i] = s1 + s2;
       }
     }
-    __syncthreads();
+    wsync();
   }
 
   // ---- sqrt_info = LLT(P^-1).matrixL()^T : partial-pivot Gauss-Jordan then Cholesky -------
+  double* LA = L.F;
+  double* LI = L.T;
   for (int i = lane; i < 225; i += 64) {
-    L.A[i] = L.P[i];
-    L.Inv[i] = (i / 15 == i % 15) ? 1.0 : 0.0;
+    LA[i] = L.P[i];
+    LI[i] = (i / 15 == i % 15) ? 1.0 : 0.0;
   }
-  __syncthreads();
+  wsync();
   for (int k = 0; k < 15; k++) {
     if (lane == 0) {
       int p = k;
-      double best = fabs(L.A[k * 15 + k]);
+      double best = fabs(LA[k * 15 + k]);
       for (int i = k + 1; i < 15; i++)
-        if (fabs(L.A[i * 15 + k]) > best) best = fabs(L.A[i * 15 + k]), p = i;
+        if (fabs(LA[i * 15 + k]) > best) best = fabs(LA[i * 15 + k]), p = i;
       L.piv[0] = (double)p;
     }
-    __syncthreads();
+    wsync();
     const int p = (int)L.piv[0];
     if (p != k && lane < 15) {
-      double t = L.A[k * 15 + lane];
-      L.A[k * 15 + lane] = L.A[p * 15 + lane];
-      L.A[p * 15 + lane] = t;
-      t = L.Inv[k * 15 + lane];
-      L.Inv[k * 15 + lane] = L.Inv[p * 15 + lane];
-      L.Inv[p * 15 + lane] = t;
+      double t = LA[k * 15 + lane];
+      LA[k * 15 + lane] = LA[p * 15 + lane];
+      LA[p * 15 + lane] = t;
+      t = LI[k * 15 + lane];
+      LI[k * 15 + lane] = LI[p * 15 + lane];
+      LI[p * 15 + lane] = t;
     }
-    __syncthreads();
-    const double piv = L.A[k * 15 + k];
+    wsync();
+    const double piv = LA[k * 15 + k];
     double fa[4], fi[4];
     for (int q = 0; q < 4; q++) {
       const int i = lane + 64 * q;
       if (i < 225) {
         const int r = i / 15, c = i % 15;
-        const double f = L.A[r * 15 + k] / piv;
-        fa[q] = (r > k && c >= k) ? L.A[i] - f * L.A[k * 15 + c] : L.A[i];
-        fi[q] = (r > k) ? L.Inv[i] - f * L.Inv[k * 15 + c] : L.Inv[i];
+        const double f = LA[r * 15 + k] / piv;
+        fa[q] = (r > k && c >= k) ? LA[i] - f * LA[k * 15 + c] : LA[i];
+        fi[q] = (r > k) ? LI[i] - f * LI[k * 15 + c] : LI[i];
       }
     }
-    __syncthreads();
+    wsync();
     for (int q = 0; q < 4; q++) {
       const int i = lane + 64 * q;
-      if (i < 225) L.A[i] = fa[q], L.Inv[i] = fi[q];
+      if (i < 225) LA[i] = fa[q], LI[i] = fi[q];
     }
-    __syncthreads();
+    wsync();
   }
   for (int k = 14; k >= 0; k--) {
-    const double piv = L.A[k * 15 + k];
-    if (lane < 15) L.Inv[k * 15 + lane] = L.Inv[k * 15 + lane] / piv;
-    __syncthreads();
+    const double piv = LA[k * 15 + k];
+    if (lane < 15) LI[k * 15 + lane] = LI[k * 15 + lane] / piv;
+    wsync();
     double fi[4];
     for (int q = 0; q < 4; q++) {
       const int i = lane + 64 * q;
       if (i < 225) {
         const int r = i / 15, c = i % 15;
-        fi[q] = (r < k) ? L.Inv[i] - L.A[r * 15 + k] * L.Inv[k * 15 + c] : L.Inv[i];
+        fi[q] = (r < k) ? LI[i] - LA[r * 15 + k] * LI[k * 15 + c] : LI[i];
       }
     }
-    __syncthreads();
+    wsync();
     for (int q = 0; q < 4; q++) {
       const int i = lane + 64 * q;
-      if (i < 225) L.Inv[i] = fi[q];
+      if (i < 225) LI[i] = fi[q];
     }
-    __syncthreads();
+    wsync();
   }
   // lower Cholesky of Inv (column algorithm, same operation order as the oracle's llt_lower), one lane per row
   for (int k = 0; k < 15; k++) {
     if (lane == 0) {
-      double x = L.Inv[k * 15 + k];
-      for (int j = 0; j < k; j++) x -= L.Inv[k * 15 + j] * L.Inv[k * 15 + j];
-      L.Inv[k * 15 + k] = sqrt(x);
+      double x = LI[k * 15 + k];
+      for (int j = 0; j < k; j++) x -= LI[k * 15 + j] * LI[k * 15 + j];
+      LI[k * 15 + k] = sqrt(x);
     }
-    __syncthreads();
+    wsync();
     if (lane > k && lane < 15) {
-      double sacc = L.Inv[lane * 15 + k];
-      for (int j = 0; j < k; j++) sacc -= L.Inv[lane * 15 + j] * L.Inv[k * 15 + j];
-      L.Inv[lane * 15 + k] = sacc / L.Inv[k * 15 + k];
+      double sacc = LI[lane * 15 + k];
+      for (int j = 0; j < k; j++) sacc -= LI[lane * 15 + j] * LI[k * 15 + j];
+      LI[lane * 15 + k] = sacc / LI[k * 15 + k];
     }
-    __syncthreads();
+    wsync();
   }
   if (live) {
     double* od = a.out_delta + iv * 10;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
       a.out_jacobian[iv * 225 + i] = L.J[i];
       a.out_covariance[iv * 225 + i] = L.P[i];
       const int r = i / 15, c = i % 15;
-      a.out_sqrt_info[iv * 225 + i] = (c >= r) ? L.Inv[c * 15 + r] : 0.0;  // U = L^T
+      a.out_sqrt_info[iv * 225 + i] = (c >= r) ? LI[c * 15 + r] : 0.0;  // U = L^T
     }
   }
 }
