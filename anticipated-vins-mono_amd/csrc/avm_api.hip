@@ -290,7 +290,11 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
       HIPCHK(c, hipMemsetAsync(dpo.blk_kind, 0, sizeof(int32_t) * B * mb, c->stream));
       HIPCHK(c, hipMemsetAsync(dpo.blk_frame, 0, sizeof(int32_t) * B * mb, c->stream));
     }
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_marginalize(sa, dpo, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, c->prof, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     if (mem == AVM_MEM_HOST) {
       HIPCHK(c, hipMemcpyAsync(prior_out->n, dpo.n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync(prior_out->nblk, dpo.nblk, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
@@ -301,7 +305,6 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
       HIPCHK(c, hipMemcpyAsync(prior_out->x0, dpo.x0, sizeof(double) * B * mb * 9, hipMemcpyDeviceToHost, c->stream));
     }
   }
-  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   if (mem == AVM_MEM_HOST) {
     const size_t B = batch->n_windows;
     HIPCHK(c, hipMemcpyAsync(batch->pose, d.pose, sizeof(double) * B * 77, hipMemcpyDeviceToHost, c->stream));
@@ -314,7 +317,9 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->last_ms["preint"] = ms;
   if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->last_ms["window_solve"] = ms;
-  if (hipEventElapsedTime(&ms, c->ev[2], c->ev[5]) == hipSuccess) c->last_ms["marginalize"] = ms;
+  c->last_ms["marginalize"] = 0.f, c->last_ms["prior_eig"] = 0.f;
+  if (marg && hipEventElapsedTime(&ms, c->ev[6], c->ev[7]) == hipSuccess) c->last_ms["marginalize"] = ms;
+  if (marg && hipEventElapsedTime(&ms, c->ev[7], c->ev[5]) == hipSuccess) c->last_ms["prior_eig"] = ms;
   return AVM_OK;
 }
 

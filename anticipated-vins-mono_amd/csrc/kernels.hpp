@@ -15,6 +15,7 @@ constexpr int MAXE = 150;              // inverse depths (e-blocks)
 constexpr int NCOL = NF + MAXE;        // 315
 constexpr int MAXOBS = MAXE * NFR;     // 1650 observation slots
 constexpr int MAXPRIOR = 96;           // prior residual dimension limit
+constexpr int MAXKEEP = 76;            // rows a marginalization may keep (prior_eig.hip holds A' and V in half a CU's LDS); this problem keeps <= 75
 constexpr int MAXPBLK = 16;
 
 struct PreintArgs {
@@ -68,6 +69,8 @@ bool fsel_horizon_supported(int H);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipStream_t stream);
+// second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior
+hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, hipStream_t stream);
 int window_solve_lds_bytes();
 
 }  // namespace avm

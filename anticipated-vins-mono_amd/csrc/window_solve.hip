@@ -2069,7 +2069,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         if (!(present & (1 << id))) continue;
         const int base = id < 11 ? 6 * id : (id < 22 ? SB0 + 9 * (id - 11) : MEX0);
         const int sz = (id >= 11 && id < 22) ? 9 : 6;
-        if (n + sz > MAXPRIOR || nb >= MAXPBLK) break;
+        if (n + sz > MAXKEEP || n + sz > PO.max_prior || nb >= MAXPBLK) break;
         kblk[nb++] = id;
         for (int q = 0; q < sz; q++) kidx[n++] = base + q;
       }
@@ -2095,10 +2095,6 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     if (t < 16) BV[t] = t < m ? lds[M_G + midx[t]] : 0.0;
     if (t >= 64 && t < 64 + n) BV[16 + t - 64] = lds[M_G + kidx[t - 64]];
     __syncthreads();
-    // Arr into registers-free staging: it has to move from packed-171 to dense n x n at offset 0; go through global scratch
-    double* GA = c.sc + Scratch::HP;  // n x n dense (<= 96 x 96)
-    for (int idx = t; idx < n * n; idx += NT) GA[idx] = Sget(kidx[idx / n], kidx[idx % n]);
-    __syncthreads();
     PROF(c, 22);
     jacobi_eig_lds<NT>(M_WCH, M_WCH + 256, 16, 16, L_HEE);
     PROF(c, 23);
@@ -2115,8 +2111,6 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       }
       __syncthreads();
     }
-    double* Ad = lds;                 // A' dense n x n, ld = n
-    double* Vd = lds + n * n;         // eigenvectors (2 n^2 <= 18432 doubles stays below the live state at L_X)
     double* GT = c.sc + Scratch::W;   // T = Arm Amm^+ : n x 16, in the scratch slot
     for (int idx = t; idx < n * 16; idx += NT) {
       const int i = idx / 16, j = idx % 16;
@@ -2125,39 +2119,24 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       GT[idx] = sacc;
     }
     __syncthreads();
-    for (int idx = t; idx < n * n; idx += NT) {
-      const int i = idx / n, j = idx % n;
-      double sacc = 0;
-      for (int k = 0; k < 16; k++) sacc += GT[i * 16 + k] * EB[j * 16 + k];
-      GA[idx] -= sacc;
-    }
-    if (t < n) {
-      double sacc = 0;
-      for (int k = 0; k < 16; k++) sacc += GT[t * 16 + k] * BV[k];
-      BV[16 + t] -= sacc;
-    }
-    __syncthreads();
-    for (int idx = t; idx < n * n; idx += NT) Ad[idx] = GA[idx];
-    __syncthreads();
-    PROF(c, 24);
-    const int nsweep = jacobi_eig_lds<NT>(0, n * n, n, n, L_HEE);
-    PROF(c, 25);
-    if (c.prof && t == 0) c.prof[29] += nsweep;
-    // linearized_jacobians = diag(sqrt(S)) V^T ; linearized_residuals = diag(1/sqrt(S)) V^T b
+    // A' and b' go to the output slots PO.J / PO.r; prior_eig_kernel (prior_eig.hip) turns them into
+    // linearized_jacobians / linearized_residuals in place
     {
       double* oJ = PO.J + (size_t)w * PO.max_prior * PO.max_prior;
       double* orr = PO.r + (size_t)w * PO.max_prior;
       for (int idx = t; idx < n * n; idx += NT) {
-        const int k = idx / n, j = idx % n;
-        const double ev = Ad[k * n + k];
-        oJ[(size_t)k * PO.max_prior + j] = (ev > o.marg_eps ? sqrt(ev) : 0.0) * Vd[j * n + k];
+        const int i = idx / n, j = idx % n;
+        if (j > i) continue;  // the eigen-solver reads the lower triangle only (as Eigen's SelfAdjointEigenSolver does)
+        double sacc = 0;
+        for (int k = 0; k < 16; k++) sacc += GT[i * 16 + k] * EB[j * 16 + k];
+        oJ[(size_t)i * PO.max_prior + j] = Sget(kidx[i], kidx[j]) - sacc;
       }
       if (t < n) {
-        const double ev = Ad[t * n + t];
-        double vb = 0;
-        for (int j = 0; j < n; j++) vb += Vd[j * n + t] * BV[16 + j];
-        orr[t] = (ev > o.marg_eps ? sqrt(1.0 / ev) : 0.0) * vb;
+        double sacc = 0;
+        for (int k = 0; k < 16; k++) sacc += GT[t * 16 + k] * BV[k];
+        orr[t] = BV[16 + t] - sacc;
       }
+      PROF(c, 24);
       if (t < nblk) {
         const int id = kblk[t];
         const int kind = id < 11 ? AVM_BLK_POSE : (id < 22 ? AVM_BLK_SPEEDBIAS : AVM_BLK_EXPOSE);

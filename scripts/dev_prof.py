@@ -28,6 +28,6 @@ for k, nm in enumerate(NAMES):
 print(f'  chol lookahead: wave0 (tile+diag) {prof[28]/n:.0f} cyc/window ; wave1 (tiles) {prof[27]/n:.0f} cyc/window')
 MN = ["load", "A: frames+imu0", "B: feat sums/PART", "D: imu0 JtJ", "E: prior", "F: feature schur", "G+extract", "eig16", "pinv+schur15", "eig n", "write out"]
 if prof[30]:
-    mt = sum(prof[16:27]); print(f"marginalize: kernel {E.ctx.kernel_ms('marginalize'):.3f} ms; per-window cycles {mt/prof[30]:.0f}")
+    mt = sum(prof[16:27]); print(f"preint {E.ctx.kernel_ms('preint'):.3f} ms; marginalize: kernel {E.ctx.kernel_ms('marginalize'):.3f} ms + prior_eig {E.ctx.kernel_ms('prior_eig'):.3f} ms; per-window cycles {mt/prof[30]:.0f}")
     print('  jacobi sweeps per window', prof[29]/prof[30])
     for k, nm in enumerate(MN): print(f"  {nm:22s} {prof[16+k]/prof[30]:12.0f} cyc/window  {100*prof[16+k]/mt:5.1f}%")
