@@ -88,17 +88,22 @@ class PriorOutArrays(_Arrays):
 
     @staticmethod
     def alloc(n_windows: int, max_prior: int = 96, max_pblk: int = 16, device=None) -> "PriorOutArrays":
-        a = {
-            "n": np.zeros(n_windows, np.int32),
-            "nblk": np.zeros(n_windows, np.int32),
-            "blk_kind": np.zeros((n_windows, max_pblk), np.int32),
-            "blk_frame": np.zeros((n_windows, max_pblk), np.int32),
-            "J": np.zeros((n_windows, max_prior, max_prior)),
-            "r": np.zeros((n_windows, max_prior)),
-            "x0": np.zeros((n_windows, max_pblk, 9)),
+        shapes = {
+            "n": ((n_windows,), "i4"),
+            "nblk": ((n_windows,), "i4"),
+            "blk_kind": ((n_windows, max_pblk), "i4"),
+            "blk_frame": ((n_windows, max_pblk), "i4"),
+            "J": ((n_windows, max_prior, max_prior), "f8"),
+            "r": ((n_windows, max_prior), "f8"),
+            "x0": ((n_windows, max_pblk, 9), "f8"),
         }
-        p = PriorOutArrays({"max_prior": max_prior, "max_pblk": max_pblk}, a)
-        return p.to_device(device) if device else p
+        if device:
+            import torch  # zero-filled in HBM directly (J alone is 74 KB per window: never staged through the host)
+
+            a = {k: torch.zeros(sh, dtype=torch.int32 if dt == "i4" else torch.float64, device=device) for k, (sh, dt) in shapes.items()}
+        else:
+            a = {k: np.zeros(sh, np.int32 if dt == "i4" else np.float64) for k, (sh, dt) in shapes.items()}
+        return PriorOutArrays({"max_prior": max_prior, "max_pblk": max_pblk}, a)
 
     def struct(self) -> abi.PriorOut:
         return self._fill(abi.PriorOut())

@@ -5,20 +5,23 @@
 // with S the eigenvalues clamped to 0 below eps (marginalization_factor.cpp:292-299).
 //
 // marginalize_kernel (window_solve.hip) leaves A' (lower triangle is read) in PO.J[w] and b' in PO.r[w]; this
-// kernel overwrites both in place.  One 512-thread workgroup per window, 70 KB of LDS and <= 128 VGPRs so
+// kernel overwrites both in place.  One 512-thread workgroup per window, 48 KB of LDS and <= 128 VGPRs so
 // TWO workgroups share a CU and fill each other's barrier / LDS latency.
 //
-// Method: cyclic Jacobi in the odd-even (Brent-Luk) ordering.  The ne indices sit on positions 0..ne-1; an even
-// step rotates the pairs on positions (2k, 2k+1), an odd step those on (2k+1, 2k+2), and after its rotation a pair
-// swaps positions, so ne steps visit every pair once.  That ordering only ever pairs neighbours, which lets
-// the eigenvector matrix live in REGISTERS: lane k of a "V wavefront" holds, for its 19 columns, the two rows
-// of V^T on positions 2k and 2k+1; an even step is lane-local, an odd step moves one row to the neighbouring
-// lane and back with DPP wave shifts.  Only A (packed lower triangle) stays in LDS, where A <- R^T A R
-// decomposes into independent 2x2 blocks (rows of pair k1, columns of pair k2, k1 > k2).
-//   wavefronts 0-3 : A blocks (four scattered 8-byte reads + writes per block); wavefront 0 then computes the
-//                    next step's rotations and applies them to the pairs' own 2x2 diagonal blocks
+// Method: cyclic Jacobi in the odd-even (Brent-Luk) ordering, carried out in POSITION space.  The ne indices sit
+// on positions 0..ne-1; an even step rotates the pairs on positions (2k, 2k+1), an odd step those on
+// (2k+1, 2k+2), and after its rotation a pair swaps positions, so ne steps visit every pair once.  Rows and
+// columns are physically exchanged with the swap, which keeps every access regular:
+//   * A (lower triangle, row-major by position, LDS): A <- R^T A R decomposes into independent 2x2 blocks (rows of
+//     pair k1, columns of pair k2, k1 >= k2) at fixed addresses - two 16-byte reads + writes per block on even
+//     steps, four 8-byte ones on odd steps, consecutive lanes on consecutive addresses;
+//   * V^T lives in REGISTERS: lane k of a "V wavefront" holds, for its 19 columns, the rows on positions 2k and
+//     2k+1; an even step is lane-local, an odd step moves one row to the neighbouring lane and back with DPP
+//     wave shifts.
+//   wavefronts 0-3 : A blocks; wavefront 0 then computes the next step's rotations from the pivots
 //   wavefronts 4-7 : V^T, half of the columns while the A blocks run, the other half under the rotation
 //                    computation (rotation tables are double buffered).  Two barriers per step.
+// The eigenpairs come out in position order, which is as good as any: J^T J and J^T r do not depend on it.
 // The rotation angle only steers convergence, so it is computed with the hardware rcp/sqrt approximations;
 // (c, s) themselves are normalised to full precision (c^2 + s^2 = 1 to 1 ulp keeps V orthogonal and the
 // similarity transform exact).
@@ -32,24 +35,19 @@ namespace pe {
 constexpr int NT = 512;
 constexpr int NMAX = MAXKEEP;         // 76: padded (even) dimension limit; kept sets of this problem have n <= 75
 constexpr int NPMAX = NMAX / 2;       // 38 rotation pairs
+constexpr int LD = NMAX;              // row stride of A and V^T in LDS (even: 2x2 blocks are 16-byte aligned)
 constexpr int AW = 256;               // threads of the A-block wavefronts (0-3)
-constexpr int MAXBLK = 3;             // ceil(38*37/2 / 256)
+constexpr int MAXBLK = 3;             // ceil(38*39/2 / 256)
 constexpr int VC = 19;                // columns of V^T per V wavefront (4 x 19 = 76)
 constexpr int VC1 = 10;               // columns done while the A blocks run; the rest overlaps the rotation computation
 
 // LDS carve (doubles)
-constexpr int P_A = 0;                               // packed lower, NMAX*(NMAX+1)/2 = 2926
-constexpr int P_V = 2926;                            // V^T [NMAX][NMAX] = 5776, written once at the end (coalesced output)
-constexpr int P_ROT = P_V + NMAX * NMAX;             // 2 x [NPMAX] double2 (c, s)
-constexpr int P_PQ = P_ROT + 2 * NPMAX * 2;          // 2 x [NPMAX] int2 (a, b): indices of the rotated pair
-constexpr int P_B = P_PQ + 2 * NPMAX;                // b' [NMAX]
-constexpr int P_FLAG = P_B + NMAX;                   // 2 ints
+constexpr int P_A = 0;                               // A by position [NMAX][LD]; reused for V^T at the end
+constexpr int P_ROT = P_A + NMAX * LD;               // 2 x [NPMAX] double2 (c, s)
+constexpr int P_B = P_ROT + 2 * NPMAX * 2;           // b' [NMAX]
+constexpr int P_EV = P_B + NMAX;                     // eigenvalues [NMAX]
+constexpr int P_FLAG = P_EV + NMAX;                  // 2 ints
 constexpr int P_END = P_FLAG + 2;
-
-__device__ __forceinline__ int tri(int i, int j) {  // packed lower index of (max, min)
-  const int a = max(i, j), b = min(i, j);
-  return ((a * (a + 1)) >> 1) + b;
-}
 
 __device__ __forceinline__ double nrm_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -64,15 +62,18 @@ __device__ __forceinline__ int shr_i(int v) { return __builtin_amdgcn_update_dpp
 __device__ __forceinline__ double shl_d(double v) {
   return __hiloint2double(shl_i(__double2hiint(v)), shl_i(__double2loint(v)));
 }
-__device__ __forceinline__ double shr_d(double v) {
-  return __hiloint2double(shr_i(__double2hiint(v)), shr_i(__double2loint(v)));
+// lane i <- v of lane i-1; lane 0 keeps `keep`
+__device__ __forceinline__ double shr_into(double keep, double v) {
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps,
+                                                                                              long long* prof) {
   extern __shared__ char pe_smem[];
   double* lds = reinterpret_cast<double*>(pe_smem);
   double* A = lds + P_A;
-  double* Vt = lds + P_V;
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int w = blockIdx.x;
   if (w >= n_windows) return;
@@ -84,13 +85,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   double* gr = PO.r + (size_t)w * PO.max_prior;
   const int ldj = PO.max_prior;
 
-  // ---- load: lower triangle of A' (pad row/column = 0), b'
+  // ---- load: lower triangle of A' (pad row/column and the unused upper triangle = 0), b'
   for (int e = t; e < ne * ne; e += NT) {
     const int i = e / ne, j = e - i * ne;
-    if (j <= i) A[((i * (i + 1)) >> 1) + j] = (i < n) ? gJ[(size_t)i * ldj + j] : 0.0;
+    A[i * LD + j] = (j <= i && i < n) ? gJ[(size_t)i * ldj + j] : 0.0;
   }
   if (t < ne) lds[P_B + t] = t < n ? gr[t] : 0.0;
-
   int* flag = reinterpret_cast<int*>(lds + P_FLAG);  // [2] "not converged", double buffered over sweeps
   if (t < 2) flag[t] = 0;
   __syncthreads();
@@ -99,37 +99,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   // rotation set, then two per step.
   if (wv < 4) {
     // ================= wavefronts 0-3: A in LDS =================
-    // static assignment of the 2x2 blocks (k1 > k2)
+    // static assignment of the 2x2 blocks, idx = k1 (k1 + 1) / 2 + k2 with k1 >= k2 >= 0
     short bk1[MAXBLK], bk2[MAXBLK];
-    const int nblk = (np * (np - 1)) >> 1;
+    const int nblk = (np * (np + 1)) >> 1;
 #pragma unroll
     for (int u = 0; u < MAXBLK; u++) {
       const int idx = t + u * AW;
       bk1[u] = -1, bk2[u] = 0;
       if (idx < nblk) {
-        // idx = k1 (k1 - 1) / 2 + k2 , k1 > k2 >= 0
-        int k1 = (int)((sqrt(8.0 * idx + 1.0) + 1.0) * 0.5);
-        while (((k1 * (k1 + 1)) >> 1) <= idx) k1++;
-        while (((k1 * (k1 - 1)) >> 1) > idx) k1--;
-        bk1[u] = (short)k1, bk2[u] = (short)(idx - ((k1 * (k1 - 1)) >> 1));
+        int k1 = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while ((((k1 + 1) * (k1 + 2)) >> 1) <= idx) k1++;
+        while (((k1 * (k1 + 1)) >> 1) > idx) k1--;
+        bk1[u] = (short)k1, bk2[u] = (short)(idx - ((k1 * (k1 + 1)) >> 1));
       }
     }
-    int pa = 2 * lane, pb = 2 * lane + 1;  // index on positions 2k / 2k+1 (used by wavefront 0 only)
 
-    // wavefront 0: rotations of the step with parity `odd` -> tables[buf]; rotates the pairs' own 2x2 diagonal
-    // blocks of A in place and advances the position -> index map (pairs swap places after their rotation)
+    // wavefront 0: rotation of pair k (= lane) for the step with parity `odd` -> table[buf]
     auto make_rotation = [&](int odd, int buf) {
       const int k = lane;
-      const int pan = shl_i(pa);                           // index on position 2k+2
-      const int pa0 = __builtin_amdgcn_readfirstlane(pa);  // index on position 0
-      // odd step: positions 0 and ne-1 sit out; they form a pseudo pair with the identity rotation so that their
-      // rows / columns of A still see the other pairs' rotations through the 2x2 block scheme
-      const int a = odd ? pb : pa, b = odd ? (k == np - 1 ? pa0 : pan) : pb;
       const bool have = odd ? (k < np - 1) : (k < np);
       double cs = 1.0, sn = 0.0;
       if (have) {
-        const int iaa = ((a * (a + 1)) >> 1) + a, ibb = ((b * (b + 1)) >> 1) + b, iab = tri(a, b);
-        const double aaa = A[iaa], abb = A[ibb], aab = A[iab];
+        const int a = 2 * k + odd;  // positions a, a + 1
+        const double aaa = A[a * LD + a], abb = A[(a + 1) * LD + a + 1], aab = A[(a + 1) * LD + a];
         // below 1e-17 sqrt(aaa abb) the pivot is under the rounding noise of the diagonal: leave it
         if (aab * aab > 1e-34 * fabs(aaa * abb) && fabs(aab) > 1e-290) {
           const double d = abb - aaa;
@@ -137,54 +129,81 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const double tt = (d >= 0 ? 2.0 : -2.0) * aab * __builtin_amdgcn_rcp(fabs(d) + h);  // tan of the rotation angle
           cs = nrm_rsqrt(1.0 + tt * tt);
           sn = tt * cs;
-          const double cc = cs * cs, ss = sn * sn, sc = cs * sn;
-          A[iaa] = cc * aaa - 2.0 * sc * aab + ss * abb;
-          A[ibb] = ss * aaa + 2.0 * sc * aab + cc * abb;
-          A[iab] = (cc - ss) * aab + sc * (aaa - abb);
         }
       }
-      if (k < np) {
-        reinterpret_cast<double2*>(lds + P_ROT)[buf * NPMAX + k] = double2{cs, sn};
-        reinterpret_cast<int2*>(lds + P_PQ)[buf * NPMAX + k] = int2{a, b};
-      }
-      if (odd) {
-        const int pbs = shr_i(pb);  // index on position 2k-1
-        if (k >= 1 && k < np) pa = pbs;
-        if (k < np - 1) pb = pan;
-      } else {
-        const int tmp = pa;
-        pa = pb, pb = tmp;
-      }
+      // odd step: positions 0 and ne-1 sit out; table entry np-1 = identity
+      if (k < np) reinterpret_cast<double2*>(lds + P_ROT)[buf * NPMAX + k] = double2{cs, sn};
     };
 
-    auto a_blocks = [&](int buf) {
-      const double2* rcs = reinterpret_cast<const double2*>(lds + P_ROT) + buf * NPMAX;
-      const int2* rpq = reinterpret_cast<const int2*>(lds + P_PQ) + buf * NPMAX;
-      double a00[MAXBLK], a01[MAXBLK], a10[MAXBLK], a11[MAXBLK];
-      double2 r1[MAXBLK], r2[MAXBLK];
-      int i00[MAXBLK], i01[MAXBLK], i10[MAXBLK], i11[MAXBLK];
-      bool act[MAXBLK];
+    // even step: block rows (2 k1, 2 k1 + 1) x columns (2 k2, 2 k2 + 1); both pairs swap positions afterwards.
+    // All addresses are static per thread.
+    int oe[MAXBLK];
+#pragma unroll
+    for (int u = 0; u < MAXBLK; u++) oe[u] = bk1[u] < 0 ? -1 : 2 * bk1[u] * LD + 2 * bk2[u];
+    auto a_even = [&]() {
+      const double2* rcs = reinterpret_cast<const double2*>(lds + P_ROT);
+      double2 u0[MAXBLK], u1[MAXBLK], r1[MAXBLK], r2[MAXBLK];
 #pragma unroll
       for (int u = 0; u < MAXBLK; u++) {
-        act[u] = false;
-        if (bk1[u] < 0) continue;
+        if (oe[u] < 0) continue;
         r1[u] = rcs[bk1[u]], r2[u] = rcs[bk2[u]];
-        if (r1[u].y == 0.0 && r2[u].y == 0.0) continue;
-        const int2 pq1 = rpq[bk1[u]], pq2 = rpq[bk2[u]];
-        act[u] = true;
-        i00[u] = tri(pq1.x, pq2.x), i01[u] = tri(pq1.x, pq2.y), i10[u] = tri(pq1.y, pq2.x), i11[u] = tri(pq1.y, pq2.y);
-        a00[u] = A[i00[u]], a01[u] = A[i01[u]], a10[u] = A[i10[u]], a11[u] = A[i11[u]];
+        u0[u] = *reinterpret_cast<const double2*>(A + oe[u]);
+        u1[u] = *reinterpret_cast<const double2*>(A + oe[u] + LD);
       }
 #pragma unroll
       for (int u = 0; u < MAXBLK; u++) {
-        if (!act[u]) continue;
+        if (oe[u] < 0) continue;
+        const double c1 = r1[u].x, s1 = r1[u].y, c2 = r2[u].x, s2 = r2[u].y;
+        const double a00 = u0[u].x, a10 = u1[u].x, a11 = u1[u].y;
+        const double a01 = bk1[u] == bk2[u] ? a10 : u0[u].y;  // diagonal block: the upper element is not stored
+        const double b00 = c1 * a00 - s1 * a10, b01 = c1 * a01 - s1 * a11;
+        const double b10 = s1 * a00 + c1 * a10, b11 = s1 * a01 + c1 * a11;
+        const double n00 = c2 * b00 - s2 * b01, n01 = s2 * b00 + c2 * b01;
+        const double n10 = c2 * b10 - s2 * b11, n11 = s2 * b10 + c2 * b11;
+        *reinterpret_cast<double2*>(A + oe[u]) = double2{n11, n10};
+        *reinterpret_cast<double2*>(A + oe[u] + LD) = double2{n01, n00};
+      }
+    };
+    // odd step: block rows (2 k1 + 1, 2 k1 + 2) x columns (2 k2 + 1, 2 k2 + 2) for k1, k2 < np - 1, rows and columns
+    // swap afterwards; the items with k1 = np - 1 are the two positions that sit out (ne - 1 and 0): identity row
+    // rotation, only the columns swap.  Load addresses li**, store addresses of n11 / n10 / n01 / n00 = so**.
+    int li00[MAXBLK], li01[MAXBLK], li10[MAXBLK], li11[MAXBLK], so11[MAXBLK], so10[MAXBLK], so01[MAXBLK], so00[MAXBLK];
+#pragma unroll
+    for (int u = 0; u < MAXBLK; u++) {
+      li00[u] = -1, li01[u] = li10[u] = li11[u] = so11[u] = so10[u] = so01[u] = so00[u] = 0;
+      if (bk1[u] < 0 || bk2[u] >= np - 1) continue;
+      const int ra = 2 * bk1[u] + 1, rb = (ra + 1 == ne) ? 0 : ra + 1, ca = 2 * bk2[u] + 1, cb = ca + 1;
+      // lower-triangle addresses: (r, c) -> [max][min]
+      li00[u] = ra * LD + ca;                              // ra >= ca always
+      li01[u] = ra >= cb ? ra * LD + cb : cb * LD + ra;    // diagonal block: same element as li10
+      li10[u] = rb >= ca ? rb * LD + ca : ca * LD + rb;    // rb = 0 (sitting out): transposed
+      li11[u] = rb >= cb ? rb * LD + cb : cb * LD + rb;
+      const bool edge = bk1[u] == np - 1;
+      so11[u] = edge ? li10[u] : li00[u];
+      so10[u] = edge ? li11[u] : li01[u];
+      so01[u] = edge ? li00[u] : li10[u];
+      so00[u] = edge ? li01[u] : li11[u];
+    }
+    auto a_odd = [&]() {
+      const double2* rcs = reinterpret_cast<const double2*>(lds + P_ROT) + NPMAX;
+      double a00[MAXBLK], a01[MAXBLK], a10[MAXBLK], a11[MAXBLK];
+      double2 r1[MAXBLK], r2[MAXBLK];
+#pragma unroll
+      for (int u = 0; u < MAXBLK; u++) {
+        if (li00[u] < 0) continue;
+        r1[u] = rcs[bk1[u]], r2[u] = rcs[bk2[u]];
+        a00[u] = A[li00[u]], a01[u] = A[li01[u]], a10[u] = A[li10[u]], a11[u] = A[li11[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < MAXBLK; u++) {
+        if (li00[u] < 0) continue;
         const double c1 = r1[u].x, s1 = r1[u].y, c2 = r2[u].x, s2 = r2[u].y;
         const double b00 = c1 * a00[u] - s1 * a10[u], b01 = c1 * a01[u] - s1 * a11[u];
         const double b10 = s1 * a00[u] + c1 * a10[u], b11 = s1 * a01[u] + c1 * a11[u];
-        A[i00[u]] = c2 * b00 - s2 * b01;
-        A[i01[u]] = s2 * b00 + c2 * b01;
-        A[i10[u]] = c2 * b10 - s2 * b11;
-        A[i11[u]] = s2 * b10 + c2 * b11;
+        A[so10[u]] = c2 * b10 - s2 * b11;
+        A[so01[u]] = s2 * b00 + c2 * b01;  // (diagonal block: same address as so10, equal up to rounding)
+        A[so00[u]] = c2 * b00 - s2 * b01;
+        A[so11[u]] = s2 * b10 + c2 * b11;
       }
     };
 
@@ -195,8 +214,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       for (int e = t; e < ne * ne; e += AW) {
         const int i = e / ne, j = e - i * ne;
         if (j < i) {
-          const double v = A[((i * (i + 1)) >> 1) + j];
-          const double dd = fabs(A[((i * (i + 1)) >> 1) + i] * A[((j * (j + 1)) >> 1) + j]);
+          const double v = A[i * LD + j];
+          const double dd = fabs(A[i * LD + i] * A[j * LD + j]);
           bad |= v * v > 1e-30 * dd;
         }
       }
@@ -208,17 +227,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       if (wv == 0) make_rotation(0, 0);
       __syncthreads();
       for (int step = 0; step < ne; step += 2) {  // ne is even: (even, odd) step pairs, tables 0 / 1
-        a_blocks(0);
+        a_even();
         __syncthreads();
         if (wv == 0) make_rotation(1, 1);
         __syncthreads();
-        a_blocks(1);
+        a_odd();
         __syncthreads();
         if (wv == 0 && step + 2 < ne) make_rotation(0, 0);
         __syncthreads();
       }
     }
-    if (wv == 0 && lane < np) reinterpret_cast<int2*>(lds + P_PQ)[lane] = int2{pa, pb};
+    if (t < ne) lds[P_EV + t] = A[t * LD + t];
     __syncthreads();
   } else {
     // ================= wavefronts 4-7: V^T in registers =================
@@ -228,11 +247,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
     for (int c = 0; c < VC; c++) X[c] = (2 * lane == c0 + c) ? 1.0 : 0.0, Y[c] = (2 * lane + 1 == c0 + c) ? 1.0 : 0.0;
 
-    // rows a, b of V^T  ->  (c a - s b, s a + c b), then the two rows swap positions.
-    // even step: a, b = this lane's X, Y
     auto rot_of = [&](int buf) {
       return lane < np ? reinterpret_cast<const double2*>(lds + P_ROT)[buf * NPMAX + lane] : double2{1.0, 0.0};
     };
+    auto rot_odd = [&]() {
+      return lane < np - 1 ? reinterpret_cast<const double2*>(lds + P_ROT)[NPMAX + lane] : double2{0.0, 1.0};
+    };
+    // rows a, b of V^T  ->  (c a - s b, s a + c b), then the two rows swap positions.
+    // even step: a, b = this lane's X, Y
     auto v_even = [&](double2 r, int cbeg, int cend) {
       const double c = r.x, s = r.y;
 #pragma unroll
@@ -243,18 +265,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         Y[q] = c * x - s * y;
       }
     };
-    // odd step: a = this lane's Y (position 2k+1), b = the next lane's X (position 2k+2)
+    // odd step: a = this lane's Y (position 2k+1), b = the next lane's X (position 2k+2).  Lane np-1 has no
+    // partner: it gets (c, s) = (0, 1), which leaves its Y alone (s y + c x_next = y) whatever the shift brought in;
+    // lane 0 has no source for the shift back and keeps its X (position 0 sits out).
     auto v_odd = [&](double2 r, int cbeg, int cend) {
       const double c = r.x, s = r.y;
-      const bool have = lane < np - 1, recv = lane >= 1 && lane < np;
 #pragma unroll
       for (int q = 0; q < VC; q++) {
         if (q < cbeg || q >= cend) continue;
         const double y = Y[q], xn = shl_d(X[q]);
-        const double ra = c * y - s * xn, rb = s * y + c * xn;
-        Y[q] = have ? rb : y;
-        const double down = shr_d(ra);  // row a moves to position 2k+2 = X of lane k+1
-        X[q] = recv ? down : X[q];
+        const double ra = c * y - s * xn;
+        Y[q] = s * y + c * xn;
+        X[q] = shr_into(X[q], ra);  // row a moves to position 2k+2 = X of lane k+1
       }
     };
 
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       if (!flag[sweep & 1]) break;
       sweeps++;
       __syncthreads();
-      for (int step = 0; step < ne; step += 2) {  // ne is even: (even, odd) step pairs, tables 0 / 1
+      for (int step = 0; step < ne; step += 2) {
         // (register-only work: pin it between the barriers it is meant to overlap with)
         const double2 re = rot_of(0);
         v_even(re, 0, VC1);
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        const double2 ro = rot_of(1);
+        const double2 ro = rot_odd();
         v_odd(ro, 0, VC1);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -285,26 +307,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
-    // V^T to LDS by index (row a of V^T = eigenvector of eigenvalue A[a][a])
+    __syncthreads();  // eigenvalues are out of A: its storage now takes V^T (row = position)
     if (lane < np) {
-      const int2 ab = reinterpret_cast<const int2*>(lds + P_PQ)[lane];
 #pragma unroll
       for (int c = 0; c < VC; c++)
-        if (c0 + c < ne) Vt[ab.x * ne + c0 + c] = X[c], Vt[ab.y * ne + c0 + c] = Y[c];
+        if (c0 + c < ne) A[2 * lane * LD + c0 + c] = X[c], A[(2 * lane + 1) * LD + c0 + c] = Y[c];
     }
   }
   __syncthreads();
+  const double* Vt = A;
   // ---- linearized_jacobians = diag(sqrt(S)) V^T ; linearized_residuals = diag(1/sqrt(S)) V^T b'
+  // An odd n carries one pad index (zero row / column of A): it only ever sees identity rotations, so its
+  // eigenvector is still exactly the unit vector e_{ne-1} and every other row of V^T has an exact 0 in that column.
+  // Its position is skipped: output row k = position k before the pad, k + 1 after it.
+  int padpos = ne;  // no pad
+  if (ne != n) {
+    // the pad eigenvector is the unit vector e_{ne-1}: the position whose V^T row has 1 in column ne-1
+    for (int k = 0; k < ne; k++)
+      if (Vt[k * LD + ne - 1] != 0.0) padpos = k;
+  }
   for (int e = t; e < n * n; e += NT) {
     const int k = e / n, j = e - k * n;
-    const double ev = A[((k * (k + 1)) >> 1) + k];
-    gJ[(size_t)k * ldj + j] = (ev > eps ? sqrt(ev) : 0.0) * Vt[k * ne + j];
+    const int pos = k < padpos ? k : k + 1;
+    const double ev = lds[P_EV + pos];
+    gJ[(size_t)k * ldj + j] = (ev > eps ? sqrt(ev) : 0.0) * Vt[pos * LD + j];
   }
   if (t < n) {
-    const double ev = A[((t * (t + 1)) >> 1) + t];
+    const int pos = t < padpos ? t : t + 1;
+    const double ev = lds[P_EV + pos];
     double vb = 0;
-    for (int j = 0; j < n; j++) vb += Vt[t * ne + j] * lds[P_B + j];
+    for (int j = 0; j < n; j++) vb += Vt[pos * LD + j] * lds[P_B + j];
     gr[t] = (ev > eps ? sqrt(1.0 / ev) : 0.0) * vb;
   }
   if (prof && t == 0) {

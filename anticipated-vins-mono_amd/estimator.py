@@ -23,7 +23,9 @@ class Estimator:
         self.last_marginalization_info = None  # PriorOutArrays after a MARGIN_OLD / SECOND_NEW solve
 
     # the reference's name
-    def optimization(self, windows: buffers.WindowArrays, want_summary: bool = True):
+    def optimization(self, windows: buffers.WindowArrays, want_summary: bool = True, prior_out: buffers.PriorOutArrays = None):
+        """Solve all windows in place.  `prior_out` lets a caller that solves batch after batch hand the same
+        output slots back in (the reference allocates a new MarginalizationInfo per call; the slots are plain data)."""
         L = self.ctx._L
         B = windows.n_windows
         s = windows.struct()
@@ -31,7 +33,7 @@ class Estimator:
         summ = buffers.summary_alloc(B, dev) if want_summary else None
         prior = None
         if self.options.marginalization_flag != abi.MARGIN_NONE:
-            prior = buffers.PriorOutArrays.alloc(B, windows.dims["max_prior"], windows.dims["max_pblk"], dev)
+            prior = prior_out or buffers.PriorOutArrays.alloc(B, windows.dims["max_prior"], windows.dims["max_pblk"], dev)
         po = prior.struct() if prior is not None else None
         rc = L.avm_window_solve_batch(self.ctx.h, C.byref(self.options), windows.mem, C.byref(s),
                                       C.byref(po) if po is not None else None,

@@ -94,10 +94,13 @@ def main():
     pristine = {k: win.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
     gathered = torch.empty((world * W, 11, 7), dtype=torch.float64, device=dev) if world > 1 else None
 
+    marg = opt.marginalization_flag != abi.MARGIN_NONE
+    prior_slots = buffers.PriorOutArrays.alloc(W, win.dims["max_prior"], win.dims["max_pblk"], dev) if marg else None
+
     def step():
         for k, v in pristine.items():
             win.a[k].copy_(v)
-        summ = E.optimization(win, want_summary=True)
+        summ = E.optimization(win, want_summary=True, prior_out=prior_slots)
         if world > 1:
             dist.all_gather_into_tensor(gathered, win.a["pose"])
         return summ
@@ -174,7 +177,7 @@ def main():
                 "hbm_secondary": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBs": alg_bytes / (k_ms * 1e-3) / 1e9,
                                   "peak_GBs": HBM_PEAK_GBS},
             },
-            "preint_kernel_ms": ctx.kernel_ms("preint"),
+            "kernel_ms": {k: ctx.kernel_ms(k) for k in ("preint", "window_solve", "marginalize", "prior_eig")},
         }
 
     # ---- feature selector: ms/frame (batch throughput) and single-frame latency
