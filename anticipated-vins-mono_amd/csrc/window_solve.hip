@@ -31,7 +31,20 @@ namespace {
 
 // the workgroup's dynamic LDS, always reached through the shared symbol (never through a generic pointer that
 // crosses a function boundary), so the compiler keeps ds_* addressing inside outlined functions
-AVM_DEV double* LDS() { return reinterpret_cast<double*>(avm_smem); }
+//
+// None of the kernels in this file has static LDS, so the dynamic segment starts at LDS address 0 (checked once per
+// workgroup by lds_base_check()).  Spelling the base as the constant instead of the symbol matters: outside a
+// kernel body the symbol's address is a load from llvm.amdgcn.dynlds.offset.table, which the compiler happily
+// re-issues (s_load + s_waitcnt) in front of every predicated LDS access of the outlined phases.
+typedef __attribute__((address_space(3))) double lds_double_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+AVM_DEV double* LDS() {
+  // (integer -> pointer keeps this the LDS address 0; a literal null would become the address-space's null, -1)
+  return (double*)reinterpret_cast<lds_double_t*>((uintptr_t)__builtin_amdgcn_readfirstlane(0));
+}
+AVM_DEV void lds_base_check() {
+  if ((unsigned)(uintptr_t)(lds_char_t*)avm_smem != 0u) __builtin_trap();
+}
 
 #define AVM_NOINL __device__ __noinline__
 #define PROF_T0() long long pt__ = clock64()
@@ -284,16 +297,33 @@ AVM_DEV void prior_block_dx(int kind, const double* xb, const double* x0, double
   }
 }
 
+// Global-memory pointers carried into the outlined phases are typed with their address space: behind a struct
+// reference the compiler cannot prove it and would fall back to flat_load/flat_store, which count against the LDS
+// counter too (every LDS wait then also waits for HBM).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) const double gcdouble;
+typedef __attribute__((address_space(1))) int32_t gint;
+typedef __attribute__((address_space(1))) long long glong;
+template <class T> AVM_DEV __attribute__((address_space(1))) T* as_global(T* p) { return (__attribute__((address_space(1))) T*)p; }
+#else  // host pass of the same translation unit: plain pointers
+typedef double gdouble;
+typedef const double gcdouble;
+typedef int32_t gint;
+typedef long long glong;
+template <class T> AVM_DEV T* as_global(T* p) { return p; }
+#endif
+
 struct WinCtx {
-  long long* prof;
-  double* sc;   // global scratch slot
-  int32_t* osf; // observation slot -> feature
-  int32_t* cov; // [11][150] features observed in frame b, in feature order
+  glong* prof;
+  gdouble* sc;   // global scratch slot
+  gint* osf;     // observation slot -> feature
+  gint* cov;     // [11][150] features observed in frame b, in feature order
   int w, nf, nobs_tot, pn, pnblk;
-  const double* obs;   // [max_obs][2]
-  const double *pdelta, *pjac, *psqrt, *psum;  // this window's 10 intervals
-  const double *lba, *lbg;
-  const double *pJ, *pr, *px0;  // prior
+  gcdouble* obs;   // [max_obs][2]
+  gcdouble *pdelta, *pjac, *psqrt, *psum;  // this window's 10 intervals
+  gcdouble *lba, *lbg;
+  gcdouble *pJ, *pr, *px0;  // prior
   int ldp;
 };
 
@@ -812,7 +842,9 @@ AVM_DEV double fast_rsqrt(double x) {
   return y;
 }
 
-// factor the nb x nb diagonal block at c0 in the registers of the calling wavefront (lane = row)
+// factor the nb x nb diagonal block at c0 in the registers of the calling wavefront (lane = row).
+// Select-free: lanes / columns outside the block (and the upper triangle) just carry finite junk that is never
+// stored - keeping 16 + 16 lane masks alive across the pivot loop costs more (SGPR spills) than the junk FMAs.
 AVM_NOINL void chol_diag_block(int c0, int nb) {
   constexpr int NB = CNB;
   double* S = LDS() + L_S;
@@ -820,29 +852,37 @@ AVM_NOINL void chol_diag_block(int c0, int nb) {
   const int r = threadIdx.x & 63;
   __builtin_amdgcn_s_setprio(3);  // this wavefront is the critical path of the factorization: win issue arbitration
   double a[NB];
+  const int rc = min(r, nb - 1);
+  double* row = S + roff(c0 + rc) + c0;
 #pragma unroll
-  for (int k = 0; k < NB; k++) a[k] = (r < nb && k <= r) ? S[roff(c0 + r) + c0 + k] : (k == r ? 1.0 : 0.0);
+  for (int k = 0; k < NB; k++) a[k] = row[min(k, rc)];  // 16 reads in flight, always a valid address
   bool bad = false;
+  double invs[NB];
 #pragma unroll
   for (int j = 0; j < NB; j++) {
     const double djj = readlane_d(a[j], j);
     if (j < nb && !(djj > 0.0)) bad = true;
     const double inv = fast_rsqrt(djj);
-    const double lij = (r == j) ? djj * inv : a[j] * inv;
+    invs[j] = inv;
+    const double lij = a[j] * inv;  // lane j: d / sqrt(d) = sqrt(d)
     a[j] = lij;
 #pragma unroll
     for (int k = j + 1; k < NB; k++) {
       const double lkj = readlane_d(lij, k);
       a[k] -= lij * lkj;
     }
-    if (r == j && j < nb) dinv[c0 + j] = inv;
   }
   if (r < nb) {
 #pragma unroll
     for (int k = 0; k < NB; k++)
-      if (k <= r) S[roff(c0 + r) + c0 + k] = a[k];
+      if (k <= r) row[k] = a[k];
   }
-  if (bad && r == 0) reinterpret_cast<int*>(LDS() + L_INT)[I_FAIL] = 1;
+  if (r == 0) {
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+      if (k < nb) dinv[c0 + k] = invs[k];
+    if (bad) reinterpret_cast<int*>(LDS() + L_INT)[I_FAIL] = 1;
+  }
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -1141,6 +1181,7 @@ AVM_DEV void state_plus() {
 }  // namespace
 
 __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
+  lds_base_check();
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
@@ -1149,22 +1190,22 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
 
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
     WinCtx c;
-    c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
-    c.osf = A.iscratch + (size_t)blockIdx.x * ISCRATCH;
+    c.sc = as_global(A.scratch + (size_t)blockIdx.x * Scratch::TOTAL);
+    c.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
     c.cov = c.osf + MAXOBS;
     c.w = w;
-    c.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
+    c.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
     c.nf = B.n_feat[w];
-    c.obs = B.obs_xy + (size_t)w * B.max_obs * 2;
-    c.pdelta = A.pre_delta + (size_t)w * 100, c.pjac = A.pre_jac + (size_t)w * 2250, c.psqrt = A.pre_sqrt + (size_t)w * 2250;
-    c.psum = A.pre_sum_dt + (size_t)w * 10;
-    c.lba = B.imu_lin_ba + (size_t)w * 30, c.lbg = B.imu_lin_bg + (size_t)w * 30;
+    c.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
+    c.pdelta = as_global(A.pre_delta + (size_t)w * 100), c.pjac = as_global(A.pre_jac + (size_t)w * 2250), c.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
+    c.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
+    c.lba = as_global(B.imu_lin_ba + (size_t)w * 30), c.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
     c.pn = B.prior_n ? B.prior_n[w] : 0;
     c.pnblk = c.pn > 0 ? B.prior_nblk[w] : 0;
     c.ldp = B.max_prior;
-    c.pJ = B.prior_J + (size_t)w * B.max_prior * B.max_prior;
-    c.pr = B.prior_r + (size_t)w * B.max_prior;
-    c.px0 = B.prior_x0 + (size_t)w * B.max_pblk * 9;
+    c.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
+    c.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
+    c.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
     __syncthreads();
     PROF_T0();
     // ---------------- load ----------------
@@ -1789,6 +1830,7 @@ AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
 }
 
 __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO) {
+  lds_base_check();
   using namespace mg;
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
@@ -1798,22 +1840,22 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
   const int flag = o.marginalization_flag;
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
     WinCtx c;
-    c.prof = A.prof ? A.prof + (size_t)blockIdx.x * 32 : nullptr;
-    c.sc = A.scratch + (size_t)blockIdx.x * Scratch::TOTAL;
-    c.osf = A.iscratch + (size_t)blockIdx.x * ISCRATCH;
+    c.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
+    c.sc = as_global(A.scratch + (size_t)blockIdx.x * Scratch::TOTAL);
+    c.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
     c.cov = c.osf + MAXOBS;
     c.w = w;
     c.nf = B.n_feat[w];
-    c.obs = B.obs_xy + (size_t)w * B.max_obs * 2;
-    c.pdelta = A.pre_delta + (size_t)w * 100, c.pjac = A.pre_jac + (size_t)w * 2250, c.psqrt = A.pre_sqrt + (size_t)w * 2250;
-    c.psum = A.pre_sum_dt + (size_t)w * 10;
-    c.lba = B.imu_lin_ba + (size_t)w * 30, c.lbg = B.imu_lin_bg + (size_t)w * 30;
+    c.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
+    c.pdelta = as_global(A.pre_delta + (size_t)w * 100), c.pjac = as_global(A.pre_jac + (size_t)w * 2250), c.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
+    c.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
+    c.lba = as_global(B.imu_lin_ba + (size_t)w * 30), c.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
     c.pn = B.prior_n ? B.prior_n[w] : 0;
     c.pnblk = c.pn > 0 ? B.prior_nblk[w] : 0;
     c.ldp = B.max_prior;
-    c.pJ = B.prior_J + (size_t)w * B.max_prior * B.max_prior;
-    c.pr = B.prior_r + (size_t)w * B.max_prior;
-    c.px0 = B.prior_x0 + (size_t)w * B.max_pblk * 9;
+    c.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
+    c.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
+    c.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
     c.nobs_tot = 0;
     __syncthreads();
     PROF_T0();
@@ -2164,6 +2206,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
 
 // Per-factor evaluation at the input state (no solve): parity-test surface for A5/A6/A8.
 __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
+  lds_base_check();
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
@@ -2173,16 +2216,16 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
   WinCtx c;
   c.sc = nullptr, c.osf = nullptr, c.w = w;
   c.nf = B.n_feat[w];
-  c.obs = B.obs_xy + (size_t)w * B.max_obs * 2;
-  c.pdelta = A.pre_delta + (size_t)w * 100, c.pjac = A.pre_jac + (size_t)w * 2250, c.psqrt = A.pre_sqrt + (size_t)w * 2250;
-  c.psum = A.pre_sum_dt + (size_t)w * 10;
-  c.lba = B.imu_lin_ba + (size_t)w * 30, c.lbg = B.imu_lin_bg + (size_t)w * 30;
+  c.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
+  c.pdelta = as_global(A.pre_delta + (size_t)w * 100), c.pjac = as_global(A.pre_jac + (size_t)w * 2250), c.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
+  c.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
+  c.lba = as_global(B.imu_lin_ba + (size_t)w * 30), c.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
   c.pn = B.prior_n ? B.prior_n[w] : 0;
   c.pnblk = c.pn > 0 ? B.prior_nblk[w] : 0;
   c.ldp = B.max_prior;
-  c.pJ = B.prior_J + (size_t)w * B.max_prior * B.max_prior;
-  c.pr = B.prior_r + (size_t)w * B.max_prior;
-  c.px0 = B.prior_x0 + (size_t)w * B.max_pblk * 9;
+  c.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
+  c.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
+  c.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
   for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
   for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
   for (int i = t; i < MAXE; i += NT) lds[L_X + XLAM + i] = i < c.nf ? B.inv_depth[(size_t)w * B.max_feat + i] : 1.0;
