@@ -551,6 +551,69 @@ AVM_NOINL double frame_task(const WinCtx& c, const avm_options& o, int b, int st
   return cost;
 }
 
+// One wavefront, one IMU factor i: J = sqrt_info * [r | J_raw] (15 x 31) and its Gram matrix on v_mfma_f64_16x16x4,
+// then S += J^T J (lower), g += J^T r; returns 0.5 r^T r on lane 0 (0 elsewhere).
+// The two 16-column accumulator tiles of J are, register for register, both the A operand (J^T) and the B operand
+// (J) of the Gram products, so nothing moves between the two steps.  Factors sharing a frame must not run
+// concurrently (the caller alternates even / odd factors).
+AVM_DEV double imu_factor_mfma(const WinCtx& c, int i) {
+  double* lds = LDS();
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  gcdouble* U = c.psqrt + i * 225;                 // upper triangular, zeros stored below the diagonal
+  gcdouble* raw = c.sc + Scratch::IJRAW + i * 465; // [15][31]: column 0 = residual, 1..30 = Jacobian
+  double ua[4], b0[4], b1[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int k = lk + 4 * m;
+    ua[m] = (li < 15 && k < 15) ? U[li * 15 + k] : 0.0;
+    b0[m] = k < 15 ? raw[k * 31 + li] : 0.0;
+    b1[m] = (k < 15 && li < 15) ? raw[k * 31 + 16 + li] : 0.0;
+  }
+  d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[m], b0[m], D0, 0, 0, 0);
+    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[m], b1[m], D1, 0, 0, 0);
+  }
+  d4 G00 = {0, 0, 0, 0}, G10 = {0, 0, 0, 0}, G11 = {0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(D0[m], D0[m], G00, 0, 0, 0);
+    G10 = __builtin_amdgcn_mfma_f64_16x16x4f64(D1[m], D0[m], G10, 0, 0, 0);
+    G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(D1[m], D1[m], G11, 0, 0, 0);
+  }
+  // scatter: combined index 0 = residual, p + 1 = local column p
+  double half_rr = 0;
+  const int ccol0 = li > 0 ? imu_col(i, li - 1) : -1;          // state column of combined column li
+  const int ccol1 = li < 15 ? imu_col(i, 15 + li) : -1;        // ... of combined column 16 + li
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int R0 = lk + 4 * r;       // combined row in tile 0
+    const int R1 = 16 + R0;          // combined row in tile 1 (31 = padding)
+    // G00: rows / columns 0..15
+    if (R0 == 0) {
+      if (li == 0) half_rr = 0.5 * G00[r];
+    } else if (li <= R0) {
+      const int sr = imu_col(i, R0 - 1);
+      if (li == 0)
+        lds[L_G + sr] += G00[r];
+      else
+        lds[L_S + roff(max(sr, ccol0)) + min(sr, ccol0)] += G00[r];
+    }
+    if (R1 < 31) {
+      const int sr = imu_col(i, R1 - 1);
+      // G10: rows 16..30, columns 0..15
+      if (li == 0)
+        lds[L_G + sr] += G10[r];
+      else
+        lds[L_S + roff(max(sr, ccol0)) + min(sr, ccol0)] += G10[r];
+      // G11: rows / columns 16..30, lower part
+      if (li < 15 && 16 + li <= R1) lds[L_S + roff(max(sr, ccol1)) + min(sr, ccol1)] += G11[r];
+    }
+  }
+  return half_rr;
+}
+
 // Full evaluation at lds[L_X]: fills S (unscaled H_ff), W, hee, g (unscaled) and returns the cost.
 AVM_NOINL double eval_jac(const WinCtx& c, const avm_options& o) {
   double* lds = LDS();
@@ -638,46 +701,11 @@ AVM_NOINL double eval_jac(const WinCtx& c, const avm_options& o) {
   for (int i = SPP + t; i < SROWS; i += NT) lds[L_S + i] = 0.0;
   __syncthreads();
   PROF(c, 3);
-  // ---- phase D: IMU factors, even then odd: IJ = sqrt_info * raw into LDS, then J^T J / J^T r
-  double* IJ5 = lds + L_Y;            // [5][15][31]
-  double* SQ5 = lds + L_Y + 5 * 465 + 3;  // [5][225], 8-byte aligned is enough
+  // ---- phase D: IMU factors on MFMA, one wavefront per factor; even factors then odd ones (neighbours share a frame)
   for (int par = 0; par < 2; par++) {
-    for (int idx = t; idx < 5 * 225; idx += NT) SQ5[idx] = c.psqrt[(2 * (idx / 225) + par) * 225 + idx % 225];
-    __syncthreads();
-    for (int idx = t; idx < 5 * 465; idx += NT) {
-      const int ii = idx / 465, i = 2 * ii + par, rc = idx % 465, r = rc / 31, cc = rc % 31;
-      double sacc = 0;
-      if (c.psum[i] <= o.max_sum_dt) {
-        const double* raw = IJR + i * 465 + cc;
-#pragma unroll 5
-        for (int k = r; k < 15; k++) sacc += SQ5[ii * 225 + r * 15 + k] * raw[k * 31];
-      }
-      IJ5[idx] = sacc;
-      if (cc == 0) acc += 0.5 * sacc * sacc;
-    }
-    __syncthreads();
-    for (int idx = t; idx < 5 * 495; idx += NT) {
-      const int ii = idx / 495, i = 2 * ii + par, q = idx % 495;
-      if (c.psum[i] > o.max_sum_dt) continue;
-      const double* Jm = IJ5 + ii * 465;
-      if (q < 465) {
-        int p = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
-        while ((p + 1) * (p + 2) / 2 <= q) p++;
-        while (p * (p + 1) / 2 > q) p--;
-        const int qq = q - p * (p + 1) / 2;
-        double sacc = 0;
-#pragma unroll
-        for (int r = 0; r < 15; r++) sacc += Jm[r * 31 + 1 + p] * Jm[r * 31 + 1 + qq];
-        const int ip = imu_col(i, p), iq = imu_col(i, qq);
-        const int hi = max(ip, iq), lo = min(ip, iq);
-        lds[L_S + roff(hi) + lo] += sacc;
-      } else {
-        const int p = q - 465;
-        double sacc = 0;
-#pragma unroll
-        for (int r = 0; r < 15; r++) sacc += Jm[r * 31 + 1 + p] * Jm[r * 31];
-        lds[L_G + imu_col(i, p)] += sacc;
-      }
+    if (wv < 5) {
+      const int i = 2 * wv + par;
+      if (c.psum[i] <= o.max_sum_dt) acc += imu_factor_mfma(c, i);
     }
     __syncthreads();
   }
