@@ -362,14 +362,23 @@ AVM_NOINL void prior_residual_dev(const WinCtx& c, int xs_off) {
     for (int k = 0; k < n; k++) lds[L_DXP + off + k] = dx[k];
   }
   __syncthreads();
-  // r_p[i] = r0[i] + sum_k J0[i][k] dx[k] : one wave per row group, lanes over k (k < 128 supported)
-  const int lane = t & 63, wv = t >> 6;
-  for (int i = wv; i < c.pn; i += NT / 64) {
+  // r_p[i] = r0[i] + sum_k J0[i][k] dx[k] : 4 lanes per row (k = part, part + 4, ...), all loads of a lane in flight
+  // at once; the four partial sums are combined in a fixed order
+  {
+    const int row = t >> 2, part = t & 3;
+    static_assert(NT >= 4 * MAXPRIOR, "one pass over the rows");
     double s = 0;
-    if (lane < c.pn) s = c.pJ[(size_t)i * c.ldp + lane] * lds[L_DXP + lane];
-    if (lane + 64 < c.pn) s += c.pJ[(size_t)i * c.ldp + lane + 64] * lds[L_DXP + lane + 64];
-    s = wave_sum(s);
-    if (lane == 0) lds[L_RP + i] = c.pr[i] + s;
+    if (row < c.pn) {
+      gcdouble* Jr = c.pJ + (size_t)row * c.ldp;
+      double v[MAXPRIOR / 4];
+#pragma unroll
+      for (int j = 0; j < MAXPRIOR / 4; j++) v[j] = (part + 4 * j < c.pn) ? Jr[part + 4 * j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < MAXPRIOR / 4; j++) s += v[j] * lds[L_DXP + part + 4 * j];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (row < c.pn && part == 0) lds[L_RP + row] = c.pr[row] + s;
   }
   __syncthreads();
 }
@@ -439,6 +448,43 @@ AVM_NOINL void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
       if (gi < pn && gj < pn) {
         HP[gi * MAXPRIOR + gj] = D[r];
         HP[gj * MAXPRIOR + gi] = D[r];
+      }
+    }
+  }
+}
+
+// Solve-kernel variant: lower triangle packed by idx = p (p + 1) / 2 + q into HPk, plus the destination of every
+// entry inside the packed S (or -1 if the prior column is not a state of the solve) - the per-iteration add is then
+// a flat gather.  All operand loads of a tile are issued before the MFMA chain.
+constexpr int HPK_MAX = MAXPRIOR * (MAXPRIOR + 1) / 2;  // 4656 doubles, followed by 4656 ints (fits the [96][96] slot)
+static_assert(HPK_MAX + HPK_MAX / 2 <= MAXPRIOR * MAXPRIOR, "packed Hp + destinations fit the HP scratch region");
+AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gint* dst) {
+  const int* pidx = reinterpret_cast<const int*>(LDS() + L_INT) + I_PIDX;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ntl = (pn + 15) >> 4;
+  for (int tile = wv; tile < ntl * (ntl + 1) / 2; tile += NT / 64) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int ca = 16 * ti + (lane & 15), cb = 16 * tj + (lane & 15);
+    double av[MAXPRIOR / 4], bv[MAXPRIOR / 4];
+#pragma unroll
+    for (int m = 0; m < MAXPRIOR / 4; m++) {
+      const int r = 4 * m + (lane >> 4);
+      av[m] = (r < pn && ca < pn) ? pJ[(size_t)r * ldp + ca] : 0.0;
+      bv[m] = (r < pn && cb < pn) ? pJ[(size_t)r * ldp + cb] : 0.0;
+    }
+    d4 D = {0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < MAXPRIOR / 4; m++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[m], D, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int gi = 16 * ti + (lane >> 4) + 4 * r, gj = 16 * tj + (lane & 15);
+      if (gi < pn && gj <= gi) {
+        const int idx = gi * (gi + 1) / 2 + gj;
+        const int ip = pidx[gi], iq = pidx[gj];
+        HPk[idx] = D[r];
+        dst[idx] = (ip < 0 || iq < 0) ? -1 : roff(max(ip, iq)) + min(ip, iq);
       }
     }
   }
@@ -710,32 +756,31 @@ AVM_NOINL double eval_jac(const WinCtx& c, const avm_options& o) {
     __syncthreads();
   }
   PROF(c, 7);
-  // ---- phase E: prior  H += Hp (mapped), g += J0^T r_p
+  // ---- phase E: prior  H += Hp (packed values + destinations prepared once per solve), g += J0^T r_p
   if (c.pn > 0) {
-    const double* HP = c.sc + Scratch::HP;
-    const int* pidx = ids + I_PIDX;
-    for (int idx = t; idx < c.pn * (c.pn + 1) / 2; idx += NT) {
-      int p = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-      while ((p + 1) * (p + 2) / 2 <= idx) p++;
-      while (p * (p + 1) / 2 > idx) p--;
-      const int q = idx - p * (p + 1) / 2;
-      const int ip = pidx[p], iq = pidx[q];
-      if (ip < 0 || iq < 0) continue;
-      const int hi = max(ip, iq), lo = min(ip, iq);
-      lds[L_S + roff(hi) + lo] += HP[p * MAXPRIOR + q];
+    gcdouble* HPk = c.sc + Scratch::HP;
+    const gint* dst = reinterpret_cast<const gint*>(c.sc + Scratch::HP + HPK_MAX);
+    const int npk = c.pn * (c.pn + 1) / 2;
+    for (int idx = t; idx < npk; idx += NT) {
+      const int d = dst[idx];
+      if (d >= 0) lds[L_S + d] += HPk[idx];
     }
-    // g += J0^T r_p : 4 lanes per column, each a quarter of the rows
+    // g += J0^T r_p : 4 lanes per column, each a quarter of the rows (rows part, part + 4, ...)
     {
+      const int* pidx = ids + I_PIDX;
       const int col = t >> 2, part = t & 3;
       double sacc = 0;
-      if (col < c.pn && pidx[col] >= 0) {
-        const int q4 = (c.pn + 3) >> 2;
-        const int i1 = min(c.pn, (part + 1) * q4);
-        for (int i = part * q4; i < i1; i++) sacc += c.pJ[(size_t)i * c.ldp + col] * lds[L_RP + i];
+      const bool on = col < c.pn && pidx[col] >= 0;
+      if (on) {
+        double v[MAXPRIOR / 4];
+#pragma unroll
+        for (int j = 0; j < MAXPRIOR / 4; j++) v[j] = (part + 4 * j < c.pn) ? c.pJ[(size_t)(part + 4 * j) * c.ldp + col] : 0.0;
+#pragma unroll
+        for (int j = 0; j < MAXPRIOR / 4; j++) sacc += v[j] * lds[L_RP + part + 4 * j];
       }
       sacc += __shfl_xor(sacc, 1, 64);
       sacc += __shfl_xor(sacc, 2, 64);
-      if (col < c.pn && part == 0 && pidx[col] >= 0) lds[L_G + pidx[col]] += sacc;
+      if (on && part == 0) lds[L_G + pidx[col]] += sacc;
     }
   }
   const double cost = block_sum<NT>(acc, lds + L_RED);
@@ -1309,7 +1354,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     }
     __syncthreads();
     // Hp = J0^T J0 (constant during the solve: hoisted out of the per-iteration J^T J)
-    if (c.pn > 0) prior_jtj_mfma(c.pJ, c.ldp, c.pn, c.sc + Scratch::HP);
+    if (c.pn > 0) prior_jtj_packed(c.pJ, c.ldp, c.pn, c.sc + Scratch::HP, reinterpret_cast<gint*>(c.sc + Scratch::HP + HPK_MAX));
     __syncthreads();
 
     PROF(c, 9);
