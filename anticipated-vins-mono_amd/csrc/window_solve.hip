@@ -1115,85 +1115,110 @@ AVM_NOINL void chol_solve_lds(int vec) {
 }
 
 // Schur complement on the inverse depths, then the right-hand side into the augmented row:
-//   S_pp -= W^T (hee + mu D_e^2)^-1 W ,  rhs = g_f - W^T (hee + mu D_e^2)^-1 g_e
+//   S_pp -= W'^T (hee' + mu D_e^2)^-1 W' ,  rhs = g'_f - W'^T (hee' + mu D_e^2)^-1 g'_e      (' = Jacobi-scaled)
+// W = E^T F stays UNSCALED in the scratch slot (W'[e][c] = s_e s_c W[e][c]); the scaling is folded in here:
+//   W'^T d' W' = s_i s_j sum_e W[e][i] (s_e^2 d'_e) W[e][j]
+// 16x16 tiles on the matrix cores, the 15 lower tiles of the 5x5 grid over the 66 (padded 80) pose columns spread
+// over the 8 wavefronts, K = features.  Operands come straight from the L2-resident slot, a batch of 8 k-steps
+// (32 loads per lane) in flight at a time - no LDS staging, no barriers.  Row 66 of the padded grid carries
+// x_e = s_e d'_e g'_e in place of a W column, so tile row 4 also delivers the right-hand-side update.
 AVM_NOINL void schur_reduce(const WinCtx& c, double mu) {
   double* lds = LDS();
   const int t = threadIdx.x;
-    // Schur complement on the inverse depths: S_pp -= W^T (hee + mu D_e^2)^-1 W ; rhs
-    if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
-    for (int i = t; i < NF; i += NT) lds[L_S + roff(NF) + i] = lds[L_G + i];  // RHS rides along as row NF
-    __syncthreads();
-    const double* W = c.sc + Scratch::W;
-    // 1/(hee + mu D_e^2) per feature (L_ST is dead here)
-    if (t < MAXE) lds[L_ST + t] = t < c.nf ? 1.0 / (lds[L_HEE + t] + mu * lds[L_DD + NF + t] * lds[L_DD + NF + t]) : 0.0;
-    // S_pp -= (W diag(1/he))^T W as 16x16 tiles on the matrix cores: 5x5 tile grid over the 66 (padded 80)
-    // pose columns, the 15 lower tiles spread over the 8 wavefronts, K = features in chunks of 32
-    const int wv = t >> 6, lane = t & 63;
-    int tti[2], ttj[2];
+  const double* scl = lds + L_SC;
+  if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
+  for (int i = t; i < NF; i += NT) lds[L_S + roff(NF) + i] = lds[L_G + i];  // RHS rides along as row NF
+  // per feature: f_e = s_e^2 / (hee' + mu D_e^2) and x_e = s_e g'_e / (hee' + mu D_e^2)   (L_ST is dead here)
+  if (t < MAXE + 2) {
+    double f = 0, x = 0;
+    if (t < c.nf) {
+      const double d = 1.0 / (lds[L_HEE + t] + mu * lds[L_DD + NF + t] * lds[L_DD + NF + t]);
+      const double se = scl[NF + t];
+      f = se * se * d, x = se * d * lds[L_G + NF + t];
+    }
+    lds[L_ST + t] = f, lds[L_ST + 152 + t] = x;
+  }
+  __syncthreads();
+  gcdouble* W = c.sc + Scratch::W;
+  const int wv = t >> 6, lane = t & 63, li = lane & 15, lk = lane >> 4;
+  int tti[2], ttj[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int tile = wv + 8 * q;  // 0..14 valid
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+    tti[q] = tile < 15 ? ti : -1;
+    ttj[q] = tile - ti * (ti + 1) / 2;
+  }
+  d4 Dt[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  constexpr int KB = 8;  // k-steps (of 4 features) per batch
+  for (int e0 = 0; e0 < c.nf; e0 += 4 * KB) {
+    double av[2][KB], bv[2][KB];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-      const int tile = wv + 8 * q;  // 0..14 valid
-      int ti = 0;
-      while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
-      tti[q] = tile < 15 ? ti : -1;
-      ttj[q] = tile - ti * (ti + 1) / 2;
-    }
-    d4 Dt[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    double accR = 0;
-    for (int e0 = 0; e0 < c.nf; e0 += WCH) {
-      const int ne = min(WCH, c.nf - e0);
-      __syncthreads();
-      for (int idx = t; idx < WCH * WLD; idx += NT) {
-        const int e = idx / WLD, cc = idx % WLD;
-        lds[L_WCH + idx] = (e < ne && cc < NPOSE) ? W[(size_t)(e0 + e) * NPOSE + cc] : 0.0;
-      }
-      __syncthreads();
+      const int ca = 16 * tti[q] + li, cb = 16 * ttj[q] + li;
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        if (tti[q] >= 0) {
-#pragma unroll
-          for (int m = 0; m < WCH / 4; m++) {
-            const int er = 4 * m + (lane >> 4);
-            const double* row = lds + L_WCH + er * WLD;
-            const double aop = er < ne ? row[16 * tti[q] + (lane & 15)] * lds[L_ST + e0 + er] : 0.0;
-            const double bop = row[16 * ttj[q] + (lane & 15)];
-            Dt[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, Dt[q], 0, 0, 0);
-          }
-        }
-      }
-      if (t < NPOSE) {
-        double sacc = 0;
-        for (int e = 0; e < ne; e++) sacc += (lds[L_WCH + e * WLD + t] * lds[L_ST + e0 + e]) * lds[L_G + NF + e0 + e];
-        accR += sacc;
+      for (int m = 0; m < KB; m++) {
+        const int e = e0 + 4 * m + lk;
+        const bool on = tti[q] >= 0 && e < c.nf;
+        av[q][m] = (on && ca < NPOSE) ? W[(size_t)e * NPOSE + ca] : 0.0;
+        bv[q][m] = (on && cb < NPOSE) ? W[(size_t)e * NPOSE + cb] : 0.0;
       }
     }
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-      if (tti[q] >= 0) {
+      const bool xrow = 16 * tti[q] + li == NPOSE;  // padded row 66: the right-hand side
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int gi = 16 * tti[q] + (lane >> 4) + 4 * r, gj = 16 * ttj[q] + (lane & 15);
-          if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= Dt[q][r];
-        }
+      for (int m = 0; m < KB; m++) {
+        const int e = min(e0 + 4 * m + lk, MAXE + 1);
+        const double aop = xrow ? lds[L_ST + 152 + e] : av[q][m] * lds[L_ST + e];
+        Dt[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bv[q][m], Dt[q], 0, 0, 0);
       }
     }
-    if (t < NPOSE) lds[L_S + roff(NF) + t] -= accR;
-    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (tti[q] >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = 16 * tti[q] + lk + 4 * r, gj = 16 * ttj[q] + li;
+        if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= scl[gi] * scl[gj] * Dt[q][r];
+        if (gi == NPOSE && gj < NPOSE) lds[L_S + roff(NF) + gj] -= scl[gj] * Dt[q][r];
+      }
+    }
+  }
+  __syncthreads();
 }
 
-// back substitution y_e = (g_e - W_e y_p) / (hee + mu D_e^2): one wavefront per feature; returns 1 if y is not finite
+// back substitution y_e = (g'_e - W'_e y_p) / (hee' + mu D_e^2) with W'[e][c] = s_e s_c W[e][c] (W unscaled in the
+// slot): 4 lanes per feature, every lane's loads in flight at once; returns 1 if y is not finite
 AVM_NOINL double back_substitute(const WinCtx& c, double mu) {
   double* lds = LDS();
   const int t = threadIdx.x;
-  const double* W = c.sc + Scratch::W;
-  const int lane = t & 63, wv = t >> 6;
-  for (int e = wv; e < c.nf; e += NT / 64) {
-    double s = W[(size_t)e * NPOSE + lane] * lds[L_Y + lane];
-    if (lane < NPOSE - 64) s += W[(size_t)e * NPOSE + 64 + lane] * lds[L_Y + 64 + lane];
-    s = wave_sum(s);
-    if (lane == 0) {
+  gcdouble* W = c.sc + Scratch::W;
+  const double* scl = lds + L_SC;
+  double* ys = lds + L_WCH;  // s_c y_c
+  if (t < NPOSE) ys[t] = scl[t] * lds[L_Y + t];
+  if (t >= NPOSE && t < NPOSE + 6) ys[t] = 0.0;
+  __syncthreads();
+  const int part = t & 3;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int e = (t >> 2) + 128 * pass;
+    double sacc = 0;
+    if (e < c.nf) {
+      gcdouble* We = W + (size_t)e * NPOSE;
+      double v[17];
+#pragma unroll
+      for (int j = 0; j < 17; j++) v[j] = (part + 4 * j < NPOSE) ? We[part + 4 * j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 17; j++) sacc += v[j] * ys[part + 4 * j];
+    }
+    sacc += __shfl_xor(sacc, 1, 64);
+    sacc += __shfl_xor(sacc, 2, 64);
+    if (e < c.nf && part == 0) {
       const double he = lds[L_HEE + e] + mu * lds[L_DD + NF + e] * lds[L_DD + NF + e];
-      lds[L_Y + NF + e] = (lds[L_G + NF + e] - s) / he;
+      lds[L_Y + NF + e] = (lds[L_G + NF + e] - scl[NF + e] * sacc) / he;
     }
   }
   __syncthreads();
@@ -1203,7 +1228,7 @@ AVM_NOINL double back_substitute(const WinCtx& c, double mu) {
   return block_max<NT>(bad, lds + L_RED);
 }
 
-// Jacobi column scaling of the assembled system: H' = S H S, W', hee', g'
+// Jacobi column scaling of the assembled system: H' = S H S, hee', g'  (W stays unscaled: see schur_reduce)
 AVM_NOINL void scale_system(const WinCtx& c) {
   double* lds = LDS();
   const int t = threadIdx.x;
@@ -1213,13 +1238,6 @@ AVM_NOINL void scale_system(const WinCtx& c) {
     double* ri = lds + L_S + roff(i);
     const double si = scl[i];
     for (int j = part; j <= i; j += 4) ri[j] *= si * scl[j];
-  }
-  double* W = c.sc + Scratch::W;
-  for (int e = t >> 6; e < c.nf; e += NT / 64) {  // one wavefront per W row
-    const double se = scl[NF + e];
-    const int lane = t & 63;
-    W[(size_t)e * NPOSE + lane] *= se * scl[lane];
-    if (lane < NPOSE - 64) W[(size_t)e * NPOSE + 64 + lane] *= se * scl[64 + lane];
   }
   if (t < c.nf) lds[L_HEE + t] *= scl[NF + t] * scl[NF + t];
   for (int i = t; i < NF + c.nf; i += NT) lds[L_G + i] *= scl[i];
