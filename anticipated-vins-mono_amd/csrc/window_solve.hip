@@ -1114,14 +1114,80 @@ AVM_NOINL void chol_solve_lds(int vec) {
   }
 }
 
+// One wavefront's share of the Schur update: the tiles (R, C), R in {R0, R1}, C in {C0, C1}, C <= R, of the 5x5
+// grid (-1 = absent).  Every 16-column block of W is loaded once per k-step and feeds all the tiles that use it.
+template <int R0, int R1, int C0, int C1>
+AVM_DEV void schur_macro_tile(const WinCtx& c) {
+  double* lds = LDS();
+  const double* scl = lds + L_SC;
+  gcdouble* W = c.sc + Scratch::W;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  constexpr int NR = R1 >= 0 ? 2 : 1, NC = C1 >= 0 ? 2 : 1;
+  constexpr int RB[2] = {R0, R1}, CB[2] = {C0, C1};
+  constexpr bool SAME = R0 == C0 && R1 == C1;  // diagonal macro tile: the row blocks are the column blocks
+  constexpr int KB = 8;                        // k-steps (of 4 features) per batch
+  d4 D[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+  for (int e0 = 0; e0 < c.nf; e0 += 4 * KB) {
+    double vr[2][KB], vc[2][KB], fe[KB], xe[KB];
+    // unconditional loads from clamped addresses, masked afterwards (a predicated load is a branch + wait)
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      const int e = e0 + 4 * m + lk, ec = min(e, c.nf - 1);
+      gcdouble* We = W + (size_t)ec * NPOSE;
+#pragma unroll
+      for (int a = 0; a < NR; a++) vr[a][m] = We[min(16 * RB[a] + li, NPOSE - 1)];
+      if (!SAME) {
+#pragma unroll
+        for (int b = 0; b < NC; b++) vc[b][m] = We[min(16 * CB[b] + li, NPOSE - 1)];
+      }
+      const int el = min(e, MAXE + 1);
+      fe[m] = lds[L_ST + el], xe[m] = lds[L_ST + 152 + el];
+    }
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      const bool on = e0 + 4 * m + lk < c.nf;
+      double aop[2], bop[2];
+#pragma unroll
+      for (int a = 0; a < NR; a++) {
+        const int col = 16 * RB[a] + li;
+        const double w = (on && col < NPOSE) ? vr[a][m] : 0.0;
+        aop[a] = col == NPOSE ? xe[m] : w * fe[m];  // padded row 66: the right-hand side
+        if (SAME) bop[a] = w;
+      }
+      if (!SAME) {
+#pragma unroll
+        for (int b = 0; b < NC; b++) bop[b] = (on && 16 * CB[b] + li < NPOSE) ? vc[b][m] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < NR; a++)
+#pragma unroll
+        for (int b = 0; b < NC; b++)
+          if (CB[b] <= RB[a]) D[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a], bop[b], D[a][b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NR; a++)
+#pragma unroll
+    for (int b = 0; b < NC; b++) {
+      if (CB[b] > RB[a]) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = 16 * RB[a] + lk + 4 * r, gj = 16 * CB[b] + li;
+        if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= scl[gi] * scl[gj] * D[a][b][r];
+        if (gi == NPOSE && gj < NPOSE) lds[L_S + roff(NF) + gj] -= scl[gj] * D[a][b][r];
+      }
+    }
+}
+
 // Schur complement on the inverse depths, then the right-hand side into the augmented row:
 //   S_pp -= W'^T (hee' + mu D_e^2)^-1 W' ,  rhs = g'_f - W'^T (hee' + mu D_e^2)^-1 g'_e      (' = Jacobi-scaled)
 // W = E^T F stays UNSCALED in the scratch slot (W'[e][c] = s_e s_c W[e][c]); the scaling is folded in here:
 //   W'^T d' W' = s_i s_j sum_e W[e][i] (s_e^2 d'_e) W[e][j]
-// 16x16 tiles on the matrix cores, the 15 lower tiles of the 5x5 grid over the 66 (padded 80) pose columns spread
-// over the 8 wavefronts, K = features.  Operands come straight from the L2-resident slot, a batch of 8 k-steps
-// (32 loads per lane) in flight at a time - no LDS staging, no barriers.  Row 66 of the padded grid carries
-// x_e = s_e d'_e g'_e in place of a W column, so tile row 4 also delivers the right-hand-side update.
+// 16x16 tiles on the matrix cores over the 66 (padded 80) pose columns, K = features.  The 15 lower tiles of the
+// 5x5 grid are grouped into 6 macro tiles, one per wavefront, so a block of W is fetched once for up to four
+// products; operands come straight from the L2-resident slot, a batch of 8 k-steps in flight at a time - no LDS
+// staging, no barriers.  Row 66 of the padded grid carries x_e = s_e d'_e g'_e in place of a W column, so tile
+// row 4 also delivers the right-hand-side update.
 AVM_NOINL void schur_reduce(const WinCtx& c, double mu) {
   double* lds = LDS();
   const int t = threadIdx.x;
@@ -1139,53 +1205,14 @@ AVM_NOINL void schur_reduce(const WinCtx& c, double mu) {
     lds[L_ST + t] = f, lds[L_ST + 152 + t] = x;
   }
   __syncthreads();
-  gcdouble* W = c.sc + Scratch::W;
-  const int wv = t >> 6, lane = t & 63, li = lane & 15, lk = lane >> 4;
-  int tti[2], ttj[2];
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int tile = wv + 8 * q;  // 0..14 valid
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
-    tti[q] = tile < 15 ? ti : -1;
-    ttj[q] = tile - ti * (ti + 1) / 2;
-  }
-  d4 Dt[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-  constexpr int KB = 8;  // k-steps (of 4 features) per batch
-  for (int e0 = 0; e0 < c.nf; e0 += 4 * KB) {
-    double av[2][KB], bv[2][KB];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int ca = 16 * tti[q] + li, cb = 16 * ttj[q] + li;
-#pragma unroll
-      for (int m = 0; m < KB; m++) {
-        const int e = e0 + 4 * m + lk;
-        const bool on = tti[q] >= 0 && e < c.nf;
-        av[q][m] = (on && ca < NPOSE) ? W[(size_t)e * NPOSE + ca] : 0.0;
-        bv[q][m] = (on && cb < NPOSE) ? W[(size_t)e * NPOSE + cb] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const bool xrow = 16 * tti[q] + li == NPOSE;  // padded row 66: the right-hand side
-#pragma unroll
-      for (int m = 0; m < KB; m++) {
-        const int e = min(e0 + 4 * m + lk, MAXE + 1);
-        const double aop = xrow ? lds[L_ST + 152 + e] : av[q][m] * lds[L_ST + e];
-        Dt[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bv[q][m], Dt[q], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    if (tti[q] >= 0) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int gi = 16 * tti[q] + lk + 4 * r, gj = 16 * ttj[q] + li;
-        if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= scl[gi] * scl[gj] * Dt[q][r];
-        if (gi == NPOSE && gj < NPOSE) lds[L_S + roff(NF) + gj] -= scl[gj] * Dt[q][r];
-      }
-    }
+  switch (t >> 6) {
+    case 0: schur_macro_tile<2, 3, 0, 1>(c); break;  // 4 tiles
+    case 1: schur_macro_tile<0, 1, 0, 1>(c); break;  // 3 tiles
+    case 2: schur_macro_tile<2, 3, 2, 3>(c); break;  // 3 tiles
+    case 3: schur_macro_tile<4, -1, 0, 1>(c); break;
+    case 4: schur_macro_tile<4, -1, 2, 3>(c); break;
+    case 5: schur_macro_tile<4, -1, 4, -1>(c); break;
+    default: break;
   }
   __syncthreads();
 }
