@@ -300,17 +300,20 @@ AVM_DEV void prior_block_dx(int kind, const double* xb, const double* x0, double
 // Global-memory pointers carried into the outlined phases are typed with their address space: behind a struct
 // reference the compiler cannot prove it and would fall back to flat_load/flat_store, which count against the LDS
 // counter too (every LDS wait then also waits for HBM).
+typedef double dv2 __attribute__((ext_vector_type(2)));
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) const double gcdouble;
 typedef __attribute__((address_space(1))) int32_t gint;
 typedef __attribute__((address_space(1))) long long glong;
+typedef __attribute__((address_space(1))) const dv2 gcdv2;
 template <class T> AVM_DEV __attribute__((address_space(1))) T* as_global(T* p) { return (__attribute__((address_space(1))) T*)p; }
 #else  // host pass of the same translation unit: plain pointers
 typedef double gdouble;
 typedef const double gcdouble;
 typedef int32_t gint;
 typedef long long glong;
+typedef const dv2 gcdv2;
 template <class T> AVM_DEV T* as_global(T* p) { return p; }
 #endif
 
@@ -456,6 +459,12 @@ AVM_NOINL void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
 // Solve-kernel variant: lower triangle packed by idx = p (p + 1) / 2 + q into HPk, plus the destination of every
 // entry inside the packed S (or -1 if the prior column is not a state of the solve) - the per-iteration add is then
 // a flat gather.  All operand loads of a tile are issued before the MFMA chain.
+// Layout of the solve kernel's per-factor products in the scratch slot: the FEATURE index runs fastest, so the
+// frame tasks (lane = feature) write, and the per-feature sums / Schur tiles / back substitution read, whole lines:
+//   Wt [NPOSE][WLE]       E^T F transposed: Wt[c][e] = (E^T F)[e][c]
+//   PFt[8][NFR][WLE]      per (quantity q, observing frame b, feature e): Ji^T Je (q < 6), Je^T Je, Je^T r
+constexpr int WLE = 152;
+static_assert(NPOSE * WLE <= MAXE * 72 && 8 * NFR * WLE <= 14 * MAXOBS, "transposed layouts fit the W / PF regions");
 constexpr int HPK_MAX = MAXPRIOR * (MAXPRIOR + 1) / 2;  // 4656 doubles, followed by 4656 ints (fits the [96][96] slot)
 static_assert(HPK_MAX + HPK_MAX / 2 <= MAXPRIOR * MAXPRIOR, "packed Hp + destinations fit the HP scratch region");
 AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gint* dst) {
@@ -548,11 +557,11 @@ AVM_NOINL double frame_task(const WinCtx& c, const avm_options& o, int b, int st
                               xs[XLAM + e], fa, b, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        W[(size_t)e * NPOSE + 6 * b + k] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
-        PF[k * MAXOBS + s] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+        W[(6 * b + k) * WLE + e] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
+        PF[(k * NFR + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
       }
-      PF[6 * MAXOBS + s] = Je[0] * Je[0] + Je[1] * Je[1];
-      PF[7 * MAXOBS + s] = Je[0] * r[0] + Je[1] * r[1];
+      PF[(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
+      PF[(7 * NFR + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
     }
     const double tag = act ? (double)fa : -1.0;
 #pragma unroll
@@ -693,29 +702,30 @@ AVM_NOINL double eval_jac(const WinCtx& c, const avm_options& o) {
   {
     double* W = c.sc + Scratch::W;
     const double* PF = c.sc + Scratch::PF;
-    // sums over the feature's own factors: one thread per (feature, quantity); zero the uncovered W blocks
+    // sums over the feature's own factors: one thread per (quantity, feature), features along the lanes; zero the
+    // uncovered W blocks
     for (int idx = t; idx < c.nf * 8; idx += NT) {
-      const int e = idx >> 3, q = idx & 7;
-      const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e], s0 = ids[I_FOBS + e];
-      const double* P = PF + q * MAXOBS + s0;
+      const int q = idx / c.nf, e = idx - q * c.nf;
+      const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
+      const double* P = PF + (q * NFR + a) * WLE + e;  // + k * WLE : the factor observed in frame a + k
       double s0a = 0, s1a = 0;
       int k = 1;
-      for (; k + 1 < no; k += 2) s0a += P[k], s1a += P[k + 1];
-      if (k < no) s0a += P[k];
+      for (; k + 1 < no; k += 2) s0a += P[k * WLE], s1a += P[(k + 1) * WLE];
+      if (k < no) s0a += P[k * WLE];
       const double sacc = s0a + s1a;
       if (q < 6)
-        W[(size_t)e * NPOSE + 6 * a + q] = sacc;
+        W[(6 * a + q) * WLE + e] = sacc;
       else if (q == 6)
         lds[L_HEE + e] = sacc;
       else
         lds[L_G + NF + e] = sacc;
     }
     for (int idx = t; idx < c.nf * NFR; idx += NT) {
-      const int e = idx / NFR, f = idx - e * NFR;
+      const int f = idx / c.nf, e = idx - f * c.nf;
       const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
       if (f < a || f >= a + no) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) W[(size_t)e * NPOSE + 6 * f + q] = 0.0;
+        for (int q = 0; q < 6; q++) W[(6 * f + q) * WLE + e] = 0.0;
       }
     }
     const double* PART = c.sc + Scratch::PART;
@@ -1120,7 +1130,7 @@ template <int R0, int R1, int C0, int C1>
 AVM_DEV void schur_macro_tile(const WinCtx& c) {
   double* lds = LDS();
   const double* scl = lds + L_SC;
-  gcdouble* W = c.sc + Scratch::W;
+  gcdouble* W = c.sc + Scratch::W;  // Wt[c][e]
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   constexpr int NR = R1 >= 0 ? 2 : 1, NC = C1 >= 0 ? 2 : 1;
   constexpr int RB[2] = {R0, R1}, CB[2] = {C0, C1};
@@ -1129,23 +1139,37 @@ AVM_DEV void schur_macro_tile(const WinCtx& c) {
   d4 D[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
   for (int e0 = 0; e0 < c.nf; e0 += 4 * KB) {
     double vr[2][KB], vc[2][KB], fe[KB], xe[KB];
-    // unconditional loads from clamped addresses, masked afterwards (a predicated load is a branch + wait)
+    // The k index of the products is a summation index, so features may be dealt to (k-step m, lane group lk) in any
+    // order: e = e0 + 8 lk + m gives every lane 8 consecutive features = 64 contiguous bytes per block of Wt.
+    // Unconditional loads from clamped rows, masked afterwards (a predicated load is a branch + wait).
+#pragma unroll
+    for (int a = 0; a < NR; a++) {
+      gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)min(16 * RB[a] + li, NPOSE - 1) * WLE + e0 + 8 * lk);
+#pragma unroll
+      for (int m2 = 0; m2 < KB / 2; m2++) {
+        const dv2 v = src[m2];
+        vr[a][2 * m2] = v.x, vr[a][2 * m2 + 1] = v.y;
+      }
+    }
+    if (!SAME) {
+#pragma unroll
+      for (int b = 0; b < NC; b++) {
+        gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)min(16 * CB[b] + li, NPOSE - 1) * WLE + e0 + 8 * lk);
+#pragma unroll
+        for (int m2 = 0; m2 < KB / 2; m2++) {
+          const dv2 v = src[m2];
+          vc[b][2 * m2] = v.x, vc[b][2 * m2 + 1] = v.y;
+        }
+      }
+    }
 #pragma unroll
     for (int m = 0; m < KB; m++) {
-      const int e = e0 + 4 * m + lk, ec = min(e, c.nf - 1);
-      gcdouble* We = W + (size_t)ec * NPOSE;
-#pragma unroll
-      for (int a = 0; a < NR; a++) vr[a][m] = We[min(16 * RB[a] + li, NPOSE - 1)];
-      if (!SAME) {
-#pragma unroll
-        for (int b = 0; b < NC; b++) vc[b][m] = We[min(16 * CB[b] + li, NPOSE - 1)];
-      }
-      const int el = min(e, MAXE + 1);
+      const int el = min(e0 + 8 * lk + m, MAXE + 1);
       fe[m] = lds[L_ST + el], xe[m] = lds[L_ST + 152 + el];
     }
 #pragma unroll
     for (int m = 0; m < KB; m++) {
-      const bool on = e0 + 4 * m + lk < c.nf;
+      const bool on = e0 + 8 * lk + m < c.nf;
       double aop[2], bop[2];
 #pragma unroll
       for (int a = 0; a < NR; a++) {
@@ -1234,10 +1258,10 @@ AVM_NOINL double back_substitute(const WinCtx& c, double mu) {
     const int e = (t >> 2) + 128 * pass;
     double sacc = 0;
     if (e < c.nf) {
-      gcdouble* We = W + (size_t)e * NPOSE;
+      gcdouble* We = W + e;  // Wt[c][e]
       double v[17];
 #pragma unroll
-      for (int j = 0; j < 17; j++) v[j] = (part + 4 * j < NPOSE) ? We[part + 4 * j] : 0.0;
+      for (int j = 0; j < 17; j++) v[j] = (part + 4 * j < NPOSE) ? We[(size_t)(part + 4 * j) * WLE] : 0.0;
 #pragma unroll
       for (int j = 0; j < 17; j++) sacc += v[j] * ys[part + 4 * j];
     }
