@@ -1863,7 +1863,14 @@ AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
   double2* rcs = reinterpret_cast<double2*>(LDS() + rot_off);        // [np] (c, s)
   int2* rpq = reinterpret_cast<int2*>(LDS() + rot_off + 2 * 64);     // [np] (p, q), p < q
   double* red = LDS() + L_RED;
-  const int t = threadIdx.x;
+  constexpr bool WAVE = NTH == 64;  // a single wavefront: wave-level ordering of its LDS traffic is enough
+  auto sync = [&]() {
+    if (WAVE)
+      wave_lds_sync();
+    else
+      __syncthreads();
+  };
+  const int t = WAVE ? (threadIdx.x & 63) : threadIdx.x;
   const int ne = (n + 1) & ~1, np = ne >> 1;
   for (int i = t; i < n * n; i += NTH) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
   // static work assignment
@@ -1885,7 +1892,7 @@ AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
   }
   const int tpp = max(1, NTH / np);          // threads per pair for the V update
   const int kv = t / tpp, rv0 = t % tpp;     // pair and first row of this thread (kv >= np: idle)
-  __syncthreads();
+  sync();
   auto Lw = [&](int i, int j) -> double& { return A[max(i, j) * ld + min(i, j)]; };
   int sweeps = 0;
   for (int sweep = 0; sweep < 20; sweep++) {
@@ -1899,7 +1906,11 @@ AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
       const double sc = sqrt(fabs(A[r * ld + r]) * fabs(A[q * ld + q]));
       off = fmax(off, sc > 0.0 ? v / sc : (v > 0.0 ? 1.0 : 0.0));
     }
-    off = block_max<NTH>(off, red);
+    if (WAVE) {
+      off = wave_max(off);
+    } else {
+      off = block_max<NTH>(off, red);
+    }
     if (off <= 1e-15) break;
     sweeps++;
     for (int step = 0; step < ne - 1; step++) {
@@ -1920,7 +1931,7 @@ AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
         rcs[t] = double2{cs, sn};
         rpq[t] = int2{pI, qI};
       }
-      __syncthreads();
+      sync();
 #pragma unroll
       for (int u = 0; u < MAXB; u++) {
         if (bk1[u] < 0) continue;
@@ -1965,7 +1976,7 @@ AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
           }
         }
       }
-      __syncthreads();
+      sync();
     }
   }
   return sweeps;
@@ -2280,7 +2291,8 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     if (t >= 64 && t < 64 + n) BV[16 + t - 64] = lds[M_G + kidx[t - 64]];
     __syncthreads();
     PROF(c, 22);
-    jacobi_eig_lds<NT>(M_WCH, M_WCH + 256, 16, 16, L_HEE);
+    if (t < 64) jacobi_eig_lds<64>(M_WCH, M_WCH + 256, 16, 16, L_HEE);  // 16 x 16: one wavefront, no block barriers
+    __syncthreads();
     PROF(c, 23);
     // Amm^+ = V diag(1/lambda > eps) V^T  -> EA (reuse) ; T = Arm Amm^+ ; A' = Arr - T Amr ; b' = br - T bm
     {
