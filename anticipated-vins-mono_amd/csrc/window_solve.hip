@@ -542,18 +542,30 @@ AVM_NOINL double frame_task(const WinCtx& c, const avm_options& o, int b, int st
     Dtot += Drun;
     Drun = d4{0, 0, 0, 0};
   };
+  // inputs of a chunk (feature id, its two observations) are fetched one chunk ahead: their HBM / L2 latency hides
+  // behind the stores, the staging and the MFMA chain of the chunk before
+  int e_nx = 0, fa_nx = 0;
+  double ob_nx[4] = {0, 0, 0, 0};
+  auto fetch = [&](int chunk0) {
+    const int idx = chunk0 + lane;
+    e_nx = cov[min(idx, max(ncov - 1, 0))];
+    fa_nx = ids[I_FSTART + e_nx];
+    const int s0 = ids[I_FOBS + e_nx], s = s0 + (b - fa_nx);
+    ob_nx[0] = c.obs[2 * s0], ob_nx[1] = c.obs[2 * s0 + 1], ob_nx[2] = c.obs[2 * s], ob_nx[3] = c.obs[2 * s + 1];
+  };
+  if (ncov > 0) fetch(0);
   for (int chunk0 = 0; chunk0 < ncov; chunk0 += 64) {
     const int idx = chunk0 + lane;
     const bool act = idx < ncov;
-    const int e = act ? cov[idx] : 0;
-    const int fa = ids[I_FSTART + e];
-    const int s0 = ids[I_FOBS + e];
-    const int s = s0 + (b - fa);
+    const int e = act ? e_nx : 0;
+    const int fa = act ? fa_nx : ids[I_FSTART];
+    const double ob0 = ob_nx[0], ob1 = ob_nx[1], ob2 = ob_nx[2], ob3 = ob_nx[3];
+    if (chunk0 + 64 < ncov) fetch(chunk0 + 64);
     double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < 12; k++) Ji[k] = 0, Jj[k] = 0;
     if (act) {
-      cost += proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1],
+      cost += proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, ob0, ob1, ob2, ob3,
                               xs[XLAM + e], fa, b, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
 #pragma unroll
       for (int k = 0; k < 6; k++) {
@@ -584,11 +596,22 @@ AVM_NOINL double frame_task(const WinCtx& c, const avm_options& o, int b, int st
         a_run = a_cur;
       }
       const double ta = (double)a_cur;
-      for (int m = (2 * l) >> 2; m < ((2 * l_end + 3) >> 2); m++) {
-        const double* row = stage + (4 * m + drow) * XLD;
-        const double v = dcol < 13 ? row[dcol] : 0.0;
-        const double bop = (row[13] == ta) ? v : 0.0;
-        Drun = __builtin_amdgcn_mfma_f64_16x16x4f64(v, bop, Drun, 0, 0, 0);
+      // k-steps of 4 staged rows, four at a time with their LDS reads issued together; a step past the run's end
+      // reads rows of another run (or stale rows): masked out of B by the tag, so it adds exact zeros
+      const int m_end = (2 * l_end + 3) >> 2;
+      for (int m0 = (2 * l) >> 2; m0 < m_end; m0 += 4) {
+        double v[4], tg[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const double* row = stage + (4 * min(m0 + u, 31) + drow) * XLD;
+          v[u] = row[min(dcol, 12)], tg[u] = row[13];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const double av = (dcol < 13 && m0 + u < m_end) ? v[u] : 0.0;
+          const double bop = (tg[u] == ta) ? av : 0.0;
+          Drun = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bop, Drun, 0, 0, 0);
+        }
       }
       l = l_end;
     }
