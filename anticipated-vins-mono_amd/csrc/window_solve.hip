@@ -84,7 +84,9 @@ constexpr int L_RP = L_DXP + MAXPRIOR;
 constexpr int L_RED = L_RP + MAXPRIOR;
 constexpr int L_INT = L_RED + 32;  // int region (as doubles): 360 doubles = 720 ints
 constexpr int L_SUM = L_INT + 360;  // cost_trace[16], radius_trace[16]
-constexpr int L_END = L_SUM + 32;
+constexpr int L_CTX = L_SUM + 32;   // WinCtx of the window being solved (24 doubles)
+constexpr int L_OPT = L_CTX + 24;   // avm_options (copied from the kernel arguments)
+constexpr int L_END = L_OPT + (int)((sizeof(avm_options) + 7) / 8);
 static_assert(L_END * 8 <= 163840, "LDS budget exceeded");
 static_assert(L_S + SPP + ASM_WAVES * XSTG <= L_G, "assembly staging overlaps live data");
 static_assert(L_Y + 5 * 465 + 8 + 5 * 225 <= L_G, "IMU staging overlaps live data");
@@ -330,6 +332,19 @@ struct WinCtx {
   int ldp;
 };
 
+static_assert(sizeof(WinCtx) <= 24 * 8, "WinCtx outgrew its LDS slot");
+// The per-window context and the options live in LDS: handed to the outlined phases by reference they would sit in
+// the caller's private (scratch) memory and every field access would be a flat load from it.
+AVM_DEV const WinCtx& lds_ctx() { return *reinterpret_cast<const WinCtx*>(LDS() + L_CTX); }
+AVM_DEV const avm_options& lds_opt() { return *reinterpret_cast<const avm_options*>(LDS() + L_OPT); }
+AVM_DEV void lds_store_ctx(const WinCtx& cl, const avm_options& ol) {  // call by all threads, then barrier
+  if (threadIdx.x == 0) *reinterpret_cast<WinCtx*>(LDS() + L_CTX) = cl;
+  const int nw = (int)(sizeof(avm_options) / 4);
+  const int* src = reinterpret_cast<const int*>(&ol);
+  int* dst = reinterpret_cast<int*>(LDS() + L_OPT);
+  for (int i = threadIdx.x; i < nw; i += NT) dst[i] = src[i];
+}
+
 // frames: R_f and A_f = ric^T R_f^T for state vector xs into frame slot `which`
 AVM_DEV void build_frames(int xs_off, int which) {
   double* lds = LDS();
@@ -349,7 +364,8 @@ AVM_DEV void build_frames(int xs_off, int which) {
 }
 
 // prior residual r_p = r0 + J0 * dx(xs) into lds[L_RP]; returns (to all threads) nothing; needs syncs by caller
-AVM_NOINL void prior_residual_dev(const WinCtx& c, int xs_off) {
+AVM_NOINL void prior_residual_dev(const WinCtx&, int xs_off) {
+  const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const double* xs = lds + xs_off;
   int* ids = reinterpret_cast<int*>(lds + L_INT);
@@ -387,7 +403,9 @@ AVM_NOINL void prior_residual_dev(const WinCtx& c, int xs_off) {
 }
 
 // residual-only cost at state xs (frames slot `which` must be built). Uses lds[L_S..] as IMU staging.
-AVM_NOINL double eval_cost(const WinCtx& c, const avm_options& o, int xs_off, int which) {
+AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int which) {
+  const WinCtx& c = lds_ctx();
+  const avm_options& o = lds_opt();
   double* lds = LDS();
   const double* xs = lds + xs_off;
   int* ids = reinterpret_cast<int*>(lds + L_INT);
@@ -507,7 +525,9 @@ AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gin
 // are consecutive; the B operand is masked per a-run to keep the (b,a)/(a,a) blocks separate.
 // Blocks (b,b), (b,a) and g_b belong to this frame only and are written straight into LDS; the (a,a)
 // contributions go to PART[b][a] in the scratch slot and are summed in a fixed order afterwards.
-AVM_NOINL double frame_task(const WinCtx& c, const avm_options& o, int b, int stage_off) {
+AVM_NOINL double frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
+  const WinCtx& c = lds_ctx();
+  const avm_options& o = lds_opt();
   double* lds = LDS();
   double* stage = lds + stage_off;
   int* ids = reinterpret_cast<int*>(lds + L_INT);
@@ -634,7 +654,8 @@ AVM_NOINL double frame_task(const WinCtx& c, const avm_options& o, int b, int st
 // The two 16-column accumulator tiles of J are, register for register, both the A operand (J^T) and the B operand
 // (J) of the Gram products, so nothing moves between the two steps.  Factors sharing a frame must not run
 // concurrently (the caller alternates even / odd factors).
-AVM_DEV double imu_factor_mfma(const WinCtx& c, int i) {
+AVM_DEV double imu_factor_mfma(const WinCtx&, int i) {
+  const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   gcdouble* U = c.psqrt + i * 225;                 // upper triangular, zeros stored below the diagonal
@@ -693,7 +714,9 @@ AVM_DEV double imu_factor_mfma(const WinCtx& c, int i) {
 }
 
 // Full evaluation at lds[L_X]: fills S (unscaled H_ff), W, hee, g (unscaled) and returns the cost.
-AVM_NOINL double eval_jac(const WinCtx& c, const avm_options& o) {
+AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
+  const WinCtx& c = lds_ctx();
+  const avm_options& o = lds_opt();
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   (void)ids;
@@ -825,7 +848,9 @@ AVM_NOINL double eval_jac(const WinCtx& c, const avm_options& o) {
 // || J' u ||^2 with J' the Jacobi-scaled Jacobian, u in lds[L_ST] (scaled space), at state lds[L_X].
 // Only needed when the Gauss-Newton step leaves the trust region (Cauchy point), so the factors are
 // simply re-evaluated here instead of keeping their Jacobians around.
-AVM_NOINL double jac_times_vec_sq(const WinCtx& c, const avm_options& o) {
+AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
+  const WinCtx& c = lds_ctx();
+  const avm_options& o = lds_opt();
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   (void)ids;
@@ -1150,7 +1175,8 @@ AVM_NOINL void chol_solve_lds(int vec) {
 // One wavefront's share of the Schur update: the tiles (R, C), R in {R0, R1}, C in {C0, C1}, C <= R, of the 5x5
 // grid (-1 = absent).  Every 16-column block of W is loaded once per k-step and feeds all the tiles that use it.
 template <int R0, int R1, int C0, int C1>
-AVM_DEV void schur_macro_tile(const WinCtx& c) {
+AVM_DEV void schur_macro_tile(const WinCtx&) {
+  const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const double* scl = lds + L_SC;
   gcdouble* W = c.sc + Scratch::W;  // Wt[c][e]
@@ -1235,7 +1261,8 @@ AVM_DEV void schur_macro_tile(const WinCtx& c) {
 // products; operands come straight from the L2-resident slot, a batch of 8 k-steps in flight at a time - no LDS
 // staging, no barriers.  Row 66 of the padded grid carries x_e = s_e d'_e g'_e in place of a W column, so tile
 // row 4 also delivers the right-hand-side update.
-AVM_NOINL void schur_reduce(const WinCtx& c, double mu) {
+AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
+  const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const int t = threadIdx.x;
   const double* scl = lds + L_SC;
@@ -1266,7 +1293,8 @@ AVM_NOINL void schur_reduce(const WinCtx& c, double mu) {
 
 // back substitution y_e = (g'_e - W'_e y_p) / (hee' + mu D_e^2) with W'[e][c] = s_e s_c W[e][c] (W unscaled in the
 // slot): 4 lanes per feature, every lane's loads in flight at once; returns 1 if y is not finite
-AVM_NOINL double back_substitute(const WinCtx& c, double mu) {
+AVM_NOINL double back_substitute(const WinCtx&, double mu) {
+  const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const int t = threadIdx.x;
   gcdouble* W = c.sc + Scratch::W;
@@ -1303,7 +1331,8 @@ AVM_NOINL double back_substitute(const WinCtx& c, double mu) {
 }
 
 // Jacobi column scaling of the assembled system: H' = S H S, hee', g'  (W stays unscaled: see schur_reduce)
-AVM_NOINL void scale_system(const WinCtx& c) {
+AVM_NOINL void scale_system(const WinCtx&) {
+  const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const int t = threadIdx.x;
   const double* scl = lds + L_SC;
@@ -1350,27 +1379,35 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
-  const avm_options& o = A.opt;
+  const avm_options& o = lds_opt();
   const avm_window_batch& B = A.b;
 
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
-    WinCtx c;
-    c.sc = as_global(A.scratch + (size_t)blockIdx.x * Scratch::TOTAL);
-    c.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
-    c.cov = c.osf + MAXOBS;
-    c.w = w;
-    c.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
-    c.nf = B.n_feat[w];
-    c.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
-    c.pdelta = as_global(A.pre_delta + (size_t)w * 100), c.pjac = as_global(A.pre_jac + (size_t)w * 2250), c.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
-    c.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
-    c.lba = as_global(B.imu_lin_ba + (size_t)w * 30), c.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
-    c.pn = B.prior_n ? B.prior_n[w] : 0;
-    c.pnblk = c.pn > 0 ? B.prior_nblk[w] : 0;
-    c.ldp = B.max_prior;
-    c.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
-    c.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
-    c.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
+    WinCtx cl;
+    cl.sc = as_global(A.scratch + (size_t)blockIdx.x * Scratch::TOTAL);
+    cl.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
+    cl.cov = cl.osf + MAXOBS;
+    cl.w = w;
+    cl.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
+    cl.nf = B.n_feat[w];
+    cl.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
+    cl.pdelta = as_global(A.pre_delta + (size_t)w * 100), cl.pjac = as_global(A.pre_jac + (size_t)w * 2250), cl.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
+    cl.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
+    cl.lba = as_global(B.imu_lin_ba + (size_t)w * 30), cl.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
+    cl.pn = B.prior_n ? B.prior_n[w] : 0;
+    cl.pnblk = cl.pn > 0 ? B.prior_nblk[w] : 0;
+    cl.ldp = B.max_prior;
+    cl.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
+    cl.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
+    cl.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
+    {
+      int tot = 0;
+      if (cl.nf > 0) tot = B.feat_obs_begin[(size_t)w * B.max_feat + cl.nf - 1] + B.feat_nobs[(size_t)w * B.max_feat + cl.nf - 1];
+      cl.nobs_tot = tot;
+    }
+    __syncthreads();  // the previous window's readers of the LDS context are done
+    lds_store_ctx(cl, A.opt);
+    const WinCtx& c = lds_ctx();
     __syncthreads();
     PROF_T0();
     // ---------------- load ----------------
@@ -1411,11 +1448,6 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
         for (int q = 0; q < n; q++) ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q : -1);
         off += n;
       }
-    }
-    {
-      int tot = 0;
-      if (c.nf > 0) tot = B.feat_obs_begin[(size_t)w * B.max_feat + c.nf - 1] + B.feat_nobs[(size_t)w * B.max_feat + c.nf - 1];
-      c.nobs_tot = tot;
     }
     if (t >= 1 && t < NFR) {  // features observed in frame t (as imu_j), in feature order
       int n = 0;
@@ -1792,7 +1824,9 @@ constexpr int PARTW = 126;  // aa 21 | g_a 6 | ex.pose0 36 | ex.ex 21 | g_ex 6 |
 // column of the joint system for W column c (0..71): poses, then ex_pose
 AVM_DEV int mg_col(int c) { return c < NPOSE ? c : mg::MEX0 + (c - NPOSE); }
 
-AVM_NOINL void marg_frame_task(const WinCtx& c, const avm_options& o, int b, int stage_off) {
+AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
+  const WinCtx& c = lds_ctx();
+  const avm_options& o = lds_opt();
   using namespace mg;
   double* lds = LDS();
   double* stage = lds + stage_off;
@@ -2011,28 +2045,31 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const avm_options& o = A.opt;
+  const avm_options& o = lds_opt();
   const avm_window_batch& B = A.b;
-  const int flag = o.marginalization_flag;
+  const int flag = A.opt.marginalization_flag;
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
-    WinCtx c;
-    c.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
-    c.sc = as_global(A.scratch + (size_t)blockIdx.x * Scratch::TOTAL);
-    c.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
-    c.cov = c.osf + MAXOBS;
-    c.w = w;
-    c.nf = B.n_feat[w];
-    c.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
-    c.pdelta = as_global(A.pre_delta + (size_t)w * 100), c.pjac = as_global(A.pre_jac + (size_t)w * 2250), c.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
-    c.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
-    c.lba = as_global(B.imu_lin_ba + (size_t)w * 30), c.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
-    c.pn = B.prior_n ? B.prior_n[w] : 0;
-    c.pnblk = c.pn > 0 ? B.prior_nblk[w] : 0;
-    c.ldp = B.max_prior;
-    c.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
-    c.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
-    c.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
-    c.nobs_tot = 0;
+    WinCtx cl;
+    cl.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
+    cl.sc = as_global(A.scratch + (size_t)blockIdx.x * Scratch::TOTAL);
+    cl.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
+    cl.cov = cl.osf + MAXOBS;
+    cl.w = w;
+    cl.nf = B.n_feat[w];
+    cl.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
+    cl.pdelta = as_global(A.pre_delta + (size_t)w * 100), cl.pjac = as_global(A.pre_jac + (size_t)w * 2250), cl.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
+    cl.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
+    cl.lba = as_global(B.imu_lin_ba + (size_t)w * 30), cl.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
+    cl.pn = B.prior_n ? B.prior_n[w] : 0;
+    cl.pnblk = cl.pn > 0 ? B.prior_nblk[w] : 0;
+    cl.ldp = B.max_prior;
+    cl.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
+    cl.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
+    cl.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
+    cl.nobs_tot = 0;
+    __syncthreads();  // the previous window's readers of the LDS context are done
+    lds_store_ctx(cl, A.opt);
+    const WinCtx& c = lds_ctx();
     __syncthreads();
     PROF_T0();
     // ---- load the post-solve state and tables
@@ -2387,22 +2424,26 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
-  const avm_options& o = A.opt;
+  const avm_options& o = lds_opt();
   const avm_window_batch& B = A.b;
   const int w = blockIdx.x;
-  WinCtx c;
-  c.sc = nullptr, c.osf = nullptr, c.w = w;
-  c.nf = B.n_feat[w];
-  c.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
-  c.pdelta = as_global(A.pre_delta + (size_t)w * 100), c.pjac = as_global(A.pre_jac + (size_t)w * 2250), c.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
-  c.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
-  c.lba = as_global(B.imu_lin_ba + (size_t)w * 30), c.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
-  c.pn = B.prior_n ? B.prior_n[w] : 0;
-  c.pnblk = c.pn > 0 ? B.prior_nblk[w] : 0;
-  c.ldp = B.max_prior;
-  c.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
-  c.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
-  c.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
+  WinCtx cl;
+  cl.sc = nullptr, cl.osf = nullptr, cl.w = w;
+  cl.nf = B.n_feat[w];
+  cl.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
+  cl.pdelta = as_global(A.pre_delta + (size_t)w * 100), cl.pjac = as_global(A.pre_jac + (size_t)w * 2250), cl.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
+  cl.psum = as_global(A.pre_sum_dt + (size_t)w * 10);
+  cl.lba = as_global(B.imu_lin_ba + (size_t)w * 30), cl.lbg = as_global(B.imu_lin_bg + (size_t)w * 30);
+  cl.pn = B.prior_n ? B.prior_n[w] : 0;
+  cl.pnblk = cl.pn > 0 ? B.prior_nblk[w] : 0;
+  cl.ldp = B.max_prior;
+  cl.pJ = as_global(B.prior_J + (size_t)w * B.max_prior * B.max_prior);
+  cl.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
+  cl.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
+  cl.prof = nullptr, cl.cov = nullptr, cl.nobs_tot = 0;
+  lds_store_ctx(cl, A.opt);
+  __syncthreads();
+  const WinCtx& c = lds_ctx();
   for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
   for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
   for (int i = t; i < MAXE; i += NT) lds[L_X + XLAM + i] = i < c.nf ? B.inv_depth[(size_t)w * B.max_feat + i] : 1.0;
