@@ -525,7 +525,7 @@ AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gin
 // are consecutive; the B operand is masked per a-run to keep the (b,a)/(a,a) blocks separate.
 // Blocks (b,b), (b,a) and g_b belong to this frame only and are written straight into LDS; the (a,a)
 // contributions go to PART[b][a] in the scratch slot and are summed in a fixed order afterwards.
-AVM_NOINL double frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
+AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
   const WinCtx& c = lds_ctx();
   const avm_options& o = lds_opt();
   double* lds = LDS();
@@ -728,8 +728,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   for (int i = t; i < SPP; i += NT) lds[L_S + i] = 0.0;
   for (int i = t; i < VEC; i += NT) lds[L_G + i] = 0.0;
   if (t < NFR) ids[I_PMASK + t] = 0;
-  double* IJR = c.sc + Scratch::IJRAW;
-  for (int i = t; i < 10 * 465; i += NT) IJR[i] = 0.0;
+  double* IJR = c.sc + Scratch::IJRAW;  // (zeroed once per window: imu_raw rewrites the same entries every time)
   __syncthreads();
   Frames fr{lds + L_FR, lds + L_FR + 99};
   double acc = 0;
@@ -748,8 +747,8 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   {
     double* W = c.sc + Scratch::W;
     const double* PF = c.sc + Scratch::PF;
-    // sums over the feature's own factors: one thread per (quantity, feature), features along the lanes; zero the
-    // uncovered W blocks
+    // sums over the feature's own factors: one thread per (quantity, feature), features along the lanes
+    // (the W blocks of frames that do not observe a feature were zeroed once, at window load)
     for (int idx = t; idx < c.nf * 8; idx += NT) {
       const int q = idx / c.nf, e = idx - q * c.nf;
       const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
@@ -765,14 +764,6 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
         lds[L_HEE + e] = sacc;
       else
         lds[L_G + NF + e] = sacc;
-    }
-    for (int idx = t; idx < c.nf * NFR; idx += NT) {
-      const int f = idx / c.nf, e = idx - f * c.nf;
-      const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
-      if (f < a || f >= a + no) {
-#pragma unroll
-        for (int q = 0; q < 6; q++) W[(6 * f + q) * WLE + e] = 0.0;
-      }
     }
     const double* PART = c.sc + Scratch::PART;
     if (t < NFR * 27) {
@@ -1477,6 +1468,21 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       }
     }
     __syncthreads();
+    // once per window: the structural zeros of the scratch slot (raw IMU Jacobians outside their blocks, E^T F of
+    // the frames that do not observe a feature) - the evaluations only ever rewrite the same nonzero entries
+    {
+      gdouble* IJR = c.sc + Scratch::IJRAW;
+      for (int i = t; i < 10 * 465; i += NT) IJR[i] = 0.0;
+      gdouble* Wt = c.sc + Scratch::W;
+      for (int idx = t; idx < c.nf * NFR; idx += NT) {
+        const int f = idx / c.nf, e = idx - f * c.nf;
+        const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
+        if (f < a || f >= a + no) {
+#pragma unroll
+          for (int q = 0; q < 6; q++) Wt[(6 * f + q) * WLE + e] = 0.0;
+        }
+      }
+    }
     // Hp = J0^T J0 (constant during the solve: hoisted out of the per-iteration J^T J)
     if (c.pn > 0) prior_jtj_packed(c.pJ, c.ldp, c.pn, c.sc + Scratch::HP, reinterpret_cast<gint*>(c.sc + Scratch::HP + HPK_MAX));
     __syncthreads();
