@@ -474,6 +474,42 @@ AVM_NOINL void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
   }
 }
 
+// Marginalization-kernel variant: the tiles of J0^T J0 are added straight into the packed system in LDS at the
+// columns pidx[] maps the prior's columns to (every lower entry is produced exactly once, so the wavefronts never
+// touch the same element).  All operand loads of a tile are issued before the MFMA chain.
+AVM_NOINL void prior_jtj_add_lds(gcdouble* pJ, int ldp, int pn, int s_off) {
+  double* lds = LDS();
+  const int* pidx = reinterpret_cast<const int*>(lds + L_INT) + I_PIDX;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ntl = (pn + 15) >> 4;
+  for (int tile = wv; tile < ntl * (ntl + 1) / 2; tile += NT / 64) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int ca = min(16 * ti + (lane & 15), pn - 1), cb = min(16 * tj + (lane & 15), pn - 1);
+    const bool va = 16 * ti + (lane & 15) < pn, vb = 16 * tj + (lane & 15) < pn;
+    double av[MAXPRIOR / 4], bv[MAXPRIOR / 4];
+#pragma unroll
+    for (int m = 0; m < MAXPRIOR / 4; m++) {
+      const int r = 4 * m + (lane >> 4), rc = min(r, pn - 1);
+      const double a = pJ[(size_t)rc * ldp + ca], b = pJ[(size_t)rc * ldp + cb];
+      av[m] = (r < pn && va) ? a : 0.0;
+      bv[m] = (r < pn && vb) ? b : 0.0;
+    }
+    d4 D = {0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < MAXPRIOR / 4; m++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[m], D, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int gi = 16 * ti + (lane >> 4) + 4 * r, gj = 16 * tj + (lane & 15);
+      if (gi < pn && gj <= gi) {
+        const int ip = pidx[gi], iq = pidx[gj];
+        if (ip >= 0 && iq >= 0) lds[s_off + roff(max(ip, iq)) + min(ip, iq)] += D[r];
+      }
+    }
+  }
+}
+
 // Solve-kernel variant: lower triangle packed by idx = p (p + 1) / 2 + q into HPk, plus the destination of every
 // entry inside the packed S (or -1 if the prior column is not a state of the solve) - the per-iteration add is then
 // a flat gather.  All operand loads of a tile are issued before the MFMA chain.
@@ -2238,21 +2274,21 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     if (use_prior) {
       prior_residual_dev(c, L_X);
       const int* pidx = ids + I_PIDX;
-      double* HPm = c.sc + Scratch::HP;
-      prior_jtj_mfma(c.pJ, c.ldp, c.pn, HPm);
-      __syncthreads();
-      for (int idx = t; idx < c.pn * (c.pn + 1) / 2; idx += NT) {
-        int pp = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-        while ((pp + 1) * (pp + 2) / 2 <= idx) pp++;
-        while (pp * (pp + 1) / 2 > idx) pp--;
-        const int q = idx - pp * (pp + 1) / 2;
-        const int ip = pidx[pp], iq = pidx[q];
-        lds[L_S + roff(max(ip, iq)) + min(ip, iq)] += HPm[pp * MAXPRIOR + q];
-      }
-      if (t < c.pn) {
+      prior_jtj_add_lds(c.pJ, c.ldp, c.pn, L_S);
+      // g += J0^T r_p : 4 lanes per column, each a quarter of the rows, all loads in flight at once
+      {
+        const int col = t >> 2, part = t & 3;
         double sacc = 0;
-        for (int i = 0; i < c.pn; i++) sacc += c.pJ[(size_t)i * c.ldp + t] * lds[L_RP + i];
-        lds[M_G + pidx[t]] += sacc;
+        if (col < c.pn) {
+          double v[MAXPRIOR / 4];
+#pragma unroll
+          for (int j = 0; j < MAXPRIOR / 4; j++) v[j] = c.pJ[(size_t)min(part + 4 * j, c.pn - 1) * c.ldp + col];
+#pragma unroll
+          for (int j = 0; j < MAXPRIOR / 4; j++) sacc += (part + 4 * j < c.pn ? v[j] : 0.0) * lds[L_RP + min(part + 4 * j, MAXPRIOR - 1)];
+        }
+        sacc += __shfl_xor(sacc, 1, 64);
+        sacc += __shfl_xor(sacc, 2, 64);
+        if (col < c.pn && part == 0) lds[M_G + pidx[col]] += sacc;
       }
     }
     __syncthreads();
