@@ -134,11 +134,13 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = flops / (k_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+        tp = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
+        tp = os.path.join(ROOT, "profiles", tp[-1]) if tp else ""  # newest committed rocprofv3 --pmc summary
         if os.path.exists(tp) and W == 4096 and args.tracks == "dense" and opt.marginalization_flag == abi.MARGIN_OLD:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/gpu_profile.sh), per launch
             tj = json.load(open(tp))["window_solve_kernel"]
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01b_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes"
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = f"profiles/{os.path.basename(tp)}: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes"
         alg_bytes = W * (44.0 * n_fac + 23.0e3 + 45.6e3 + 3.0e3 + 2.6e3)  # ~140 KB / solve at K=1500
         result = {
             "metric": "sliding-window solves/sec (10 KF, 150 feats)",
