@@ -422,14 +422,31 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
     if (c.psum[i] <= o.max_sum_dt)
       imu_raw<false>(xs, fr.R, o, c.pdelta + i * 10, c.pjac + i * 225, c.psum[i], c.lba + i * 3, c.lbg + i * 3, i, lds + L_S + i * 465);
   }
-  for (int s = t; s < c.nobs_tot; s += NT) {
-    const int e = c.osf[s];
-    const int s0 = ids[I_FOBS + e];
-    if (s == s0) continue;
-    const int fa = ids[I_FSTART + e], fb = fa + (s - s0);
-    double r[2];
-    acc += proj_eval<false>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1],
-                            xs[XLAM + e], fa, fb, sqi, o.cauchy_a, true, r, nullptr, nullptr, nullptr);
+  if (c.nobs_tot > 0) {
+    // thread per observation slot; the feature id and the two observations of every slot a thread owns are
+    // fetched up front (two dependent rounds of loads in total instead of two per slot); slots past the end are
+    // clamped to the last valid one, so every address stays inside the window's tables
+    constexpr int NSL = (MAXOBS + NT - 1) / NT;
+    int es[NSL], s0s[NSL];
+    double ob[NSL][4];
+#pragma unroll
+    for (int u = 0; u < NSL; u++) es[u] = c.osf[min(t + u * NT, c.nobs_tot - 1)];
+#pragma unroll
+    for (int u = 0; u < NSL; u++) {
+      const int s = min(t + u * NT, c.nobs_tot - 1);
+      s0s[u] = ids[I_FOBS + es[u]];
+      ob[u][0] = c.obs[2 * s0s[u]], ob[u][1] = c.obs[2 * s0s[u] + 1], ob[u][2] = c.obs[2 * s], ob[u][3] = c.obs[2 * s + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < NSL; u++) {
+      const int s = t + u * NT;
+      if (s >= c.nobs_tot || s == s0s[u]) continue;
+      const int e = es[u];
+      const int fa = ids[I_FSTART + e], fb = fa + (s - s0s[u]);
+      double r[2];
+      acc += proj_eval<false>(xs, fr, lds + L_RIC, lds + L_RIC + 9, ob[u][0], ob[u][1], ob[u][2], ob[u][3], xs[XLAM + e], fa, fb, sqi,
+                              o.cauchy_a, true, r, nullptr, nullptr, nullptr);
+    }
   }
   __syncthreads();
   if (t < 150) {
@@ -789,10 +806,17 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       const int q = idx / c.nf, e = idx - q * c.nf;
       const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
       const double* P = PF + (q * NFR + a) * WLE + e;  // + k * WLE : the factor observed in frame a + k
+      // all (<= 10) loads in flight, clamped to the feature's last observation and masked; same pairing of the
+      // partial sums as a sequential two-accumulator loop
+      double pv[NFR - 1];
+#pragma unroll
+      for (int k = 1; k < NFR; k++) pv[k - 1] = P[min(k, max(no - 1, 0)) * WLE];
       double s0a = 0, s1a = 0;
-      int k = 1;
-      for (; k + 1 < no; k += 2) s0a += P[k * WLE], s1a += P[(k + 1) * WLE];
-      if (k < no) s0a += P[k * WLE];
+#pragma unroll
+      for (int k = 1; k < NFR; k++) {
+        const double v = k < no ? pv[k - 1] : 0.0;
+        if (k & 1) s0a += v; else s1a += v;
+      }
       const double sacc = s0a + s1a;
       if (q < 6)
         W[(6 * a + q) * WLE + e] = sacc;
@@ -805,8 +829,12 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     if (t < NFR * 27) {
       const int f = t / 27, q = t % 27;
       double sacc = 0;
-      for (int b = f + 1; b < NFR; b++)
-        if (ids[I_PMASK + b] & (1 << f)) sacc += PART[((size_t)b * NFR + f) * 27 + q];
+      double pp[NFR - 1];
+#pragma unroll
+      for (int b = 1; b < NFR; b++) pp[b - 1] = PART[((size_t)b * NFR + f) * 27 + q];  // unconditional, masked below
+#pragma unroll
+      for (int b = 1; b < NFR; b++)
+        if (b > f && (ids[I_PMASK + b] & (1 << f))) sacc += pp[b - 1];
       if (q < 21) {
         int i = 0;
         while ((i + 1) * (i + 2) / 2 <= q) i++;
@@ -844,9 +872,18 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     gcdouble* HPk = c.sc + Scratch::HP;
     const gint* dst = reinterpret_cast<const gint*>(c.sc + Scratch::HP + HPK_MAX);
     const int npk = c.pn * (c.pn + 1) / 2;
-    for (int idx = t; idx < npk; idx += NT) {
-      const int d = dst[idx];
-      if (d >= 0) lds[L_S + d] += HPk[idx];
+    {
+      constexpr int NIT = (HPK_MAX + NT - 1) / NT;  // 10 rounds cover the largest prior
+      int dd[NIT];
+      double hv[NIT];
+#pragma unroll
+      for (int u = 0; u < NIT; u++) {
+        const int idx = min(t + u * NT, npk - 1);
+        dd[u] = dst[idx], hv[u] = HPk[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < NIT; u++)
+        if (t + u * NT < npk && dd[u] >= 0) lds[L_S + dd[u]] += hv[u];
     }
     // g += J0^T r_p : 4 lanes per column, each a quarter of the rows (rows part, part + 4, ...)
     {
