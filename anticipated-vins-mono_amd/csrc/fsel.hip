@@ -352,22 +352,32 @@ __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int round)
   double ubt = (row < T) ? log(A.dpp[(size_t)p * T + r] + pr * D[r * T + r]) : 0.0;
 #pragma unroll
   for (int o = HALF / 2; o > 0; o >>= 1) ubt += __shfl_xor(ubt, o, 64);
-  // in-register Cholesky, lane = row
-  double ld = 0;
+  // in-register Cholesky, lane = row.  The pivot chain carries only a reciprocal square root (v_rsq_f64 + two
+  // Newton steps); the logarithms of the diagonal are taken afterwards by all lanes at once and added up in
+  // pivot order.  (Utility::logdet sums log(diag(L)); parity is on the selected ids)
+  // The loop is bound by the LDS crossbar: ~2 T^2 / 2 ds_bpermute per candidate pair.
+  double myd = 1.0;  // lane j keeps the pivot d_jj
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const double djj = __shfl(Ar[j], j, HALF);
     if (!(djj > 0.0)) bad = true;
-    const double d = sqrt(djj);
-    ld += log(d);
-    const double lij = Ar[j] / d;
+    if (row == j) myd = djj;
+    double inv = __builtin_amdgcn_rsq(djj);
+    inv = inv * (1.5 - (0.5 * djj) * inv * inv);
+    inv = inv * (1.5 - (0.5 * djj) * inv * inv);
+    const double lij = Ar[j] * inv;
 #pragma unroll
     for (int k = j + 1; k < T; k++) {
       const double lkj = __shfl(lij, k, HALF);
       Ar[k] -= lij * lkj;
     }
   }
+  // log(sqrt(d_jj)) per lane, then the sum in pivot order (same order as a sequential accumulation)
+  const double mylog = (row < T && myd > 0.0) ? 0.5 * log(myd) : 0.0;
+  double ld = 0;
+#pragma unroll
+  for (int j = 0; j < T; j++) ld += __shfl(mylog, j, HALF);
   if (live && row == 0) {
     const double f = bad ? __builtin_nan("") : (A.consts[(size_t)p * 4] + 2.0 * ld);
     A.fval[(size_t)p * b.max_cand + l] = f;
