@@ -2226,15 +2226,29 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         const int no = ids[I_FNOBS + e], s0 = ids[I_FOBS + e];
         if (f == 0 || f == 11) {
           const double* P = f == 0 ? PF : PF2;
-          double sacc[6] = {0, 0, 0, 0, 0, 0};
-          for (int k = 1; k < no; k++)
+          // all loads of the feature's (<= 10) factors in flight at once, clamped to its last observation and masked
+          double pv[6][NFR - 1];
 #pragma unroll
-            for (int q = 0; q < 6; q++) sacc[q] += P[q * MAXOBS + s0 + k];
+          for (int k = 1; k < NFR; k++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) pv[q][k - 1] = P[q * MAXOBS + s0 + min(k, max(no - 1, 0))];
+          double sacc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int k = 1; k < NFR; k++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
 #pragma unroll
           for (int q = 0; q < 6; q++) W[(size_t)e * 72 + 6 * f + q] = sacc[q];
           if (f == 0) {
+            double hv[2][NFR - 1];
+#pragma unroll
+            for (int k = 1; k < NFR; k++) {
+              const int kk = s0 + min(k, max(no - 1, 0));
+              hv[0][k - 1] = PF[6 * MAXOBS + kk], hv[1][k - 1] = PF[7 * MAXOBS + kk];
+            }
             double he = 0, ge = 0;
-            for (int k = 1; k < no; k++) he += PF[6 * MAXOBS + s0 + k], ge += PF[7 * MAXOBS + s0 + k];
+#pragma unroll
+            for (int k = 1; k < NFR; k++) he += k < no ? hv[0][k - 1] : 0.0, ge += k < no ? hv[1][k - 1] : 0.0;
             lds[L_HEE + e] = he;
             lds[M_GE + e] = ge;
           }
