@@ -1903,6 +1903,76 @@ constexpr int PARTW = 126;  // aa 21 | g_a 6 | ex.pose0 36 | ex.ex 21 | g_ex 6 |
 // column of the joint system for W column c (0..71): poses, then ex_pose
 AVM_DEV int mg_col(int c) { return c < NPOSE ? c : mg::MEX0 + (c - NPOSE); }
 
+// One wavefront's share of the elimination of the start-0 inverse depths (marginalization): the tiles (R, C),
+// R in {R0, R1}, C in {C0, C1}, C <= R, of  W^T diag(1 / E^T E) W  over the 72 (padded 80) columns of W = E^T F
+// (66 pose + 6 ex_pose columns, row-major [e][72] here).  Padded row 72 carries g_e / (E^T E) in place of a W column,
+// so tile row 4 also delivers the right-hand-side update.  Operands straight from the scratch slot, 8 k-steps of
+// loads in flight, no staging, no barriers.
+template <int R0, int R1, int C0, int C1>
+AVM_DEV void marg_schur_macro_tile(int nf0) {
+  using namespace mg;
+  const WinCtx& c = lds_ctx();
+  double* lds = LDS();
+  gcdouble* W = c.sc + Scratch::W;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  constexpr int NR = R1 >= 0 ? 2 : 1, NC = C1 >= 0 ? 2 : 1;
+  constexpr int RB[2] = {R0, R1}, CB[2] = {C0, C1};
+  constexpr bool SAME = R0 == C0 && R1 == C1;
+  constexpr int KB = 8, NW = 72;
+  d4 D[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+  for (int e0 = 0; e0 < nf0; e0 += 4 * KB) {
+    double vr[2][KB], vc[2][KB], fe[KB], xe[KB];
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      const int e = e0 + 4 * m + lk, ec = min(e, nf0 - 1);
+      gcdouble* We = W + (size_t)ec * NW;
+#pragma unroll
+      for (int a = 0; a < NR; a++) vr[a][m] = We[min(16 * RB[a] + li, NW - 1)];
+      if (!SAME) {
+#pragma unroll
+        for (int b = 0; b < NC; b++) vc[b][m] = We[min(16 * CB[b] + li, NW - 1)];
+      }
+      fe[m] = lds[L_HEE + ec], xe[m] = lds[L_HEE + ec] * lds[M_GE + ec];
+    }
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      const bool on = e0 + 4 * m + lk < nf0;
+      double aop[2], bop[2];
+#pragma unroll
+      for (int a = 0; a < NR; a++) {
+        const int col = 16 * RB[a] + li;
+        const double w = (on && col < NW) ? vr[a][m] : 0.0;
+        aop[a] = col == NW ? (on ? xe[m] : 0.0) : w * fe[m];
+        if (SAME) bop[a] = w;
+      }
+      if (!SAME) {
+#pragma unroll
+        for (int b = 0; b < NC; b++) bop[b] = (on && 16 * CB[b] + li < NW) ? vc[b][m] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < NR; a++)
+#pragma unroll
+        for (int b = 0; b < NC; b++)
+          if (CB[b] <= RB[a]) D[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a], bop[b], D[a][b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NR; a++)
+#pragma unroll
+    for (int b = 0; b < NC; b++) {
+      if (CB[b] > RB[a]) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = 16 * RB[a] + lk + 4 * r, gj = 16 * CB[b] + li;
+        if (gi < NW && gj <= gi) {
+          const int si = mg_col(gi), sj = mg_col(gj);
+          lds[L_S + roff(max(si, sj)) + min(si, sj)] -= D[a][b][r];
+        }
+        if (gi == NW && gj < NW) lds[M_G + mg_col(gj)] -= D[a][b][r];
+      }
+    }
+}
+
 AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
   const WinCtx& c = lds_ctx();
   const avm_options& o = lds_opt();
@@ -2348,42 +2418,16 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     if (flag == AVM_MARGIN_OLD && nf0 > 0) {
       const double* W = c.sc + Scratch::W;
       if (t < MAXE) lds[L_HEE + t] = (t < nf0 && lds[L_HEE + t] > o.marg_eps) ? 1.0 / lds[L_HEE + t] : 0.0;  // 1 / E^T E in place
-      int ei[6], ej[6];
-      double accS[6];
-      for (int q = 0; q < 6; q++) {
-        accS[q] = 0;
-        const int idx = t + q * NT;
-        int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-        while ((i + 1) * (i + 2) / 2 <= idx) i++;
-        while (i * (i + 1) / 2 > idx) i--;
-        ei[q] = idx < 72 * 73 / 2 ? i : -1;
-        ej[q] = idx - i * (i + 1) / 2;
-      }
-      double accR = 0;
-      for (int e0 = 0; e0 < nf0; e0 += MWCH) {
-        const int ne = min(MWCH, nf0 - e0);
-        __syncthreads();
-        for (int idx = t; idx < ne * 72; idx += NT) lds[M_WCH + (idx / 72) * WLD + idx % 72] = W[(size_t)(e0 + idx / 72) * 72 + idx % 72];
-        __syncthreads();
-        for (int q = 0; q < 6; q++)
-          if (ei[q] >= 0) {
-            double sacc = 0;
-            for (int e = 0; e < ne; e++) sacc += (lds[M_WCH + e * WLD + ei[q]] * lds[L_HEE + e0 + e]) * lds[M_WCH + e * WLD + ej[q]];
-            accS[q] += sacc;
-          }
-        if (t < 72) {
-          double sacc = 0;
-          for (int e = 0; e < ne; e++) sacc += (lds[M_WCH + e * WLD + t] * lds[L_HEE + e0 + e]) * lds[M_GE + e0 + e];
-          accR += sacc;
-        }
-      }
       __syncthreads();
-      for (int q = 0; q < 6; q++)
-        if (ei[q] >= 0) {
-          const int gi = mg_col(ei[q]), gj = mg_col(ej[q]);
-          lds[L_S + roff(max(gi, gj)) + min(gi, gj)] -= accS[q];
-        }
-      if (t < 72) lds[M_G + mg_col(t)] -= accR;
+      switch (t >> 6) {
+        case 0: marg_schur_macro_tile<2, 3, 0, 1>(nf0); break;
+        case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0); break;
+        case 2: marg_schur_macro_tile<2, 3, 2, 3>(nf0); break;
+        case 3: marg_schur_macro_tile<4, -1, 0, 1>(nf0); break;
+        case 4: marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
+        case 5: marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
+        default: break;
+      }
     }
     __syncthreads();
     PROF(c, 21);
