@@ -268,6 +268,10 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   sa.pre_delta = c->pre_delta, sa.pre_jac = c->pre_jac, sa.pre_sqrt = c->pre_sqrt, sa.pre_sum_dt = c->pre_sum;
   sa.scratch = c->scratch, sa.iscratch = c->iscratch, sa.summary = d_sum, sa.n_slots = c->n_slots;
   sa.prof = c->prof;
+  {
+    const char* ns = getenv("AVM_NO_SPECULATE");
+    sa.speculate = (ns && ns[0] == '1') ? 0 : 1;
+  }
   if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * 32 * c->n_slots, c->stream));
   HIPCHK(c, launch_window_solve(sa, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));

@@ -46,6 +46,7 @@ struct SolveArgs {
   avm_solve_summary* summary;                                 // [B] or null
   int n_slots;
   long long* prof;  // optional [n_slots][32] per-phase shader-clock accumulators (debug)
+  int speculate;    // 1: evaluate the Jacobian at the candidate directly while steps keep being accepted (window_solve.hip)
 };
 
 struct EvalArgs {

@@ -1581,9 +1581,8 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       return sqrt(block_sum<NT>(s, lds + L_RED));
     };
     // evaluate + scaling + gradient max norm at lds[L_X]
-    auto evaluate_x = [&]() {
-      { PROF_T0(); (void)pt__; }
-      x_cost = eval_jac(c, o);
+    // what follows a Jacobian evaluation at lds[L_X]: scaling, gradient max norm
+    auto post_evaluate = [&]() {
       PROF_T0();
       // Jacobi scaling from the column norms of the first Jacobian (diag of unscaled H)
       if (first) {
@@ -1612,6 +1611,40 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       scale_system(c);
       PROF(c, 10);
     };
+    auto evaluate_x = [&]() {
+      x_cost = eval_jac(c, o);
+      post_evaluate();
+    };
+    // eval_jac() stages the frame tasks' rows in the LDS range that also holds the Gauss-Newton step, the dogleg step
+    // and the candidate state, so a speculative evaluation parks what a rejection needs (current point, GN step)
+    // in the spare tail of the slot's prior region
+    gdouble* spec_save = c.sc + Scratch::HP + HPK_MAX + HPK_MAX / 2 + 8;
+    static_assert(HPK_MAX + HPK_MAX / 2 + 8 + XN + VEC <= MAXPRIOR * MAXPRIOR, "speculation backup fits the slot");
+    auto spec_enter = [&]() {  // x -> backup, x <- candidate
+      __syncthreads();
+      for (int i = t; i < XN; i += NT) spec_save[i] = lds[L_X + i], lds[L_X + i] = lds[L_XC + i];
+      for (int i = t; i < VEC; i += NT) spec_save[XN + i] = lds[L_Y + i];
+      __syncthreads();
+    };
+    auto spec_restore = [&]() {  // x <- backup, candidate <- x
+      __syncthreads();
+      for (int i = t; i < XN; i += NT) {
+        const double cand = lds[L_X + i];
+        lds[L_X + i] = spec_save[i];
+        lds[L_XC + i] = cand;
+      }
+      __syncthreads();
+    };
+    auto spec_restore_gn_step = [&]() {  // after the system at x has been rebuilt (eval_jac stages over it again)
+      for (int i = t; i < VEC; i += NT) lds[L_Y + i] = spec_save[XN + i];
+      __syncthreads();
+    };
+    // Speculation (exact: the same evaluations, fewer of them).  Ceres evaluates the cost at the candidate and, if
+    // the step is accepted, evaluates residuals AND Jacobians at that same point again.  While steps keep being
+    // accepted with a good model fit, the Jacobian is evaluated at the candidate right away (its cost decides the
+    // step) and nothing is recomputed on acceptance; a rejected speculation pays one extra evaluation to restore
+    // the system at x, and switches speculation off until a step with rho > 0.75 comes by.
+    bool speculate = A.speculate != 0;
 
     x_norm = amb_norm(lds + L_X);
     evaluate_x();
@@ -1762,32 +1795,50 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       PROF_T0();
       state_plus();
       __syncthreads();
-      build_frames(L_XC, 1);
-      __syncthreads();
-      const double cand_cost = eval_cost(c, o, L_XC, 1);
-      PROF(c, 15);
       double d2 = 0;
       for (int i = t; i < 176 + c.nf; i += NT) {
         const double d = lds[L_X + i] - lds[L_XC + i];
         d2 += d * d;
       }
       const double step_norm = sqrt(block_sum<NT>(d2, lds + L_RED));
+      const bool spec = speculate;
+      double cand_cost;
+      if (spec) {
+        spec_enter();  // x <- candidate; the current point and the GN step are parked in the slot
+        cand_cost = eval_jac(c, o);
+        PROF(c, 15);
+      } else {
+        build_frames(L_XC, 1);
+        __syncthreads();
+        cand_cost = eval_cost(c, o, L_XC, 1);
+        PROF(c, 15);
+      }
       if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
+        if (spec) spec_restore();  // the minimizer stops at the current point, not at the candidate
         termination = AVM_TERM_PARAMETER_TOL;
         break;
       }
       const double cost_change = x_cost - cand_cost;
       if (fabs(cost_change) <= o.function_tolerance * x_cost) {
+        if (spec) spec_restore();
         termination = AVM_TERM_FUNCTION_TOL;
         break;
       }
       const double rel = (ref_cost - cand_cost) / model_cost_change;
       if (rel > o.min_relative_decrease) {
-        __syncthreads();
-        for (int i = t; i < XN; i += NT) lds[L_X + i] = lds[L_XC + i];
-        __syncthreads();
-        x_norm = amb_norm(lds + L_X);
-        evaluate_x();
+        if (spec) {
+          // the system at the accepted point is already assembled
+          x_norm = amb_norm(lds + L_X);
+          x_cost = cand_cost;
+          post_evaluate();
+        } else {
+          __syncthreads();
+          for (int i = t; i < XN; i += NT) lds[L_X + i] = lds[L_XC + i];
+          __syncthreads();
+          x_norm = amb_norm(lds + L_X);
+          evaluate_x();
+        }
+        speculate = A.speculate != 0 && rel > 0.75;
         step_ok = true;
         if (rel < 0.25) radius *= 0.5;
         if (rel > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
@@ -1795,6 +1846,13 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
         reuse = false;
         ref_cost = cand_cost;
       } else {
+        if (spec) {
+          // back to the current point: rebuild its system (g, E^T F, raw IMU Jacobians) for the retried step
+          spec_restore();
+          evaluate_x();
+          spec_restore_gn_step();
+        }
+        speculate = false;
         radius *= 0.5;
         reuse = true;
       }
