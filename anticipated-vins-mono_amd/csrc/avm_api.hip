@@ -378,6 +378,41 @@ int avm_debug_copy_sqrt_info(avm_ctx* c, int n_windows, double* host_out) {
   return AVM_OK;
 }
 
+int avm_triangulate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, double init_depth) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (!batch || batch->n_windows < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (batch->max_feat > MAXE) return fail(c, AVM_ERR_CAPACITY, "max_feat > 150");
+  if (batch->max_obs > MAXOBS) return fail(c, AVM_ERR_CAPACITY, "max_obs > 1650");
+  if (batch->n_windows == 0) return AVM_OK;
+  const size_t B = batch->n_windows;
+  avm_window_batch d = *batch;
+  if (mem == AVM_MEM_HOST) {
+    // only the fields the triangulation reads travel
+    int rc;
+#define ST(field, type, count)                                                                                        \
+  if ((rc = stage_in<type>(c, "w_" #field, batch->field, (count), (const type**)&d.field)) != AVM_OK) return rc;
+    ST(pose, double, B * 77)
+    ST(ex_pose, double, B * 7)
+    ST(inv_depth, double, B * batch->max_feat)
+    ST(n_feat, int32_t, B)
+    ST(feat_start, int32_t, B * batch->max_feat)
+    ST(feat_nobs, int32_t, B * batch->max_feat)
+    ST(feat_obs_begin, int32_t, B * batch->max_feat)
+    ST(obs_xy, double, B * batch->max_obs * 2)
+#undef ST
+  }
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  HIPCHK(c, launch_triangulate(d, init_depth, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  if (mem == AVM_MEM_HOST)
+    HIPCHK(c, hipMemcpyAsync(batch->inv_depth, d.inv_depth, sizeof(double) * B * batch->max_feat, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->last_ms["triangulate"] = ms;
+  return AVM_OK;
+}
+
 int avm_window_eval_factors(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* batch, int apply_loss,
                             double* proj_r, double* proj_J, double* imu_r, double* imu_J, double* prior_res, double* cost) {
   if (!c) return AVM_ERR_INVALID;

@@ -1,0 +1,121 @@
+// triangulate.hip — FeatureManager::triangulate (vins_estimator/src/feature_manager.cpp:202-257) on gfx950:
+// linear multi-view triangulation of the features that have no depth yet, in the camera frame of their first
+// observation.  One thread per (window, feature); the (2 nobs) x 4 system (nobs <= 11) lives in the thread's
+// registers as four columns.  Eigen::JacobiSVD is replaced by a one-sided (Hestenes) Jacobi SVD on those columns -
+// right singular vectors to working precision - and only the last right singular vector is used, through the ratio
+// v[2] / v[3], so its sign does not matter.  HBM-trivial (a few hundred bytes per feature); the kernel exists so that
+// the state never has to leave the device between the steps of solveOdometry().
+#include "devmath.hpp"
+#include "kernels.hpp"
+
+namespace avm {
+
+namespace {
+constexpr int TRI_NT = 64;
+constexpr int TRI_ROWS = 2 * NFR;  // 22
+}
+
+__global__ __launch_bounds__(TRI_NT) void triangulate_kernel(avm_window_batch B, double init_depth) {
+  const long gid = (long)blockIdx.x * TRI_NT + threadIdx.x;
+  const int w = (int)(gid / B.max_feat), e = (int)(gid % B.max_feat);
+  if (w >= B.n_windows || e >= B.n_feat[w]) return;
+  double* lam = B.inv_depth + (size_t)w * B.max_feat + e;
+  if (*lam > 0.0) return;
+  const int start = B.feat_start[(size_t)w * B.max_feat + e], nobs = B.feat_nobs[(size_t)w * B.max_feat + e];
+  const double* obs = B.obs_xy + ((size_t)w * B.max_obs + B.feat_obs_begin[(size_t)w * B.max_feat + e]) * 2;
+  const double* pose = B.pose + (size_t)w * NFR * 7;
+  const double* ex = B.ex_pose + (size_t)w * 7;
+  const v3 tic = mk3(ex[0], ex[1], ex[2]);
+  double ric[9];
+  q2R(quat{ex[6], ex[3], ex[4], ex[5]}, ric);
+  auto cam = [&](int f, double* R, v3& t) {  // camera f in the world: R = Rs ric, t = Ps + Rs tic
+    double Rs[9];
+    q2R(quat{pose[f * 7 + 6], pose[f * 7 + 3], pose[f * 7 + 4], pose[f * 7 + 5]}, Rs);
+    mat3mul(Rs, ric, R);
+    t = mk3(pose[f * 7], pose[f * 7 + 1], pose[f * 7 + 2]) + Rmul(Rs, tic);
+  };
+  double R0[9];
+  v3 t0;
+  cam(start, R0, t0);
+  double A[4][TRI_ROWS];
+#pragma unroll
+  for (int k = 0; k < NFR; k++) {
+    double row0[4] = {0, 0, 0, 0}, row1[4] = {0, 0, 0, 0};
+    if (k < nobs) {
+      double R1[9];
+      v3 t1;
+      cam(start + k, R1, t1);
+      // R = R0^T R1, t = R0^T (t1 - t0);  P = [R^T | -R^T t] = [R1^T R0 | -R1^T (t1 - t0)]
+      const v3 d = t1 - t0;
+      double P[3][4];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          // (R^T)(a, b) = R(b, a) = sum_m R0(m, b) R1(m, a)
+          P[a][b] = R0[0 * 3 + b] * R1[0 * 3 + a] + R0[1 * 3 + b] * R1[1 * 3 + a] + R0[2 * 3 + b] * R1[2 * 3 + a];
+        }
+      }
+      // t = R0^T d ; -R^T t
+      const v3 tt = mk3(R0[0] * d.x + R0[3] * d.y + R0[6] * d.z, R0[1] * d.x + R0[4] * d.y + R0[7] * d.z, R0[2] * d.x + R0[5] * d.y + R0[8] * d.z);
+#pragma unroll
+      for (int a = 0; a < 3; a++) P[a][3] = -(P[a][0] * tt.x + P[a][1] * tt.y + P[a][2] * tt.z);
+      const double ox = obs[2 * k], oy = obs[2 * k + 1];
+      const double nrm = sqrt(ox * ox + oy * oy + 1.0);
+      const double f0 = ox / nrm, f1 = oy / nrm, f2 = 1.0 / nrm;
+#pragma unroll
+      for (int b = 0; b < 4; b++) row0[b] = f0 * P[2][b] - f2 * P[0][b], row1[b] = f1 * P[2][b] - f2 * P[1][b];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) A[b][2 * k] = row0[b], A[b][2 * k + 1] = row1[b];
+  }
+  // one-sided Jacobi on the four columns (rows beyond 2 nobs are zero and stay zero)
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) {
+        double app = 0, aqq = 0, apq = 0;
+#pragma unroll
+        for (int i = 0; i < TRI_ROWS; i++) app += A[p][i] * A[p][i], aqq += A[q][i] * A[q][i], apq += A[p][i] * A[q][i];
+        if (fabs(apq) <= 1e-300 || fabs(apq) <= 2.3e-16 * sqrt(app * aqq)) continue;
+        rotated = true;
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double tn = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        const double c = 1.0 / sqrt(1.0 + tn * tn), s = tn * c;
+#pragma unroll
+        for (int i = 0; i < TRI_ROWS; i++) {
+          const double x = A[p][i], y = A[q][i];
+          A[p][i] = c * x - s * y, A[q][i] = s * x + c * y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const double x = V[i][p], y = V[i][q];
+          V[i][p] = c * x - s * y, V[i][q] = s * x + c * y;
+        }
+      }
+    if (!rotated) break;
+  }
+  double bn = 0, v2 = 0, v3v = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < TRI_ROWS; i++) s += A[j][i] * A[j][i];
+    if (j == 0 || s < bn) bn = s, v2 = V[2][j], v3v = V[3][j];
+  }
+  double depth = v2 / v3v;
+  if (!(depth >= 0.1)) depth = init_depth;  // `estimated_depth < 0.1` -> INIT_DEPTH (a NaN ratio also falls back)
+  *lam = 1.0 / depth;
+}
+
+hipError_t launch_triangulate(const avm_window_batch& b, double init_depth, hipStream_t stream) {
+  const long n = (long)b.n_windows * b.max_feat;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(triangulate_kernel, dim3((unsigned)((n + TRI_NT - 1) / TRI_NT)), dim3(TRI_NT), 0, stream, b, init_depth);
+  return hipGetLastError();
+}
+
+}  // namespace avm

@@ -43,6 +43,13 @@ class Estimator:
         self.last_marginalization_info = prior
         return summ
 
+    def triangulate(self, windows: buffers.WindowArrays, init_depth: float = 5.0):
+        """FeatureManager::triangulate (feature_manager.cpp:202-257), the step before optimization() in solveOdometry():
+        features whose inverse depth is <= 0 get 1 / depth from the multi-view linear triangulation, in place."""
+        s = windows.struct()
+        rc = self.ctx._L.avm_triangulate_batch(self.ctx.h, windows.mem, C.byref(s), float(init_depth))
+        self.ctx.check(rc, "avm_triangulate_batch")
+
     def preintegrate(self, windows: buffers.WindowArrays):
         """IntegrationBase for every interval: returns delta [B,10,10], jacobian, covariance [B,10,15,15], sum_dt [B,10]."""
         assert not windows.on_device

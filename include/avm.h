@@ -237,6 +237,16 @@ int avm_imu_preintegrate_batch(avm_ctx* ctx, const avm_options* opt, avm_mem mem
                                const avm_window_batch* batch, double* out_delta, double* out_jacobian,
                                double* out_covariance, double* out_sum_dt);
 
+/* SURVEY 8(f)1 - the step right before optimization() in solveOdometry() (estimator.cpp:471):
+ * FeatureManager::triangulate (feature_manager.cpp:202-257).  Every feature whose inv_depth is <= 0
+ * ("no depth yet": estimated_depth = -1 at construction, feature_manager.h:61) gets 1 / depth from the linear
+ * multi-view triangulation over all of its observations, in the camera frame of its first observation: the
+ * smallest right singular vector v of the (2 nobs) x 4 system, depth = v[2] / v[3]; depths < 0.1 fall back to
+ * init_depth (INIT_DEPTH = 5.0, parameters.cpp:113).  In place on batch->inv_depth; reads pose, ex_pose and the
+ * feature tables only.  (IntegrationBase::repropagate, the other half of that row, is
+ * avm_imu_preintegrate_batch() with the new linearization biases in imu_lin_ba / imu_lin_bg.) */
+int avm_triangulate_batch(avm_ctx* ctx, avm_mem mem, avm_window_batch* batch, double init_depth);
+
 /* A5/A6/A8 only: evaluate every factor once at the current state and return
  * residuals/Jacobians (local 6-column pose blocks).  Used by the per-factor parity tests.
  *   proj_r [B][max_obs][2], proj_J [B][max_obs][2][13]  (pose_i 6 | pose_j 6 | inv_depth 1), index = observation slot

@@ -16,6 +16,7 @@
 
 #include "fsel.hpp"
 #include "solver.hpp"
+#include "triangulate.hpp"
 
 using namespace avmo;
 
@@ -365,6 +366,36 @@ int avmo_eig_sym(int n, const double* A, double* w, double* V) {
   eig_sym(M, d, VV);
   std::memcpy(w, d.data(), sizeof(double) * n);
   std::memcpy(V, VV.a.data(), sizeof(double) * n * n);
+  return 0;
+}
+
+// FeatureManager::triangulate for every feature of every window whose inverse depth is <= 0 ("no depth yet":
+// estimated_depth starts at -1, feature_manager.h:63); writes 1 / depth back.  Also exposes the (2 nobs) x 4 matrix
+// of one feature for the numpy SVD known-answer test (A_out may be null).
+int avmo_triangulate_batch(avm_window_batch* B, double init_depth, int n_threads) {
+  const int nw = B->n_windows;
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (int w = next++; w < nw; w = next++) {
+      const double(*pose)[7] = reinterpret_cast<const double(*)[7]>(B->pose + (size_t)w * AVM_NFRAMES * 7);
+      for (int e = 0; e < B->n_feat[w]; e++) {
+        double& lam = B->inv_depth[(size_t)w * B->max_feat + e];
+        if (lam > 0) continue;
+        const int start = B->feat_start[(size_t)w * B->max_feat + e], nobs = B->feat_nobs[(size_t)w * B->max_feat + e];
+        const double* obs = B->obs_xy + ((size_t)w * B->max_obs + B->feat_obs_begin[(size_t)w * B->max_feat + e]) * 2;
+        lam = 1.0 / triangulate_feature(pose, B->ex_pose + (size_t)w * 7, start, nobs, obs, init_depth);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < std::max(1, n_threads); i++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  return 0;
+}
+
+int avmo_smallest_right_singular_vector(int n, const double* A, double* v) {
+  smallest_right_singular_vector(std::vector<double>(A, A + (size_t)n * 4), n, v);
   return 0;
 }
 

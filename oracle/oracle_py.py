@@ -82,3 +82,22 @@ def fsel_information(fsel):
     rc = lib().avmo_fsel_information(C.byref(s), abi.dptr(om), abi.dptr(dl), abi.iptr(va))
     assert rc == 0
     return om, dl, va
+
+
+def triangulate(win, init_depth=5.0, n_threads=1):
+    """FeatureManager::triangulate in place on host WindowArrays (inverse depths <= 0 are replaced)."""
+    s = win.struct()
+    L = lib()
+    L.avmo_triangulate_batch.argtypes = [C.c_void_p, C.c_double, C.c_int]
+    rc = L.avmo_triangulate_batch(C.byref(s), float(init_depth), int(n_threads))
+    assert rc == 0
+
+
+def smallest_right_singular_vector(A):
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    A = np.ascontiguousarray(A, float)
+    v = np.zeros(4)
+    rc = lib().avmo_smallest_right_singular_vector(int(A.shape[0]), abi.dptr(A), abi.dptr(v))
+    assert rc == 0
+    return v

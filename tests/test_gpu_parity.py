@@ -86,6 +86,37 @@ def _assert_state_parity(wg, wo, sg, so):
         assert rel(wg.a[k], wo.a[k]) < STATE_TOL, (k, rel(wg.a[k], wo.a[k]))
 
 
+def test_triangulation_matches_oracle(estimator, oracle):
+    """SURVEY 8(f)1: FeatureManager::triangulate on device (the step before optimization() in solveOdometry())."""
+    for tracks, nf in (("sparse", 60), ("dense", 150)):
+        w = synth.make_windows(4, tracks=tracks, n_feat=nf, max_feat=150)
+        keep = w.a["inv_depth"].copy()
+        w.a["inv_depth"][:, ::2] = -1.0  # "no depth yet"
+        w.a["inv_depth"][0, 1] = 0.0
+        wg, wo = w.copy(), w.copy()
+        estimator.triangulate(wg, init_depth=5.0)
+        oracle.triangulate(wo, init_depth=5.0)
+        assert np.array_equal(wg.a["inv_depth"][:, 3::2], keep[:, 3::2])      # features with a depth are left alone
+        for b in range(4):
+            n = w.a["n_feat"][b]
+            assert (wg.a["inv_depth"][b, :n] > 0).all()
+            assert rel(wg.a["inv_depth"][b, :n], wo.a["inv_depth"][b, :n]) < 1e-9
+        # device-resident buffers give the same result
+        wd = w.to_device("cuda:0")
+        estimator.triangulate(wd, init_depth=5.0)
+        assert np.array_equal(wd.to_host().a["inv_depth"], wg.a["inv_depth"])
+    # a feature seen from (almost) one place only has no usable parallax: depth < 0.1 or NaN -> INIT_DEPTH
+    w = synth.make_windows(1, tracks="dense", n_feat=8, max_feat=150)
+    w.a["pose"][0, :, :3] = w.a["pose"][0, 0, :3]
+    w.a["pose"][0, :, 3:] = w.a["pose"][0, 0, 3:]
+    w.a["obs_xy"][0, :, :] = 0.3
+    w.a["inv_depth"][:] = -1.0
+    wg, wo = w.copy(), w.copy()
+    estimator.triangulate(wg, init_depth=5.0)
+    oracle.triangulate(wo, init_depth=5.0)
+    assert rel(wg.a["inv_depth"][0, :8], wo.a["inv_depth"][0, :8]) < 1e-9
+
+
 @pytest.mark.parametrize("tracks,nf", [("sparse", 60), ("dense", 150), ("sparse", 150), ("dense", 12)])
 def test_window_solve_parity(estimator, oracle, tracks, nf):
     w = synth.make_windows(3, tracks=tracks, n_feat=nf, max_feat=150)

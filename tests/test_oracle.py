@@ -295,3 +295,58 @@ def test_selector_kappa_zero_and_empty_cloud(oracle):
     out = buffers.FselOutArrays.alloc(1, 4)
     oracle.fsel_select(pr, out)
     assert int(out.a["n_selected"][0]) == 0  # kappa = max(0, maxFeatures - |subset|) = 0
+
+
+def _numpy_triangulate(win, b, e):
+    """Independent numpy statement of feature_manager.cpp:209-249 (numpy.linalg.svd instead of Eigen::JacobiSVD)."""
+    def q2R(q):  # x y z w
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    a = win.a
+    ex = a["ex_pose"][b]
+    tic, ric = ex[:3], q2R(ex[3:])
+    st, no, ob = a["feat_start"][b, e], a["feat_nobs"][b, e], a["feat_obs_begin"][b, e]
+    P_ = lambda f: a["pose"][b, f, :3]
+    R_ = lambda f: q2R(a["pose"][b, f, 3:])
+    t0, R0 = P_(st) + R_(st) @ tic, R_(st) @ ric
+    rows = []
+    for k in range(no):
+        j = st + k
+        t1, R1 = P_(j) + R_(j) @ tic, R_(j) @ ric
+        t, R = R0.T @ (t1 - t0), R0.T @ R1
+        P = np.hstack([R.T, (-R.T @ t)[:, None]])
+        f = np.array([a["obs_xy"][b, ob + k, 0], a["obs_xy"][b, ob + k, 1], 1.0])
+        f = f / np.linalg.norm(f)
+        rows += [f[0] * P[2] - f[2] * P[0], f[1] * P[2] - f[2] * P[1]]
+    A = np.array(rows)
+    v = np.linalg.svd(A)[2][-1]
+    return A, v[2] / v[3]
+
+
+def test_triangulate_matches_numpy_svd(oracle):
+    """SURVEY 8(f)1: FeatureManager::triangulate. Pins the oracle's one-sided Jacobi SVD and its construction of the
+    (2 nobs) x 4 system against numpy.linalg.svd / an independent numpy statement."""
+    rng = np.random.default_rng(3)
+    for n in (4, 7, 22):
+        A = rng.normal(size=(n, 4))
+        A[:, 3] = A[:, :3] @ rng.normal(size=3) + 1e-3 * rng.normal(size=n)   # a small last singular value
+        v, vr = oracle.smallest_right_singular_vector(A), np.linalg.svd(A)[2][-1]
+        assert min(np.abs(v - vr).max(), np.abs(v + vr).max()) < 1e-11
+    w = synth.make_windows(3, tracks="sparse", n_feat=40, max_feat=150)
+    keep = w.a["inv_depth"].copy()
+    w.a["inv_depth"][:, ::2] = -1.0          # estimated_depth = -1: "no depth yet"; odd features keep theirs
+    oracle.triangulate(w, init_depth=5.0)
+    assert np.array_equal(w.a["inv_depth"][:, 1::2], keep[:, 1::2])
+    checked = 0
+    for b in range(3):
+        for e in range(0, w.a["n_feat"][b], 2):
+            _, d = _numpy_triangulate(w, b, e)
+            exp = 1.0 / d if d >= 0.1 else 1.0 / 5.0
+            assert abs(w.a["inv_depth"][b, e] - exp) <= 1e-9 * abs(exp), (b, e)
+            checked += 1
+    assert checked > 40
+    # the triangulated depths are close to the ones the generator perturbed (poses are 5 cm / 1 deg off, 1.5 px noise)
+    r = np.concatenate([w.a["inv_depth"][b, : w.a["n_feat"][b] : 2] / keep[b, : w.a["n_feat"][b] : 2] for b in range(3)])
+    assert np.median(np.abs(r - 1)) < 0.3
