@@ -413,6 +413,34 @@ int avm_triangulate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, doub
   return AVM_OK;
 }
 
+int avm_imu_propagate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, const double g[3]) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (!batch || !g || batch->n_windows < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (batch->n_windows == 0) return AVM_OK;
+  const size_t B = batch->n_windows;
+  avm_window_batch d = *batch;
+  if (mem == AVM_MEM_HOST) {
+    int rc;
+#define ST(field, type, count)                                                                                        \
+  if ((rc = stage_in<type>(c, "w_" #field, batch->field, (count), (const type**)&d.field)) != AVM_OK) return rc;
+    ST(pose, double, B * 77)
+    ST(speedbias, double, B * 99)
+    ST(imu_n, int32_t, B * 10)
+    ST(imu_dt, double, B * 10 * batch->max_samp)
+    ST(imu_acc, double, B * 10 * (batch->max_samp + 1) * 3)
+    ST(imu_gyr, double, B * 10 * (batch->max_samp + 1) * 3)
+#undef ST
+  }
+  HIPCHK(c, launch_imu_propagate(d, g, c->stream));
+  if (mem == AVM_MEM_HOST) {
+    HIPCHK(c, hipMemcpyAsync(batch->pose, d.pose, sizeof(double) * B * 77, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(batch->speedbias, d.speedbias, sizeof(double) * B * 99, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
+}
+
 int avm_window_eval_factors(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* batch, int apply_loss,
                             double* proj_r, double* proj_J, double* imu_r, double* imu_J, double* prior_res, double* cost) {
   if (!c) return AVM_ERR_INVALID;

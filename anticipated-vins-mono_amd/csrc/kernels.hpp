@@ -68,6 +68,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
                        hipStream_t stream);
 bool fsel_horizon_supported(int H);
 hipError_t launch_triangulate(const avm_window_batch& b, double init_depth, hipStream_t stream);
+hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipStream_t stream);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipStream_t stream);

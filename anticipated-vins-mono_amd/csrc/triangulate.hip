@@ -111,6 +111,52 @@ __global__ __launch_bounds__(TRI_NT) void triangulate_kernel(avm_window_batch B,
   *lam = 1.0 / depth;
 }
 
+// Estimator::processIMU dead-reckoning of the newest frame (estimator.cpp:100-107): one thread per window, sequential
+// over the (<= max_samp) samples of the last interval.  Rs stays a matrix multiplied by toRotationMatrix() of the
+// unnormalized deltaQ, exactly like the reference; the quaternion is formed at the end.
+__global__ __launch_bounds__(TRI_NT) void imu_propagate_kernel(avm_window_batch B, double gx, double gy, double gz) {
+  const int w = blockIdx.x * TRI_NT + threadIdx.x;
+  if (w >= B.n_windows) return;
+  const size_t iv = (size_t)w * (NFR - 1) + (NFR - 2);
+  double* pose = B.pose + ((size_t)w * NFR + (NFR - 1)) * 7;
+  double* sb = B.speedbias + ((size_t)w * NFR + (NFR - 1)) * 9;
+  const int n = B.imu_n[iv];
+  const double* dt = B.imu_dt + iv * B.max_samp;
+  const double* acc = B.imu_acc + iv * (B.max_samp + 1) * 3;
+  const double* gyr = B.imu_gyr + iv * (B.max_samp + 1) * 3;
+  v3 P = mk3(pose[0], pose[1], pose[2]), V = mk3(sb[0], sb[1], sb[2]);
+  const v3 Ba = mk3(sb[3], sb[4], sb[5]), Bg = mk3(sb[6], sb[7], sb[8]), g = mk3(gx, gy, gz);
+  double R[9];
+  q2R(quat{pose[6], pose[3], pose[4], pose[5]}, R);
+  v3 acc0 = mk3(acc[0], acc[1], acc[2]), gyr0 = mk3(gyr[0], gyr[1], gyr[2]);
+  for (int s = 0; s < n; s++) {
+    const v3 a1 = mk3(acc[3 * (s + 1)], acc[3 * (s + 1) + 1], acc[3 * (s + 1) + 2]);
+    const v3 w1 = mk3(gyr[3 * (s + 1)], gyr[3 * (s + 1) + 1], gyr[3 * (s + 1) + 2]);
+    const double h = dt[s];
+    const v3 un_acc_0 = Rmul(R, acc0 - Ba) - g;
+    const v3 un_gyr = 0.5 * (gyr0 + w1) - Bg;
+    double dR[9], Rn[9];
+    q2R(deltaQ(h * un_gyr), dR);
+    mat3mul(R, dR, Rn);
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = Rn[k];
+    const v3 un_acc_1 = Rmul(R, a1 - Ba) - g;
+    const v3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
+    P = P + h * V + (0.5 * h * h) * un_acc;
+    V = V + h * un_acc;
+    acc0 = a1, gyr0 = w1;
+  }
+  const quat q = R2q(R);
+  pose[0] = P.x, pose[1] = P.y, pose[2] = P.z, pose[3] = q.x, pose[4] = q.y, pose[5] = q.z, pose[6] = q.w;
+  sb[0] = V.x, sb[1] = V.y, sb[2] = V.z;
+}
+
+hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipStream_t stream) {
+  if (b.n_windows == 0) return hipSuccess;
+  hipLaunchKernelGGL(imu_propagate_kernel, dim3((b.n_windows + TRI_NT - 1) / TRI_NT), dim3(TRI_NT), 0, stream, b, g[0], g[1], g[2]);
+  return hipGetLastError();
+}
+
 hipError_t launch_triangulate(const avm_window_batch& b, double init_depth, hipStream_t stream) {
   const long n = (long)b.n_windows * b.max_feat;
   if (n == 0) return hipSuccess;

@@ -50,6 +50,13 @@ class Estimator:
         rc = self.ctx._L.avm_triangulate_batch(self.ctx.h, windows.mem, C.byref(s), float(init_depth))
         self.ctx.check(rc, "avm_triangulate_batch")
 
+    def imu_propagate(self, windows: buffers.WindowArrays):
+        """Estimator::processIMU's dead-reckoning of the newest frame (estimator.cpp:100-107), in place."""
+        s = windows.struct()
+        g = (C.c_double * 3)(*[float(x) for x in self.options.g])
+        rc = self.ctx._L.avm_imu_propagate_batch(self.ctx.h, windows.mem, C.byref(s), g)
+        self.ctx.check(rc, "avm_imu_propagate_batch")
+
     def preintegrate(self, windows: buffers.WindowArrays):
         """IntegrationBase for every interval: returns delta [B,10,10], jacobian, covariance [B,10,15,15], sum_dt [B,10]."""
         assert not windows.on_device

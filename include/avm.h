@@ -247,6 +247,14 @@ int avm_imu_preintegrate_batch(avm_ctx* ctx, const avm_options* opt, avm_mem mem
  * avm_imu_preintegrate_batch() with the new linearization biases in imu_lin_ba / imu_lin_bg.) */
 int avm_triangulate_batch(avm_ctx* ctx, avm_mem mem, avm_window_batch* batch, double init_depth);
 
+/* SURVEY 8(f)1, second half: the dead-reckoning of the newest frame in Estimator::processIMU (estimator.cpp:100-107).
+ * Frame AVM_WINDOW_SIZE of every window (which slideWindow() left holding a copy of the previous newest frame) is
+ * carried through the raw samples of the last interval (imu_* [B][AVM_WINDOW_SIZE-1], row 0 of acc/gyr = the sample
+ * the interval was constructed with): world-frame midpoint integration with the biases of that frame and gravity g;
+ * Rs is propagated as a matrix times the rotation matrix of the UNNORMALIZED deltaQ, as the reference does, and turned
+ * into the pose quaternion at the end.  In place on batch->pose[.][10] and batch->speedbias[.][10][0..2]. */
+int avm_imu_propagate_batch(avm_ctx* ctx, avm_mem mem, avm_window_batch* batch, const double g[3]);
+
 /* A5/A6/A8 only: evaluate every factor once at the current state and return
  * residuals/Jacobians (local 6-column pose blocks).  Used by the per-factor parity tests.
  *   proj_r [B][max_obs][2], proj_J [B][max_obs][2][13]  (pose_i 6 | pose_j 6 | inv_depth 1), index = observation slot

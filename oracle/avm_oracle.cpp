@@ -399,4 +399,15 @@ int avmo_smallest_right_singular_vector(int n, const double* A, double* v) {
   return 0;
 }
 
+// Estimator::processIMU dead-reckoning of frame WINDOW_SIZE from the samples of the last interval
+int avmo_imu_propagate_batch(avm_window_batch* B, const double* g) {
+  for (int w = 0; w < B->n_windows; w++) {
+    const size_t iv = (size_t)w * AVM_WINDOW_SIZE + (AVM_WINDOW_SIZE - 1);
+    propagate_newest_frame(B->pose + ((size_t)w * AVM_NFRAMES + AVM_WINDOW_SIZE) * 7, B->speedbias + ((size_t)w * AVM_NFRAMES + AVM_WINDOW_SIZE) * 9,
+                           B->imu_n[iv], B->imu_dt + iv * B->max_samp, B->imu_acc + iv * (B->max_samp + 1) * 3,
+                           B->imu_gyr + iv * (B->max_samp + 1) * 3, V3(g[0], g[1], g[2]));
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -101,3 +101,13 @@ def smallest_right_singular_vector(A):
     rc = lib().avmo_smallest_right_singular_vector(int(A.shape[0]), abi.dptr(A), abi.dptr(v))
     assert rc == 0
     return v
+
+
+def imu_propagate(win, g):
+    """Estimator::processIMU dead-reckoning of the newest frame, in place on host WindowArrays."""
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    s = win.struct()
+    gg = np.ascontiguousarray(g, float)
+    rc = lib().avmo_imu_propagate_batch(C.byref(s), abi.dptr(gg))
+    assert rc == 0

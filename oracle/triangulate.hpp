@@ -85,4 +85,31 @@ inline double triangulate_feature(const double (*pose)[7], const double* ex, int
   return depth;
 }
 
+// Estimator::processIMU, the dead-reckoning of the newest frame (estimator.cpp:100-107): world-frame midpoint
+// integration of the raw samples of the last interval, starting from the state slideWindow() left in frame j
+// (a copy of the previous newest frame).  Rs is a MATRIX that is multiplied by the rotation matrix of the
+// unnormalized deltaQ (no re-orthonormalization); the quaternion is only formed afterwards (vector2double,
+// estimator.cpp:486).  acc/gyr: row 0 = the sample the interval's IntegrationBase was constructed with (acc_0).
+inline void propagate_newest_frame(double pose[7], double sb[9], int n, const double* dt, const double* acc, const double* gyr, V3 g) {
+  V3 P(pose[0], pose[1], pose[2]), V(sb[0], sb[1], sb[2]);
+  const V3 Ba(sb[3], sb[4], sb[5]), Bg(sb[6], sb[7], sb[8]);
+  M3 R = toR(Q(pose[6], pose[3], pose[4], pose[5]));
+  V3 acc0(acc[0], acc[1], acc[2]), gyr0(gyr[0], gyr[1], gyr[2]);
+  for (int s = 0; s < n; s++) {
+    const V3 a1(acc[3 * (s + 1)], acc[3 * (s + 1) + 1], acc[3 * (s + 1) + 2]), w1(gyr[3 * (s + 1)], gyr[3 * (s + 1) + 1], gyr[3 * (s + 1) + 2]);
+    const double h = dt[s];
+    const V3 un_acc_0 = R * (acc0 - Ba) - g;
+    const V3 un_gyr = 0.5 * (gyr0 + w1) - Bg;
+    R = R * toR(deltaQ(un_gyr * h));
+    const V3 un_acc_1 = R * (a1 - Ba) - g;
+    const V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
+    P = P + h * V + (0.5 * h * h) * un_acc;
+    V = V + h * un_acc;
+    acc0 = a1, gyr0 = w1;
+  }
+  const Q q = fromR(R);
+  pose[0] = P.x, pose[1] = P.y, pose[2] = P.z, pose[3] = q.x, pose[4] = q.y, pose[5] = q.z, pose[6] = q.w;
+  sb[0] = V.x, sb[1] = V.y, sb[2] = V.z;
+}
+
 }  // namespace avmo

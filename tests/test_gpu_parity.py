@@ -86,6 +86,23 @@ def _assert_state_parity(wg, wo, sg, so):
         assert rel(wg.a[k], wo.a[k]) < STATE_TOL, (k, rel(wg.a[k], wo.a[k]))
 
 
+def test_newest_frame_dead_reckoning_matches_oracle(estimator, oracle):
+    """SURVEY 8(f)1: Estimator::processIMU dead-reckoning on device."""
+    w = synth.make_windows(5, tracks="sparse", n_feat=8, max_feat=150)
+    w.a["pose"][:, 10] = w.a["pose"][:, 9]
+    w.a["speedbias"][:, 10] = w.a["speedbias"][:, 9]
+    w.a["imu_n"][2, 9] = 3
+    w.a["imu_n"][3, 9] = 0
+    wg, wo = w.copy(), w.copy()
+    estimator.imu_propagate(wg)
+    oracle.imu_propagate(wo, np.array(list(estimator.options.g)))
+    assert rel(wg.a["pose"], wo.a["pose"]) < 1e-13 and rel(wg.a["speedbias"], wo.a["speedbias"]) < 1e-13
+    assert np.array_equal(wg.a["pose"][:, :10], w.a["pose"][:, :10])
+    wd = w.to_device("cuda:0")
+    estimator.imu_propagate(wd)
+    assert np.array_equal(wd.to_host().a["pose"], wg.a["pose"])
+
+
 def test_triangulation_matches_oracle(estimator, oracle):
     """SURVEY 8(f)1: FeatureManager::triangulate on device (the step before optimization() in solveOdometry())."""
     for tracks, nf in (("sparse", 60), ("dense", 150)):

@@ -350,3 +350,36 @@ def test_triangulate_matches_numpy_svd(oracle):
     # the triangulated depths are close to the ones the generator perturbed (poses are 5 cm / 1 deg off, 1.5 px noise)
     r = np.concatenate([w.a["inv_depth"][b, : w.a["n_feat"][b] : 2] / keep[b, : w.a["n_feat"][b] : 2] for b in range(3)])
     assert np.median(np.abs(r - 1)) < 0.3
+
+
+def test_newest_frame_dead_reckoning_matches_numpy(oracle, opt):
+    """SURVEY 8(f)1: Estimator::processIMU (estimator.cpp:100-107) against an independent numpy statement."""
+    def q2R(q):  # x y z w, Eigen toRotationMatrix (no normalization)
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    w = synth.make_windows(3, tracks="sparse", n_feat=8, max_feat=150)
+    w.a["pose"][:, 10] = w.a["pose"][:, 9]            # what slideWindow() leaves behind
+    w.a["speedbias"][:, 10] = w.a["speedbias"][:, 9]
+    w.a["imu_n"][1, 9] = 7                             # ragged
+    g = np.array(list(opt.g))
+    ref = w.copy()
+    oracle.imu_propagate(w, g)
+    for b in range(3):
+        P, V = ref.a["pose"][b, 10, :3].copy(), ref.a["speedbias"][b, 10, :3].copy()
+        Ba, Bg = ref.a["speedbias"][b, 10, 3:6], ref.a["speedbias"][b, 10, 6:9]
+        R = q2R(ref.a["pose"][b, 10, 3:])
+        acc, gyr, dt = ref.a["imu_acc"][b, 9], ref.a["imu_gyr"][b, 9], ref.a["imu_dt"][b, 9]
+        a0, w0 = acc[0], gyr[0]
+        for s_ in range(ref.a["imu_n"][b, 9]):
+            a1, w1, h = acc[s_ + 1], gyr[s_ + 1], dt[s_]
+            ua0 = R @ (a0 - Ba) - g
+            ug = 0.5 * (w0 + w1) - Bg
+            R = R @ q2R(np.array([ug[0] * h / 2, ug[1] * h / 2, ug[2] * h / 2, 1.0]))
+            ua = 0.5 * (ua0 + R @ (a1 - Ba) - g)
+            P, V = P + h * V + 0.5 * h * h * ua, V + h * ua
+            a0, w0 = a1, w1
+        assert rel(w.a["pose"][b, 10, :3], P) < 1e-13 and rel(w.a["speedbias"][b, 10, :3], V) < 1e-13
+        assert rel(q2R(w.a["pose"][b, 10, 3:]), R) < 1e-9      # R is only orthonormal to first order (unnormalized deltaQ)
+        assert np.array_equal(w.a["pose"][b, :10], ref.a["pose"][b, :10]) and np.array_equal(w.a["speedbias"][b, 10, 3:], ref.a["speedbias"][b, 10, 3:])
