@@ -19,6 +19,7 @@ AVM_DEV void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_sched_barrier(0);  // keep the phases of a sample from being interleaved (register pressure)
 }
 
 struct PreLds {
@@ -38,7 +39,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //                                                   A-layout registers of F (of V) double as the B operand F^T (V^T)
 // F and V are rebuilt per sample as small LDS images (only their sample-dependent 3x3 blocks are rewritten) and
 // each lane fetches its 4 + 5 operand entries from there.
-__global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
+__global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8))) void preint_kernel(PreintArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   PreLds* all = reinterpret_cast<PreLds*>(smem_raw);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
