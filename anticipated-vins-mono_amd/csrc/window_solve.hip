@@ -60,7 +60,7 @@ constexpr int XSB = 77, XLAM = 176;
 // L_G is dead while the projection factors are being assembled, so that range doubles as the per-wave
 // staging area of the MFMA X^T X products (ASM_WAVES x XSTG doubles).
 constexpr int SPP = 2244;          // roff(66): packed rows 0..65 = pose-pose block
-constexpr int WCH = 32;            // features per Schur staging chunk (x 80 padded columns)
+constexpr int WCH = 32;            // rows of the scratch tile at L_WCH (x 80 columns): diag-block temporaries, back-substitution vector
 constexpr int WLD = 80;
 constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r | start-frame tag
 constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows
@@ -70,7 +70,7 @@ constexpr int L_S = 0;
 constexpr int L_Y = L_S + SROWS;   // Gauss-Newton solution y of (H + mu D^2) y = g
 constexpr int L_ST = L_Y + VEC;    // trust region step (scaled space)
 constexpr int L_XC = L_ST + VEC;   // candidate state
-constexpr int L_WCH = L_XC + XN;   // Schur staging [32][80]
+constexpr int L_WCH = L_XC + XN;   // [32][80] scratch tile
 constexpr int L_G = L_WCH + WCH * WLD;  // scaled gradient g (f | e)
 constexpr int L_DG = L_G + VEC;    // g / D
 constexpr int L_DD = L_DG + VEC;   // D
@@ -89,7 +89,6 @@ constexpr int L_OPT = L_CTX + 24;   // avm_options (copied from the kernel argum
 constexpr int L_END = L_OPT + (int)((sizeof(avm_options) + 7) / 8);
 static_assert(L_END * 8 <= 163840, "LDS budget exceeded");
 static_assert(L_S + SPP + ASM_WAVES * XSTG <= L_G, "assembly staging overlaps live data");
-static_assert(L_Y + 5 * 465 + 8 + 5 * 225 <= L_G, "IMU staging overlaps live data");
 // int carve (offsets in ints from L_INT)
 constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 546, I_PBLK = 560 /* kind,frame,off x16 */, I_FAIL = 620,
               I_NCOV = 624 /* [11] factors observed in frame b */, I_FRW = 636 /* [11] assembling wave of frame b */,
@@ -464,34 +463,8 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
   return block_sum<NT>(acc, lds + L_RED);
 }
 
-// HP[p][q] = sum_i J0[i][p] J0[i][q] (lower tiles; mirrored) on the matrix cores: 16x16 tiles, K = prior rows.
-AVM_NOINL void prior_jtj_mfma(const double* pJ, int ldp, int pn, double* HP) {
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int ntl = (pn + 15) >> 4;
-  for (int tile = wv; tile < ntl * (ntl + 1) / 2; tile += NT / 64) {
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
-    const int tj = tile - ti * (ti + 1) / 2;
-    const int ca = 16 * ti + (lane & 15), cb = 16 * tj + (lane & 15);
-    d4 D = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < pn; k0 += 4) {
-      const int r = k0 + (lane >> 4);
-      const double aop = (r < pn && ca < pn) ? pJ[(size_t)r * ldp + ca] : 0.0;
-      const double bop = (r < pn && cb < pn) ? pJ[(size_t)r * ldp + cb] : 0.0;
-      D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int gi = 16 * ti + (lane >> 4) + 4 * r, gj = 16 * tj + (lane & 15);
-      if (gi < pn && gj < pn) {
-        HP[gi * MAXPRIOR + gj] = D[r];
-        HP[gj * MAXPRIOR + gi] = D[r];
-      }
-    }
-  }
-}
-
-// Marginalization-kernel variant: the tiles of J0^T J0 are added straight into the packed system in LDS at the
+// Prior J0^T J0 on the matrix cores (16x16 tiles, K = prior rows), marginalization-kernel variant: the tiles are
+// added straight into the packed system in LDS at the
 // columns pidx[] maps the prior's columns to (every lower entry is produced exactly once, so the wavefronts never
 // touch the same element).  All operand loads of a tile are issued before the MFMA chain.
 AVM_NOINL void prior_jtj_add_lds(gcdouble* pJ, int ldp, int pn, int s_off) {
@@ -1945,7 +1918,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
 // Deterministic block order (the reference's is address-hash order): kept = poses by frame,
 // speed-bias by frame, ex_pose.
 namespace mg {
-constexpr int MNF = 171, MEX0 = 165, MROWS = 14792;  // roff(171)
+constexpr int MEX0 = 165, MROWS = 14792;  // 171 variables: MROWS = roff(171)
 constexpr int MXLD = 24;                              // Jj 0-5 | Ji 6-11 | r 12 | tag 13 | 0 0 | Jex 16-21 | 0 0
 constexpr int MXSTG = 128 * MXLD;
 constexpr int MASM = 3;                               // assembling wavefronts (staging must stay below row 165)
@@ -2474,7 +2447,6 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     PROF(c, 20);
     // ---- phase F: eliminate the start-0 inverse depths (scalar pivots)
     if (flag == AVM_MARGIN_OLD && nf0 > 0) {
-      const double* W = c.sc + Scratch::W;
       if (t < MAXE) lds[L_HEE + t] = (t < nf0 && lds[L_HEE + t] > o.marg_eps) ? 1.0 / lds[L_HEE + t] : 0.0;  // 1 / E^T E in place
       __syncthreads();
       switch (t >> 6) {
@@ -2532,7 +2504,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     double* EA = lds + M_WCH;            // Amm 16 x 16, then its eigenvectors next to it
     double* EV = EA + 256;               // 16 x 16
     double* EB = EV + 256;               // Arm : n x 16   (n <= 96 -> 1536)  (M_WCH region holds 1920+; spills into the dead L_G.. vectors)
-    double* ROT = lds + L_HEE;           // rotation records (hee / dxp / rp are dead by now: 344 doubles >= 4 * 64 + ints)
+    // (the 16x16 eigen-solver keeps its rotation records at L_HEE: hee / dxp / rp are dead by now)
     double* BV = lds + L_FR + 198;       // b_m (16), b_r (96): the candidate-state frame slot is unused here
     for (int idx = t; idx < 16 * 16; idx += NT) {
       const int i = idx / 16, j = idx % 16;
