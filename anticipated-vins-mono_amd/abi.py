@@ -125,6 +125,35 @@ SUMMARY_DTYPE = np.dtype(
 )
 
 
+class FselHorizonIn(C.Structure):
+    """avm_fsel_horizon_in (include/avm.h): inputs of HorizonGenerator::imu."""
+    _fields_ = [
+        ("n_problems", C.c_int32),
+        ("horizon", C.c_int32),
+        ("k_pos", c_dp), ("k_quat", c_dp), ("k_ba", c_dp),
+        ("k1_pos", c_dp), ("k1_vel", c_dp), ("k1_quat", c_dp),
+        ("acc", c_dp), ("gyr", c_dp),
+        ("nr_imu", c_ip), ("delta_imu", c_dp),
+    ]
+
+
+def horizon_in(horizon, k_pos, k_quat, k_ba, k1_pos, k1_vel, k1_quat, acc, gyr, nr_imu, delta_imu):
+    """Build an avm_fsel_horizon_in from host numpy arrays (kept alive on the returned struct)."""
+    import numpy as np
+
+    f64 = lambda a, n: np.ascontiguousarray(np.asarray(a, float).reshape(-1, n))
+    arrs = dict(k_pos=f64(k_pos, 3), k_quat=f64(k_quat, 4), k_ba=f64(k_ba, 3), k1_pos=f64(k1_pos, 3), k1_vel=f64(k1_vel, 3),
+                k1_quat=f64(k1_quat, 4), acc=f64(acc, 3), gyr=f64(gyr, 3), delta_imu=np.ascontiguousarray(np.asarray(delta_imu, float).reshape(-1)))
+    nr = np.ascontiguousarray(np.asarray(nr_imu, np.int32).reshape(-1))
+    s = FselHorizonIn()
+    s.n_problems, s.horizon = arrs["k_pos"].shape[0], int(horizon)
+    for k, v in arrs.items():
+        setattr(s, k, dptr(v))
+    s.nr_imu = iptr(nr)
+    s._keep = (arrs, nr)
+    return s
+
+
 class FselBatch(C.Structure):
     _fields_ = [
         ("n_problems", C.c_int32),

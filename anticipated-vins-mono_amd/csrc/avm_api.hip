@@ -580,6 +580,42 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   return AVM_OK;
 }
 
+int avm_fsel_horizon_imu(avm_ctx* c, avm_mem mem, const avm_fsel_horizon_in* in, double* hor_pos, double* hor_quat) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (!in || !hor_pos || !hor_quat || in->n_problems < 0 || in->horizon < 1) return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (in->n_problems == 0) return AVM_OK;
+  const size_t P = in->n_problems, H1 = (size_t)in->horizon + 1;
+  avm_fsel_horizon_in d = *in;
+  double *dp = hor_pos, *dq = hor_quat;
+  if (mem == AVM_MEM_HOST) {
+    int rc;
+#define ST(field, type, count)                                                                                     \
+  if ((rc = stage_in<type>(c, "h_" #field, in->field, (count), (const type**)&d.field)) != AVM_OK) return rc;
+    ST(k_pos, double, P * 3)
+    ST(k_quat, double, P * 4)
+    ST(k_ba, double, P * 3)
+    ST(k1_pos, double, P * 3)
+    ST(k1_vel, double, P * 3)
+    ST(k1_quat, double, P * 4)
+    ST(acc, double, P * 3)
+    ST(gyr, double, P * 3)
+    ST(nr_imu, int32_t, P)
+    ST(delta_imu, double, P)
+#undef ST
+    dp = static_cast<double*>(pool_get(c, "h_pos", sizeof(double) * P * H1 * 3));
+    dq = static_cast<double*>(pool_get(c, "h_quat", sizeof(double) * P * H1 * 4));
+    if (!dp || !dq) return fail(c, AVM_ERR_HIP, "hipMalloc failed (horizon out)");
+  }
+  HIPCHK(c, launch_fsel_horizon_imu(d, dp, dq, c->stream));
+  if (mem == AVM_MEM_HOST) {
+    HIPCHK(c, hipMemcpyAsync(hor_pos, dp, sizeof(double) * P * H1 * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hor_quat, dq, sizeof(double) * P * H1 * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
+}
+
 int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, double* omega, double* delta_cand, int32_t* cand_valid) {
   if (!c) return AVM_ERR_INVALID;
   (void)hipSetDevice(c->device);

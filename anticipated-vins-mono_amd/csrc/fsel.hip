@@ -485,6 +485,41 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   return hipGetLastError();
 }
 
+// ---- B4: HorizonGenerator::imu (utility/horizon_generator.cpp:25-69), one thread per frame ------------------------
+__global__ __launch_bounds__(64) void fsel_horizon_imu_kernel(avm_fsel_horizon_in in, double* hor_pos, double* hor_quat) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= in.n_problems) return;
+  const int H = in.horizon;
+  double* pos = hor_pos + (size_t)p * (H + 1) * 3;
+  double* qo = hor_quat + (size_t)p * (H + 1) * 4;
+  const v3 gravity = mk3(0, 0, -9.80665);  // state_defs.h:37-41
+  const v3 Ba = mk3(in.k_ba[3 * p], in.k_ba[3 * p + 1], in.k_ba[3 * p + 2]);
+  const v3 a = mk3(in.acc[3 * p], in.acc[3 * p + 1], in.acc[3 * p + 2]), w = mk3(in.gyr[3 * p], in.gyr[3 * p + 1], in.gyr[3 * p + 2]);
+  for (int k = 0; k < 3; k++) pos[k] = in.k_pos[3 * p + k], pos[3 + k] = in.k1_pos[3 * p + k];
+  for (int k = 0; k < 4; k++) qo[k] = in.k_quat[4 * p + k], qo[4 + k] = in.k1_quat[4 * p + k];
+  const double dI = in.delta_imu[p];
+  const int nr = in.nr_imu[p];
+  const quat Qimu = deltaQ(dI * w);  // unnormalized, and the attitude is never renormalized in the loop
+  v3 pp = mk3(in.k1_pos[3 * p], in.k1_pos[3 * p + 1], in.k1_pos[3 * p + 2]), vv = mk3(in.k1_vel[3 * p], in.k1_vel[3 * p + 1], in.k1_vel[3 * p + 2]);
+  quat q{in.k1_quat[4 * p + 3], in.k1_quat[4 * p], in.k1_quat[4 * p + 1], in.k1_quat[4 * p + 2]};
+  for (int h = 2; h <= H; h++) {
+    for (int i = 0; i < nr; i++) {
+      q = qmul(q, Qimu);
+      const v3 qa = qrot(q, a - Ba);
+      vv = vv + dI * (gravity + qa);
+      pp = pp + dI * vv + dI * (dI * (0.5 * gravity)) + dI * (dI * (0.5 * qa));
+    }
+    pos[3 * h] = pp.x, pos[3 * h + 1] = pp.y, pos[3 * h + 2] = pp.z;
+    qo[4 * h] = q.x, qo[4 * h + 1] = q.y, qo[4 * h + 2] = q.z, qo[4 * h + 3] = q.w;
+  }
+}
+
+hipError_t launch_fsel_horizon_imu(const avm_fsel_horizon_in& in, double* hor_pos, double* hor_quat, hipStream_t stream) {
+  if (in.n_problems == 0) return hipSuccess;
+  hipLaunchKernelGGL(fsel_horizon_imu_kernel, dim3((in.n_problems + 63) / 64), dim3(64), 0, stream, in, hor_pos, hor_quat);
+  return hipGetLastError();
+}
+
 bool fsel_horizon_supported(int H) { return H == 2 || H == 3 || H == 5 || H == 10 || H == 13; }
 
 }  // namespace avm

@@ -32,6 +32,16 @@ class FeatureSelector:
         self.ctx.check(rc, "avm_fsel_select_batch")
         return out
 
+    def generateFutureHorizon(self, horizon, k_pos, k_quat, k_ba, k1_pos, k1_vel, k1_quat, acc, gyr, nr_imu, delta_imu):
+        """FeatureSelector::generateFutureHorizon in IMU mode = HorizonGenerator::imu (horizon_generator.cpp:25-69) for P
+        frames: returns hor_pos [P, H+1, 3], hor_quat [P, H+1, 4] (x y z w), the arrays avm_fsel_batch consumes."""
+        s = abi.horizon_in(horizon, k_pos, k_quat, k_ba, k1_pos, k1_vel, k1_quat, acc, gyr, nr_imu, delta_imu)
+        P = s.n_problems
+        hp, hq = np.zeros((P, horizon + 1, 3)), np.zeros((P, horizon + 1, 4))
+        rc = self.ctx._L.avm_fsel_horizon_imu(self.ctx.h, abi.AVM_MEM_HOST, C.byref(s), abi.dptr(hp), abi.dptr(hq))
+        self.ctx.check(rc, "avm_fsel_horizon_imu")
+        return hp, hq
+
     def information(self, problems: buffers.FselArrays):
         """Omega_kkH (+prior) [P,N,N], compact Delta_ell [P,max_cand,3H,3H], valid [P,max_cand] (host arrays)."""
         assert not problems.on_device

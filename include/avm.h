@@ -207,6 +207,25 @@ typedef struct avm_fsel_out {
   double* fvalues;       /* [P][max_features] fMax of each round (nullable) */
 } avm_fsel_out;
 
+/* B4: FeatureSelector::generateFutureHorizon in IMU mode = HorizonGenerator::imu
+ * (utility/horizon_generator.cpp:25-69; state_defs.h:15-19,37-41).  Inputs are what
+ * setNextStateFromImuPropagation latched (feature_selector.cpp:38-70): state_k_ (tail of the window), state_k1_
+ * (IMU-propagated current frame), the body acceleration / angular rate a_k1, w_k1. */
+typedef struct avm_fsel_horizon_in {
+  int32_t n_problems;
+  int32_t horizon;          /* H: states 0..H are produced */
+  const double* k_pos;      /* [P][3] state_k_  position */
+  const double* k_quat;     /* [P][4] state_k_  attitude x y z w */
+  const double* k_ba;       /* [P][3] state_k_  accelerometer bias (held constant over the horizon) */
+  const double* k1_pos;     /* [P][3] state_k1_ position */
+  const double* k1_vel;     /* [P][3] state_k1_ velocity */
+  const double* k1_quat;    /* [P][4] state_k1_ attitude x y z w */
+  const double* acc;        /* [P][3] a_k1 */
+  const double* gyr;        /* [P][3] w_k1 */
+  const int32_t* nr_imu;    /* [P] nrImuMeasurements */
+  const double* delta_imu;  /* [P] deltaImu */
+} avm_fsel_horizon_in;
+
 typedef struct avm_config {
   int32_t device;       /* HIP device ordinal */
   int32_t max_windows;  /* capacity of one avm_window_solve_batch call */
@@ -254,6 +273,12 @@ int avm_triangulate_batch(avm_ctx* ctx, avm_mem mem, avm_window_batch* batch, do
  * Rs is propagated as a matrix times the rotation matrix of the UNNORMALIZED deltaQ, as the reference does, and turned
  * into the pose quaternion at the end.  In place on batch->pose[.][10] and batch->speedbias[.][10][0..2]. */
 int avm_imu_propagate_batch(avm_ctx* ctx, avm_mem mem, avm_window_batch* batch, const double g[3]);
+
+/* B4 (see avm_fsel_horizon_in): constant body acceleration / angular rate propagation of states 2..H with
+ * Qimu = deltaQ(w * deltaImu) - UNNORMALIZED and never renormalized in the loop (horizon_generator.cpp:46,54) - and
+ * gravity (0, 0, -9.80665).  Writes hor_pos [P][H+1][3] and hor_quat [P][H+1][4] (x y z w), the layout
+ * avm_fsel_batch consumes. */
+int avm_fsel_horizon_imu(avm_ctx* ctx, avm_mem mem, const avm_fsel_horizon_in* in, double* hor_pos, double* hor_quat);
 
 /* A5/A6/A8 only: evaluate every factor once at the current state and return
  * residuals/Jacobians (local 6-column pose blocks).  Used by the per-factor parity tests.

@@ -410,4 +410,12 @@ int avmo_imu_propagate_batch(avm_window_batch* B, const double* g) {
   return 0;
 }
 
+int avmo_fsel_horizon_imu(const avm_fsel_horizon_in* in, double* hor_pos, double* hor_quat) {
+  const int H = in->horizon;
+  for (int p = 0; p < in->n_problems; p++)
+    horizon_imu(H, in->k_pos + 3 * p, in->k_quat + 4 * p, in->k_ba + 3 * p, in->k1_pos + 3 * p, in->k1_vel + 3 * p, in->k1_quat + 4 * p,
+                in->acc + 3 * p, in->gyr + 3 * p, in->nr_imu[p], in->delta_imu[p], hor_pos + (size_t)p * (H + 1) * 3, hor_quat + (size_t)p * (H + 1) * 4);
+  return 0;
+}
+
 }  // extern "C"

@@ -237,4 +237,28 @@ inline FselResult fsel_select(const FselProblem& p) {
   return R;
 }
 
+// HorizonGenerator::imu (utility/horizon_generator.cpp:25-69).  States 0 and 1 are given; 2..H are propagated with a
+// constant body acceleration a and angular rate w; Qimu = deltaQ(w deltaImu) is unnormalized and the attitude is never
+// renormalized inside the loop.  pos/quat: [H+1][3] / [H+1][4] (x y z w).
+inline void horizon_imu(int H, const double* k_pos, const double* k_quat, const double* k_ba, const double* k1_pos, const double* k1_vel,
+                        const double* k1_quat, const double* a_, const double* w_, int nrImu, double deltaImu, double* pos, double* quat) {
+  const V3 gravity(0, 0, -9.80665);  // state_defs.h:37-41
+  const V3 Ba(k_ba[0], k_ba[1], k_ba[2]), a(a_[0], a_[1], a_[2]), w(w_[0], w_[1], w_[2]);
+  for (int k = 0; k < 3; k++) pos[k] = k_pos[k], pos[3 + k] = k1_pos[k];
+  for (int k = 0; k < 4; k++) quat[k] = k_quat[k], quat[4 + k] = k1_quat[k];
+  const Q Qimu = deltaQ(w * deltaImu);
+  V3 p(k1_pos[0], k1_pos[1], k1_pos[2]), v(k1_vel[0], k1_vel[1], k1_vel[2]);
+  Q q(k1_quat[3], k1_quat[0], k1_quat[1], k1_quat[2]);
+  for (int h = 2; h <= H; h++) {
+    for (int i = 0; i < nrImu; i++) {
+      q = q * Qimu;
+      const V3 qa = rot(q, a - Ba);
+      v = v + (gravity + qa) * deltaImu;
+      p = p + v * deltaImu + ((0.5 * gravity) * deltaImu) * deltaImu + ((0.5 * qa) * deltaImu) * deltaImu;
+    }
+    pos[3 * h] = p.x, pos[3 * h + 1] = p.y, pos[3 * h + 2] = p.z;
+    quat[4 * h] = q.x, quat[4 * h + 1] = q.y, quat[4 * h + 2] = q.z, quat[4 * h + 3] = q.w;
+  }
+}
+
 }  // namespace avmo

@@ -341,6 +341,32 @@ def test_selector_information_and_ids(selector, oracle, H, nc, nu, mf, P):
     assert rel(out.a["fvalues"][0, :n], oo.a["fvalues"][0, :n]) < 1e-9
 
 
+def test_horizon_generator_imu_matches_oracle(selector, oracle):
+    """B4: HorizonGenerator::imu on device, and its output feeding select()."""
+    rng = np.random.default_rng(11)
+    for H in (3, 10, 13):
+        q = rng.normal(size=(6, 2, 4)); q /= np.linalg.norm(q, axis=-1, keepdims=True)
+        i = dict(k_pos=rng.normal(size=(6, 3)), k_quat=q[:, 0], k_ba=0.02 * rng.normal(size=(6, 3)), k1_pos=rng.normal(size=(6, 3)),
+                 k1_vel=rng.normal(size=(6, 3)), k1_quat=q[:, 1], acc=np.array([0, 0, 9.8]) + rng.normal(size=(6, 3)),
+                 gyr=0.3 * rng.normal(size=(6, 3)), nr_imu=rng.integers(0, 25, 6), delta_imu=np.full(6, 0.005))
+        gp, gq = selector.generateFutureHorizon(H, **i)
+        op, oq = oracle.fsel_horizon_imu(H, **i)
+        assert rel(gp, op) < 1e-13 and rel(gq, oq) < 1e-13
+    # a generated horizon drives the selector to the same ids as the oracle
+    prob = synth.make_fsel(2, horizon=5, n_cand=60, n_cloud=40, max_features=15)
+    P = 2
+    hp, hq = prob.a["hor_pos"], prob.a["hor_quat"]
+    vel = (hp[:, 1] - hp[:, 0]) / (prob.a["nr_imu"] * prob.a["delta_imu"])[:, None]
+    args = dict(k_pos=hp[:, 0], k_quat=hq[:, 0], k_ba=np.zeros((P, 3)), k1_pos=hp[:, 1], k1_vel=vel, k1_quat=hq[:, 1],
+                acc=np.tile([0.1, 0.0, 9.80665], (P, 1)), gyr=np.tile([0.0, 0.0, 0.1], (P, 1)), nr_imu=prob.a["nr_imu"], delta_imu=prob.a["delta_imu"])
+    gp, gq = selector.generateFutureHorizon(5, **args)
+    prob.a["hor_pos"], prob.a["hor_quat"] = gp, gq
+    out = selector.select_batch(prob).to_host()
+    oo = buffers.FselOutArrays.alloc(P, 15)
+    oracle.fsel_select(prob, oo)
+    assert np.array_equal(out.a["n_selected"], oo.a["n_selected"]) and np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+
+
 def test_selector_headline_500_to_150(selector, oracle):
     pr = synth.make_fsel(1, horizon=10, n_cand=500, n_used=0, max_features=150)
     out = selector.select_batch(pr)

@@ -383,3 +383,40 @@ def test_newest_frame_dead_reckoning_matches_numpy(oracle, opt):
         assert rel(w.a["pose"][b, 10, :3], P) < 1e-13 and rel(w.a["speedbias"][b, 10, :3], V) < 1e-13
         assert rel(q2R(w.a["pose"][b, 10, 3:]), R) < 1e-9      # R is only orthonormal to first order (unnormalized deltaQ)
         assert np.array_equal(w.a["pose"][b, :10], ref.a["pose"][b, :10]) and np.array_equal(w.a["speedbias"][b, 10, 3:], ref.a["speedbias"][b, 10, 3:])
+
+
+def _horizon_inputs(P, rng):
+    q = rng.normal(size=(P, 2, 4)); q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    return dict(k_pos=rng.normal(size=(P, 3)), k_quat=q[:, 0], k_ba=0.02 * rng.normal(size=(P, 3)), k1_pos=rng.normal(size=(P, 3)),
+                k1_vel=rng.normal(size=(P, 3)), k1_quat=q[:, 1], acc=np.array([0, 0, 9.8]) + rng.normal(size=(P, 3)),
+                gyr=0.3 * rng.normal(size=(P, 3)), nr_imu=rng.integers(1, 25, P), delta_imu=np.full(P, 0.005))
+
+
+def test_horizon_generator_imu_matches_numpy(oracle):
+    """B4: HorizonGenerator::imu (utility/horizon_generator.cpp:25-69) against an independent numpy statement
+    (Hamilton product, unnormalized deltaQ, no renormalization, gravity (0, 0, -9.80665))."""
+    def qmul(a, b):  # w x y z
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+    def qrot(q, v):  # Eigen: v + w t + qv x t, t = 2 qv x v
+        t = 2 * np.cross(q[1:], v)
+        return v + q[0] * t + np.cross(q[1:], t)
+    rng = np.random.default_rng(11)
+    H, P = 10, 5
+    i = _horizon_inputs(P, rng)
+    hp, hq = oracle.fsel_horizon_imu(H, **i)
+    g = np.array([0, 0, -9.80665])
+    for p in range(P):
+        assert np.array_equal(hp[p, 0], i["k_pos"][p]) and np.array_equal(hp[p, 1], i["k1_pos"][p])
+        assert np.array_equal(hq[p, 0], i["k_quat"][p]) and np.array_equal(hq[p, 1], i["k1_quat"][p])
+        dI, w, a, Ba = i["delta_imu"][p], i["gyr"][p], i["acc"][p], i["k_ba"][p]
+        Qimu = np.array([1.0, *(w * dI / 2)])
+        q = np.array([i["k1_quat"][p][3], *i["k1_quat"][p][:3]])
+        pos, vel = i["k1_pos"][p].copy(), i["k1_vel"][p].copy()
+        for h in range(2, H + 1):
+            for _ in range(i["nr_imu"][p]):
+                q = qmul(q, Qimu)
+                qa = qrot(q, a - Ba)
+                vel = vel + (g + qa) * dI
+                pos = pos + vel * dI + 0.5 * g * dI * dI + 0.5 * qa * dI * dI
+            assert rel(hp[p, h], pos) < 1e-13 and rel(hq[p, h], np.array([q[1], q[2], q[3], q[0]])) < 1e-13
