@@ -11,6 +11,12 @@ from helpers import abi, blank_windows, buffers, golden, imu_window_from_golden,
 
 pytestmark = pytest.mark.gpu
 
+
+def importlib_est():
+    import importlib
+
+    return importlib.import_module("anticipated-vins-mono_amd.estimator")
+
 STATE_TOL = 1e-6   # north_star: pose states within 1e-6 relative
 FACTOR_TOL = 1e-10
 
@@ -217,6 +223,29 @@ def test_solve_is_bit_reproducible_and_shard_invariant(estimator):
     estimator.optimization(hi)
     for k in ("pose", "speedbias", "inv_depth"):
         assert np.array_equal(np.concatenate([lo.a[k], hi.a[k]]), a.a[k])
+
+
+def test_full_size_batch_properties(ctx):
+    """BASELINE.json configs[3] size (4096 windows x 150 features x 1500 factors, MARGIN_OLD) through size-independent
+    properties: every copy of a window gives bit-identical states / priors whichever workgroup slot solved it, costs
+    decrease, everything is finite, and the new prior reproduces A' = J^T J of the oracle-checked small case shape."""
+    opt = abi.default_options()
+    E = importlib_est().Estimator(ctx=ctx, options=opt)
+    base = synth.make_windows(32, tracks="dense")
+    big = synth.tile_windows(base, 4096).to_device("cuda:0")
+    summ = buffers.summary_to_numpy(E.optimization(big))
+    out, prior = big.to_host(), E.last_marginalization_info.to_host()
+    assert np.isfinite(out.a["pose"]).all() and np.isfinite(prior.a["J"]).all()
+    assert (summ["final_cost"] <= summ["initial_cost"]).all() and (summ["num_successful"] >= 1).all()
+    assert (prior.a["n"] == 75).all() and (prior.a["nblk"] == 12).all()
+    for k in ("pose", "speedbias", "inv_depth"):
+        a = out.a[k].reshape(128, 32, *out.a[k].shape[1:])
+        assert (a == a[0]).all(), k                                   # 128 copies of each of the 32 windows
+    J = prior.a["J"].reshape(128, 32, 96, 96)
+    assert (J == J[0]).all()
+    # the prior is a square root: J^T J is symmetric positive semi-definite with the kept dimension's rank or less
+    A = J[0, 0, :75, :75].T @ J[0, 0, :75, :75]
+    assert np.linalg.eigvalsh(A).min() > -1e-6 * np.abs(A).max()
 
 
 def test_device_resident_buffers_match_host_path(estimator):
