@@ -125,6 +125,26 @@ SUMMARY_DTYPE = np.dtype(
 )
 
 
+class TdFactorBatch(C.Structure):
+    """avm_td_factor_batch (include/avm.h): inputs of ProjectionTdFactor, one entry per factor."""
+    _fields_ = [("n", C.c_int32)] + [(k, c_dp) for k in ("pose_i", "pose_j", "ex_pose", "inv_depth", "td", "pts_i", "pts_j", "vel_i", "vel_j",
+                                                        "td_i", "td_j", "row_i", "row_j")] + [("tr", C.c_double), ("row", C.c_double), ("focal_length", C.c_double)]
+
+
+def td_factor_batch(arrays: dict, tr: float, row: float, focal_length: float = 460.0):
+    """Build an avm_td_factor_batch from host numpy arrays (kept alive on the returned struct)."""
+    import numpy as np
+
+    keep = {k: np.ascontiguousarray(np.asarray(v, float)) for k, v in arrays.items()}
+    s = TdFactorBatch()
+    s.n = keep["inv_depth"].shape[0]
+    for k, v in keep.items():
+        setattr(s, k, dptr(v))
+    s.tr, s.row, s.focal_length = float(tr), float(row), float(focal_length)
+    s._keep = keep
+    return s
+
+
 class FselHorizonIn(C.Structure):
     """avm_fsel_horizon_in (include/avm.h): inputs of HorizonGenerator::imu."""
     _fields_ = [

@@ -441,6 +441,35 @@ int avm_imu_propagate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, co
   return AVM_OK;
 }
 
+int avm_projection_td_eval(avm_ctx* c, avm_mem mem, const avm_td_factor_batch* f, double* residual, double* jac) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (!f || !residual || f->n < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (f->n == 0) return AVM_OK;
+  const size_t n = f->n;
+  avm_td_factor_batch d = *f;
+  double *dr = residual, *dj = jac;
+  if (mem == AVM_MEM_HOST) {
+    int rc;
+#define ST(field, count)                                                                                          \
+  if ((rc = stage_in<double>(c, "td_" #field, f->field, (count), (const double**)&d.field)) != AVM_OK) return rc;
+    ST(pose_i, n * 7) ST(pose_j, n * 7) ST(ex_pose, n * 7) ST(inv_depth, n) ST(td, n)
+    ST(pts_i, n * 2) ST(pts_j, n * 2) ST(vel_i, n * 2) ST(vel_j, n * 2)
+    ST(td_i, n) ST(td_j, n) ST(row_i, n) ST(row_j, n)
+#undef ST
+    dr = static_cast<double*>(pool_get(c, "td_res", sizeof(double) * n * 2));
+    dj = jac ? static_cast<double*>(pool_get(c, "td_jac", sizeof(double) * n * 40)) : nullptr;
+    if (!dr || (jac && !dj)) return fail(c, AVM_ERR_HIP, "hipMalloc failed (td factor out)");
+  }
+  HIPCHK(c, launch_projection_td_eval(d, dr, dj, c->stream));
+  if (mem == AVM_MEM_HOST) {
+    HIPCHK(c, hipMemcpyAsync(residual, dr, sizeof(double) * n * 2, hipMemcpyDeviceToHost, c->stream));
+    if (jac) HIPCHK(c, hipMemcpyAsync(jac, dj, sizeof(double) * n * 40, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
+}
+
 int avm_window_eval_factors(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* batch, int apply_loss,
                             double* proj_r, double* proj_J, double* imu_r, double* imu_J, double* prior_res, double* cost) {
   if (!c) return AVM_ERR_INVALID;

@@ -70,6 +70,7 @@ bool fsel_horizon_supported(int H);
 hipError_t launch_fsel_horizon_imu(const avm_fsel_horizon_in& in, double* hor_pos, double* hor_quat, hipStream_t stream);
 hipError_t launch_triangulate(const avm_window_batch& b, double init_depth, hipStream_t stream);
 hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipStream_t stream);
+hipError_t launch_projection_td_eval(const avm_td_factor_batch& f, double* residual, double* jac, hipStream_t stream);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipStream_t stream);

@@ -1,4 +1,5 @@
-// triangulate.hip — FeatureManager::triangulate (vins_estimator/src/feature_manager.cpp:202-257) on gfx950:
+// triangulate.hip — the small per-feature / per-factor kernels around the solve (also: newest-frame dead-reckoning,
+// ProjectionTdFactor evaluation).  FeatureManager::triangulate (vins_estimator/src/feature_manager.cpp:202-257) on gfx950:
 // linear multi-view triangulation of the features that have no depth yet, in the camera frame of their first
 // observation.  One thread per (window, feature); the (2 nobs) x 4 system (nobs <= 11) lives in the thread's
 // registers as four columns.  Eigen::JacobiSVD is replaced by a one-sided (Hestenes) Jacobi SVD on those columns -
@@ -154,6 +155,96 @@ __global__ __launch_bounds__(TRI_NT) void imu_propagate_kernel(avm_window_batch 
 hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipStream_t stream) {
   if (b.n_windows == 0) return hipSuccess;
   hipLaunchKernelGGL(imu_propagate_kernel, dim3((b.n_windows + TRI_NT - 1) / TRI_NT), dim3(TRI_NT), 0, stream, b, g[0], g[1], g[2]);
+  return hipGetLastError();
+}
+
+// A7: ProjectionTdFactor::Evaluate (factor/projection_td_factor.cpp:34-141), one thread per factor.
+__global__ __launch_bounds__(TRI_NT) void projection_td_eval_kernel(avm_td_factor_batch f, double* residual, double* jac) {
+  const int i = blockIdx.x * TRI_NT + threadIdx.x;
+  if (i >= f.n) return;
+  const double* pi = f.pose_i + 7 * (size_t)i;
+  const double* pj = f.pose_j + 7 * (size_t)i;
+  const double* ex = f.ex_pose + 7 * (size_t)i;
+  const v3 Pi = mk3(pi[0], pi[1], pi[2]), Pj = mk3(pj[0], pj[1], pj[2]), tic = mk3(ex[0], ex[1], ex[2]);
+  const quat Qi{pi[6], pi[3], pi[4], pi[5]}, Qj{pj[6], pj[3], pj[4], pj[5]}, qic{ex[6], ex[3], ex[4], ex[5]};
+  const double lam = f.inv_depth[i], td = f.td[i], s = f.focal_length / 1.5;
+  const v3 pts_i = mk3(f.pts_i[2 * i], f.pts_i[2 * i + 1], 1.0), pts_j = mk3(f.pts_j[2 * i], f.pts_j[2 * i + 1], 1.0);
+  const v3 vel_i = mk3(f.vel_i[2 * i], f.vel_i[2 * i + 1], 0.0), vel_j = mk3(f.vel_j[2 * i], f.vel_j[2 * i + 1], 0.0);
+  const double row_i = f.row_i[i] - f.row / 2, row_j = f.row_j[i] - f.row / 2;
+  const v3 pts_i_td = pts_i - (td - f.td_i[i] + f.tr / f.row * row_i) * vel_i;
+  const v3 pts_j_td = pts_j - (td - f.td_j[i] + f.tr / f.row * row_j) * vel_j;
+  const v3 pts_camera_i = (1.0 / lam) * pts_i_td;
+  const v3 pts_imu_i = qrot(qic, pts_camera_i) + tic;
+  const v3 pts_w = qrot(Qi, pts_imu_i) + Pi;
+  const v3 pts_imu_j = qrot(qinv(Qj), pts_w - Pj);
+  const v3 pts_camera_j = qrot(qinv(qic), pts_imu_j - tic);
+  const double dep_j = pts_camera_j.z;
+  residual[2 * (size_t)i] = s * ((pts_camera_j.x / dep_j) - pts_j_td.x);
+  residual[2 * (size_t)i + 1] = s * ((pts_camera_j.y / dep_j) - pts_j_td.y);
+  if (!jac) return;
+  double* J = jac + 40 * (size_t)i;
+  double Ri[9], Rj[9], ric[9];
+  q2R(Qi, Ri), q2R(Qj, Rj), q2R(qic, ric);
+  const double red[2][3] = {{s / dep_j, 0.0, s * (-pts_camera_j.x / (dep_j * dep_j))}, {0.0, s / dep_j, s * (-pts_camera_j.y / (dep_j * dep_j))}};
+  // reduce * M for a 3x3 M (row-major) -> J(:, col0 .. col0+2)
+  auto put = [&](const double* M, int col0) {
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) J[r * 20 + col0 + c] = red[r][0] * M[c] + red[r][1] * M[3 + c] + red[r][2] * M[6 + c];
+  };
+  double ricT[9], RjT[9], A[9], B[9], T[9], S[9], neg[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) ricT[r * 3 + c] = ric[c * 3 + r], RjT[r * 3 + c] = Rj[c * 3 + r];
+  // pose_i : [ric^T Rj^T | ric^T Rj^T Ri (-[pts_imu_i]x)]
+  mat3mul(ricT, RjT, A);
+  put(A, 0);
+  mat3mul(A, Ri, T);
+  skew9(pts_imu_i, S);
+#pragma unroll
+  for (int k = 0; k < 9; k++) neg[k] = -S[k];
+  mat3mul(T, neg, B);
+  put(B, 3);
+  // pose_j : [-ric^T Rj^T | ric^T [pts_imu_j]x]
+#pragma unroll
+  for (int k = 0; k < 9; k++) neg[k] = -A[k];
+  put(neg, 6);
+  skew9(pts_imu_j, S);
+  mat3mul(ricT, S, B);
+  put(B, 9);
+  // ex_pose
+  {
+    double RjTRi[9], M[9], tmp_r[9];
+    mat3mul(RjT, Ri, RjTRi);
+#pragma unroll
+    for (int k = 0; k < 9; k++) M[k] = RjTRi[k] - ((k % 4 == 0) ? 1.0 : 0.0);
+    mat3mul(ricT, M, B);
+    put(B, 12);
+    mat3mul(T, ric, tmp_r);  // ric^T Rj^T Ri ric
+    double S1[9], S2[9], S3[9], P1[9];
+    skew9(pts_camera_i, S1);
+    mat3mul(tmp_r, S1, P1);
+    skew9(Rmul(tmp_r, pts_camera_i), S2);
+    const v3 inner = Rmul(RjT, Rmul(Ri, tic) + Pi - Pj) - tic;
+    skew9(Rmul(ricT, inner), S3);
+#pragma unroll
+    for (int k = 0; k < 9; k++) B[k] = -P1[k] + S2[k] + S3[k];
+    put(B, 15);
+    // inverse depth and td
+    const v3 vf = Rmul(tmp_r, pts_i_td), vt = Rmul(tmp_r, vel_i);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      J[r * 20 + 18] = (red[r][0] * vf.x + red[r][1] * vf.y + red[r][2] * vf.z) * -1.0 / (lam * lam);
+      J[r * 20 + 19] = (red[r][0] * vt.x + red[r][1] * vt.y + red[r][2] * vt.z) / lam * -1.0 + s * (r == 0 ? vel_j.x : vel_j.y);
+    }
+  }
+}
+
+hipError_t launch_projection_td_eval(const avm_td_factor_batch& f, double* residual, double* jac, hipStream_t stream) {
+  if (f.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(projection_td_eval_kernel, dim3((f.n + TRI_NT - 1) / TRI_NT), dim3(TRI_NT), 0, stream, f, residual, jac);
   return hipGetLastError();
 }
 

@@ -50,6 +50,15 @@ class Estimator:
         rc = self.ctx._L.avm_triangulate_batch(self.ctx.h, windows.mem, C.byref(s), float(init_depth))
         self.ctx.check(rc, "avm_triangulate_batch")
 
+    def projection_td_eval(self, arrays: dict, tr: float, row: float, focal_length: float = 460.0):
+        """ProjectionTdFactor::Evaluate (projection_td_factor.cpp:34-141) for n factors given as host arrays
+        (abi.td_factor_batch): returns residual [n, 2] and Jacobian [n, 2, 20] (pose_i 6 | pose_j 6 | ex 6 | lambda | td)."""
+        f = abi.td_factor_batch(arrays, tr, row, focal_length)
+        r, J = np.zeros((f.n, 2)), np.zeros((f.n, 2, 20))
+        rc = self.ctx._L.avm_projection_td_eval(self.ctx.h, abi.AVM_MEM_HOST, C.byref(f), abi.dptr(r), abi.dptr(J))
+        self.ctx.check(rc, "avm_projection_td_eval")
+        return r, J
+
     def imu_propagate(self, windows: buffers.WindowArrays):
         """Estimator::processIMU's dead-reckoning of the newest frame (estimator.cpp:100-107), in place."""
         s = windows.struct()

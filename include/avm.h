@@ -226,6 +226,28 @@ typedef struct avm_fsel_horizon_in {
   const double* delta_imu;  /* [P] deltaImu */
 } avm_fsel_horizon_in;
 
+/* A7: inputs of ProjectionTdFactor (factor/projection_td_factor.cpp:6-32,34-141; call site estimator.cpp:732-747),
+ * one entry per factor.  The solve itself does not take td as a variable yet (estimate_td must be 0); this is the
+ * factor on its own, for hosts that assemble the td problem themselves and for the parity tests. */
+typedef struct avm_td_factor_batch {
+  int32_t n;
+  const double* pose_i;    /* [n][7] x y z qx qy qz qw */
+  const double* pose_j;    /* [n][7] */
+  const double* ex_pose;   /* [n][7] */
+  const double* inv_depth; /* [n] */
+  const double* td;        /* [n] current time offset (para_Td) */
+  const double* pts_i;     /* [n][2] normalized plane, z == 1 */
+  const double* pts_j;     /* [n][2] */
+  const double* vel_i;     /* [n][2] image velocity of the feature in frame i (FeaturePerFrame::velocity) */
+  const double* vel_j;     /* [n][2] */
+  const double* td_i;      /* [n] cur_td when frame i was taken */
+  const double* td_j;      /* [n] */
+  const double* row_i;     /* [n] image row (uv.y()), before the ROW / 2 shift of the constructor */
+  const double* row_j;     /* [n] */
+  double tr, row;          /* TR (rolling shutter read-out time), ROW (image height): parameters.cpp */
+  double focal_length;     /* sqrt_info = focal_length / 1.5 * I2 (estimator.cpp:17) */
+} avm_td_factor_batch;
+
 typedef struct avm_config {
   int32_t device;       /* HIP device ordinal */
   int32_t max_windows;  /* capacity of one avm_window_solve_batch call */
@@ -279,6 +301,10 @@ int avm_imu_propagate_batch(avm_ctx* ctx, avm_mem mem, avm_window_batch* batch, 
  * gravity (0, 0, -9.80665).  Writes hor_pos [P][H+1][3] and hor_quat [P][H+1][4] (x y z w), the layout
  * avm_fsel_batch consumes. */
 int avm_fsel_horizon_imu(avm_ctx* ctx, avm_mem mem, const avm_fsel_horizon_in* in, double* hor_pos, double* hor_quat);
+
+/* A7: ProjectionTdFactor::Evaluate for n factors: residual [n][2], jac [n][2][20] with columns
+ * pose_i 6 | pose_j 6 | ex_pose 6 | inv_depth 1 | td 1 (local 6-column pose blocks, like avm_window_eval_factors). */
+int avm_projection_td_eval(avm_ctx* ctx, avm_mem mem, const avm_td_factor_batch* f, double* residual, double* jac);
 
 /* A5/A6/A8 only: evaluate every factor once at the current state and return
  * residuals/Jacobians (local 6-column pose blocks).  Used by the per-factor parity tests.

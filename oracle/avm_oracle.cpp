@@ -418,4 +418,13 @@ int avmo_fsel_horizon_imu(const avm_fsel_horizon_in* in, double* hor_pos, double
   return 0;
 }
 
+int avmo_projection_td_eval(const avm_td_factor_batch* f, double* residual, double* jac) {
+  const double s = f->focal_length / 1.5;
+  for (int i = 0; i < f->n; i++)
+    projection_td_factor_evaluate(f->pts_i + 2 * i, f->pts_j + 2 * i, f->vel_i + 2 * i, f->vel_j + 2 * i, f->td_i[i], f->td_j[i], f->row_i[i], f->row_j[i],
+                                  f->tr, f->row, s, f->pose_i + 7 * i, f->pose_j + 7 * i, f->ex_pose + 7 * i, f->inv_depth[i], f->td[i],
+                                  residual + 2 * i, jac ? jac + 40 * (size_t)i : nullptr);
+  return 0;
+}
+
 }  // extern "C"

@@ -250,6 +250,64 @@ inline void imu_factor_evaluate(const PreIntegration& pre, const Mat& sqrt_info,
   }
 }
 
+// ProjectionTdFactor::Evaluate (projection_td_factor.cpp:34-141), UNIT_SPHERE_ERROR off: ProjectionFactor with the
+// observations shifted along their image velocity by the camera-IMU time offset td (and the rolling-shutter row
+// time), plus the 2x1 Jacobian with respect to td.  row_i / row_j are the raw image rows (the constructor subtracts
+// ROW / 2, :19-20).  jac: 2 x 20 row-major, columns pose_i 6 | pose_j 6 | ex_pose 6 | inv_depth 1 | td 1.
+inline void projection_td_factor_evaluate(const double* pts_i2, const double* pts_j2, const double* vel_i2, const double* vel_j2, double td_i,
+                                          double td_j, double row_i_raw, double row_j_raw, double TR, double ROW, double sqrt_info_s,
+                                          const double* pose_i, const double* pose_j, const double* ex_pose, double inv_dep_i, double td,
+                                          double* residuals, double* jac20) {
+  V3 Pi, Pj, tic;
+  Q Qi, Qj, qic;
+  getPose(pose_i, Pi, Qi);
+  getPose(pose_j, Pj, Qj);
+  getPose(ex_pose, tic, qic);
+  const V3 pts_i(pts_i2[0], pts_i2[1], 1.0), pts_j(pts_j2[0], pts_j2[1], 1.0);
+  const V3 velocity_i(vel_i2[0], vel_i2[1], 0.0), velocity_j(vel_j2[0], vel_j2[1], 0.0);
+  const double row_i = row_i_raw - ROW / 2, row_j = row_j_raw - ROW / 2;
+  const V3 pts_i_td = pts_i - (td - td_i + TR / ROW * row_i) * velocity_i;
+  const V3 pts_j_td = pts_j - (td - td_j + TR / ROW * row_j) * velocity_j;
+  const V3 pts_camera_i = pts_i_td / inv_dep_i;
+  const V3 pts_imu_i = rot(qic, pts_camera_i) + tic;
+  const V3 pts_w = rot(Qi, pts_imu_i) + Pi;
+  const V3 pts_imu_j = rot(inverse(Qj), pts_w - Pj);
+  const V3 pts_camera_j = rot(inverse(qic), pts_imu_j - tic);
+  const double dep_j = pts_camera_j.z;
+  residuals[0] = sqrt_info_s * ((pts_camera_j.x / dep_j) - pts_j_td.x);
+  residuals[1] = sqrt_info_s * ((pts_camera_j.y / dep_j) - pts_j_td.y);
+  if (!jac20) return;
+  const M3 Ri = toR(Qi), Rj = toR(Qj), ric = toR(qic);
+  double reduce[2][3] = {{1. / dep_j, 0, -pts_camera_j.x / (dep_j * dep_j)}, {0, 1. / dep_j, -pts_camera_j.y / (dep_j * dep_j)}};
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 3; j++) reduce[i][j] = sqrt_info_s * reduce[i][j];
+  auto red = [&](const M3& A, const M3& B, int col0) {
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 3; j++) {
+        double sa = 0, sb = 0;
+        for (int k = 0; k < 3; k++) sa += reduce[i][k] * A(k, j), sb += reduce[i][k] * B(k, j);
+        jac20[i * 20 + col0 + j] = sa;
+        jac20[i * 20 + col0 + 3 + j] = sb;
+      }
+  };
+  auto redv = [&](V3 v, int i) { return reduce[i][0] * v.x + reduce[i][1] * v.y + reduce[i][2] * v.z; };
+  const M3 ricT = transpose(ric), RjT = transpose(Rj);
+  red(ricT * RjT, ricT * RjT * Ri * (-skew(pts_imu_i)), 0);
+  red(ricT * (-RjT), ricT * skew(pts_imu_j), 6);
+  {
+    const M3 A = ricT * (RjT * Ri - M3::identity());
+    const M3 tmp_r = ricT * RjT * Ri * ric;
+    const M3 B = (-tmp_r) * skew(pts_camera_i) + skew(tmp_r * pts_camera_i) + skew(ricT * (RjT * (Ri * tic + Pi - Pj) - tic));
+    red(A, B, 12);
+  }
+  const M3 chain = ricT * RjT * Ri * ric;
+  const V3 vf = chain * pts_i_td, vt = chain * velocity_i;
+  for (int i = 0; i < 2; i++) {
+    jac20[i * 20 + 18] = redv(vf, i) * -1.0 / (inv_dep_i * inv_dep_i);
+    jac20[i * 20 + 19] = redv(vt, i) / inv_dep_i * -1.0 + sqrt_info_s * velocity_j[i];
+  }
+}
+
 // ProjectionFactor::Evaluate (projection_factor.cpp:21-121), UNIT_SPHERE_ERROR off.
 // jac[0],jac[1],jac[2]: 2x7 row-major; jac[3]: 2x1.
 inline void projection_factor_evaluate(V3 pts_i, V3 pts_j, double sqrt_info_s, const double* pose_i, const double* pose_j,

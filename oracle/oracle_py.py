@@ -121,3 +121,13 @@ def fsel_horizon_imu(horizon, k_pos, k_quat, k_ba, k1_pos, k1_vel, k1_quat, acc,
     rc = lib().avmo_fsel_horizon_imu(C.byref(s), abi.dptr(hp), abi.dptr(hq))
     assert rc == 0
     return hp, hq
+
+
+def projection_td_eval(arrays, tr, row, focal_length=460.0):
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    f = abi.td_factor_batch(arrays, tr, row, focal_length)
+    r, J = np.zeros((f.n, 2)), np.zeros((f.n, 2, 20))
+    rc = lib().avmo_projection_td_eval(C.byref(f), abi.dptr(r), abi.dptr(J))
+    assert rc == 0
+    return r, J

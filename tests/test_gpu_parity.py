@@ -109,6 +109,28 @@ def test_newest_frame_dead_reckoning_matches_oracle(estimator, oracle):
     assert np.array_equal(wd.to_host().a["pose"], wg.a["pose"])
 
 
+def test_projection_td_factor_matches_oracle(estimator, oracle):
+    """A7: ProjectionTdFactor::Evaluate on device (residual + all five Jacobian blocks)."""
+    rng = np.random.default_rng(5)
+    n = 300
+    def unit(a):
+        return a / np.linalg.norm(a, axis=-1, keepdims=True)
+    def pose(scale):
+        return np.hstack([scale * rng.normal(size=(n, 3)), unit(np.array([0, 0, 0, 1.0]) + 0.2 * rng.normal(size=(n, 4)))])
+    a = dict(pose_i=pose(0.5), pose_j=pose(0.5), ex_pose=pose(0.05), inv_depth=1.0 / rng.uniform(2, 15, n), td=0.01 * rng.normal(size=n),
+             pts_i=0.4 * rng.normal(size=(n, 2)), pts_j=0.4 * rng.normal(size=(n, 2)), vel_i=0.3 * rng.normal(size=(n, 2)),
+             vel_j=0.3 * rng.normal(size=(n, 2)), td_i=0.01 * rng.normal(size=n), td_j=0.01 * rng.normal(size=n),
+             row_i=rng.uniform(0, 480, n), row_j=rng.uniform(0, 480, n))
+    rg, Jg = estimator.projection_td_eval(a, 0.033, 480.0, 460.0)
+    ro, Jo = oracle.projection_td_eval(a, 0.033, 480.0, 460.0)
+    assert rel(rg, ro) < FACTOR_TOL and rel(Jg, Jo) < FACTOR_TOL
+    # with no image velocity the factor is ProjectionFactor: same residuals whatever td is
+    a0 = dict(a, vel_i=np.zeros((n, 2)), vel_j=np.zeros((n, 2)))
+    r0, J0 = estimator.projection_td_eval(a0, 0.033, 480.0, 460.0)
+    r1, _ = estimator.projection_td_eval(dict(a0, td=a0["td"] + 0.5), 0.033, 480.0, 460.0)
+    assert np.array_equal(r0, r1) and np.abs(J0[:, :, 19]).max() == 0.0
+
+
 def test_triangulation_matches_oracle(estimator, oracle):
     """SURVEY 8(f)1: FeatureManager::triangulate on device (the step before optimization() in solveOdometry())."""
     for tracks, nf in (("sparse", 60), ("dense", 150)):

@@ -420,3 +420,63 @@ def test_horizon_generator_imu_matches_numpy(oracle):
                 vel = vel + (g + qa) * dI
                 pos = pos + vel * dI + 0.5 * g * dI * dI + 0.5 * qa * dI * dI
             assert rel(hp[p, h], pos) < 1e-13 and rel(hq[p, h], np.array([q[1], q[2], q[3], q[0]])) < 1e-13
+
+
+def _td_factor_inputs(n, rng):
+    def unit(a):
+        return a / np.linalg.norm(a, axis=-1, keepdims=True)
+    def pose(scale):
+        q = unit(np.array([0, 0, 0, 1.0]) + 0.2 * rng.normal(size=(n, 4)))
+        return np.hstack([scale * rng.normal(size=(n, 3)), q])
+    return dict(pose_i=pose(0.5), pose_j=pose(0.5), ex_pose=pose(0.05), inv_depth=1.0 / rng.uniform(2, 15, n), td=0.01 * rng.normal(size=n),
+                pts_i=0.4 * rng.normal(size=(n, 2)), pts_j=0.4 * rng.normal(size=(n, 2)), vel_i=0.3 * rng.normal(size=(n, 2)),
+                vel_j=0.3 * rng.normal(size=(n, 2)), td_i=0.01 * rng.normal(size=n), td_j=0.01 * rng.normal(size=n),
+                row_i=rng.uniform(0, 480, n), row_j=rng.uniform(0, 480, n))
+
+
+def test_projection_td_factor_residual_and_fd_jacobian(oracle):
+    """A7: ProjectionTdFactor::Evaluate (projection_td_factor.cpp:34-141).  Residual against an independent numpy
+    statement; all 20 Jacobian columns against central differences through the local parameterization
+    (p + dp, q * deltaQ(dtheta): pose_local_parameterization.cpp:3-27), the convention of the reference's own check()."""
+    rng = np.random.default_rng(5)
+    n, TR, ROW, F = 6, 0.033, 480.0, 460.0
+    a = _td_factor_inputs(n, rng)
+    r, J = oracle.projection_td_eval(a, TR, ROW, F)
+
+    def q2R(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def residual(k, pi, pj, ex, lam, td):
+        Ri, Rj, ric = q2R(pi[3:] / np.linalg.norm(pi[3:])), q2R(pj[3:] / np.linalg.norm(pj[3:])), q2R(ex[3:] / np.linalg.norm(ex[3:]))
+        pts_i = np.array([*a["pts_i"][k], 1.0]) - (td - a["td_i"][k] + TR / ROW * (a["row_i"][k] - ROW / 2)) * np.array([*a["vel_i"][k], 0.0])
+        pts_j = np.array([*a["pts_j"][k], 1.0]) - (td - a["td_j"][k] + TR / ROW * (a["row_j"][k] - ROW / 2)) * np.array([*a["vel_j"][k], 0.0])
+        pc = ric.T @ (Rj.T @ (Ri @ (ric @ (pts_i / lam) + ex[:3]) + pi[:3] - pj[:3]) - ex[:3])
+        return F / 1.5 * (pc[:2] / pc[2] - pts_j[:2])
+
+    def plus(p, d):  # x y z qx qy qz qw (+) [dp, dtheta]
+        x, y, z, w = p[3:]
+        dq = np.array([d[3] / 2, d[4] / 2, d[5] / 2, 1.0])
+        q = np.array([w * dq[0] + x * dq[3] + y * dq[2] - z * dq[1], w * dq[1] - x * dq[2] + y * dq[3] + z * dq[0],
+                      w * dq[2] + x * dq[1] - y * dq[0] + z * dq[3], w * dq[3] - x * dq[0] - y * dq[1] - z * dq[2]])
+        return np.hstack([p[:3] + d[:3], q / np.linalg.norm(q)])
+
+    for k in range(n):
+        args = [a["pose_i"][k], a["pose_j"][k], a["ex_pose"][k], a["inv_depth"][k], a["td"][k]]
+        assert rel(r[k], residual(k, *args)) < 1e-11
+        eps = 1e-6
+        for col in range(20):
+            blk, off = (col // 6, col % 6) if col < 18 else (col - 15, 0)
+            def shifted(sgn):
+                b = list(args)
+                if blk < 3:
+                    d = np.zeros(6); d[off] = sgn * eps
+                    b[blk] = plus(b[blk], d)
+                else:
+                    b[blk] = b[blk] + sgn * eps * (abs(b[blk]) if blk == 3 else 1.0)
+                return residual(k, *b)
+            scale = abs(args[3]) if blk == 3 else 1.0
+            fd = (shifted(+1) - shifted(-1)) / (2 * eps * scale)
+            assert np.abs(fd - J[k, :, col]).max() < 2e-5 * max(1.0, np.abs(J[k, :, col]).max()), (k, col)
