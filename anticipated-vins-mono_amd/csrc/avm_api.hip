@@ -645,6 +645,49 @@ int avm_fsel_horizon_imu(avm_ctx* c, avm_mem mem, const avm_fsel_horizon_in* in,
   return AVM_OK;
 }
 
+int avm_fsel_build_cloud(avm_ctx* c, avm_mem mem, const avm_window_batch* windows, const double* k1_pos, const double* k1_quat, int32_t max_cloud,
+                         int32_t* n_cloud, double* cloud_xy, double* cloud_depth) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (!windows || !k1_pos || !k1_quat || !n_cloud || !cloud_xy || !cloud_depth || windows->n_windows < 0 || max_cloud < 1)
+    return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (windows->n_windows == 0) return AVM_OK;
+  const size_t B = windows->n_windows;
+  avm_window_batch d = *windows;
+  const double *dp = k1_pos, *dq = k1_quat;
+  int32_t* dn = n_cloud;
+  double *dxy = cloud_xy, *ddep = cloud_depth;
+  if (mem == AVM_MEM_HOST) {
+    int rc;
+#define ST(field, type, count)                                                                                          \
+  if ((rc = stage_in<type>(c, "w_" #field, windows->field, (count), (const type**)&d.field)) != AVM_OK) return rc;
+    ST(pose, double, B * 77)
+    ST(ex_pose, double, B * 7)
+    ST(inv_depth, double, B * windows->max_feat)
+    ST(n_feat, int32_t, B)
+    ST(feat_start, int32_t, B * windows->max_feat)
+    ST(feat_obs_begin, int32_t, B * windows->max_feat)
+    ST(obs_xy, double, B * windows->max_obs * 2)
+#undef ST
+    if ((rc = stage_in<double>(c, "c_k1p", k1_pos, B * 3, &dp)) != AVM_OK) return rc;
+    if ((rc = stage_in<double>(c, "c_k1q", k1_quat, B * 4, &dq)) != AVM_OK) return rc;
+    dn = static_cast<int32_t*>(pool_get(c, "c_n", sizeof(int32_t) * B));
+    dxy = static_cast<double*>(pool_get(c, "c_xy", sizeof(double) * B * max_cloud * 2));
+    ddep = static_cast<double*>(pool_get(c, "c_dep", sizeof(double) * B * max_cloud));
+    if (!dn || !dxy || !ddep) return fail(c, AVM_ERR_HIP, "hipMalloc failed (cloud out)");
+    HIPCHK(c, hipMemsetAsync(dxy, 0, sizeof(double) * B * max_cloud * 2, c->stream));
+    HIPCHK(c, hipMemsetAsync(ddep, 0, sizeof(double) * B * max_cloud, c->stream));
+  }
+  HIPCHK(c, launch_fsel_build_cloud(d, dp, dq, max_cloud, dn, dxy, ddep, c->stream));
+  if (mem == AVM_MEM_HOST) {
+    HIPCHK(c, hipMemcpyAsync(n_cloud, dn, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cloud_xy, dxy, sizeof(double) * B * max_cloud * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cloud_depth, ddep, sizeof(double) * B * max_cloud, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
+}
+
 int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, double* omega, double* delta_cand, int32_t* cand_valid) {
   if (!c) return AVM_ERR_INVALID;
   (void)hipSetDevice(c->device);

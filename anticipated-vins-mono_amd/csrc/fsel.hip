@@ -520,6 +520,48 @@ hipError_t launch_fsel_horizon_imu(const avm_fsel_horizon_in& in, double* hor_po
   return hipGetLastError();
 }
 
+// ---- B8 (first half): the depth cloud of initKDTree() (feature_selector.cpp:396-419), one thread per window ---------
+__global__ __launch_bounds__(64) void fsel_build_cloud_kernel(avm_window_batch B, const double* k1_pos, const double* k1_quat, int max_cloud,
+                                                              int32_t* n_cloud, double* cloud_xy, double* cloud_depth) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= B.n_windows) return;
+  const double* ex = B.ex_pose + (size_t)w * 7;
+  const v3 tic = mk3(ex[0], ex[1], ex[2]);
+  const quat qic{ex[6], ex[3], ex[4], ex[5]};
+  double ric[9];
+  q2R(qic, ric);
+  const quat qk1{k1_quat[4 * w + 3], k1_quat[4 * w], k1_quat[4 * w + 1], k1_quat[4 * w + 2]};
+  const v3 pk1 = mk3(k1_pos[3 * w], k1_pos[3 * w + 1], k1_pos[3 * w + 2]);
+  const double* pose = B.pose + (size_t)w * NFR * 7;
+  double* xy = cloud_xy + (size_t)w * max_cloud * 2;
+  double* dep = cloud_depth + (size_t)w * max_cloud;
+  int n = 0;
+  for (int e = 0; e < B.n_feat[w] && n < max_cloud; e++) {
+    const int f = B.feat_start[(size_t)w * B.max_feat + e];
+    if (f > (NFR - 1) * 3.0 / 4.0) continue;
+    const double est_depth = 1.0 / B.inv_depth[(size_t)w * B.max_feat + e];
+    if (!(est_depth >= 0)) continue;
+    double Rs[9];
+    q2R(quat{pose[f * 7 + 6], pose[f * 7 + 3], pose[f * 7 + 4], pose[f * 7 + 5]}, Rs);
+    const double* o = B.obs_xy + ((size_t)w * B.max_obs + B.feat_obs_begin[(size_t)w * B.max_feat + e]) * 2;
+    const v3 pts_i = est_depth * mk3(o[0], o[1], 1.0);
+    const v3 w_pts = Rmul(Rs, Rmul(ric, pts_i) + tic) + mk3(pose[f * 7], pose[f * 7 + 1], pose[f * 7 + 2]);
+    const v3 p_IL = qrot(qinv(qk1), w_pts - pk1);
+    const v3 p_CL = qrot(qinv(qic), p_IL - tic);
+    xy[2 * n] = p_CL.x / p_CL.z, xy[2 * n + 1] = p_CL.y / p_CL.z, dep[n] = est_depth;
+    n++;
+  }
+  n_cloud[w] = n;
+}
+
+hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,
+                                   double* cloud_xy, double* cloud_depth, hipStream_t stream) {
+  if (b.n_windows == 0) return hipSuccess;
+  hipLaunchKernelGGL(fsel_build_cloud_kernel, dim3((b.n_windows + 63) / 64), dim3(64), 0, stream, b, k1_pos, k1_quat, max_cloud, n_cloud, cloud_xy,
+                     cloud_depth);
+  return hipGetLastError();
+}
+
 bool fsel_horizon_supported(int H) { return H == 2 || H == 3 || H == 5 || H == 10 || H == 13; }
 
 }  // namespace avm

@@ -42,6 +42,19 @@ class FeatureSelector:
         self.ctx.check(rc, "avm_fsel_horizon_imu")
         return hp, hq
 
+    def initKDTree(self, windows: buffers.WindowArrays, k1_pos, k1_quat, max_cloud: int = 150):
+        """The depth cloud FeatureSelector::initKDTree() builds (feature_selector.cpp:380-433), one per window (host
+        arrays): returns n_cloud [B], cloud_xy [B, max_cloud, 2], cloud_depth [B, max_cloud]."""
+        assert not windows.on_device
+        B = windows.n_windows
+        kp, kq = np.ascontiguousarray(k1_pos, float), np.ascontiguousarray(k1_quat, float)
+        n, xy, dep = np.zeros(B, np.int32), np.zeros((B, max_cloud, 2)), np.zeros((B, max_cloud))
+        s = windows.struct()
+        rc = self.ctx._L.avm_fsel_build_cloud(self.ctx.h, windows.mem, C.byref(s), abi.dptr(kp), abi.dptr(kq), int(max_cloud), abi.iptr(n),
+                                              abi.dptr(xy), abi.dptr(dep))
+        self.ctx.check(rc, "avm_fsel_build_cloud")
+        return n, xy, dep
+
     def information(self, problems: buffers.FselArrays):
         """Omega_kkH (+prior) [P,N,N], compact Delta_ell [P,max_cand,3H,3H], valid [P,max_cand] (host arrays)."""
         assert not problems.on_device

@@ -52,6 +52,7 @@ def lib():
         L.avm_fsel_information.argtypes = [vp, C.c_int, C.POINTER(abi.FselBatch), abi.c_dp, abi.c_dp, abi.c_ip]
         L.avm_fsel_horizon_imu.argtypes = [vp, C.c_int, C.POINTER(abi.FselHorizonIn), abi.c_dp, abi.c_dp]
         L.avm_projection_td_eval.argtypes = [vp, C.c_int, C.POINTER(abi.TdFactorBatch), abi.c_dp, abi.c_dp]
+        L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
         L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
         _lib = L
     return _lib
@@ -60,7 +61,7 @@ def lib():
 EXPORTS = [
     "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
     "avm_window_solve_batch", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
-    "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval",
+    "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
 ]
 
 

@@ -306,6 +306,16 @@ int avm_fsel_horizon_imu(avm_ctx* ctx, avm_mem mem, const avm_fsel_horizon_in* i
  * pose_i 6 | pose_j 6 | ex_pose 6 | inv_depth 1 | td 1 (local 6-column pose blocks, like avm_window_eval_factors). */
 int avm_projection_td_eval(avm_ctx* ctx, avm_mem mem, const avm_td_factor_batch* f, double* residual, double* jac);
 
+/* B8, first half: the depth cloud FeatureSelector::initKDTree() builds (feature_selector.cpp:380-433), one cloud per
+ * window: every feature of the window (they all pass used_num >= 2 && start_frame < WINDOW_SIZE - 2 by construction)
+ * with start_frame <= WINDOW_SIZE * 3 / 4 and solve_flag == 1 (depth = 1 / inv_depth >= 0, feature_manager.cpp:141-159)
+ * is lifted to the world with its first observation and its depth, moved into camera k+1 (state_k1_: k1_pos [B][3],
+ * k1_quat [B][4] x y z w; extrinsic = the window's ex_pose) and projected to the normalized plane.  Output in feature
+ * order, the layout avm_fsel_batch consumes: n_cloud [B], cloud_xy [B][max_cloud][2], cloud_depth [B][max_cloud].
+ * (The nearest-neighbour lookup itself, findNNDepth, runs inside avm_fsel_select_batch.) */
+int avm_fsel_build_cloud(avm_ctx* ctx, avm_mem mem, const avm_window_batch* windows, const double* k1_pos, const double* k1_quat,
+                         int32_t max_cloud, int32_t* n_cloud, double* cloud_xy, double* cloud_depth);
+
 /* A5/A6/A8 only: evaluate every factor once at the current state and return
  * residuals/Jacobians (local 6-column pose blocks).  Used by the per-factor parity tests.
  *   proj_r [B][max_obs][2], proj_J [B][max_obs][2][13]  (pose_i 6 | pose_j 6 | inv_depth 1), index = observation slot

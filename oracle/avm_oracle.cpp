@@ -427,4 +427,16 @@ int avmo_projection_td_eval(const avm_td_factor_batch* f, double* residual, doub
   return 0;
 }
 
+int avmo_fsel_build_cloud(const avm_window_batch* B, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,
+                          double* cloud_xy, double* cloud_depth) {
+  for (int w = 0; w < B->n_windows; w++) {
+    const double(*pose)[7] = reinterpret_cast<const double(*)[7]>(B->pose + (size_t)w * AVM_NFRAMES * 7);
+    n_cloud[w] = build_cloud(pose, B->ex_pose + (size_t)w * 7, B->n_feat[w], B->feat_start + (size_t)w * B->max_feat,
+                             B->feat_obs_begin + (size_t)w * B->max_feat, B->obs_xy + (size_t)w * B->max_obs * 2,
+                             B->inv_depth + (size_t)w * B->max_feat, k1_pos + 3 * (size_t)w, k1_quat + 4 * (size_t)w, max_cloud,
+                             cloud_xy + (size_t)w * max_cloud * 2, cloud_depth + (size_t)w * max_cloud);
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -261,4 +261,32 @@ inline void horizon_imu(int H, const double* k_pos, const double* k_quat, const 
   }
 }
 
+// FeatureSelector::initKDTree, the cloud construction (feature_selector.cpp:396-419) for one window.
+// Returns the number of cloud points; xy [max_cloud][2], depth [max_cloud].
+inline int build_cloud(const double (*pose)[7], const double* ex, int nf, const int* start, const int* obs_begin, const double* obs_xy,
+                       const double* inv_depth, const double* k1_pos, const double* k1_quat, int max_cloud, double* xy, double* depth) {
+  const V3 tic(ex[0], ex[1], ex[2]);
+  const Q qic(ex[6], ex[3], ex[4], ex[5]);
+  const M3 ric = toR(qic);
+  const Q qk1(k1_quat[3], k1_quat[0], k1_quat[1], k1_quat[2]);
+  const V3 pk1(k1_pos[0], k1_pos[1], k1_pos[2]);
+  int n = 0;
+  for (int e = 0; e < nf && n < max_cloud; e++) {
+    if (start[e] > 10 * 3.0 / 4.0) continue;         // start_frame > WINDOW_SIZE * 3.0 / 4.0
+    const double est_depth = 1.0 / inv_depth[e];
+    if (!(est_depth >= 0)) continue;                // solve_flag != 1 (depth < 0 -> 2; NaN never qualifies)
+    const int f = start[e];
+    const M3 Rs = toR(Q(pose[f][6], pose[f][3], pose[f][4], pose[f][5]));
+    const V3 Ps(pose[f][0], pose[f][1], pose[f][2]);
+    const V3 pts_i = V3(obs_xy[2 * obs_begin[e]], obs_xy[2 * obs_begin[e] + 1], 1.0) * est_depth;
+    const V3 w_pts_i = Rs * (ric * pts_i + tic) + Ps;
+    const V3 p_IL = rot(inverse(qk1), w_pts_i - pk1);
+    const V3 p_CL = rot(inverse(qic), p_IL - tic);
+    const V3 nip = p_CL / p_CL.z;
+    xy[2 * n] = nip.x, xy[2 * n + 1] = nip.y, depth[n] = est_depth;
+    n++;
+  }
+  return n;
+}
+
 }  // namespace avmo

@@ -131,3 +131,15 @@ def projection_td_eval(arrays, tr, row, focal_length=460.0):
     rc = lib().avmo_projection_td_eval(C.byref(f), abi.dptr(r), abi.dptr(J))
     assert rc == 0
     return r, J
+
+
+def fsel_build_cloud(win, k1_pos, k1_quat, max_cloud=150):
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    B = win.n_windows
+    kp, kq = np.ascontiguousarray(k1_pos, float), np.ascontiguousarray(k1_quat, float)
+    n, xy, dep = np.zeros(B, np.int32), np.zeros((B, max_cloud, 2)), np.zeros((B, max_cloud))
+    s = win.struct()
+    rc = lib().avmo_fsel_build_cloud(C.byref(s), abi.dptr(kp), abi.dptr(kq), int(max_cloud), abi.iptr(n), abi.dptr(xy), abi.dptr(dep))
+    assert rc == 0
+    return n, xy, dep

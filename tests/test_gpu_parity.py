@@ -392,6 +392,32 @@ def test_selector_information_and_ids(selector, oracle, H, nc, nu, mf, P):
     assert rel(out.a["fvalues"][0, :n], oo.a["fvalues"][0, :n]) < 1e-9
 
 
+def test_depth_cloud_matches_oracle(selector, oracle):
+    """B8 (first half): FeatureSelector::initKDTree's cloud on device; it then feeds select() unchanged."""
+    B = 5
+    w = synth.make_windows(B, tracks="sparse", n_feat=90, max_feat=150)
+    w.a["inv_depth"][:, 3::7] *= -1.0
+    w.a["n_feat"][4] = 0                                          # empty window -> empty cloud
+    rng = np.random.default_rng(5)
+    k1_pos = w.a["pose"][:, 10, :3] + 0.1 * rng.normal(size=(B, 3))
+    k1_quat = w.a["pose"][:, 10, 3:].copy()
+    for mc in (150, 9):
+        n, xy, dep = selector.initKDTree(w, k1_pos, k1_quat, max_cloud=mc)
+        on, oxy, odep = oracle.fsel_build_cloud(w, k1_pos, k1_quat, max_cloud=mc)
+        assert np.array_equal(n, on) and n[4] == 0 and n[:4].min() > 0
+        assert rel(xy, oxy) < 1e-13 and np.array_equal(dep, odep)
+    # the device-built cloud drives the selector to the oracle's ids
+    P = 2
+    prob = synth.make_fsel(P, horizon=5, n_cand=60, n_cloud=40, max_features=15)
+    mc = prob.a["cloud_xy"].shape[1]
+    n, xy, dep = selector.initKDTree(w, k1_pos, k1_quat, max_cloud=mc)
+    prob.a["n_cloud"][:], prob.a["cloud_xy"][:], prob.a["cloud_depth"][:] = n[:P], xy[:P], dep[:P]
+    out = selector.select_batch(prob).to_host()
+    oo = buffers.FselOutArrays.alloc(P, 15)
+    oracle.fsel_select(prob, oo)
+    assert np.array_equal(out.a["n_selected"], oo.a["n_selected"]) and np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+
+
 def test_horizon_generator_imu_matches_oracle(selector, oracle):
     """B4: HorizonGenerator::imu on device, and its output feeding select()."""
     rng = np.random.default_rng(11)

@@ -422,6 +422,43 @@ def test_horizon_generator_imu_matches_numpy(oracle):
             assert rel(hp[p, h], pos) < 1e-13 and rel(hq[p, h], np.array([q[1], q[2], q[3], q[0]])) < 1e-13
 
 
+def test_depth_cloud_matches_numpy(oracle):
+    """SURVEY B8: the cloud FeatureSelector::initKDTree builds (feature_selector.cpp:396-419), against numpy."""
+    def q2R(q):  # x y z w
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    B = 3
+    w = synth.make_windows(B, tracks="sparse", n_feat=60, max_feat=150)
+    a = w.a
+    a["inv_depth"][:, 5::11] *= -1.0                    # solve_flag == 2 (negative depth): never in the cloud
+    rng = np.random.default_rng(8)
+    k1_pos = a["pose"][:, 10, :3] + 0.1 * rng.normal(size=(B, 3))
+    k1_quat = a["pose"][:, 10, 3:].copy()
+    n, xy, dep = oracle.fsel_build_cloud(w, k1_pos, k1_quat, max_cloud=150)
+    for b in range(B):
+        ric, tic = q2R(a["ex_pose"][b, 3:]), a["ex_pose"][b, :3]
+        Rk1 = q2R(k1_quat[b])
+        exp = []
+        for e in range(a["n_feat"][b]):
+            st = a["feat_start"][b, e]
+            if st > 7 or a["inv_depth"][b, e] <= 0:
+                continue
+            d = 1.0 / a["inv_depth"][b, e]
+            o = a["obs_xy"][b, a["feat_obs_begin"][b, e]]
+            pw = q2R(a["pose"][b, st, 3:]) @ (ric @ (d * np.array([o[0], o[1], 1.0])) + tic) + a["pose"][b, st, :3]
+            pc = ric.T @ (Rk1.T @ (pw - k1_pos[b]) - tic)
+            exp.append((pc[0] / pc[2], pc[1] / pc[2], d))
+        exp = np.array(exp)
+        assert n[b] == len(exp) and 0 < n[b] < a["n_feat"][b]
+        assert np.abs(xy[b, : n[b]] - exp[:, :2]).max() < 1e-11 and np.array_equal(dep[b, : n[b]], exp[:, 2])
+        assert not xy[b, n[b]:].any()
+    # capacity clamp keeps the first max_cloud qualifying features
+    n2, xy2, dep2 = oracle.fsel_build_cloud(w, k1_pos, k1_quat, max_cloud=7)
+    assert (n2 == 7).all() and np.array_equal(xy2, xy[:, :7]) and np.array_equal(dep2, dep[:, :7])
+
+
 def _td_factor_inputs(n, rng):
     def unit(a):
         return a / np.linalg.norm(a, axis=-1, keepdims=True)
