@@ -102,9 +102,9 @@ AVM_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-AVM_DEV int roff(int i) {
+AVM_DEV int roff(int i) {  // even i = 2q: 2q(q+1); odd i = 2q+1: 2(q+1)^2 -> every row starts 16-byte aligned
   const int q = i >> 1;
-  return (i & 1) ? 2 * (q + 1) * (q + 1) : 2 * q * (q + 1);
+  return 2 * (q + 1) * (q + (i & 1));
 }
 
 struct Frames {
@@ -1010,46 +1010,69 @@ AVM_DEV double fast_rsqrt(double x) {
   return y;
 }
 
-// factor the nb x nb diagonal block at c0 in the registers of the calling wavefront (lane = row).
-// Select-free: lanes / columns outside the block (and the upper triangle) just carry finite junk that is never
-// stored - keeping 16 + 16 lane masks alive across the pivot loop costs more (SGPR spills) than the junk FMAs.
+// Scratch of the factorization inside the [32][80] tile at L_WCH (dead while S is being factored): L^-T of the current
+// diagonal block, a 16x16 identity, and a per-lane dump slot for the masked-out stores.
+constexpr int L_CLT = L_WCH, L_CID = L_WCH + 256, L_CDUMP = L_WCH + 512;
+
+// Factor the nb x nb diagonal block at c0 in the registers of the calling wavefront (lane = row, register = column).
+//  * Select-free: lanes / columns outside the block (and the upper triangle) just carry finite junk that is never stored.
+//  * Lanes 16..31 carry the rows of the identity through the same eliminations: lane 16+i ends with row i of L^-T, which the
+//    MFMA panel solve multiplies the rows below with (zero extra instructions in the pivot chain).
+//  * Square-root free: column j is divided by its pivot with v_rcp_f64 + two Newton steps; rows and L^-T are stored
+//    unscaled (times sqrt(d_c) per column c, the pivot d_c itself on the diagonal) and the consumers apply rsqrt(d_c):
+//    the panel solve (which also raises the non-positive-pivot flag) and chol_solve_lds.
+//  * The wavefront is instruction-issue bound (~4.5 cycles per FP64 / v_readlane instruction, 3 instructions per
+//    (pivot, column) pair), so everything else is kept out of it: no pivot bookkeeping, stores by address select, and the
+//    rank-1 update of pivot j-1 is software-pipelined by hand into the latency shadows of pivot j's reciprocal chain.
 AVM_NOINL void chol_diag_block(int c0, int nb) {
   constexpr int NB = CNB;
   double* S = LDS() + L_S;
-  double* dinv = LDS() + L_ST;
   const int r = threadIdx.x & 63;
   __builtin_amdgcn_s_setprio(3);  // this wavefront is the critical path of the factorization: win issue arbitration
   double a[NB];
+  const bool idl = (r & 48) == 16;
   const int rc = min(r, nb - 1);
   double* row = S + roff(c0 + rc) + c0;
+  {
+    const double* src = idl ? LDS() + L_CID + (r & 15) * NB : row;
+    const int kc = idl ? NB - 1 : rc;
 #pragma unroll
-  for (int k = 0; k < NB; k++) a[k] = row[min(k, rc)];  // 16 reads in flight, always a valid address
-  bool bad = false;
-  double invs[NB];
+    for (int k = 0; k < NB; k++) a[k] = src[min(k, kc)];  // 16 reads in flight, always a valid address
+  }
+  double uprev = 0.0;
 #pragma unroll
   for (int j = 0; j < NB; j++) {
+    if (j > 0) a[j] = fma(-uprev, readlane_d(a[j - 1], j), a[j]);
     const double djj = readlane_d(a[j], j);
-    if (j < nb && !(djj > 0.0)) bad = true;
-    const double inv = fast_rsqrt(djj);
-    invs[j] = inv;
-    const double lij = a[j] * inv;  // lane j: d / sqrt(d) = sqrt(d)
-    a[j] = lij;
-#pragma unroll
-    for (int k = j + 1; k < NB; k++) {
-      const double lkj = readlane_d(lij, k);
-      a[k] -= lij * lkj;
-    }
+    double y = __builtin_amdgcn_rcp(djj), e = 0;
+#define AVM_TAIL(slot)                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  if (j > 0) {                                                                                                         \
+    double sk[3];                                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 3; q++) sk[q] = readlane_d(a[j - 1], min(j + 1 + (slot) + 5 * q, NB - 1));   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 3; q++)                                                                      \
+      if (j + 1 + (slot) + 5 * q < NB) a[j + 1 + (slot) + 5 * q] = fma(-uprev, sk[q], a[j + 1 + (slot) + 5 * q]);      \
+  }                                                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+    AVM_TAIL(0)
+    e = fma(-djj, y, 1.0);
+    AVM_TAIL(1)
+    y = fma(y, e, y);
+    AVM_TAIL(2)
+    e = fma(-djj, y, 1.0);
+    AVM_TAIL(3)
+    y = fma(y, e, y);
+    AVM_TAIL(4)
+#undef AVM_TAIL
+    uprev = a[j] * y;
   }
-  if (r < nb) {
+  {
+    double* dst = idl ? LDS() + L_CLT + (r & 15) * NB : row;
+    double* dump = LDS() + L_CDUMP + r;
+    const int kmax = idl ? NB - 1 : (r < nb ? r : -1);
 #pragma unroll
-    for (int k = 0; k < NB; k++)
-      if (k <= r) row[k] = a[k];
-  }
-  if (r == 0) {
-#pragma unroll
-    for (int k = 0; k < NB; k++)
-      if (k < nb) dinv[c0 + k] = invs[k];
-    if (bad) reinterpret_cast<int*>(LDS() + L_INT)[I_FAIL] = 1;
+    for (int k = 0; k < NB; k++) *(k <= kmax ? dst + k : dump) = a[k];
   }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -1099,6 +1122,7 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
   constexpr int NR = NF + 1;  // rows incl. the augmented RHS row
   int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
   if (t == 0) *s_fail = 0;
+  if (t < NB * NB) lds[L_CID + t] = (t >> 4) == (t & 15) ? 1.0 : 0.0;
   __syncthreads();
   PROF_T0();
   if (wv == 0) chol_diag_block(0, NB);
@@ -1106,29 +1130,43 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
   PROF(c, 4);
   for (int c0 = 0; c0 < NF; c0 += NB) {
     const int nb = min(NB, NF - c0), c1 = c0 + nb;
-    if (*s_fail) return false;
-    // (a) panel solve: x_j = (A[i][c0+j] - sum_{l<j} x_l L[c0+j][c0+l]) / L[c0+j][c0+j] ; rows below + the RHS row
-    for (int i = c1 + t; i < NR; i += NT) {
-      double* ri = S + roff(i) + c0;
-      double x[NB];
+    // (a) panel solve X = A L^-T on the MFMA: one 16-row block per wavefront pass, B operand = L^-T (lds[L_WCH], left there
+    //     by chol_diag_block); rows below the block + the RHS row
+    {
+      const int lane = t & 63, lr = lane & 15, lk = lane >> 4;
+      const double* LT = lds + L_CLT;
+      double bop[NB / 4];
 #pragma unroll
-      for (int j = 0; j < NB; j++) x[j] = j < nb ? ri[j] : 0.0;
+      for (int m = 0; m < NB / 4; m++) bop[m] = LT[(lk + 4 * m) * NB + lr];
+      // L^-T is stored times sqrt(d_c) per column (see chol_diag_block): the pivots sit on the diagonal of the block
+      const int cc = c0 + min(lr, nb - 1);
+      const double dc = S[roff(cc) + cc];
+      if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront sees the same values
+      const double isq = fast_rsqrt(dc);
 #pragma unroll
-      for (int j = 0; j < NB; j++) {
-        if (j < nb) {
-          const double* lj = S + roff(c0 + j) + c0;
-          double v = x[j];
+      for (int m = 0; m < NB / 4; m++) bop[m] = (lk + 4 * m < nb && lr < nb) ? bop[m] * isq : 0.0;
+      for (int ti = (c1 >> 4) + wv; ti <= 10; ti += NT / 64) {
+        const int row = 16 * ti + lr;
+        const double* pa = S + roff(min(row, NR - 1)) + c0 + lk;
+        const bool va = row < NR && row >= c1;
+        double aop[NB / 4];
 #pragma unroll
-          for (int l = 0; l < j; l++) v -= x[l] * lj[l];
-          x[j] = v * dinv[c0 + j];
+        for (int m = 0; m < NB / 4; m++) aop[m] = pa[4 * m];  // past-the-row reads stay inside the LDS carve and are masked below
+#pragma unroll
+        for (int m = 0; m < NB / 4; m++) aop[m] = (va && lk + 4 * m < nb) ? aop[m] : 0.0;
+        d4 D = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < NB / 4; m++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[m], bop[m], D, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = 16 * ti + lk + 4 * r;
+          if (gi < NR && gi >= c1 && lr < nb) S[roff(gi) + c0 + lr] = D[r];
         }
       }
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        if (j < nb) ri[j] = x[j];
     }
     __syncthreads();
     PROF(c, 5);
+    if (*s_fail) return false;
     if (c1 >= NF) break;
     // (b) trailing update + look-ahead factorization of the next diagonal block
     {
@@ -1169,44 +1207,69 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
   return true;
 }
 
-// Backward substitution L^T x = z with z in the augmented row of lds[L_S] (left there by cholesky_lds),
-// result to lds[vec..vec+NF).  Blocks of 16: the triangle is solved by 16 lanes of wavefront 0
-// (values exchanged with v_readlane), then every thread applies the finished block to one remaining row.
+// Backward substitution L^T x = z with z in the augmented row of lds[L_S] (left there by cholesky_lds), result to
+// lds[vec..vec+NF).  13.6K multiply-adds on an 11-block serial chain: all of it runs in wavefront 0 with no workgroup
+// barrier (a barrier costs ~250 cycles, two per block were most of the old version's time).  Per 16-column block, last
+// to first:  lane r (mod 16) holds column r of the block triangle scaled so that x_r comes straight out of v_readlane
+// (x_r = d_r^-1/2 z_r - d_r^-1 sum_i raw[i][r] x_i; the diagonal blocks are stored unscaled, see chol_diag_block) and
+// the 16 steps are readlane -> fma; entries at or above the diagonal are finite junk that only reaches values that
+// have already been consumed.  The finished x_i stay in SGPRs and are applied to the remaining b[j], j < c0, by all
+// 64 lanes (loads issued ahead of the chain).
+template <int NBV>
+AVM_DEV void chol_solve_block(double* S, double* b, int c0, int lane) {
+  const int rr = min(lane & 15, NBV - 1);
+  const double* col = S + c0 + rr;  // + roff(row): column c0+rr
+  const double dr = col[roff(c0 + rr)];
+  double colv[NBV];
+#pragma unroll
+  for (int i = 0; i < NBV; i++) colv[i] = col[roff(c0 + max(i, rr))];  // always a valid (row >= column) address
+  double bv = b[c0 + rr];
+  // rows of the block for the first 64 remaining columns: in flight during the chain
+  const int j0 = min(lane, max(c0 - 1, 0));
+  double v0[NBV];
+#pragma unroll
+  for (int i = 0; i < NBV; i++) v0[i] = S[roff(c0 + i) + j0];
+  const double isq = fast_rsqrt(dr), di2 = isq * isq;
+  bv *= isq;
+#pragma unroll
+  for (int i = 0; i < NBV; i++) colv[i] *= di2;
+  double xs[NBV], xout = 0.0;
+#pragma unroll
+  for (int jj = NBV - 1; jj >= 0; jj--) {
+    xs[jj] = readlane_d(bv, jj);
+    bv = fma(-colv[jj], xs[jj], bv);
+    xout = lane == jj ? xs[jj] : xout;
+  }
+  if (lane < NBV) b[c0 + lane] = xout;
+  for (int jb = 0; jb < c0; jb += 64) {
+    const int j = min(jb + lane, c0 - 1);
+    double acc = b[j];
+    if (jb > 0) {
+#pragma unroll
+      for (int i = 0; i < NBV; i++) v0[i] = S[roff(c0 + i) + j];
+    }
+#pragma unroll
+    for (int i = 0; i < NBV; i++) acc = fma(-v0[i], xs[i], acc);
+    if (jb + lane < c0) b[j] = acc;
+  }
+  wave_lds_sync();
+}
+
 AVM_NOINL void chol_solve_lds(int vec) {
   double* lds = LDS();
   double* S = lds + L_S;
-  const double* dinv = lds + L_ST;
   double* b = lds + vec;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   constexpr int NB = 16;
-  for (int i = t; i < NF; i += NT) b[i] = S[roff(NF) + i];
-  __syncthreads();
-  for (int c1 = NF; c1 > 0; c1 = ((c1 - 1) / NB) * NB) {
-    const int c0 = ((c1 - 1) / NB) * NB, nb = c1 - c0;
-    if (wv == 0) {
-      const int r = lane;  // lane r owns x_{c0+r}; needs column r of the block triangle: L[c0+i][c0+r], i > r
-      double colv[NB];
+  if (wv == 0) {
 #pragma unroll
-      for (int i = 0; i < NB; i++) colv[i] = (i > r && i < nb) ? S[roff(c0 + i) + c0 + r] : 0.0;
-      double bv = r < nb ? b[c0 + r] : 0.0;
-      const double di = r < nb ? dinv[c0 + r] : 1.0;
-#pragma unroll
-      for (int jj = NB - 1; jj >= 0; jj--) {
-        const double xj = readlane_d(bv * di, jj);
-        if (r < jj) bv -= colv[jj] * xj;
-        if (r == jj) bv = xj;
-      }
-      if (r < nb) b[c0 + r] = bv;
-    }
-    __syncthreads();
-    for (int j = t; j < c0; j += NT) {
-      double v = b[j];
-#pragma unroll 4
-      for (int i = c0; i < c1; i++) v -= S[roff(i) + j] * b[i];
-      b[j] = v;
-    }
-    __syncthreads();
+    for (int q = 0; q < 3; q++)
+      if (lane + 64 * q < NF) b[lane + 64 * q] = S[roff(NF) + lane + 64 * q];
+    wave_lds_sync();
+    if (NF % NB) chol_solve_block<(NF % NB) ? (NF % NB) : NB>(S, b, (NF / NB) * NB, lane);
+    for (int blk = NF / NB - 1; blk >= 0; blk--) chol_solve_block<NB>(S, b, blk << 4, lane);
   }
+  __syncthreads();
 }
 
 // One wavefront's share of the Schur update: the tiles (R, C), R in {R0, R1}, C in {C0, C1}, C <= R, of the 5x5
