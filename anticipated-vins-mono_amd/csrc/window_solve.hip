@@ -62,8 +62,10 @@ constexpr int XSB = 77, XLAM = 176;
 constexpr int SPP = 2244;          // roff(66): packed rows 0..65 = pose-pose block
 constexpr int WCH = 32;            // rows of the scratch tile at L_WCH (x 80 columns): diag-block temporaries, back-substitution vector
 constexpr int WLD = 80;
-constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r | start-frame tag
-constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows
+constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r (+1 pad)
+constexpr int XRS = 132;           // column stride of the frame tasks' column-major staging tile: 128 rows + 4 (bank spread)
+constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows (>= 13 * XRS)
+static_assert(13 * XRS <= XSTG, "column-major staging tile fits");
 constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diagonal block); trailing tiles stay 16x16
 constexpr int ASM_WAVES = 7;       // wavefronts assembling projection factors (the 8th does the IMU factors)
 constexpr int L_S = 0;
@@ -104,7 +106,7 @@ AVM_DEV void wave_lds_sync() {
 
 AVM_DEV int roff(int i) {  // even i = 2q: 2q(q+1); odd i = 2q+1: 2(q+1)^2 -> every row starts 16-byte aligned
   const int q = i >> 1;
-  return 2 * (q + 1) * (q + (i & 1));
+  return 2 * __mul24(q + 1, q + (i & 1));  // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
 }
 
 struct Frames {
@@ -123,14 +125,16 @@ AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const do
   const v3 Pa = mk3(x[fa * 7], x[fa * 7 + 1], x[fa * 7 + 2]);
   const v3 Pb = mk3(x[fb * 7], x[fb * 7 + 1], x[fb * 7 + 2]);
   const v3 t = mk3(tic[0], tic[1], tic[2]);
-  const v3 pci = mk3(pix / lam, piy / lam, 1.0 / lam);
+  const double il = 1.0 / lam;
+  const v3 pci = mk3(pix * il, piy * il, il);
   const v3 pimu_i = Rmul(ric, pci) + t;
   const v3 pw = Rmul(Ra, pimu_i) + Pa;
   const v3 pimu_j = RTmul(Rb, pw - Pb);
   const v3 pcj = RTmul(ric, pimu_j - t);
   const double dep = pcj.z;
-  double r0 = sqi * (pcj.x / dep - pjx);
-  double r1 = sqi * (pcj.y / dep - pjy);
+  const double id = 1.0 / dep;  // one division per quantity: the quotients below are products with the reciprocal
+  double r0 = sqi * (pcj.x * id - pjx);
+  double r1 = sqi * (pcj.y * id - pjy);
   const double sn = r0 * r0 + r1 * r1;
   // ceres::CauchyLoss + Corrector: rho'' < 0 => residual and Jacobian scale by sqrt(rho')
   const double b = cauchy_a * cauchy_a, c = 1.0 / b;
@@ -142,7 +146,7 @@ AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const do
   r[1] = srho * r1;
   if (WANT_J) {
     const double* Ab = fr.A + fb * 9;
-    const double id = 1.0 / dep, id2 = 1.0 / (dep * dep);
+    const double id2 = id * id;
     const double red[6] = {sqi * id, 0.0, sqi * (-pcj.x * id2), 0.0, sqi * id, sqi * (-pcj.y * id2)};
     double M[6], MR[6], N[6];
 #pragma unroll
@@ -157,7 +161,7 @@ AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const do
 #pragma unroll
       for (int cc = 0; cc < 3; cc++) MR[rr * 3 + cc] = M[rr * 3] * Ra[cc] + M[rr * 3 + 1] * Ra[3 + cc] + M[rr * 3 + 2] * Ra[6 + cc];
     const v3 u = Rmul(ric, mk3(pix, piy, 1.0));  // ric * pts_i
-    const double il2 = -1.0 / (lam * lam);
+    const double il2 = -(il * il);
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
       const v3 m = mk3(M[rr * 3], M[rr * 3 + 1], M[rr * 3 + 2]);
@@ -567,12 +571,14 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
   double* W = c.sc + Scratch::W;
   double* PF = c.sc + Scratch::PF;
   double* PART = c.sc + Scratch::PART + (size_t)b * NFR * 27;
-  d4 Dtot = {0, 0, 0, 0}, Drun = {0, 0, 0, 0};
+  d4 Dtot = {0, 0, 0, 0}, Drun = {0, 0, 0, 0}, Drun1 = {0, 0, 0, 0}, Drun2 = {0, 0, 0, 0}, Drun3 = {0, 0, 0, 0};
   int a_run = -1, pmask = 0;
   double cost = 0;
   const int drow = lane >> 4, dcol = lane & 15;
   auto flush = [&]() {
     if (a_run < 0) return;
+    Drun = (Drun + Drun1) + (Drun2 + Drun3);
+    Drun1 = Drun2 = Drun3 = d4{0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = drow + 4 * r;
@@ -621,14 +627,13 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
       PF[(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
       PF[(7 * NFR + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
     }
-    const double tag = act ? (double)fa : -1.0;
+    // staged column-major, X^T[col][row], row = 2 lane + residual row: one 16-byte store per column, contiguous
+    // across the lanes (a row-major [row][14] tile puts the 64 lanes of a store on 8 banks)
+    {
+      dv2* st = reinterpret_cast<dv2*>(stage) + lane;
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-      double* row = stage + (2 * lane + rr) * XLD;
-#pragma unroll
-      for (int k = 0; k < 6; k++) row[k] = Jj[rr * 6 + k], row[6 + k] = Ji[rr * 6 + k];
-      row[12] = r[rr];
-      row[13] = tag;
+      for (int k = 0; k < 6; k++) st[k * (XRS / 2)] = dv2{Jj[k], Jj[6 + k]}, st[(6 + k) * (XRS / 2)] = dv2{Ji[k], Ji[6 + k]};
+      st[12 * (XRS / 2)] = dv2{r[0], r[1]};
     }
     wave_lds_sync();
     const int nact = min(64, ncov - chunk0);
@@ -641,22 +646,28 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
         flush();
         a_run = a_cur;
       }
-      const double ta = (double)a_cur;
-      // k-steps of 4 staged rows, four at a time with their LDS reads issued together; a step past the run's end
-      // reads rows of another run (or stale rows): masked out of B by the tag, so it adds exact zeros
-      const int m_end = (2 * l_end + 3) >> 2;
-      for (int m0 = (2 * l) >> 2; m0 < m_end; m0 += 4) {
-        double v[4], tg[4];
+      // The k index of X^T X is a summation index: lane group drow takes the two rows of factor 4 j + drow for the
+      // k-step pair j (one 16-byte read, conflict-free with the 132-row column stride), four pairs = eight MFMAs at a
+      // time with the reads issued together, on four independent chains (an MFMA issues every 16 cycles but completes
+      // after 64).  Factors outside the run are masked out by their index, so they add exact zeros.
+      const int j_end = (l_end + 3) >> 2;
+#pragma unroll 1
+      for (int j0 = l >> 2; j0 < j_end; j0 += 4) {
+        dv2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS + 8 * min(j0 + u, 15) + 2 * drow);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const double* row = stage + (4 * min(m0 + u, 31) + drow) * XLD;
-          v[u] = row[min(dcol, 12)], tg[u] = row[13];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const double av = (dcol < 13 && m0 + u < m_end) ? v[u] : 0.0;
-          const double bop = (tg[u] == ta) ? av : 0.0;
-          Drun = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bop, Drun, 0, 0, 0);
+          const int f = 4 * (j0 + u) + drow;
+          const bool in = dcol < 13 && f >= l && f < l_end;
+          const double a0 = in ? v[u][0] : 0.0, a1 = in ? v[u][1] : 0.0;
+          if (u & 1) {
+            Drun2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, Drun2, 0, 0, 0);
+            Drun3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, Drun3, 0, 0, 0);
+          } else {
+            Drun = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, Drun, 0, 0, 0);
+            Drun1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, Drun1, 0, 0, 0);
+          }
         }
       }
       l = l_end;
@@ -952,45 +963,71 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
-// two independent tiles at once (same panel): interleaved by the compiler
-AVM_DEV void chol_trailing_tile2(int c0, int c1, int ti0, int tj0, int ti1, int tj1) {
+// Scratch of the factorization inside the [32][80] tile at L_WCH (dead while S is being factored): L^-T of the current
+// diagonal block, a 16x16 identity, and a per-lane dump slot for the masked-out stores.
+constexpr int L_CLT = L_WCH, L_CID = L_WCH + 256, L_CDUMP = L_WCH + 512;
+
+// ---- trailing update S -= X X^T of one 16-column panel, in 16x16 tiles on v_mfma_f64_16x16x4 (K = 16 -> 4 MFMAs) ----
+// Everything is unconditional (a predicated LDS access compiles to a branch with its own s_waitcnt): operand rows are
+// clamped to the last valid row (the duplicates only reach outputs that are not stored), destination loads are clamped to
+// a valid address and masked-out stores go to a per-lane dump slot.  The k index of the product is a summation index, so
+// lane group lk takes columns c0 + 4 lk + {0..3}: two 16-byte loads per operand instead of four 8-byte ones.
+struct CholTile {
+  dv2 a[2], b[2];
+  double d[4];
+  int o[4];  // destination offsets (doubles from lds[0]); masked-out entries point at the dump slot
+};
+
+AVM_DEV void chol_tile_load(CholTile& T, int c0, int ti, int tj) {
   constexpr int NR = NF + 1;
   double* S = LDS() + L_S;
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-  const int ra0 = 16 * ti0 + lr, rb0 = 16 * tj0 + lr, ra1 = 16 * ti1 + lr, rb1 = 16 * tj1 + lr;
-  const double* pa0 = S + roff(min(ra0, NR - 1)) + c0 + lk;
-  const double* pb0 = S + roff(min(rb0, NF - 1)) + c0 + lk;
-  const double* pa1 = S + roff(min(ra1, NR - 1)) + c0 + lk;
-  const double* pb1 = S + roff(min(rb1, NF - 1)) + c0 + lk;
-  const bool va0 = ra0 < NR && ra0 >= c1, vb0 = rb0 < NF && rb0 >= c1, va1 = ra1 < NR && ra1 >= c1, vb1 = rb1 < NF && rb1 >= c1;
-  double x0[CNB / 4], y0[CNB / 4], x1[CNB / 4], y1[CNB / 4];
-#pragma unroll
-  for (int m = 0; m < CNB / 4; m++) {
-    x0[m] = va0 ? pa0[4 * m] : 0.0, y0[m] = vb0 ? pb0[4 * m] : 0.0;
-    x1[m] = va1 ? pa1[4 * m] : 0.0, y1[m] = vb1 ? pb1[4 * m] : 0.0;
-  }
-  // pre-load the destination entries so the read latency hides under the MFMAs
-  double d0[4], d1[4];
-  int o0[4], o1[4];
+  const dv2* pa = reinterpret_cast<const dv2*>(S + roff(min(16 * ti + lr, NR - 1)) + c0 + 4 * lk);
+  const dv2* pb = reinterpret_cast<const dv2*>(S + roff(min(16 * tj + lr, NF - 1)) + c0 + 4 * lk);
+  T.a[0] = pa[0], T.a[1] = pa[1];
+  T.b[0] = pb[0], T.b[1] = pb[1];
+  const int gj = 16 * tj + lr;
+  const int dump = L_CDUMP + lane;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const int gi0 = 16 * ti0 + lk + 4 * r, gj0 = 16 * tj0 + lr, gi1 = 16 * ti1 + lk + 4 * r, gj1 = 16 * tj1 + lr;
-    o0[r] = (gi0 < NR && gi0 >= c1 && gj0 < NF && gj0 >= c1 && gj0 <= gi0) ? roff(gi0) + gj0 : -1;
-    o1[r] = (gi1 < NR && gi1 >= c1 && gj1 < NF && gj1 >= c1 && gj1 <= gi1) ? roff(gi1) + gj1 : -1;
-    d0[r] = o0[r] >= 0 ? S[o0[r]] : 0.0;
-    d1[r] = o1[r] >= 0 ? S[o1[r]] : 0.0;
+    const int gi = 16 * ti + lk + 4 * r;
+    const bool ok = gi < NR && gj < NF && gj <= gi;
+    const int gic = min(gi, NR - 1);
+    const int ol = L_S + roff(gic) + min(gj, min(gic, NF - 1));
+    T.d[r] = LDS()[ol];
+    T.o[r] = ok ? ol : dump;
   }
+}
+
+AVM_DEV void chol_tile_store(const CholTile& T, const d4& D) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) LDS()[T.o[r]] = T.d[r] - D[r];
+}
+
+#define AVM_TILE_MFMA(T, D)                                                   \
+  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[0][0], T.b[0][0], D, 0, 0, 0); \
+  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[0][1], T.b[0][1], D, 0, 0, 0); \
+  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[1][0], T.b[1][0], D, 0, 0, 0); \
+  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[1][1], T.b[1][1], D, 0, 0, 0);
+
+// two independent tiles at once (same panel): the LDS latencies and the MFMA chains of the pair overlap
+AVM_DEV void chol_trailing_tile2(int c0, int ti0, int tj0, int ti1, int tj1) {
+  CholTile T0, T1;
+  chol_tile_load(T0, c0, ti0, tj0);
+  chol_tile_load(T1, c0, ti1, tj1);
   d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
-#pragma unroll
-  for (int m = 0; m < CNB / 4; m++) {
-    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[m], y0[m], D0, 0, 0, 0);
-    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[m], y1[m], D1, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    if (o0[r] >= 0) S[o0[r]] = d0[r] - D0[r];
-    if (o1[r] >= 0) S[o1[r]] = d1[r] - D1[r];
-  }
+  AVM_TILE_MFMA(T0, D0)
+  AVM_TILE_MFMA(T1, D1)
+  chol_tile_store(T0, D0);
+  chol_tile_store(T1, D1);
+}
+
+AVM_DEV void chol_trailing_tile(int c0, int ti, int tj) {
+  CholTile T;
+  chol_tile_load(T, c0, ti, tj);
+  d4 D = {0, 0, 0, 0};
+  AVM_TILE_MFMA(T, D)
+  chol_tile_store(T, D);
 }
 
 // In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
@@ -1009,10 +1046,6 @@ AVM_DEV double fast_rsqrt(double x) {
   y = y * (1.5 - (0.5 * x) * y * y);
   return y;
 }
-
-// Scratch of the factorization inside the [32][80] tile at L_WCH (dead while S is being factored): L^-T of the current
-// diagonal block, a 16x16 identity, and a per-lane dump slot for the masked-out stores.
-constexpr int L_CLT = L_WCH, L_CID = L_WCH + 256, L_CDUMP = L_WCH + 512;
 
 // Factor the nb x nb diagonal block at c0 in the registers of the calling wavefront (lane = row, register = column).
 //  * Select-free: lanes / columns outside the block (and the upper triangle) just carry finite junk that is never stored.
@@ -1077,31 +1110,6 @@ AVM_NOINL void chol_diag_block(int c0, int nb) {
   __builtin_amdgcn_s_setprio(0);
 }
 
-// one 16x16 tile (ti, tj) of the trailing update with panel columns [c0, c0+CNB); only entries at or
-// beyond row/column c1 (the first trailing index) are touched
-AVM_DEV void chol_trailing_tile(int c0, int c1, int ti, int tj) {
-  constexpr int NR = NF + 1;
-  double* S = LDS() + L_S;
-  const int lane = threadIdx.x & 63;
-  const int ri = 16 * ti + (lane & 15), rj = 16 * tj + (lane & 15);
-  const double* pa = S + roff(min(ri, NR - 1)) + c0 + (lane >> 4);
-  const double* pb = S + roff(min(rj, NF - 1)) + c0 + (lane >> 4);
-  const bool va = ri < NR && ri >= c1, vb = rj < NF && rj >= c1;
-  d4 D = {0, 0, 0, 0};
-#pragma unroll
-  for (int m = 0; m < CNB / 4; m++) {
-    const double aop = va ? pa[4 * m] : 0.0;
-    const double bop = vb ? pb[4 * m] : 0.0;
-    D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, D, 0, 0, 0);
-  }
-  const int gj = 16 * tj + (lane & 15);
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int gi = 16 * ti + (lane >> 4) + 4 * r;
-    if (gi < NR && gi >= c1 && gj < NF && gj >= c1 && gj <= gi) S[roff(gi) + gj] -= D[r];
-  }
-}
-
 // In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
 // The right-hand side rides along as row NF of the packed storage, so the forward substitution
 // L z = b happens as part of the panel solves / trailing updates (z ends up in that row).
@@ -1160,7 +1168,7 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int gi = 16 * ti + lk + 4 * r;
-          if (gi < NR && gi >= c1 && lr < nb) S[roff(gi) + c0 + lr] = D[r];
+          lds[(gi < NR && gi >= c1 && lr < nb) ? L_S + roff(gi) + c0 + lr : L_CDUMP + lane] = D[r];
         }
       }
     }
@@ -1175,7 +1183,7 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
       const int ntile = nt * (nt + 1) / 2;
       if (wv == 0) {
         const long long q0 = clock64();
-        chol_trailing_tile(c0, c1, tm, tm);
+        chol_trailing_tile(c0, tm, tm);
         wave_lds_sync();
         chol_diag_block(c1, min(NB, NF - c1));
         if (c.prof && t == 0) c.prof[28] += clock64() - q0;
@@ -1193,9 +1201,9 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
             int a1 = a0;
             while ((a1 + 1) * (a1 + 2) / 2 <= tile1) a1++;
             const int b1 = tile1 - a1 * (a1 + 1) / 2;
-            chol_trailing_tile2(c0, c1, tm + a0, tm + b0, tm + a1, tm + b1);
+            chol_trailing_tile2(c0, tm + a0, tm + b0, tm + a1, tm + b1);
           } else {
-            chol_trailing_tile(c0, c1, tm + a0, tm + b0);
+            chol_trailing_tile(c0, tm + a0, tm + b0);
           }
         }
         if (c.prof && t == 64) c.prof[27] += clock64() - q0;
