@@ -147,15 +147,17 @@ AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const do
   if (WANT_J) {
     const double* Ab = fr.A + fb * 9;
     const double id2 = id * id;
+    // reduce = sqrt_info [1/z 0 -x/z^2; 0 1/z -y/z^2], with the loss scaling folded in: two terms per entry
+    const double rd = srho * sqi * id, rx = -(srho * sqi) * (pcj.x * id2), ry = -(srho * sqi) * (pcj.y * id2);
     const double red[6] = {sqi * id, 0.0, sqi * (-pcj.x * id2), 0.0, sqi * id, sqi * (-pcj.y * id2)};
     double M[6], MR[6], N[6];
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) {
-        M[rr * 3 + cc] = srho * (red[rr * 3] * Ab[cc] + red[rr * 3 + 1] * Ab[3 + cc] + red[rr * 3 + 2] * Ab[6 + cc]);
-        N[rr * 3 + cc] = srho * (red[rr * 3] * ric[cc * 3] + red[rr * 3 + 1] * ric[cc * 3 + 1] + red[rr * 3 + 2] * ric[cc * 3 + 2]);
-      }
+    for (int cc = 0; cc < 3; cc++) {
+      M[cc] = rd * Ab[cc] + rx * Ab[6 + cc];
+      M[3 + cc] = rd * Ab[3 + cc] + ry * Ab[6 + cc];
+      N[cc] = rd * ric[cc * 3] + rx * ric[cc * 3 + 2];
+      N[3 + cc] = rd * ric[cc * 3 + 1] + ry * ric[cc * 3 + 2];
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; rr++)
 #pragma unroll
