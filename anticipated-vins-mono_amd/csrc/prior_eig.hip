@@ -49,7 +49,8 @@ constexpr int P_A = 0;                        // A' -> rows = columns of G
 constexpr int PL = 40;                        // lanes that hold columns (np <= 38, + the boundary lane of the odd steps)
 constexpr int P_PART = P_A + NMAX * LD;       // [2 buffers][2 values][NW][PL] partial dot products
 constexpr int P_B = P_PART + 2 * 2 * NW * PL;
-constexpr int P_END = P_B + NMAX;
+constexpr int P_DG = P_B + NMAX;              // running diagonal of the Cholesky factorization
+constexpr int P_END = P_DG + NMAX;
 
 __device__ __forceinline__ double nrm_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
   extern __shared__ char pe_smem[];
   double* lds = reinterpret_cast<double*>(pe_smem);
   double* A = lds + P_A;
-  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;  // wv: provably uniform
   const int w = blockIdx.x;
   if (w >= n_windows) return;
   const int n = PO.n[w];
@@ -103,26 +104,40 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
   double* gr = PO.r + (size_t)w * PO.max_prior;
   const int ldj = PO.max_prior;
 
-  // ---- load: A' as a full symmetric array (pad rows / columns = 0), b'
-  for (int e = t; e < NMAX * NMAX; e += NT) {
-    const int i = e / NMAX, j = e - i * NMAX;
-    A[e] = (i < n && j < n) ? gJ[(size_t)max(i, j) * ldj + min(i, j)] : 0.0;
+  // ---- load: A' into REGISTERS (thread = columns lane, lane + 64; rows wv, wv + 4, ...), its diagonal and b' into LDS,
+  // the array that will hold G zeroed (the columns of indices that are never eliminated stay zero)
+  const int col0 = lane, col1 = lane + 64;  // col1 only exists on lanes < NMAX - 64
+  double R0[RW], R1[RW];
+#pragma unroll
+  for (int q = 0; q < RW; q++) {
+    const int i = wv + NW * q, ic = min(i, n - 1), c0c = min(col0, n - 1), c1c = min(col1, n - 1);
+    R0[q] = gJ[(size_t)max(ic, c0c) * ldj + min(ic, c0c)];
+    R1[q] = gJ[(size_t)max(ic, c1c) * ldj + min(ic, c1c)];
   }
+  double* dgl = lds + P_DG;
+  for (int e = t; e < NMAX * NMAX; e += NT) A[e] = 0.0;
   if (t < NMAX) lds[P_B + t] = t < n ? gr[t] : 0.0;
+  double dmine = t < n ? gJ[(size_t)t * ldj + t] : 0.0;  // threads 0..75 carry the running diagonal
+  if (t < NMAX) dgl[t] = dmine;
+#pragma unroll
+  for (int q = 0; q < RW; q++) {
+    const int i = wv + NW * q;
+    R0[q] = (i < n && col0 < n) ? R0[q] : 0.0;
+    R1[q] = (i < n && col1 < n) ? R1[q] : 0.0;
+  }
   __syncthreads();
 
-  // ---- diagonally pivoted Cholesky, G's column of pivot p over row p of the array.  The set of eliminated indices is
-  // a uniform bit mask that every thread tracks in registers (pad indices start eliminated).
+  // ---- diagonally pivoted Cholesky.  A' stays in registers; per step only the scaled pivot row (= column of G, stored as
+  // row p of the LDS array) and the running diagonal go through LDS.  The set of eliminated indices is a uniform bit mask
+  // that every thread tracks (pad indices start eliminated).
   unsigned long long done_lo = n >= 64 ? 0ull : ~0ull << n, done_hi = n >= 64 ? ~0ull << (n - 64) : ~0ull;
-  auto is_done = [&](int i) { return (int)(((i < 64 ? done_lo : done_hi) >> (i & 63)) & 1ull); };
   double dmax0 = 0.0;
-  const int col0 = lane, col1 = lane + 64;  // this thread's columns of the update (col1 only on lanes < NMAX - 64)
   for (int j = 0; j < n; j++) {
     // every wavefront finds the same pivot: largest remaining diagonal (lowest index among those equal in all but the
     // last 7 mantissa bits, which carry the index through the reduction)
     double key = 0.0;
     {
-      const double v0 = A[col0 * LD + col0], v1 = A[min(col1, NMAX - 1) * LD + min(col1, NMAX - 1)];
+      const double v0 = dgl[col0], v1 = dgl[min(col1, NMAX - 1)];
       if (!((done_lo >> lane) & 1ull) && v0 > 0.0)
         key = __longlong_as_double((__double_as_longlong(v0) & ~0x7fll) | (long long)(127 - col0));
       if (col1 < NMAX && !((done_hi >> lane) & 1ull) && v1 > 0.0)
@@ -130,50 +145,45 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
     }
     key = wave_max_pos(key);
     if (!(key > 0.0)) break;
-    const int bi = 127 - (int)(__double_as_longlong(key) & 0x7fll);
-    const double bv = A[bi * LD + bi];
+    const int p = 127 - (int)(__double_as_longlong(key) & 0x7fll);
+    const double bv = dgl[p];
     if (j == 0) dmax0 = bv;
     if (!(bv > (double)NMAX * 2.3e-16 * dmax0)) break;  // rank reached (uniform: every lane has the same pivot)
-    const int p = bi;
     const double isq = nrm_rsqrt(bv);
-    // (slower wavefronts may still be reading the diagonals for their pivot search: the diagonal entry waits for the barrier)
-    if (t < NMAX && t != p) A[p * LD + t] = is_done(t) ? 0.0 : A[p * LD + t] * isq;
+    double* g = A + p * LD;
+    if (wv == (p & (NW - 1))) {  // the wavefront that owns row p publishes g = row p / sqrt(pivot), 0 on eliminated columns
+      const int qp = p >> 2;
+      double r0 = 0, r1 = 0;
+#pragma unroll
+      for (int q = 0; q < RW; q++)
+        if (q == qp) r0 = R0[q], r1 = R1[q];  // (uniform)
+      g[col0] = col0 == p ? bv * isq : (((done_lo >> lane) & 1ull) ? 0.0 : r0 * isq);
+      if (col1 < NMAX) g[col1] = col1 == p ? bv * isq : (((done_hi >> lane) & 1ull) ? 0.0 : r1 * isq);
+    }
     if (p < 64) done_lo |= 1ull << p; else done_hi |= 1ull << (p - 64);
     __syncthreads();
-    if (t == p) A[p * LD + p] = bv * isq;
-    // A <- A - g g^T.  Eliminated rows / columns have g = 0 (exact no-op on the stored columns of G); row and column p
-    // are skipped.  Lane = column (coalesced rows), wavefront w takes rows w, w + NW, ...
+    // A <- A - g g^T.  Eliminated rows / columns have g = 0; row and column p are left alone (g_p is zeroed for the update)
     {
-      const double* g = A + p * LD;
       const double g0 = col0 == p ? 0.0 : g[col0], g1 = (col1 < NMAX && col1 != p) ? g[col1] : 0.0;
-      const int c1 = min(col1, NMAX - 1);
-      double a0[RW], a1[RW], gi[RW];
+      double gi[RW];
 #pragma unroll
-      for (int q = 0; q < RW; q++) {
-        const int i = wv + NW * q;
-        gi[q] = g[i], a0[q] = A[i * LD + col0], a1[q] = A[i * LD + c1];
+      for (int q = 0; q < RW; q++) gi[q] = g[wv + NW * q];
+      if (t < NMAX) {
+        const double gt = g[t];
+        dmine = fma(-gt, gt, dmine);
+        dgl[t] = dmine;
       }
 #pragma unroll
       for (int q = 0; q < RW; q++) {
-        const int i = wv + NW * q;
-        if (i == p) continue;  // (uniform)
-        const double v0 = fma(-gi[q], g0, a0[q]);
-        A[i * LD + col0] = v0;
-        if (col1 < NMAX) A[i * LD + col1] = fma(-gi[q], g1, a1[q]);
+        const double gq = (wv + NW * q == p) ? 0.0 : gi[q];
+        R0[q] = fma(-gq, g0, R0[q]);
+        R1[q] = fma(-gq, g1, R1[q]);
       }
     }
     __syncthreads();
   }
   __syncthreads();
-  // rows of indices that were never eliminated (rank deficiency) hold the remaining Schur complement, not a column of
-  // G: zero columns (the pad rows are zero already)
-  for (int e = t; e < NMAX * NMAX; e += NT) {
-    const int i = e / NMAX;
-    if (i < n && !is_done(i)) A[e] = 0.0;
-  }
-  __syncthreads();
 
-  const long long t_chol = prof ? (long long)__builtin_readcyclecounter() : 0;
   // ---- one-sided Jacobi on the columns of G.  Lane k: X = column on position 2k, Y = column on position 2k+1.
   double X[RW], Y[RW];
   const int r0 = wv * RW;
@@ -310,7 +320,6 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
   if (prof && t == 0) {
     atomicAdd(reinterpret_cast<unsigned long long*>(prof + 25), (unsigned long long)((long long)__builtin_readcyclecounter() - t_start));
     atomicAdd(reinterpret_cast<unsigned long long*>(prof + 29), (unsigned long long)sweeps);
-    atomicAdd(reinterpret_cast<unsigned long long*>(prof + 26), (unsigned long long)(t_chol - t_start));
   }
 }
 
