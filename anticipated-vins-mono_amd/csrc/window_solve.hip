@@ -1992,9 +1992,8 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
 // speed-bias by frame, ex_pose.
 namespace mg {
 constexpr int MEX0 = 165, MROWS = 14792;  // 171 variables: MROWS = roff(171)
-constexpr int MXLD = 24;                              // Jj 0-5 | Ji 6-11 | r 12 | tag 13 | 0 0 | Jex 16-21 | 0 0
-constexpr int MXSTG = 128 * MXLD;
-constexpr int MASM = 3;                               // assembling wavefronts (staging must stay below row 165)
+constexpr int MXSTG = 19 * XRS;                       // column-major staging tile: Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18, XRS rows each
+constexpr int MASM = 4;                               // assembling wavefronts (staging must stay below row 165)
 constexpr int M_G = MROWS;                            // b over the 171 variables (176)
 constexpr int M_GE = M_G + 176;                       // g_e (152)
 constexpr int M_WCH = M_GE + 152;                     // [24][80] Schur staging / IMU factor rows
@@ -2095,7 +2094,7 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
   double* PF = c.sc + Scratch::PF;     // 8 rows here + 6 more in IJRAW's tail (see MPF2)
   double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;  // [6][MAXOBS] Jex^T Je
   double* PART = c.sc + Scratch::PART + (size_t)b * PARTW;
-  d4 D00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, D11 = {0, 0, 0, 0};
+  d4 D00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, D11 = {0, 0, 0, 0}, E00 = {0, 0, 0, 0}, E10 = {0, 0, 0, 0}, E11 = {0, 0, 0, 0};
   const int drow = lane >> 4, dcol = lane & 15;
   for (int chunk0 = 0; chunk0 < ncov; chunk0 += 64) {
     const int idx = chunk0 + lane;
@@ -2118,25 +2117,48 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
       PF[6 * MAXOBS + s] = Je[0] * Je[0] + Je[1] * Je[1];
       PF[7 * MAXOBS + s] = Je[0] * r[0] + Je[1] * r[1];
     }
+    // staged column-major like the solve kernel's frame tasks (Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18): one 16-byte store
+    // per column, contiguous across the lanes; inactive lanes stage zeros, so no row needs masking
+    {
+      dv2* st = reinterpret_cast<dv2*>(stage) + lane;
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-      double* row = stage + (2 * lane + rr) * MXLD;
-#pragma unroll
-      for (int k = 0; k < 6; k++) row[k] = Jj[rr * 6 + k], row[6 + k] = Ji[rr * 6 + k], row[16 + k] = Jx[rr * 6 + k];
-      row[12] = r[rr];
-      row[13] = 0.0, row[14] = 0.0, row[15] = 0.0, row[22] = 0.0, row[23] = 0.0;
+      for (int k = 0; k < 6; k++) {
+        st[k * (XRS / 2)] = dv2{Jj[k], Jj[6 + k]};
+        st[(6 + k) * (XRS / 2)] = dv2{Ji[k], Ji[6 + k]};
+        st[(13 + k) * (XRS / 2)] = dv2{Jx[k], Jx[6 + k]};
+      }
+      st[12 * (XRS / 2)] = dv2{r[0], r[1]};
     }
     wave_lds_sync();
     const int nact = min(64, ncov - chunk0);
-    for (int m = 0; m < ((2 * nact + 3) >> 2); m++) {
-      const double* row = stage + (4 * m + drow) * MXLD;
-      const double v0 = row[dcol], v1 = row[16 + dcol];
-      D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, D00, 0, 0, 0);
-      D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v0, D10, 0, 0, 0);
-      D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, D11, 0, 0, 0);
+    // lane group drow takes the two rows of factor 4 j + drow (one 16-byte read per tile), four j at a time: 24 MFMAs on
+    // six independent chains
+    const int j_end = (nact + 3) >> 2;
+#pragma unroll 1
+    for (int j0 = 0; j0 < j_end; j0 += 4) {
+      dv2 u0[4], u1[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int ro = 8 * min(j0 + u, 15) + 2 * drow;
+        u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS + ro);
+        u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 5)) * XRS + ro);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool on = j0 + u < j_end;
+        const double a0 = (on && dcol < 13) ? u0[u][0] : 0.0, a1 = (on && dcol < 13) ? u0[u][1] : 0.0;
+        const double x0 = (on && dcol < 6) ? u1[u][0] : 0.0, x1 = (on && dcol < 6) ? u1[u][1] : 0.0;
+        D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
+        D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
+        D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
+        E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
+        E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
+        E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+      }
     }
     wave_lds_sync();
   }
+  D00 += E00, D10 += E10, D11 += E11;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = drow + 4 * r;
