@@ -1232,13 +1232,19 @@ AVM_DEV void chol_solve_block(double* S, double* b, int c0, int lane) {
   const double dr = col[roff(c0 + rr)];
   double colv[NBV];
 #pragma unroll
-  for (int i = 0; i < NBV; i++) colv[i] = col[roff(c0 + max(i, rr))];  // always a valid (row >= column) address
+  for (int i = 0; i < NBV; i++) colv[i] = col[roff(c0 + i)];  // uniform row offset; i < rr reads (finite) entries of the next rows
   double bv = b[c0 + rr];
-  // rows of the block for the first 64 remaining columns: in flight during the chain
-  const int j0 = min(lane, max(c0 - 1, 0));
-  double v0[NBV];
+  // rows of the block for all (<= 160 = 3 x 64) remaining columns: in flight during the chain (clamped addresses; a
+  // segment beyond c0 is simply not stored)
+  const int jc = max(c0 - 1, 0);
+  double v0[3][NBV], acc[3];
 #pragma unroll
-  for (int i = 0; i < NBV; i++) v0[i] = S[roff(c0 + i) + j0];
+  for (int sgm = 0; sgm < 3; sgm++) {
+    const int j = min(64 * sgm + lane, jc);
+    acc[sgm] = b[j];
+#pragma unroll
+    for (int i = 0; i < NBV; i++) v0[sgm][i] = S[roff(c0 + i) + j];
+  }
   const double isq = fast_rsqrt(dr), di2 = isq * isq;
   bv *= isq;
 #pragma unroll
@@ -1251,16 +1257,15 @@ AVM_DEV void chol_solve_block(double* S, double* b, int c0, int lane) {
     xout = lane == jj ? xs[jj] : xout;
   }
   if (lane < NBV) b[c0 + lane] = xout;
-  for (int jb = 0; jb < c0; jb += 64) {
-    const int j = min(jb + lane, c0 - 1);
-    double acc = b[j];
-    if (jb > 0) {
 #pragma unroll
-      for (int i = 0; i < NBV; i++) v0[i] = S[roff(c0 + i) + j];
+  for (int sgm = 0; sgm < 3; sgm++) {
+    if (64 * sgm >= c0) break;  // (uniform)
+    double a0 = acc[sgm], a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NBV; i++) {
+      if (i & 1) a1 = fma(-v0[sgm][i], xs[i], a1); else a0 = fma(-v0[sgm][i], xs[i], a0);
     }
-#pragma unroll
-    for (int i = 0; i < NBV; i++) acc = fma(-v0[i], xs[i], acc);
-    if (jb + lane < c0) b[j] = acc;
+    if (64 * sgm + lane < c0) b[64 * sgm + lane] = a0 + a1;
   }
   wave_lds_sync();
 }
