@@ -15,8 +15,8 @@ def q(db, sql):
 
 
 tr = os.path.join(src, "trace", "run_results.db")
-out.append("## rocprofv3 --kernel-trace --stats (durations in us)\n")
-out.append("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|")
+out.append("## rocprofv3 --kernel-trace --stats (durations in ms; the rocpd top_kernels view reports microseconds)\n")
+out.append("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|")
 for name, calls, tot, avg, pct in q(tr, "select name,total_calls,total_duration,average,percentage from top_kernels"):
     out.append(f"| `{name[:90]}` | {calls} | {tot/1e3:.1f} | {avg/1e3:.2f} | {pct:.1f} |")
 out.append("")
