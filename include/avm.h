@@ -316,6 +316,35 @@ int avm_projection_td_eval(avm_ctx* ctx, avm_mem mem, const avm_td_factor_batch*
 int avm_fsel_build_cloud(avm_ctx* ctx, avm_mem mem, const avm_window_batch* windows, const double* k1_pos, const double* k1_quat,
                          int32_t max_cloud, int32_t* n_cloud, double* cloud_xy, double* cloud_depth);
 
+/* ---- SURVEY 8(f)4 + B4 (ground-truth mode): host-side format adapters.  Pure host bookkeeping like their
+ * reference counterparts: no device work, no avm_ctx, usable without a GPU. ---------------------------------------- */
+
+/* EuRoC ground-truth table with the reference's seek cursor (HorizonGenerator::truth_, seek_idx_, horizon_generator.h). */
+typedef struct avm_gt avm_gt;
+/* HorizonGenerator::loadGroundTruth (horizon_generator.cpp:169-196): first line = header, then
+ * timestamp[ns], p(3), q(w x y z), v(3), w(3), a(3); the timestamp is stod(field) * 1e-9.  NULL on I/O / parse error. */
+avm_gt* avm_gt_load_csv(const char* data_csv);
+/* the same table from memory: rows [n][17], column 0 already in nanoseconds as a double */
+avm_gt* avm_gt_from_rows(const double* rows, int32_t n);
+void avm_gt_free(avm_gt* gt);
+int32_t avm_gt_size(const avm_gt* gt);
+int32_t avm_gt_seek(const avm_gt* gt); /* current seek_idx_ */
+/* HorizonGenerator::groundTruth (horizon_generator.cpp:73-123) incl. getNextFrameTruth (:200-210): the H future poses
+ * from the relative motion of the ground truth, starting at state k (timestamp, k_pos [3], k_quat [4] x y z w).
+ * Stateful like the reference: the seek cursor only moves forward (and moves by at least one row per call).
+ * Out: hor_pos [H+1][3], hor_quat [H+1][4] (x y z w; the products are not renormalized, as in the reference).
+ * AVM_ERR_INVALID where the reference would read past the end of the table. */
+int avm_fsel_horizon_ground_truth(avm_gt* gt, int32_t horizon, double timestamp_k, const double* k_pos, const double* k_quat,
+                                  double delta_frame, double* hor_pos, double* hor_quat);
+
+/* The feature message decode of estimator_node.cpp:303-321 (sensor_msgs::PointCloud -> image_t): points [n][3] float32
+ * (geometry_msgs/Point32), channels[0..5] = id_of_point, u, v, velocity_x, velocity_y, probability (float32 each, [n]).
+ * feature_id = int(ch0 + 0.5) / num_cam, camera_id = ... % num_cam; xyz_uv_velocity [n][8] = x y z u v vx vy prob.
+ * Output in image_t order: ascending feature_id (std::map), message order within an id.  AVM_ERR_INVALID if a z != 1
+ * (ROS_ASSERT(z == 1), :317). */
+int avm_image_from_pointcloud(int32_t n_points, const float* points_xyz, const float* const* channels, int32_t num_cam,
+                              int32_t* feature_id, int32_t* camera_id, double* xyz_uv_velocity);
+
 /* A5/A6/A8 only: evaluate every factor once at the current state and return
  * residuals/Jacobians (local 6-column pose blocks).  Used by the per-factor parity tests.
  *   proj_r [B][max_obs][2], proj_J [B][max_obs][2][13]  (pose_i 6 | pose_j 6 | inv_depth 1), index = observation slot

@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "fsel.hpp"
+#include "adapters.hpp"
 #include "solver.hpp"
 #include "triangulate.hpp"
 
@@ -437,6 +438,29 @@ int avmo_fsel_build_cloud(const avm_window_batch* B, const double* k1_pos, const
                              cloud_xy + (size_t)w * max_cloud * 2, cloud_depth + (size_t)w * max_cloud);
   }
   return 0;
+}
+
+void* avmo_gt_from_rows(const double* rows, int n) {
+  GroundTruth* g = new GroundTruth;
+  g->load(rows, n);
+  return g;
+}
+void avmo_gt_free(void* g) { delete static_cast<GroundTruth*>(g); }
+int avmo_gt_seek(void* g) { return static_cast<GroundTruth*>(g)->seek_idx; }
+int avmo_fsel_horizon_ground_truth(void* gp, int H, double t0, const double* k_pos, const double* k_quat, double deltaFrame, double* hor_pos,
+                                   double* hor_quat) {
+  GroundTruth* g = static_cast<GroundTruth*>(gp);
+  std::vector<V3> pos;
+  std::vector<Q> quat;
+  if (!g->horizon(H, t0, V3(k_pos[0], k_pos[1], k_pos[2]), Q(k_quat[3], k_quat[0], k_quat[1], k_quat[2]), deltaFrame, pos, quat)) return -1;
+  for (int h = 0; h <= H; h++) {
+    hor_pos[3 * h] = pos[h].x, hor_pos[3 * h + 1] = pos[h].y, hor_pos[3 * h + 2] = pos[h].z;
+    hor_quat[4 * h] = quat[h].x, hor_quat[4 * h + 1] = quat[h].y, hor_quat[4 * h + 2] = quat[h].z, hor_quat[4 * h + 3] = quat[h].w;
+  }
+  return 0;
+}
+int avmo_image_from_pointcloud(int n, const float* pts, const float* const* ch, int num_cam, int32_t* fid, int32_t* cam, double* out) {
+  return image_from_pointcloud(n, pts, ch, num_cam, fid, cam, out) ? 0 : -1;
 }
 
 }  // extern "C"
