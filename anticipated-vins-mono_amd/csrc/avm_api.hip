@@ -413,6 +413,46 @@ int avm_triangulate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, doub
   return AVM_OK;
 }
 
+int avm_slide_window(avm_ctx* c, avm_mem mem, avm_window_batch* batch, int32_t flag, int32_t shift_depth, double init_depth) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (!batch || batch->n_windows < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
+  if (flag != AVM_MARGIN_OLD && flag != AVM_MARGIN_SECOND_NEW) return fail(c, AVM_ERR_INVALID, "marginalization_flag must be MARGIN_OLD or MARGIN_SECOND_NEW");
+  if (batch->n_windows == 0) return AVM_OK;
+  const size_t B = batch->n_windows;
+  avm_window_batch d = *batch;
+  // (field, element type, elements) of everything the roll reads or rewrites
+#define AVM_SLIDE_FIELDS(X)                                                                                              \
+  X(pose, double, B * 77) X(speedbias, double, B * 99) X(ex_pose, double, B * 7) X(inv_depth, double, B * batch->max_feat)    \
+  X(n_feat, int32_t, B) X(feat_start, int32_t, B * batch->max_feat) X(feat_nobs, int32_t, B * batch->max_feat)                \
+  X(feat_obs_begin, int32_t, B * batch->max_feat) X(obs_xy, double, B * batch->max_obs * 2) X(imu_n, int32_t, B * 10)         \
+  X(imu_dt, double, B * 10 * batch->max_samp) X(imu_acc, double, B * 10 * (batch->max_samp + 1) * 3)                          \
+  X(imu_gyr, double, B * 10 * (batch->max_samp + 1) * 3) X(imu_lin_ba, double, B * 30) X(imu_lin_bg, double, B * 30)
+  if (mem == AVM_MEM_HOST) {
+    int rc;
+#define ST(field, type, count) \
+  if ((rc = stage_in<type>(c, "w_" #field, batch->field, (count), (const type**)&d.field)) != AVM_OK) return rc;
+    AVM_SLIDE_FIELDS(ST)
+#undef ST
+  }
+  int* derr = static_cast<int*>(pool_get(c, "slide_err", sizeof(int)));
+  if (!derr) return fail(c, AVM_ERR_HIP, "hipMalloc failed (slide flag)");
+  HIPCHK(c, hipMemsetAsync(derr, 0, sizeof(int), c->stream));
+  HIPCHK(c, launch_slide_window(d, flag, shift_depth, init_depth, derr, c->stream));
+  int herr = 0;
+  HIPCHK(c, hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (mem == AVM_MEM_HOST) {
+#define BK(field, type, count) \
+  HIPCHK(c, hipMemcpyAsync(const_cast<type*>(batch->field), d.field, sizeof(type) * (count), hipMemcpyDeviceToHost, c->stream));
+    AVM_SLIDE_FIELDS(BK)
+#undef BK
+  }
+#undef AVM_SLIDE_FIELDS
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (herr) return fail(c, AVM_ERR_CAPACITY, "MARGIN_SECOND_NEW: interval 8 + interval 9 exceed max_samp samples");
+  return AVM_OK;
+}
+
 int avm_imu_propagate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, const double g[3]) {
   if (!c) return AVM_ERR_INVALID;
   (void)hipSetDevice(c->device);

@@ -72,6 +72,7 @@ hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_p
 hipError_t launch_fsel_horizon_imu(const avm_fsel_horizon_in& in, double* hor_pos, double* hor_quat, hipStream_t stream);
 hipError_t launch_triangulate(const avm_window_batch& b, double init_depth, hipStream_t stream);
 hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipStream_t stream);
+hipError_t launch_slide_window(const avm_window_batch& b, int flag, int shift_depth, double init_depth, int* err, hipStream_t stream);
 hipError_t launch_projection_td_eval(const avm_td_factor_batch& f, double* residual, double* jac, hipStream_t stream);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);

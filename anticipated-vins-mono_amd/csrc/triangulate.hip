@@ -158,6 +158,126 @@ hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipS
   return hipGetLastError();
 }
 
+// ---- 8(f)2: Estimator::slideWindow (estimator.cpp:996-1107) + removeBackShiftDepth / removeBack / removeFront
+// (feature_manager.cpp:275-352), in place.  One wavefront per window: the lanes move the frame / IMU arrays, lane 0 walks
+// the feature list (order-preserving compaction of <= 150 entries: not worth a scan).
+__global__ __launch_bounds__(64) void slide_window_kernel(avm_window_batch B, int flag, int shift_depth, double init_depth, int* err) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  double* pose = B.pose + (size_t)w * NFR * 7;
+  double* sb = B.speedbias + (size_t)w * NFR * 9;
+  int32_t* imu_n = const_cast<int32_t*>(B.imu_n) + (size_t)w * 10;
+  double* dt = const_cast<double*>(B.imu_dt) + (size_t)w * 10 * B.max_samp;
+  double* acc = const_cast<double*>(B.imu_acc) + (size_t)w * 10 * (B.max_samp + 1) * 3;
+  double* gyr = const_cast<double*>(B.imu_gyr) + (size_t)w * 10 * (B.max_samp + 1) * 3;
+  double* lba = const_cast<double*>(B.imu_lin_ba) + (size_t)w * 30;
+  double* lbg = const_cast<double*>(B.imu_lin_bg) + (size_t)w * 30;
+  const int SD = B.max_samp, SA = (B.max_samp + 1) * 3;
+  // back_R0 / back_P0 (estimator.cpp:1001-1002)
+  double back[7];
+  for (int k = 0; k < 7; k++) back[k] = pose[k];
+  const int n9 = imu_n[9];
+  double a0[3], g0[3];  // acc_0 / gyr_0: the last sample pushed
+  for (int k = 0; k < 3; k++) a0[k] = acc[9 * SA + n9 * 3 + k], g0[k] = gyr[9 * SA + n9 * 3 + k];
+  __syncthreads();
+  if (flag == AVM_MARGIN_OLD) {
+    for (int i = 0; i < NFR - 1; i++) {
+      if (lane < 7) pose[i * 7 + lane] = pose[(i + 1) * 7 + lane];
+      if (lane < 9) sb[i * 9 + lane] = sb[(i + 1) * 9 + lane];
+      __syncthreads();
+    }
+    for (int j = 0; j < 9; j++) {
+      const int n = imu_n[j + 1];
+      __syncthreads();
+      for (int k = lane; k < n; k += 64) dt[j * SD + k] = dt[(j + 1) * SD + k];
+      for (int k = lane; k < (n + 1) * 3; k += 64) acc[j * SA + k] = acc[(j + 1) * SA + k], gyr[j * SA + k] = gyr[(j + 1) * SA + k];
+      if (lane < 3) lba[j * 3 + lane] = lba[(j + 1) * 3 + lane], lbg[j * 3 + lane] = lbg[(j + 1) * 3 + lane];
+      if (lane == 0) imu_n[j] = n;
+      __syncthreads();
+    }
+  } else {
+    // pre_integrations[9 - 1]->push_back(...) for every sample of interval 9 (estimator.cpp:1051-1062)
+    const int n8 = imu_n[8];
+    if (n8 + n9 > SD) {
+      if (lane == 0) *err = 1;
+      return;
+    }
+    for (int k = lane; k < n9; k += 64) dt[8 * SD + n8 + k] = dt[9 * SD + k];
+    for (int k = lane; k < n9 * 3; k += 64) acc[8 * SA + (n8 + 1) * 3 + k] = acc[9 * SA + 3 + k], gyr[8 * SA + (n8 + 1) * 3 + k] = gyr[9 * SA + 3 + k];
+    if (lane < 7) pose[9 * 7 + lane] = pose[10 * 7 + lane];
+    if (lane < 9) sb[9 * 9 + lane] = sb[10 * 9 + lane];
+    __syncthreads();
+    if (lane == 0) imu_n[8] = n8 + n9;
+  }
+  // the fresh pre_integrations[WINDOW_SIZE] (estimator.cpp:1027-1028, 1071-1072)
+  if (lane < 3) {
+    acc[9 * SA + lane] = a0[lane], gyr[9 * SA + lane] = g0[lane];
+    lba[27 + lane] = sb[10 * 9 + 3 + lane], lbg[27 + lane] = sb[10 * 9 + 6 + lane];
+  }
+  if (lane == 0) imu_n[9] = 0;
+  __syncthreads();
+  if (lane != 0) return;
+  // ---- feature list
+  int32_t* n_feat = const_cast<int32_t*>(B.n_feat) + w;
+  int32_t* fstart = const_cast<int32_t*>(B.feat_start) + (size_t)w * B.max_feat;
+  int32_t* fnobs = const_cast<int32_t*>(B.feat_nobs) + (size_t)w * B.max_feat;
+  int32_t* fobs = const_cast<int32_t*>(B.feat_obs_begin) + (size_t)w * B.max_feat;
+  double* obs = const_cast<double*>(B.obs_xy) + (size_t)w * B.max_obs * 2;
+  double* lam = B.inv_depth + (size_t)w * B.max_feat;
+  const double* ex = B.ex_pose + (size_t)w * 7;
+  double ric[9], Rb[9], Rn[9];
+  q2R(quat{ex[6], ex[3], ex[4], ex[5]}, ric);
+  const v3 tic = mk3(ex[0], ex[1], ex[2]);
+  q2R(quat{back[6], back[3], back[4], back[5]}, Rb);
+  q2R(quat{pose[6], pose[3], pose[4], pose[5]}, Rn);
+  // R0 = back_R0 ric, P0 = back_P0 + back_R0 tic; R1 = Rs[0] ric, P1 = Ps[0] + Rs[0] tic   (estimator.cpp:1098-1103)
+  const v3 P0 = mk3(back[0], back[1], back[2]) + Rmul(Rb, tic), P1 = mk3(pose[0], pose[1], pose[2]) + Rmul(Rn, tic);
+  const int nf = *n_feat;
+  int o = 0;
+  for (int e = 0; e < nf; e++) {
+    int st = fstart[e], no = fnobs[e], ob = fobs[e];
+    double l = lam[e];
+    bool keep = true;
+    if (flag == AVM_MARGIN_OLD) {
+      if (st != 0) {
+        st--;
+      } else {
+        const double ux = obs[2 * ob], uy = obs[2 * ob + 1];
+        ob++, no--;
+        if (shift_depth) {
+          if (no < 2) {
+            keep = false;
+          } else {
+            const double depth = 1.0 / l;
+            const v3 pts_i = depth * mk3(ux, uy, 1.0);
+            const v3 w_pts = Rmul(Rb, Rmul(ric, pts_i)) + P0;
+            const v3 pts_j = RTmul(ric, RTmul(Rn, w_pts - P1));
+            l = 1.0 / (pts_j.z > 0 ? pts_j.z : init_depth);
+          }
+        } else if (no == 0) {
+          keep = false;
+        }
+      }
+    } else {
+      if (st == NFR - 1) {
+        st--;
+      } else if (st + no - 1 >= NFR - 2) {  // endFrame() >= frame_count - 1: it has an observation in frame 9
+        const int j = NFR - 2 - st;
+        for (int k = j; k + 1 < no; k++) obs[2 * (ob + k)] = obs[2 * (ob + k + 1)], obs[2 * (ob + k) + 1] = obs[2 * (ob + k + 1) + 1];
+        no--;
+        if (no == 0) keep = false;
+      }
+    }
+    if (keep) fstart[o] = st, fnobs[o] = no, fobs[o] = ob, lam[o] = l, o++;
+  }
+  *n_feat = o;
+}
+
+hipError_t launch_slide_window(const avm_window_batch& b, int flag, int shift_depth, double init_depth, int* err, hipStream_t stream) {
+  if (b.n_windows == 0) return hipSuccess;
+  hipLaunchKernelGGL(slide_window_kernel, dim3(b.n_windows), dim3(64), 0, stream, b, flag, shift_depth, init_depth, err);
+  return hipGetLastError();
+}
+
 // A7: ProjectionTdFactor::Evaluate (factor/projection_td_factor.cpp:34-141), one thread per factor.
 __global__ __launch_bounds__(TRI_NT) void projection_td_eval_kernel(avm_td_factor_batch f, double* residual, double* jac) {
   const int i = blockIdx.x * TRI_NT + threadIdx.x;

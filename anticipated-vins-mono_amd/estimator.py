@@ -66,6 +66,14 @@ class Estimator:
         rc = self.ctx._L.avm_imu_propagate_batch(self.ctx.h, windows.mem, C.byref(s), g)
         self.ctx.check(rc, "avm_imu_propagate_batch")
 
+    def slideWindow(self, windows: buffers.WindowArrays, marginalization_flag=None, shift_depth=True, init_depth=5.0):
+        """Estimator::slideWindow (estimator.cpp:996-1107) + removeBackShiftDepth / removeBack / removeFront
+        (feature_manager.cpp:275-352), in place on the batch tables (host or device resident)."""
+        flag = self.options.marginalization_flag if marginalization_flag is None else marginalization_flag
+        s = windows.struct()
+        rc = self.ctx._L.avm_slide_window(self.ctx.h, windows.mem, C.byref(s), int(flag), int(bool(shift_depth)), float(init_depth))
+        self.ctx.check(rc, "avm_slide_window")
+
     def preintegrate(self, windows: buffers.WindowArrays):
         """IntegrationBase for every interval: returns delta [B,10,10], jacobian, covariance [B,10,15,15], sum_dt [B,10]."""
         assert not windows.on_device

@@ -54,6 +54,7 @@ def lib():
         L.avm_projection_td_eval.argtypes = [vp, C.c_int, C.POINTER(abi.TdFactorBatch), abi.c_dp, abi.c_dp]
         L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
         L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
+        L.avm_slide_window.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.c_int32, C.c_int32, C.c_double]
         L.avm_gt_load_csv.restype = vp
         L.avm_gt_load_csv.argtypes = [C.c_char_p]
         L.avm_gt_from_rows.restype = vp
@@ -71,7 +72,7 @@ EXPORTS = [
     "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
     "avm_window_solve_batch", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
     "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
-    "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud",
+    "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
 ]
 
 

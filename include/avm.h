@@ -316,6 +316,25 @@ int avm_projection_td_eval(avm_ctx* ctx, avm_mem mem, const avm_td_factor_batch*
 int avm_fsel_build_cloud(avm_ctx* ctx, avm_mem mem, const avm_window_batch* windows, const double* k1_pos, const double* k1_quat,
                          int32_t max_cloud, int32_t* n_cloud, double* cloud_xy, double* cloud_depth);
 
+/* the window roll, Estimator::slideWindow (estimator.cpp:996-1107) with FeatureManager::removeBackShiftDepth /
+ * removeBack / removeFront (feature_manager.cpp:275-352), applied IN PLACE to the batch so that the next solve can run on
+ * the same (device-resident) tables; the prior hand-off is already part of avm_window_solve_batch (blk_frame carries the
+ * addr_shift).  frame_count == WINDOW_SIZE is assumed.  The const qualifiers of the batch's table pointers are cast away:
+ * the caller owns writable memory of the declared strides.
+ *   AVM_MARGIN_OLD:        poses / speed-biases / IMU intervals move down by one (frame 10 keeps its values, interval 9
+ *                          becomes empty: imu_n = 0, row 0 of imu_acc / imu_gyr = the last sample pushed, linearization
+ *                          biases = those of frame 10); a feature with start_frame != 0 starts one frame earlier, the
+ *                          others lose their first observation and are erased when fewer than 2 remain (shift_depth != 0,
+ *                          i.e. solver_flag == NON_LINEAR; their depth is re-anchored in the new first frame, init_depth
+ *                          where it comes out non-positive) or when none remains (shift_depth == 0).
+ *   AVM_MARGIN_SECOND_NEW: frame 10 overwrites frame 9, the samples of interval 9 are appended to interval 8
+ *                          (AVM_ERR_CAPACITY if that exceeds max_samp); a feature that starts in frame 10 starts in 9,
+ *                          the others lose their frame-9 observation if they were still tracked in frame 9, and are
+ *                          erased when none remains.
+ * Erasing compacts the per-feature arrays in order (std::list order); observations stay where they are, only
+ * feat_obs_begin / feat_nobs change (one element moves for removeFront).  inv_depth holds 1 / estimated_depth. */
+int avm_slide_window(avm_ctx* ctx, avm_mem mem, avm_window_batch* windows, int32_t marginalization_flag, int32_t shift_depth, double init_depth);
+
 /* ---- SURVEY 8(f)4 + B4 (ground-truth mode): host-side format adapters.  Pure host bookkeeping like their
  * reference counterparts: no device work, no avm_ctx, usable without a GPU. ---------------------------------------- */
 

@@ -16,6 +16,7 @@
 
 #include "fsel.hpp"
 #include "adapters.hpp"
+#include "slide.hpp"
 #include "solver.hpp"
 #include "triangulate.hpp"
 
@@ -461,6 +462,25 @@ int avmo_fsel_horizon_ground_truth(void* gp, int H, double t0, const double* k_p
 }
 int avmo_image_from_pointcloud(int n, const float* pts, const float* const* ch, int num_cam, int32_t* fid, int32_t* cam, double* out) {
   return image_from_pointcloud(n, pts, ch, num_cam, fid, cam, out) ? 0 : -1;
+}
+
+// tables rewritten in place; the oracle repacks the observations (feat_obs_begin differs from the device's in-place roll:
+// compare observations through feat_obs_begin, not raw obs_xy)
+int avmo_slide_window(avm_window_batch* B, int flag, int shift_depth, double init_depth) {
+  for (int w = 0; w < B->n_windows; w++) {
+    int nf = B->n_feat[w];
+    const bool ok = slide_window_one(
+        flag, shift_depth != 0, init_depth, reinterpret_cast<double(*)[7]>(B->pose + (size_t)w * 77), reinterpret_cast<double(*)[9]>(B->speedbias + (size_t)w * 99),
+        B->ex_pose + (size_t)w * 7, B->max_samp, const_cast<int32_t*>(B->imu_n) + (size_t)w * 10, const_cast<double*>(B->imu_dt) + (size_t)w * 10 * B->max_samp,
+        const_cast<double*>(B->imu_acc) + (size_t)w * 10 * (B->max_samp + 1) * 3, const_cast<double*>(B->imu_gyr) + (size_t)w * 10 * (B->max_samp + 1) * 3,
+        const_cast<double*>(B->imu_lin_ba) + (size_t)w * 30, const_cast<double*>(B->imu_lin_bg) + (size_t)w * 30, nf,
+        const_cast<int32_t*>(B->feat_start) + (size_t)w * B->max_feat, const_cast<int32_t*>(B->feat_nobs) + (size_t)w * B->max_feat,
+        const_cast<int32_t*>(B->feat_obs_begin) + (size_t)w * B->max_feat, const_cast<double*>(B->obs_xy) + (size_t)w * B->max_obs * 2,
+        B->inv_depth + (size_t)w * B->max_feat);
+    if (!ok) return -3;
+    const_cast<int32_t*>(B->n_feat)[w] = nf;
+  }
+  return 0;
 }
 
 }  // extern "C"

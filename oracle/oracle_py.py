@@ -190,3 +190,11 @@ def image_from_pointcloud(points, channels, num_cam=1):
     L.avmo_image_from_pointcloud.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.POINTER(C.c_float)), C.c_int, abi.c_ip, abi.c_ip, abi.c_dp]
     rc = L.avmo_image_from_pointcloud(n, pts.ctypes.data_as(C.POINTER(C.c_float)), arr, int(num_cam), abi.iptr(fid), abi.iptr(cam), abi.dptr(out))
     return rc, fid, cam, out
+
+
+def slide_window(win, flag, shift_depth=True, init_depth=5.0):
+    """Estimator::slideWindow on host WindowArrays, in place; returns the status (0, or -3 on sample-capacity overflow)."""
+    s = win.struct()
+    L = lib()
+    L.avmo_slide_window.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    return L.avmo_slide_window(C.byref(s), int(flag), int(bool(shift_depth)), float(init_depth))

@@ -517,3 +517,118 @@ def test_projection_td_factor_residual_and_fd_jacobian(oracle):
             scale = abs(args[3]) if blk == 3 else 1.0
             fd = (shifted(+1) - shifted(-1)) / (2 * eps * scale)
             assert np.abs(fd - J[k, :, col]).max() < 2e-5 * max(1.0, np.abs(J[k, :, col]).max()), (k, col)
+
+
+def _roll_inputs(B=4, seed=2):
+    """Windows whose tables look like a feature manager's: ragged tracks plus a few features that the solve would not
+    take (single observations, tracks starting in the last frames) and a few untriangulated depths."""
+    w = synth.make_windows(B, tracks="sparse", n_feat=60, max_feat=150, max_samp=40)
+    a = w.a
+    rng = np.random.default_rng(seed)
+    a["imu_n"][:] = rng.integers(5, 18, a["imu_n"].shape)
+    for b in range(B):
+        n, o = int(a["n_feat"][b]), int(a["feat_obs_begin"][b, a["n_feat"][b] - 1] + a["feat_nobs"][b, a["n_feat"][b] - 1])
+        extra = [(0, 1), (0, 2), (3, 1), (9, 1), (9, 2), (10, 1), (10, 1)]
+        for st, no in sorted(extra):                  # std::list order = non-decreasing start frame
+            a["feat_start"][b, n], a["feat_nobs"][b, n], a["feat_obs_begin"][b, n] = st, no, o
+            a["obs_xy"][b, o:o + no] = rng.normal(scale=0.3, size=(no, 2))
+            a["inv_depth"][b, n] = rng.uniform(0.1, 0.5)
+            n, o = n + 1, o + no
+        order = np.argsort(a["feat_start"][b, :n], kind="stable")
+        for k in ("feat_start", "feat_nobs", "feat_obs_begin", "inv_depth"):
+            a[k][b, :n] = a[k][b, :n][order]
+        a["n_feat"][b] = n
+        a["inv_depth"][b, 1:n:9] = -1.0                 # estimated_depth = -1: not triangulated yet
+        a["inv_depth"][b, 2:n:13] = -0.2                # a negative depth (solve_flag == 2 material)
+    return w
+
+
+def _roll_python(a, b, flag, shift_depth, INIT_DEPTH):
+    """Independent statement with Python lists: estimator.cpp:996-1107, feature_manager.cpp:275-352."""
+    def q2R(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    P = [a["pose"][b, i, :3].copy() for i in range(11)]
+    R = [q2R(a["pose"][b, i, 3:]) for i in range(11)]
+    poses = [a["pose"][b, i].copy() for i in range(11)]
+    sbs = [a["speedbias"][b, i].copy() for i in range(11)]
+    ric, tic = q2R(a["ex_pose"][b, 3:]), a["ex_pose"][b, :3]
+    feats = []
+    for e in range(a["n_feat"][b]):
+        ob, no = a["feat_obs_begin"][b, e], a["feat_nobs"][b, e]
+        feats.append(dict(start=int(a["feat_start"][b, e]), obs=[tuple(v) for v in a["obs_xy"][b, ob:ob + no]], depth=1.0 / a["inv_depth"][b, e]))
+    imu = [dict(dt=list(a["imu_dt"][b, j, :a["imu_n"][b, j]]), acc=[tuple(v) for v in a["imu_acc"][b, j, :a["imu_n"][b, j] + 1]],
+                gyr=[tuple(v) for v in a["imu_gyr"][b, j, :a["imu_n"][b, j] + 1]], ba=a["imu_lin_ba"][b, j].copy(), bg=a["imu_lin_bg"][b, j].copy())
+           for j in range(10)]
+    acc_0, gyr_0 = imu[9]["acc"][-1], imu[9]["gyr"][-1]
+    if flag == abi.MARGIN_OLD:
+        back_R0, back_P0 = R[0], P[0]
+        poses, sbs = poses[1:] + [poses[10]], sbs[1:] + [sbs[10]]
+        imu = imu[1:]
+        R1, P1 = R[1] @ ric, P[1] + R[1] @ tic
+        R0, P0 = back_R0 @ ric, back_P0 + back_R0 @ tic
+        out = []
+        for f in feats:
+            if f["start"] != 0:
+                f["start"] -= 1
+            else:
+                uv = np.array([*f["obs"].pop(0), 1.0])
+                if shift_depth:
+                    if len(f["obs"]) < 2:
+                        continue
+                    dep = (R1.T @ (R0 @ (uv * f["depth"]) + P0 - P1))[2]
+                    f["depth"] = dep if dep > 0 else INIT_DEPTH
+                elif len(f["obs"]) == 0:
+                    continue
+            out.append(f)
+        feats = out
+    else:
+        imu[8]["dt"] += imu[9]["dt"]; imu[8]["acc"] += imu[9]["acc"][1:]; imu[8]["gyr"] += imu[9]["gyr"][1:]
+        imu = imu[:9]
+        poses[9], sbs[9] = poses[10], sbs[10]
+        out = []
+        for f in feats:
+            if f["start"] == 10:
+                f["start"] = 9
+            elif f["start"] + len(f["obs"]) - 1 >= 9:
+                f["obs"].pop(9 - f["start"])
+                if not f["obs"]:
+                    continue
+            out.append(f)
+        feats = out
+    imu.append(dict(dt=[], acc=[acc_0], gyr=[gyr_0], ba=sbs[10][3:6], bg=sbs[10][6:9]))
+    return poses, sbs, imu, feats
+
+
+def check_roll(a, ref, b):
+    poses, sbs, imu, feats = ref
+    assert np.array_equal(a["pose"][b], np.array(poses)) and np.array_equal(a["speedbias"][b], np.array(sbs))
+    assert a["n_feat"][b] == len(feats)
+    for e, f in enumerate(feats):
+        ob, no = a["feat_obs_begin"][b, e], a["feat_nobs"][b, e]
+        assert (a["feat_start"][b, e], no) == (f["start"], len(f["obs"])), (b, e)
+        assert np.array_equal(a["obs_xy"][b, ob:ob + no], np.array(f["obs"]).reshape(-1, 2)), (b, e)
+        assert abs(a["inv_depth"][b, e] * f["depth"] - 1) < 1e-12, (b, e)
+    for j in range(10):
+        n = a["imu_n"][b, j]
+        assert n == len(imu[j]["dt"]) and np.array_equal(a["imu_dt"][b, j, :n], np.array(imu[j]["dt"]))
+        assert np.array_equal(a["imu_acc"][b, j, :n + 1], np.array(imu[j]["acc"])) and np.array_equal(a["imu_gyr"][b, j, :n + 1], np.array(imu[j]["gyr"]))
+        assert np.array_equal(a["imu_lin_ba"][b, j], imu[j]["ba"]) and np.array_equal(a["imu_lin_bg"][b, j], imu[j]["bg"])
+
+
+def test_window_roll_matches_python_lists(oracle):
+    """slideWindow + removeBackShiftDepth / removeBack / removeFront on the batch tables."""
+    for flag, shift in ((abi.MARGIN_OLD, True), (abi.MARGIN_OLD, False), (abi.MARGIN_SECOND_NEW, True)):
+        w = _roll_inputs()
+        ref = [_roll_python(w.a, b, flag, shift, 5.0) for b in range(w.n_windows)]
+        n0 = w.a["n_feat"].copy()
+        assert oracle.slide_window(w, flag, shift, 5.0) == 0
+        for b in range(w.n_windows):
+            check_roll(w.a, ref[b], b)
+        assert (w.a["n_feat"] < n0).all()            # every window erased something
+    # the re-anchored depth of a good track is the point's depth in the new first camera (positive, same 3-D point)
+    w = _roll_inputs()
+    w.a["imu_n"][:, 8], w.a["imu_n"][:, 9] = 30, 20
+    assert oracle.slide_window(w, abi.MARGIN_SECOND_NEW, True, 5.0) == -3    # 50 samples do not fit max_samp = 40
