@@ -1112,22 +1112,59 @@ AVM_NOINL void chol_diag_block(int c0, int nb) {
   __builtin_amdgcn_s_setprio(0);
 }
 
+// U_ij = A_ij - sum_{p < j} X_ip X_jp^T: the update of tile (ti, tj) by the panels [p_begin, p_end) at once (LEFT-looking),
+// accumulated in registers over the solved panels - 4 tj MFMAs on four independent chains - and ONE read-modify-write of the destination
+// (right-looking costs a destination round trip per panel, and the LDS write path is the slow one: ~70 B/clk).
+AVM_DEV void chol_left_tile(int ti, int tj, int p_begin, int p_end) {
+  constexpr int NR = NF + 1;
+  double* S = LDS() + L_S;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const dv2* pa = reinterpret_cast<const dv2*>(S + roff(min(16 * ti + lr, NR - 1)) + 4 * lk);
+  const dv2* pb = reinterpret_cast<const dv2*>(S + roff(min(16 * tj + lr, NF - 1)) + 4 * lk);
+  CholTile T;  // (destination part only)
+  {
+    const int gj = 16 * tj + lr;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int gi = 16 * ti + lk + 4 * r;
+      const bool ok = gi < NR && gj < NF && gj <= gi;
+      const int gic = min(gi, NR - 1);
+      const int ol = L_S + roff(gic) + min(gj, min(gic, NF - 1));
+      T.d[r] = LDS()[ol];
+      T.o[r] = ok ? ol : L_CDUMP + lane;
+    }
+  }
+  d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0}, D2 = {0, 0, 0, 0}, D3 = {0, 0, 0, 0};
+  const bool diag = ti == tj;
+#pragma unroll 2
+  for (int p = p_begin; p < p_end; p++) {
+    const dv2 a0 = pa[8 * p], a1 = pa[8 * p + 1];
+    dv2 b0 = a0, b1 = a1;
+    if (!diag) b0 = pb[8 * p], b1 = pb[8 * p + 1];
+    D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], D0, 0, 0, 0);
+    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], D1, 0, 0, 0);
+    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], D2, 0, 0, 0);
+    D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], D3, 0, 0, 0);
+  }
+  const d4 D = (D0 + D1) + (D2 + D3);
+#pragma unroll
+  for (int r = 0; r < 4; r++) LDS()[T.o[r]] = T.d[r] - D[r];
+}
+
 // In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
-// The right-hand side rides along as row NF of the packed storage, so the forward substitution
-// L z = b happens as part of the panel solves / trailing updates (z ends up in that row).
-// Right-looking, 8-column panels, with look-ahead:
-//   per panel:  (a) rows below the diagonal block (and the RHS row) are solved against its triangle,
-//                   one thread per row;
-//               (b) trailing update in 16x16 tiles on v_mfma_f64_16x16x4 (K = 8 -> 2 MFMAs per tile);
-//                   wavefront 0 takes the tile holding the next diagonal block first and immediately
-//                   factors that block in its registers (lane = row, pivots broadcast with v_readlane,
-//                   v_rsq_f64 + Newton) while the other wavefronts finish the remaining tiles.
+// The right-hand side rides along as row NF of the packed storage, so the forward substitution L z = b happens as part of
+// the factorization (z ends up in that row).  LEFT-looking by 16-column blocks, with look-ahead:
+//   P_j: panel solve of block column j, X_ij = U_ij L_jj^-T on the MFMA (L_jj^-T comes out of chol_diag_block); wavefront 0
+//        takes row block j + 1 first;
+//   Q_j: every tile (i, j + 1) receives its whole update sum_{p <= j} X_ip X_{j+1,p}^T at once (chol_left_tile); wavefront 0
+//        does the diagonal tile (j + 1, j + 1) and immediately factors it in its registers (chol_diag_block) while the
+//        others finish the rest of the column.
+// The critical path per block column is wavefront 0's: one row-block solve, one tile update, the 16-pivot chain.
 AVM_NOINL bool cholesky_lds(long long* prof) {
   struct { long long* prof; } c{prof};
   double* lds = LDS();
   double* S = lds + L_S;
-  double* dinv = lds + L_ST;
-  const int t = threadIdx.x, wv = t >> 6;
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, lr = lane & 15, lk = lane >> 4;
   constexpr int NB = CNB;
   constexpr int NR = NF + 1;  // rows incl. the augmented RHS row
   int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
@@ -1140,15 +1177,13 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
   PROF(c, 4);
   for (int c0 = 0; c0 < NF; c0 += NB) {
     const int nb = min(NB, NF - c0), c1 = c0 + nb;
-    // (a) panel solve X = A L^-T on the MFMA: one 16-row block per wavefront pass, B operand = L^-T (lds[L_WCH], left there
-    //     by chol_diag_block); rows below the block + the RHS row
+    // ---- P_j: X = U L^-T for the rows below the block (and the RHS row); B operand = L^-T (lds[L_CLT], left there by
+    //      chol_diag_block, stored times sqrt(d_c) per column: the pivots sit on the diagonal of the block)
     {
-      const int lane = t & 63, lr = lane & 15, lk = lane >> 4;
       const double* LT = lds + L_CLT;
       double bop[NB / 4];
 #pragma unroll
       for (int m = 0; m < NB / 4; m++) bop[m] = LT[(lk + 4 * m) * NB + lr];
-      // L^-T is stored times sqrt(d_c) per column (see chol_diag_block): the pivots sit on the diagonal of the block
       const int cc = c0 + min(lr, nb - 1);
       const double dc = S[roff(cc) + cc];
       if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront sees the same values
@@ -1164,9 +1199,12 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
         for (int m = 0; m < NB / 4; m++) aop[m] = pa[4 * m];  // past-the-row reads stay inside the LDS carve and are masked below
 #pragma unroll
         for (int m = 0; m < NB / 4; m++) aop[m] = (va && lk + 4 * m < nb) ? aop[m] : 0.0;
-        d4 D = {0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < NB / 4; m++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[m], bop[m], D, 0, 0, 0);
+        d4 Da = {0, 0, 0, 0}, Db = {0, 0, 0, 0};
+        Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], bop[0], Da, 0, 0, 0);
+        Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], bop[1], Db, 0, 0, 0);
+        Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], bop[2], Da, 0, 0, 0);
+        Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], bop[3], Db, 0, 0, 0);
+        const d4 D = Da + Db;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int gi = 16 * ti + lk + 4 * r;
@@ -1178,35 +1216,25 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
     PROF(c, 5);
     if (*s_fail) return false;
     if (c1 >= NF) break;
-    // (b) trailing update + look-ahead factorization of the next diagonal block
+    // ---- Q_j: block column j + 1 gets all its updates; look-ahead factorization of its diagonal block
     {
-      const int tm = c1 >> 4;            // first tile row/col with trailing entries
-      const int nt = 11 - tm;            // tile indices tm .. 10 (row 165 = RHS lives in tile row 10)
-      const int ntile = nt * (nt + 1) / 2;
+      const int tm = c1 >> 4;  // = j + 1
       if (wv == 0) {
         const long long q0 = clock64();
-        chol_trailing_tile(c0, tm, tm);
+        chol_left_tile(tm, tm, tm - 1, tm);  // the panels before the last one were applied a phase ago (below)
         wave_lds_sync();
         chol_diag_block(c1, min(NB, NF - c1));
         if (c.prof && t == 0) c.prof[28] += clock64() - q0;
       } else {
         const long long q0 = clock64();
-        // tiles 1 .. ntile-1 over wavefronts 1..7 (tile 0 = (tm,tm) belongs to wavefront 0), two tiles in flight
-        // per wavefront so the LDS latencies and the MFMA chains of the pair overlap
-        constexpr int NW = NT / 64 - 1;
-        for (int tile = wv; tile < ntile; tile += 2 * NW) {
-          int a0 = 0;
-          while ((a0 + 1) * (a0 + 2) / 2 <= tile) a0++;
-          const int b0 = tile - a0 * (a0 + 1) / 2;
-          const int tile1 = tile + NW;
-          if (tile1 < ntile) {
-            int a1 = a0;
-            while ((a1 + 1) * (a1 + 2) / 2 <= tile1) a1++;
-            const int b1 = tile1 - a1 * (a1 + 1) / 2;
-            chol_trailing_tile2(c0, tm + a0, tm + b0, tm + a1, tm + b1);
-          } else {
-            chol_trailing_tile(c0, tm + a0, tm + b0);
-          }
+        // items: tiles (tm + 1 .. 10, tm), then the early part of the NEXT diagonal tile (tm + 1, tm + 1): all panels solved
+        // so far, so that wavefront 0 only has to add one panel to it before it factors the block
+        const int nitem = (10 - tm) + (tm + 1 <= 10 ? 1 : 0);
+        for (int k = wv - 1; k < nitem; k += NT / 64 - 1) {
+          if (k < 10 - tm)
+            chol_left_tile(tm + 1 + k, tm, 0, tm);
+          else
+            chol_left_tile(tm + 1, tm + 1, 0, tm);
         }
         if (c.prof && t == 64) c.prof[27] += clock64() - q0;
       }
