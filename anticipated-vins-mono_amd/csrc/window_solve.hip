@@ -969,77 +969,16 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
 // diagonal block, a 16x16 identity, and a per-lane dump slot for the masked-out stores.
 constexpr int L_CLT = L_WCH, L_CID = L_WCH + 256, L_CDUMP = L_WCH + 512;
 
-// ---- trailing update S -= X X^T of one 16-column panel, in 16x16 tiles on v_mfma_f64_16x16x4 (K = 16 -> 4 MFMAs) ----
+// ---- tiles of the factorization, 16x16 on v_mfma_f64_16x16x4 --------------------------------------------------------
 // Everything is unconditional (a predicated LDS access compiles to a branch with its own s_waitcnt): operand rows are
 // clamped to the last valid row (the duplicates only reach outputs that are not stored), destination loads are clamped to
-// a valid address and masked-out stores go to a per-lane dump slot.  The k index of the product is a summation index, so
-// lane group lk takes columns c0 + 4 lk + {0..3}: two 16-byte loads per operand instead of four 8-byte ones.
+// a valid address and masked-out stores go to a per-lane dump slot.  The k index of a product is a summation index, so
+// lane group lk takes columns 4 lk + {0..3} of a 16-column block: two 16-byte loads per operand instead of four 8-byte ones.
 struct CholTile {
-  dv2 a[2], b[2];
   double d[4];
   int o[4];  // destination offsets (doubles from lds[0]); masked-out entries point at the dump slot
 };
 
-AVM_DEV void chol_tile_load(CholTile& T, int c0, int ti, int tj) {
-  constexpr int NR = NF + 1;
-  double* S = LDS() + L_S;
-  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-  const dv2* pa = reinterpret_cast<const dv2*>(S + roff(min(16 * ti + lr, NR - 1)) + c0 + 4 * lk);
-  const dv2* pb = reinterpret_cast<const dv2*>(S + roff(min(16 * tj + lr, NF - 1)) + c0 + 4 * lk);
-  T.a[0] = pa[0], T.a[1] = pa[1];
-  T.b[0] = pb[0], T.b[1] = pb[1];
-  const int gj = 16 * tj + lr;
-  const int dump = L_CDUMP + lane;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int gi = 16 * ti + lk + 4 * r;
-    const bool ok = gi < NR && gj < NF && gj <= gi;
-    const int gic = min(gi, NR - 1);
-    const int ol = L_S + roff(gic) + min(gj, min(gic, NF - 1));
-    T.d[r] = LDS()[ol];
-    T.o[r] = ok ? ol : dump;
-  }
-}
-
-AVM_DEV void chol_tile_store(const CholTile& T, const d4& D) {
-#pragma unroll
-  for (int r = 0; r < 4; r++) LDS()[T.o[r]] = T.d[r] - D[r];
-}
-
-#define AVM_TILE_MFMA(T, D)                                                   \
-  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[0][0], T.b[0][0], D, 0, 0, 0); \
-  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[0][1], T.b[0][1], D, 0, 0, 0); \
-  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[1][0], T.b[1][0], D, 0, 0, 0); \
-  D = __builtin_amdgcn_mfma_f64_16x16x4f64(T.a[1][1], T.b[1][1], D, 0, 0, 0);
-
-// two independent tiles at once (same panel): the LDS latencies and the MFMA chains of the pair overlap
-AVM_DEV void chol_trailing_tile2(int c0, int ti0, int tj0, int ti1, int tj1) {
-  CholTile T0, T1;
-  chol_tile_load(T0, c0, ti0, tj0);
-  chol_tile_load(T1, c0, ti1, tj1);
-  d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
-  AVM_TILE_MFMA(T0, D0)
-  AVM_TILE_MFMA(T1, D1)
-  chol_tile_store(T0, D0);
-  chol_tile_store(T1, D1);
-}
-
-AVM_DEV void chol_trailing_tile(int c0, int ti, int tj) {
-  CholTile T;
-  chol_tile_load(T, c0, ti, tj);
-  d4 D = {0, 0, 0, 0};
-  AVM_TILE_MFMA(T, D)
-  chol_tile_store(T, D);
-}
-
-// In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
-// The right-hand side rides along as row NF of the packed storage, so the forward substitution
-// L z = b happens as part of the panel solves / trailing updates (z ends up in that row).
-// Right-looking, 16-column panels:
-//   (1) the 16x16 diagonal block is factored in the registers of wavefront 0 (lane = row, pivots
-//       broadcast with v_readlane, one rsqrt per pivot), reciprocal pivots go to lds[L_ST];
-//   (2) the rows below (and the RHS row) are solved against that triangle, one thread per row;
-//   (3) the trailing matrix is updated tile by tile with v_mfma_f64_16x16x4 (K = 16 -> 4 MFMAs per tile).
 // raw v_rsq_f64 + two Newton steps (the library rsqrt spends ~3x as long in range handling we do not need:
 // pivots of an SPD matrix are normal positive numbers)
 AVM_DEV double fast_rsqrt(double x) {
