@@ -526,16 +526,24 @@ AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gin
     while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
     const int tj = tile - ti * (ti + 1) / 2;
     const int ca = 16 * ti + (lane & 15), cb = 16 * tj + (lane & 15);
+    // all 48 loads in flight (clamped to a valid element, masked afterwards: a predicated load is a branch with its own
+    // s_waitcnt), four independent MFMA chains
     double av[MAXPRIOR / 4], bv[MAXPRIOR / 4];
+    const int cac = min(ca, pn - 1), cbc = min(cb, pn - 1);
 #pragma unroll
     for (int m = 0; m < MAXPRIOR / 4; m++) {
-      const int r = 4 * m + (lane >> 4);
-      av[m] = (r < pn && ca < pn) ? pJ[(size_t)r * ldp + ca] : 0.0;
-      bv[m] = (r < pn && cb < pn) ? pJ[(size_t)r * ldp + cb] : 0.0;
+      const int r = min(4 * m + (lane >> 4), pn - 1);
+      av[m] = pJ[(size_t)r * ldp + cac];
+      bv[m] = pJ[(size_t)r * ldp + cbc];
     }
-    d4 D = {0, 0, 0, 0};
+    d4 Dq[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int m = 0; m < MAXPRIOR / 4; m++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[m], D, 0, 0, 0);
+    for (int m = 0; m < MAXPRIOR / 4; m++) {
+      const bool rv = 4 * m + (lane >> 4) < pn;
+      const double a = (rv && ca < pn) ? av[m] : 0.0, b = (rv && cb < pn) ? bv[m] : 0.0;
+      Dq[m & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, Dq[m & 3], 0, 0, 0);
+    }
+    const d4 D = (Dq[0] + Dq[1]) + (Dq[2] + Dq[3]);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int gi = 16 * ti + (lane >> 4) + 4 * r, gj = 16 * tj + (lane & 15);
