@@ -701,20 +701,36 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
 // The two 16-column accumulator tiles of J are, register for register, both the A operand (J^T) and the B operand
 // (J) of the Gram products, so nothing moves between the two steps.  Factors sharing a frame must not run
 // concurrently (the caller alternates even / odd factors).
-AVM_DEV double imu_factor_mfma(const WinCtx&, int i) {
+struct ImuOperands {
+  double ua[4], b0[4], b1[4];
+};
+// operands of factor i: clamped unconditional loads (issued for both factors of a wavefront before the first is used)
+AVM_DEV void imu_factor_load(int i, ImuOperands& o) {
   const WinCtx& c = lds_ctx();
-  double* lds = LDS();
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   gcdouble* U = c.psqrt + i * 225;                 // upper triangular, zeros stored below the diagonal
   gcdouble* raw = c.sc + Scratch::IJRAW + i * 465; // [15][31]: column 0 = residual, 1..30 = Jacobian
-  double ua[4], b0[4], b1[4];
+  const int lic = min(li, 14);
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-    const int k = lk + 4 * m;
-    ua[m] = (li < 15 && k < 15) ? U[li * 15 + k] : 0.0;
-    b0[m] = k < 15 ? raw[k * 31 + li] : 0.0;
-    b1[m] = (k < 15 && li < 15) ? raw[k * 31 + 16 + li] : 0.0;
+    const int k = min(lk + 4 * m, 14);
+    o.ua[m] = U[lic * 15 + k], o.b0[m] = raw[k * 31 + li], o.b1[m] = raw[k * 31 + 16 + lic];
   }
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const bool kv = lk + 4 * m < 15;
+    o.ua[m] = (li < 15 && kv) ? o.ua[m] : 0.0;
+    o.b0[m] = kv ? o.b0[m] : 0.0;
+    o.b1[m] = (kv && li < 15) ? o.b1[m] : 0.0;
+  }
+}
+
+AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
+  double* lds = LDS();
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  double ua[4], b0[4], b1[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) ua[m] = ops.ua[m], b0[m] = ops.b0[m], b1[m] = ops.b1[m];
   d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
 #pragma unroll
   for (int m = 0; m < 4; m++) {
@@ -728,35 +744,39 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i) {
     G10 = __builtin_amdgcn_mfma_f64_16x16x4f64(D1[m], D0[m], G10, 0, 0, 0);
     G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(D1[m], D1[m], G11, 0, 0, 0);
   }
-  // scatter: combined index 0 = residual, p + 1 = local column p
+  // scatter: combined index 0 = residual, p + 1 = local column p.  Branch-free: every lane computes the destination of
+  // its (up to) 12 entries - or its private dump slot in the scratch tile - then all reads, all adds, all writes
+  // (a predicated LDS read-modify-write is a branch with its own s_waitcnt; 16 of them in a row cost ~2K cycles).
   double half_rr = 0;
   const int ccol0 = li > 0 ? imu_col(i, li - 1) : -1;          // state column of combined column li
   const int ccol1 = li < 15 ? imu_col(i, 15 + li) : -1;        // ... of combined column 16 + li
+  const int dump = L_WCH + 512 + lane;
+  int off[12];
+  double val[12];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int R0 = lk + 4 * r;       // combined row in tile 0
     const int R1 = 16 + R0;          // combined row in tile 1 (31 = padding)
-    // G00: rows / columns 0..15
-    if (R0 == 0) {
-      if (li == 0) half_rr = 0.5 * G00[r];
-    } else if (li <= R0) {
-      const int sr = imu_col(i, R0 - 1);
-      if (li == 0)
-        lds[L_G + sr] += G00[r];
-      else
-        lds[L_S + roff(max(sr, ccol0)) + min(sr, ccol0)] += G00[r];
-    }
-    if (R1 < 31) {
-      const int sr = imu_col(i, R1 - 1);
-      // G10: rows 16..30, columns 0..15
-      if (li == 0)
-        lds[L_G + sr] += G10[r];
-      else
-        lds[L_S + roff(max(sr, ccol0)) + min(sr, ccol0)] += G10[r];
-      // G11: rows / columns 16..30, lower part
-      if (li < 15 && 16 + li <= R1) lds[L_S + roff(max(sr, ccol1)) + min(sr, ccol1)] += G11[r];
-    }
+    const int sr0 = imu_col(i, max(R0 - 1, 0)), sr1 = imu_col(i, min(R1 - 1, 29));
+    // G00: rows / columns 0..15, lower part; row 0 is the residual row (its (0,0) entry is r^T r)
+    if (R0 == 0 && li == 0) half_rr = 0.5 * G00[r];
+    const bool v00 = R0 > 0 && li <= R0;
+    off[3 * r] = !v00 ? dump : (li == 0 ? L_G + sr0 : L_S + roff(max(sr0, ccol0)) + min(sr0, ccol0));
+    val[3 * r] = G00[r];
+    // G10: rows 16..30, columns 0..15
+    const bool v10 = R1 < 31;
+    off[3 * r + 1] = !v10 ? dump : (li == 0 ? L_G + sr1 : L_S + roff(max(sr1, ccol0)) + min(sr1, ccol0));
+    val[3 * r + 1] = G10[r];
+    // G11: rows / columns 16..30, lower part
+    const bool v11 = R1 < 31 && li < 15 && 16 + li <= R1;
+    off[3 * r + 2] = !v11 ? dump : L_S + roff(max(sr1, ccol1)) + min(sr1, ccol1);
+    val[3 * r + 2] = G11[r];
   }
+  double cur[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) cur[q] = lds[off[q]];
+#pragma unroll
+  for (int q = 0; q < 12; q++) lds[off[q]] = cur[q] + val[q];
   return half_rr;
 }
 
@@ -853,12 +873,17 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   __syncthreads();
   PROF(c, 3);
   // ---- phase D: IMU factors on MFMA, one wavefront per factor; even factors then odd ones (neighbours share a frame)
-  for (int par = 0; par < 2; par++) {
-    if (wv < 5) {
-      const int i = 2 * wv + par;
-      if (c.psum[i] <= o.max_sum_dt) acc += imu_factor_mfma(c, i);
+  {
+    ImuOperands io[2];
+    if (wv < 5) imu_factor_load(2 * wv, io[0]), imu_factor_load(2 * wv + 1, io[1]);
+#pragma unroll
+    for (int par = 0; par < 2; par++) {
+      if (wv < 5) {
+        const int i = 2 * wv + par;
+        if (c.psum[i] <= o.max_sum_dt) acc += imu_factor_mfma(c, i, io[par]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   PROF(c, 7);
   // ---- phase E: prior  H += Hp (packed values + destinations prepared once per solve), g += J0^T r_p
