@@ -1358,12 +1358,19 @@ AVM_DEV void schur_macro_tile(const WinCtx&) {
 #pragma unroll
     for (int b = 0; b < NC; b++) {
       if (CB[b] > RB[a]) continue;
+      // branch-free: destination (or this lane's dump slot in the scratch tile), all reads, then all writes
+      int off[4];
+      double sc[4], cur[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int gi = 16 * RB[a] + lk + 4 * r, gj = 16 * CB[b] + li;
-        if (gi < NPOSE && gj <= gi) lds[L_S + roff(gi) + gj] -= scl[gi] * scl[gj] * D[a][b][r];
-        if (gi == NPOSE && gj < NPOSE) lds[L_S + roff(NF) + gj] -= scl[gj] * D[a][b][r];
+        const bool body = gi < NPOSE && gj <= gi, rhs = gi == NPOSE && gj < NPOSE;
+        off[r] = body ? L_S + roff(gi) + gj : (rhs ? L_S + roff(NF) + gj : L_WCH + 512 + (threadIdx.x & 63));
+        sc[r] = (body ? scl[min(gi, NPOSE - 1)] : 1.0) * scl[min(gj, NPOSE - 1)];
+        cur[r] = lds[off[r]];
       }
+#pragma unroll
+      for (int r = 0; r < 4; r++) lds[off[r]] = cur[r] - sc[r] * D[a][b][r];
     }
 }
 
