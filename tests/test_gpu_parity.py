@@ -329,6 +329,31 @@ def test_marginalization_parity(ctx, oracle, flag, tracks, nf):
         assert abs(cg - co) <= 1e-3 * co
 
 
+def test_marginalization_rank_deficient_amm_takes_the_eigen_path(ctx, oracle):
+    """Amm^+ of the marginalized pose0 / speed-bias0 block: the Cholesky fast path is only taken when no eigenvalue can be
+    below eps (trace(Amm^-1) < 1/eps).  Without a prior and with IMU factor 0 skipped (sum_dt > 10 s) the speed-bias of
+    frame 0 has no information at all: zero pivots -> eigen-decomposition with clamped eigenvalues, as in the reference."""
+    est_m = __import__("importlib").import_module("anticipated-vins-mono_amd.estimator")
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    w = synth.make_windows(2, tracks="dense", n_feat=60, max_feat=150, with_prior=False, max_samp=60)
+    w.a["imu_n"][:, 0] = 55
+    w.a["imu_dt"][:, 0, :55] = 0.2                       # 11 s: pre_integrations[1]->sum_dt > 10 -> factor skipped (estimator.cpp:705)
+    w.a["imu_acc"][:, 0, 1:56] = w.a["imu_acc"][:, 0, :1]
+    w.a["imu_gyr"][:, 0, 1:56] = 0.0
+    wg, wo = w.copy(), w.copy()
+    E.optimization(wg)
+    pg, po = E.last_marginalization_info, buffers.PriorOutArrays.alloc(2)
+    oracle.window_solve(o, wo, po, buffers.summary_alloc(2))
+    assert np.array_equal(pg.a["n"], po.a["n"]) and np.array_equal(pg.a["nblk"], po.a["nblk"])
+    for i in range(2):
+        n, Hg, gg, cg = _prior_quadratic(pg, i)
+        _, Ho, go, co = _prior_quadratic(po, i)
+        d = 1.0 / np.sqrt(np.maximum(np.diag(Ho), 1e-300))
+        assert np.isfinite(Hg).all() and rel(Hg, Ho) < 1e-5
+        assert rel(Hg * d[:, None] * d[None, :], Ho * d[:, None] * d[None, :]) < 2e-3
+
+
 def test_marginalization_keeps_old_prior_when_second_new_has_nothing_to_drop(ctx, oracle):
     est_m = __import__("importlib").import_module("anticipated-vins-mono_amd.estimator")
     o = abi.default_options()
