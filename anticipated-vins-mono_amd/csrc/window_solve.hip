@@ -1159,9 +1159,9 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
       const int cc = c0 + min(lr, nb - 1);
       const double dc = S[roff(cc) + cc];
       if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront sees the same values
-      const double isq = fast_rsqrt(dc);
+      const double isq = fast_rsqrt(dc);  // applied to the product's columns below: its latency hides under the loads and MFMAs
 #pragma unroll
-      for (int m = 0; m < NB / 4; m++) bop[m] = (lk + 4 * m < nb && lr < nb) ? bop[m] * isq : 0.0;
+      for (int m = 0; m < NB / 4; m++) bop[m] = (lk + 4 * m < nb && lr < nb) ? bop[m] : 0.0;
       for (int ti = (c1 >> 4) + wv; ti <= 10; ti += NT / 64) {
         const int row = 16 * ti + lr;
         const double* pa = S + roff(min(row, NR - 1)) + c0 + lk;
@@ -1176,7 +1176,7 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
         Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], bop[1], Db, 0, 0, 0);
         Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], bop[2], Da, 0, 0, 0);
         Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], bop[3], Db, 0, 0, 0);
-        const d4 D = Da + Db;
+        const d4 D = (Da + Db) * isq;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int gi = 16 * ti + lk + 4 * r;
