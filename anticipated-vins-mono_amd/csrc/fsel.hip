@@ -25,6 +25,7 @@ namespace avm {
 namespace {
 
 constexpr int FS_NT = 256;
+constexpr int FS_CPW = 4;  // candidates per wavefront in the Delta slices of the setup kernel
 
 struct FselDev {
   avm_fsel_batch b;  // device pointers
@@ -64,8 +65,10 @@ AVM_DEV quat slerp_eigen(quat a, double t, quat b) {
 
 // Delta_ell position blocks of one feature (calcInfoFromFeatures), written as dense T x T.
 // cam[h] (h = 1..H): t_WC (3), R of q_WC^-1 (9), R of (q_WC * q_IC)^-1 (9)  => 21 doubles per h
-AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* out /*T*T*/) {
-  const int T = 3 * H;
+// front part: per-frame blocks C_h (Ch, 6 per h), W = (sum C_h)^-1 (Wm); false if the feature is seen in no future frame
+// WAVE: called by all 64 lanes of a wavefront for the same feature - the nearest-neighbour search is split over the lanes
+template <bool WAVE>
+AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* Ch /*13*6*/, double* Wm /*9*/) {
   // findNNDepth: exact 1-NN, first strictly smaller distance wins
   double dep = 1.0;
   const int ncl = b.n_cloud ? b.n_cloud[p] : 0;
@@ -73,10 +76,29 @@ AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, do
     const double* cxy = b.cloud_xy + (size_t)p * b.max_cloud * 2;
     int best = 0;
     double bd = DBL_MAX;
-    for (int i = 0; i < ncl; i++) {
-      const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
-      const double d = dx * dx + dy * dy;
-      if (d < bd) bd = d, best = i;
+    if (WAVE) {
+      // lane l takes points l, l + 64, ...; then the lexicographic minimum of (distance, index) = the sequential loop's
+      // "first strictly smaller distance wins"
+      const int lane = threadIdx.x & 63;
+      best = ncl;
+      for (int i = lane; i < ncl; i += 64) {
+        const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
+        const double d = dx * dx + dy * dy;
+        if (d < bd) bd = d, best = i;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double od = __shfl_xor(bd, o, 64);
+        const int ob = __shfl_xor(best, o, 64);
+        if (od < bd || (od == bd && ob < best)) bd = od, best = ob;
+      }
+      if (best >= ncl) best = 0;  // (every distance was NaN / DBL_MAX: the sequential loop keeps index 0)
+    } else {
+      for (int i = 0; i < ncl; i++) {
+        const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
+        const double d = dx * dx + dy * dy;
+        if (d < bd) bd = d, best = i;
+      }
     }
     dep = b.cloud_depth[(size_t)p * b.max_cloud + best];
   }
@@ -88,8 +110,7 @@ AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, do
   const double* c1 = cam + 1 * 30;
   const v3 pell = mk3(c1[0], c1[1], c1[2]) + Rmul(c1 + 21, feat);
   int numVisible = 1;
-  double Ch[13 * 6];  // symmetric 3x3 per h: xx xy xz yy yz zz
-  for (int i = 0; i < H * 6; i++) Ch[i] = 0.0;
+  for (int i = 0; i < H * 6; i++) Ch[i] = 0.0;  // symmetric 3x3 per h: xx xy xz yy yz zz
   double E[6] = {0, 0, 0, 0, 0, 0};
   auto addC = [&](int hidx, v3 u, const double* Rinv2) {
     // Bh = skew(u) * Rinv2 ; C = Bh^T Bh
@@ -127,7 +148,6 @@ AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, do
   addC(0, fn, c1 + 12);
   // W = EtE^-1 (cofactors / det)
   const double a00 = E[0], a01 = E[1], a02 = E[2], a11 = E[3], a12 = E[4], a22 = E[5];
-  double Wm[9];
   {
     const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
     const double c10 = a12 * a02 - a01 * a22, c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12;
@@ -137,32 +157,40 @@ AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, do
     Wm[0] = id * c00, Wm[1] = id * c01, Wm[2] = id * c02, Wm[3] = id * c10, Wm[4] = id * c11, Wm[5] = id * c12, Wm[6] = id * c20,
     Wm[7] = id * c21, Wm[8] = id * c22;
   }
+  return true;
+}
+
+// block (i, j), 1 <= j <= i <= H, of Delta_ell = blkdiag(C_h) - [C_i W C_j^T] (and its mirror image), dense T x T
+AVM_DEV void feature_pair(const double* Ch, const double* Wm, int i, int j, int T, double* out) {
   auto full = [&](int hidx, double* M) {
     const double* C = Ch + hidx * 6;
     M[0] = C[0], M[1] = C[1], M[2] = C[2], M[3] = C[1], M[4] = C[3], M[5] = C[4], M[6] = C[2], M[7] = C[4], M[8] = C[5];
   };
-  for (int j = 1; j <= H; ++j) {
-    double Cj[9];
-    full(j - 1, Cj);
-    for (int i = j; i <= H; ++i) {
-      double Ci[9], CW[9], D[9];
-      full(i - 1, Ci);
-      mat3mul(Ci, Wm, CW);
-      // Dij = Ci * W * Cj^T
-      for (int a = 0; a < 3; a++)
-        for (int c = 0; c < 3; c++) D[a * 3 + c] = CW[a * 3] * Cj[c * 3] + CW[a * 3 + 1] * Cj[c * 3 + 1] + CW[a * 3 + 2] * Cj[c * 3 + 2];
-      for (int a = 0; a < 3; a++)
-        for (int c = 0; c < 3; c++) {
-          const int r = 3 * (i - 1) + a, q = 3 * (j - 1) + c;
-          if (i == j) {
-            out[r * T + q] = Ci[a * 3 + c] - D[a * 3 + c];
-          } else {
-            out[r * T + q] = -D[a * 3 + c];
-            out[q * T + r] = -D[a * 3 + c];
-          }
-        }
+  double Cj[9], Ci[9], CW[9], D[9];
+  full(j - 1, Cj);
+  full(i - 1, Ci);
+  mat3mul(Ci, Wm, CW);
+  // Dij = Ci * W * Cj^T
+  for (int a = 0; a < 3; a++)
+    for (int c = 0; c < 3; c++) D[a * 3 + c] = CW[a * 3] * Cj[c * 3] + CW[a * 3 + 1] * Cj[c * 3 + 1] + CW[a * 3 + 2] * Cj[c * 3 + 2];
+  for (int a = 0; a < 3; a++)
+    for (int c = 0; c < 3; c++) {
+      const int r = 3 * (i - 1) + a, q = 3 * (j - 1) + c;
+      if (i == j) {
+        out[r * T + q] = Ci[a * 3 + c] - D[a * 3 + c];
+      } else {
+        out[r * T + q] = -D[a * 3 + c];
+        out[q * T + r] = -D[a * 3 + c];
+      }
     }
-  }
+}
+
+// Delta_ell of one feature by one thread (the used subset; the candidates go one per wavefront, see fsel_setup_kernel)
+AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* out /*T*T*/) {
+  double Ch[13 * 6], Wm[9];
+  if (!feature_front<false>(b, p, cam, fx_, fy_, H, Ch, Wm)) return false;
+  for (int j = 1; j <= H; ++j)
+    for (int i = j; i <= H; ++i) feature_pair(Ch, Wm, i, j, 3 * H, out);
   return true;
 }
 
@@ -172,6 +200,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
   double* lds = reinterpret_cast<double*>(smem_raw);
   const avm_fsel_batch& b = A.b;
   const int p = blockIdx.x, t = threadIdx.x;
+  const int slice = blockIdx.y;  // 0: Omega, its partial factorization, the used features; >= 1: candidates [256 (slice-1), 256 slice)
   const int H = b.horizon, N = 9 * (H + 1), T = 3 * H;
   double* Om = lds;                 // N*N
   double* Wh = Om + N * N;          // [H+1][81] Omega_h (h>=1)
@@ -234,6 +263,39 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
     q2R(qwc, c + 21);                      // q_WC (frame k+1 back-projection)
   }
   __syncthreads();
+  if (slice > 0) {
+    // Delta of this slice's candidates (the camera frames above are all they need), FS_CPW candidates per wavefront: every
+    // lane runs the short front part (uniform), lane 0 parks C_h and W in LDS, then the H (H + 1) / 2 block pairs go one
+    // per lane - the T x T block is written by 64 lanes at once instead of 900 scattered stores from one thread.
+    const int lane = t & 63, wv = t >> 6;
+    double* wl = Om + wv * 96;  // (Omega's storage is unused in these slices)
+    const int npair = H * (H + 1) / 2;
+    for (int u = 0; u < FS_CPW; u++) {
+      const int k = ((slice - 1) * (FS_NT / 64) + wv) * FS_CPW + u;
+      if (k >= b.n_cand[p]) break;  // (wave-uniform)
+      const double* xy = b.cand_xy + ((size_t)p * b.max_cand + k) * 2;
+      double Ch[13 * 6], Wm[9];
+      const bool ok = feature_front<true>(b, p, cam, xy[0], xy[1], H, Ch, Wm);
+      if (ok) {
+        if (lane == 0) {
+          for (int i = 0; i < H * 6; i++) wl[i] = Ch[i];
+          for (int i = 0; i < 9; i++) wl[80 + i] = Wm[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double* out = A.delta + ((size_t)p * b.max_cand + k) * T * T;
+        for (int q = lane; q < npair; q += 64) {
+          int j = 1, rem = q;  // pairs in the order j = 1..H, i = j..H
+          while (rem >= H - j + 1) rem -= H - j + 1, j++;
+          feature_pair(wl, wl + 80, j + rem, j, T, out);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) A.valid[(size_t)p * b.max_cand + k] = ok, A.black[(size_t)p * b.max_cand + k] = 0;
+    }
+    return;
+  }
   for (int idx = t; idx < H * 81; idx += FS_NT) {  // Th = A^T W
     const int h = 1 + idx / 81, i = (idx % 81) / 9, j = idx % 9;
     double s = 0;
@@ -278,10 +340,28 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
     ld += log(d);
     for (int i = t; i < N; i += FS_NT) col[i] = (i > k || isp[i]) && i != k ? Om[i * N + k] / d : 0.0;
     __syncthreads();
-    for (int idx = t; idx < N * N; idx += FS_NT) {
-      const int i = idx / N, j = idx % N;
-      const double li = col[i], lj = col[j];
-      if (li != 0.0 && lj != 0.0) Om[idx] -= li * lj;
+    {
+      // two threads per row (no integer division by the runtime N); rows whose multiplier is zero are skipped as a whole
+      const int i = t >> 1;
+      const double li = i < N ? col[i] : 0.0;
+      if (li != 0.0) {
+        // unconditional (a zero multiplier subtracts an exact zero), eight columns in flight: a predicated LDS
+        // read-modify-write is a branch with its own s_waitcnt
+        double* row = Om + i * N;
+        for (int j0 = t & 1; j0 < N; j0 += 16) {
+          double rv[8], lj[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int j = min(j0 + 2 * u, N - 1);
+            rv[u] = row[j], lj[u] = col[j];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int j = j0 + 2 * u;
+            *(j < N ? row + j : red + (t & 63)) = rv[u] - li * lj[u];  // the tail goes to a dump slot
+          }
+        }
+      }
     }
     __syncthreads();
   }
@@ -296,19 +376,12 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
     A.nsel[p] = 0;
     A.done[p] = 0;
   }
-  // Delta of candidates and of the already-used subset
-  const int nc = b.n_cand[p], nu = b.n_used ? b.n_used[p] : 0;
-  for (int f = t; f < nc + nu; f += FS_NT) {
-    const bool isu = f >= nc;
-    const int k = isu ? f - nc : f;
-    const double* xy = isu ? b.used_xy + ((size_t)p * b.max_used + k) * 2 : b.cand_xy + ((size_t)p * b.max_cand + k) * 2;
-    double* out = isu ? A.delta_u + ((size_t)p * b.max_used + k) * T * T : A.delta + ((size_t)p * b.max_cand + k) * T * T;
-    for (int i = 0; i < T * T; i++) out[i] = 0.0;
-    const bool ok = feature_delta(b, p, cam, xy[0], xy[1], H, out);
-    if (isu)
-      A.valid_u[(size_t)p * b.max_used + k] = ok;
-    else
-      A.valid[(size_t)p * b.max_cand + k] = ok, A.black[(size_t)p * b.max_cand + k] = 0;
+  // Delta of the already-used subset (the candidates are done by the other slices of the grid).  feature_delta writes
+  // every entry of the T x T block unless it returns false, and an invalid feature's block is never read.
+  const int nu = b.n_used ? b.n_used[p] : 0;
+  for (int k = t; k < nu; k += FS_NT) {
+    const double* xy = b.used_xy + ((size_t)p * b.max_used + k) * 2;
+    A.valid_u[(size_t)p * b.max_used + k] = feature_delta(b, p, cam, xy[0], xy[1], H, A.delta_u + ((size_t)p * b.max_used + k) * T * T);
   }
   __syncthreads();
   // Omega += sum of Delta_used (ascending id order = input order)
@@ -326,59 +399,76 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
 }
 
 // ---- one greedy round: f_l = logdet(Omega + OmegaS + p_l Delta_l) for every live candidate ----
+AVM_DEV double fs_readlane_d(double v, int srclane) {  // srclane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// One candidate per wavefront, lane = row of the T x T matrix, registers = columns.  The factorization is the same
+// register-resident, square-root-free pivot chain as the solve's diagonal blocks (window_solve.hip, chol_diag_block):
+// pivots and column entries are broadcast through SGPRs with v_readlane (the previous version packed two candidates into
+// a wavefront and had to go through the LDS crossbar, ~930 ds_bpermute per pair), column j is divided by its pivot with
+// v_rcp_f64 + two Newton steps, and the rank-1 update of pivot j-1 is software-pipelined into the latency shadows of pivot
+// j's reciprocal chain.  logdet = sum_j log(d_j) over the LDL^T pivots (Utility::logdet sums log(diag(L)) of L L^T:
+// diag(L)_j = sqrt(d_j)); the logarithms are taken afterwards by all lanes at once and added up in pivot order.
 template <int T>
 __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int round) {
-  constexpr int PER_WAVE = (T <= 32) ? 2 : 1;
-  constexpr int HALF = (T <= 32) ? 32 : 64;
   const avm_fsel_batch& b = A.b;
   const int p = blockIdx.y;
   const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
   if (round >= kappa || A.done[p]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int sub = lane / HALF, row = lane % HALF;
-  const int l = (blockIdx.x * (FS_NT / 64) + wv) * PER_WAVE + sub;
+  const int l = blockIdx.x * (FS_NT / 64) + wv;  // (wave-uniform)
   const int nc = b.n_cand[p];
-  const bool live = l < nc && A.valid[(size_t)p * b.max_cand + l] && !A.black[(size_t)p * b.max_cand + l];
-  // whole (half-)wave idle?
-  if (__ballot(live) == 0) return;
-  const double pr = live ? b.cand_prob[(size_t)p * b.max_cand + l] : 0.0;
+  if (!(l < nc && A.valid[(size_t)p * b.max_cand + l] && !A.black[(size_t)p * b.max_cand + l])) return;
+  const double pr = b.cand_prob[(size_t)p * b.max_cand + l];
   const double* C = A.C + (size_t)p * T * T;
-  const double* D = A.delta + ((size_t)p * b.max_cand + (live ? l : 0)) * T * T;
-  const int r = row < T ? row : T - 1;
-  double Ar[T];
+  const double* D = A.delta + ((size_t)p * b.max_cand + l) * T * T;
+  const int r = lane < T ? lane : T - 1;
+  double a[T];
 #pragma unroll
-  for (int k = 0; k < T; k++) Ar[k] = C[r * T + k] + pr * D[r * T + k];
+  for (int k = 0; k < T; k++) a[k] = C[r * T + k] + pr * D[r * T + k];
   // Hadamard upper bound (sortedlogDetUB): sum of log of the diagonal of Omega + OmegaS + p Delta
-  double ubt = (row < T) ? log(A.dpp[(size_t)p * T + r] + pr * D[r * T + r]) : 0.0;
+  double ubt = (lane < T) ? log(A.dpp[(size_t)p * T + r] + pr * D[r * T + r]) : 0.0;
 #pragma unroll
-  for (int o = HALF / 2; o > 0; o >>= 1) ubt += __shfl_xor(ubt, o, 64);
-  // in-register Cholesky, lane = row.  The pivot chain carries only a reciprocal square root (v_rsq_f64 + two
-  // Newton steps); the logarithms of the diagonal are taken afterwards by all lanes at once and added up in
-  // pivot order.  (Utility::logdet sums log(diag(L)); parity is on the selected ids)
-  // The loop is bound by the LDS crossbar: ~2 T^2 / 2 ds_bpermute per candidate pair.
-  double myd = 1.0;  // lane j keeps the pivot d_jj
+  for (int o = 32; o > 0; o >>= 1) ubt += __shfl_xor(ubt, o, 64);
+  double myd = 1.0, uprev = 0.0;  // lane j keeps the pivot d_jj
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < T; j++) {
-    const double djj = __shfl(Ar[j], j, HALF);
+    if (j > 0) a[j] = fma(-uprev, fs_readlane_d(a[j - 1], j), a[j]);
+    const double djj = fs_readlane_d(a[j], j);
     if (!(djj > 0.0)) bad = true;
-    if (row == j) myd = djj;
-    double inv = __builtin_amdgcn_rsq(djj);
-    inv = inv * (1.5 - (0.5 * djj) * inv * inv);
-    inv = inv * (1.5 - (0.5 * djj) * inv * inv);
-    const double lij = Ar[j] * inv;
-#pragma unroll
-    for (int k = j + 1; k < T; k++) {
-      const double lkj = __shfl(lij, k, HALF);
-      Ar[k] -= lij * lkj;
-    }
+    myd = lane == j ? djj : myd;
+    double y = __builtin_amdgcn_rcp(djj), e = 0;
+    constexpr int NS = (T + 3) / 5;  // tail elements per slot (5 slots)
+#define AVM_FS_TAIL(slot)                                                                                  \
+  if (j > 0) {                                                                                             \
+    double sk[NS];                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < NS; q++) sk[q] = fs_readlane_d(a[j - 1], min(j + 1 + (slot) + 5 * q, T - 1)); \
+    _Pragma("unroll") for (int q = 0; q < NS; q++)                                                         \
+      if (j + 1 + (slot) + 5 * q < T) a[j + 1 + (slot) + 5 * q] = fma(-uprev, sk[q], a[j + 1 + (slot) + 5 * q]); \
+  }
+    AVM_FS_TAIL(0)
+    e = fma(-djj, y, 1.0);
+    AVM_FS_TAIL(1)
+    y = fma(y, e, y);
+    AVM_FS_TAIL(2)
+    e = fma(-djj, y, 1.0);
+    AVM_FS_TAIL(3)
+    y = fma(y, e, y);
+    AVM_FS_TAIL(4)
+#undef AVM_FS_TAIL
+    uprev = a[j] * y;
   }
   // log(sqrt(d_jj)) per lane, then the sum in pivot order (same order as a sequential accumulation)
-  const double mylog = (row < T && myd > 0.0) ? 0.5 * log(myd) : 0.0;
+  const double mylog = (lane < T && myd > 0.0) ? 0.5 * log(myd) : 0.0;
   double ld = 0;
 #pragma unroll
-  for (int j = 0; j < T; j++) ld += __shfl(mylog, j, HALF);
-  if (live && row == 0) {
+  for (int j = 0; j < T; j++) ld += fs_readlane_d(mylog, j);
+  if (lane == 0) {
     const double f = bad ? __builtin_nan("") : (A.consts[(size_t)p * 4] + 2.0 * ld);
     A.fval[(size_t)p * b.max_cand + l] = f;
     A.ub[(size_t)p * b.max_cand + l] = A.consts[(size_t)p * 4 + 1] + ubt;
@@ -466,10 +556,11 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   const size_t lds = fsel_setup_lds_bytes(H);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fsel_setup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems), dim3(FS_NT), lds, stream, d);
+  const int cand_per_wg = (FS_NT / 64) * FS_CPW;
+  hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems, 1 + (b.max_cand + cand_per_wg - 1) / cand_per_wg), dim3(FS_NT), lds, stream, d);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (!run_rounds) return hipSuccess;
-  const int per_block = (FS_NT / 64) * (T <= 32 ? 2 : 1);
+  const int per_block = FS_NT / 64;  // one candidate per wavefront
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
   for (int r = 0; r < b.max_features; r++) {
     switch (T) {
