@@ -1108,7 +1108,7 @@ AVM_DEV void chol_left_tile(int ti, int tj, int p_begin, int p_end) {
   }
   d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0}, D2 = {0, 0, 0, 0}, D3 = {0, 0, 0, 0};
   const bool diag = ti == tj;
-#pragma unroll 2
+#pragma unroll 1
   for (int p = p_begin; p < p_end; p++) {
     const dv2 a0 = pa[8 * p], a1 = pa[8 * p + 1];
     dv2 b0 = a0, b1 = a1;
