@@ -170,6 +170,18 @@ def test_window_solve_parity(estimator, oracle, tracks, nf):
     assert (sg["final_cost"] < 1e-3 * sg["initial_cost"]).all()
 
 
+def test_window_solve_parity_over_many_windows(estimator, oracle):
+    """A wider sweep than the fixed cases: 48 different windows (three id ranges, both track shapes, with and without
+    prior): identical iteration / accept traces and termination, states within the north-star tolerance."""
+    worst = 0.0
+    for first_id, tracks, nf, prior in ((1000, "sparse", 90, True), (2000, "dense", 150, True), (3000, "sparse", 150, False)):
+        w = synth.make_windows(16, first_id=first_id, tracks=tracks, n_feat=nf, max_feat=150, with_prior=prior)
+        wg, wo, sg, so = _solve_both(estimator, oracle, w)
+        _assert_state_parity(wg, wo, sg, so)
+        worst = max(worst, rel(wg.a["pose"], wo.a["pose"]))
+    assert worst < 1e-8, worst  # measured ~1e-10; the contract is 1e-6
+
+
 def test_window_solve_without_prior_and_mixed_batch(estimator, oracle):
     a = synth.make_windows(2, tracks="sparse", n_feat=40, max_feat=150, with_prior=False)
     b = synth.make_windows(2, first_id=7, tracks="dense", n_feat=100, max_feat=150)
