@@ -429,6 +429,17 @@ def test_selector_information_and_ids(selector, oracle, H, nc, nu, mf, P):
     assert rel(out.a["fvalues"][0, :n], oo.a["fvalues"][0, :n]) < 1e-9
 
 
+def test_selector_ids_over_many_frames(selector, oracle):
+    """24 different frames (three horizons): selected ids identical to the oracle's, in selection order."""
+    for H, nc, mf in ((10, 200, 60), (5, 150, 50), (13, 120, 30)):
+        pr = synth.make_fsel(8, horizon=H, n_cand=nc, n_used=4, max_features=mf)
+        out = selector.select_batch(pr)
+        oo = buffers.FselOutArrays.alloc(8, mf)
+        oracle.fsel_select(pr, oo, n_threads=8)
+        assert np.array_equal(out.a["n_selected"], oo.a["n_selected"]) and (oo.a["n_selected"] > 0).all()
+        assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+
+
 def test_depth_cloud_matches_oracle(selector, oracle):
     """B8 (first half): FeatureSelector::initKDTree's cloud on device; it then feeds select() unchanged."""
     B = 5
