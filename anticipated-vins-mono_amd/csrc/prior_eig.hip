@@ -59,15 +59,18 @@ __device__ __forceinline__ double nrm_rsqrt(double x) {
   return y;
 }
 
-// lane i <- lane i+1 (the last lane keeps its own value)
-__device__ __forceinline__ int shl_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+// Wavefront shifts with bound_ctrl: a lane without a source gets 0 - exactly what the column exchange wants (the lanes
+// beyond the last pair hold zero columns), and no "old value" register has to be set up in front of every DPP move.
+// lane i <- lane i+1 (the last lane gets 0)
 __device__ __forceinline__ double shl_d(double v) {
-  return __hiloint2double(shl_i(__double2hiint(v)), shl_i(__double2loint(v)));
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
-// lane i <- v of lane i-1; lane 0 gets `keep`
-__device__ __forceinline__ double shr_into(double keep, double v) {
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), 0x138, 0xf, 0xf, false);
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), 0x138, 0xf, 0xf, false);
+// lane i <- lane i-1 (lane 0 gets 0)
+__device__ __forceinline__ double shr_d(double v) {
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
       step(X, Y, nX, nY, false);
       // odd step: positions (2k-1, 2k) = (Y of lane k-1, X of lane k); positions 0 and ne-1 sit out
 #pragma unroll
-      for (int r = 0; r < RW; r++) Y[r] = shr_into(0.0, Y[r]);
-      nY = shr_into(0.0, nY);
+      for (int r = 0; r < RW; r++) Y[r] = shr_d(Y[r]);
+      nY = shr_d(nY);
       step(Y, X, nY, nX, lane == 0 || lane == np);
 #pragma unroll
       for (int r = 0; r < RW; r++) Y[r] = shl_d(Y[r]);
