@@ -146,6 +146,97 @@ def test_solver_decreases_cost_and_is_deterministic(oracle, opt, tracks, nf):
     assert np.abs(a.a["pose"] - w.a["pose"]).max() > 1e-3
 
 
+def test_first_iteration_step_matches_dense_numpy_normal_equations(oracle):
+    """Pins the oracle's linear path (Jacobi scaling, LM diagonal, Schur elimination of the inverse depths, Cholesky, the
+    Gauss-Newton branch of the dogleg, Plus) against a dense numpy statement of Ceres' first trust-region iteration built
+    only from the per-factor residuals / Jacobians (which the golden vectors pin): (H' + mu D^2) y = g' on the full
+    315-column system, x <- Plus(x, -S y).  Compared on gauge-invariant quantities, because the post-solve yaw / position
+    alignment of double2vector moves the absolute poses."""
+    o = abi.default_options()
+    o.marginalization_flag = abi.MARGIN_NONE
+    o.max_num_iterations = 1
+    o.initial_trust_region_radius = 1e6   # keeps the Gauss-Newton step inside the region (checked below): no dogleg blend
+    w = synth.make_windows(2, tracks="sparse", n_feat=40, max_feat=150)
+    f = oracle.eval_factors(o, w, apply_loss=True)
+    ws = w.copy()
+    summ = buffers.summary_alloc(2)
+    oracle.window_solve(o, ws, None, summ)
+
+    def q2R(q):  # x y z w
+        x, y, z, ww = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)],
+                         [2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)],
+                         [2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)]])
+
+    def qmul(a, b):  # x y z w
+        ax, ay, az, aw = a
+        bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+    for b in range(2):
+        a = w.a
+        nf = int(a["n_feat"][b])
+        NF = 165
+        rows_J, rows_r = [], []
+        for e in range(nf):
+            st, no, ob = a["feat_start"][b, e], a["feat_nobs"][b, e], a["feat_obs_begin"][b, e]
+            for k in range(1, no):
+                J = np.zeros((2, NF + nf))
+                Jf = f["proj_J"][b, ob + k]
+                J[:, 6 * st:6 * st + 6], J[:, 6 * (st + k):6 * (st + k) + 6], J[:, NF + e] = Jf[:, :6], Jf[:, 6:12], Jf[:, 12]
+                rows_J.append(J), rows_r.append(f["proj_r"][b, ob + k])
+        for i in range(10):
+            J = np.zeros((15, NF + nf))
+            Jf = f["imu_J"][b, i]
+            J[:, 6 * i:6 * i + 6], J[:, 66 + 9 * i:66 + 9 * i + 9] = Jf[:, :6], Jf[:, 6:15]
+            J[:, 6 * (i + 1):6 * (i + 1) + 6], J[:, 66 + 9 * (i + 1):66 + 9 * (i + 1) + 9] = Jf[:, 15:21], Jf[:, 21:30]
+            rows_J.append(J), rows_r.append(f["imu_r"][b, i])
+        n = int(a["prior_n"][b])
+        Jp, off = np.zeros((n, NF + nf)), 0
+        for k in range(int(a["prior_nblk"][b])):
+            kind, fr = a["prior_blk_kind"][b, k], a["prior_blk_frame"][b, k]
+            sz = 9 if kind == abi.BLK_SPEEDBIAS else 6
+            if kind == abi.BLK_POSE:
+                Jp[:, 6 * fr:6 * fr + 6] = a["prior_J"][b, :n, off:off + 6]
+            elif kind == abi.BLK_SPEEDBIAS:
+                Jp[:, 66 + 9 * fr:66 + 9 * fr + 9] = a["prior_J"][b, :n, off:off + 9]
+            off += sz                                   # (ex_pose: constant in the solve, no columns)
+        rows_J.append(Jp), rows_r.append(f["prior_res"][b, :n])
+        J, r = np.vstack(rows_J), np.concatenate(rows_r)
+        # (the reported cost is sum 1/2 rho(|r|^2); the corrected residuals only reproduce it to first order in the loss)
+        assert abs(0.5 * r @ r - summ[b]["initial_cost"]) < 1e-4 * summ[b]["initial_cost"]
+        H, g = J.T @ J, J.T @ r
+        S = 1.0 / (1.0 + np.sqrt(np.diag(H)))          # Jacobi scaling
+        Hs, gs = H * S[:, None] * S[None, :], g * S
+        D2 = np.clip(np.diag(Hs), o.min_lm_diagonal, o.max_lm_diagonal)
+        y = np.linalg.solve(Hs + 1e-8 * np.diag(D2), gs)   # DoglegStrategy: mu = min_mu = 1e-8 regularizes the Gauss-Newton solve
+        assert np.sqrt(np.sum(D2 * y * y)) < o.initial_trust_region_radius   # Gauss-Newton step inside the region
+        dx = -S * y
+        # Plus
+        pose = a["pose"][b].copy()
+        for i in range(11):
+            d = dx[6 * i:6 * i + 6]
+            pose[i, :3] += d[:3]
+            q = qmul(pose[i, 3:], np.array([d[3] / 2, d[4] / 2, d[5] / 2, 1.0]))
+            pose[i, 3:] = q / np.linalg.norm(q)
+        sbias = a["speedbias"][b] + dx[66:165].reshape(11, 9)
+        lam = a["inv_depth"][b, :nf] + dx[NF:]
+        assert summ[b]["num_successful"] == 1
+        got = ws.a
+        assert rel(got["inv_depth"][b, :nf], lam) < 1e-7
+        assert rel(got["speedbias"][b, :, 3:], sbias[:, 3:]) < 1e-7          # biases (the velocities are rotated by the gauge fix)
+        R0n, R0g = q2R(pose[0, 3:]), q2R(got["pose"][b, 0, 3:])
+        reln = np.array([R0n.T @ (pose[i, :3] - pose[0, :3]) for i in range(11)])
+        relg = np.array([R0g.T @ (got["pose"][b, i, :3] - got["pose"][b, 0, :3]) for i in range(11)])
+        assert rel(relg, reln) < 1e-7
+        for i in range(1, 11):
+            assert np.abs(R0g.T @ q2R(got["pose"][b, i, 3:]) - R0n.T @ q2R(pose[i, 3:])).max() < 1e-8
+        veln = np.array([R0n.T @ sbias[i, :3] for i in range(11)])
+        velg = np.array([R0g.T @ got["speedbias"][b, i, :3] for i in range(11)])
+        assert rel(velg, veln) < 1e-7
+
+
 def test_small_trust_region_exercises_dogleg_and_rejections(oracle):
     o = abi.default_options()
     o.marginalization_flag = abi.MARGIN_NONE
