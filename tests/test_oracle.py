@@ -381,6 +381,40 @@ def test_selector_properties(oracle):
     assert nld > 0
 
 
+def test_greedy_selection_matches_numpy_brute_force(oracle):
+    """Pins selectInformativeFeatures (feature_selector.cpp:613-686) and the hoists of the restatement (reduced position
+    system, Hadamard bound ordering) against a brute-force numpy greedy: every round, slogdet of the FULL 9(H+1) x 9(H+1)
+    matrix Omega + OmegaS + p Delta for every remaining candidate, arg max."""
+    for H, nc, mf in ((3, 25, 8), (5, 30, 10)):
+        pr = synth.make_fsel(2, horizon=H, n_cand=nc, n_used=0, max_features=mf)
+        om, dl, va = oracle.fsel_information(pr)
+        out = buffers.FselOutArrays.alloc(2, mf)
+        oracle.fsel_select(pr, out)
+        N, T = 9 * (H + 1), 3 * H
+        pos = np.array([9 * (1 + i // 3) + i % 3 for i in range(T)])          # position rows of horizon states 1..H
+        for p in range(2):
+            M = om[p].copy()
+            live = [c for c in range(nc) if va[p, c]]
+            ids, fvals = [], []
+            for _ in range(mf):
+                best, bf = None, -1.0
+                for c in live:
+                    Mc = M.copy()
+                    Mc[np.ix_(pos, pos)] += pr.a["cand_prob"][p, c] * dl[p, c]
+                    sign, ld = np.linalg.slogdet(Mc)
+                    assert sign > 0
+                    if ld > bf:
+                        best, bf = c, ld
+                if best is None:
+                    break
+                M[np.ix_(pos, pos)] += pr.a["cand_prob"][p, best] * dl[p, best]
+                live.remove(best)
+                ids.append(int(pr.a["cand_id"][p, best])), fvals.append(bf)
+            n = int(out.a["n_selected"][p])
+            assert n == len(ids) and out.a["selected_ids"][p, :n].tolist() == ids
+            assert rel(out.a["fvalues"][p, :n], np.array(fvals)) < 1e-10
+
+
 def test_selector_kappa_zero_and_empty_cloud(oracle):
     pr = synth.make_fsel(1, horizon=3, n_cand=10, n_used=4, max_features=4, n_cloud=0)
     out = buffers.FselOutArrays.alloc(1, 4)
