@@ -381,6 +381,135 @@ def test_selector_properties(oracle):
     assert nld > 0
 
 
+def test_horizon_imu_information_matches_numpy(oracle):
+    """Pins calcInfoFromRobotMotion + createLinearImuMatrices + addOmegaPrior (feature_selector.cpp:463-609) against a numpy
+    statement built from Eigen's documented slerp and a dense inverse of the covariance of eq. (52)."""
+    def q2R(q):  # x y z w
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def slerp(qa, qb, t):
+        d = float(qa @ qb)
+        ad = abs(d)
+        if ad >= 1.0 - np.finfo(float).eps:
+            s0, s1 = 1.0 - t, t
+        else:
+            th = np.arccos(ad)
+            s0, s1 = np.sin((1.0 - t) * th) / np.sin(th), np.sin(t * th) / np.sin(th)
+        if d < 0:
+            s1 = -s1
+        return s0 * qa + s1 * qb
+
+    H = 4
+    pr = synth.make_fsel(3, horizon=H, n_cand=8, n_used=0, n_cloud=4, max_features=4)
+    om, _, _ = oracle.fsel_information(pr)
+    a, sc = pr.a, pr.scalars
+    I3 = np.eye(3)
+    for p in range(3):
+        n, dt = int(a["nr_imu"][p]), float(a["delta_imu"][p])
+        Om = np.zeros((9 * (H + 1), 9 * (H + 1)))
+        for h in range(1, H + 1):
+            qi, qj = a["hor_quat"][p, h - 1], a["hor_quat"][p, h]
+            Nij, Mij, c11, c12 = np.zeros((3, 3)), np.zeros((3, 3)), 0.0, 0.0
+            for i in range(n):
+                R = q2R(slerp(qi, qj, i / n))
+                jkh = n - i - 0.5
+                Nij += jkh * R
+                Mij += R
+                c11 += jkh * jkh
+                c12 += jkh
+            cov = np.zeros((9, 9))
+            cov[0:3, 0:3] = I3 * n * c11 * dt ** 4 * sc["acc_var"]
+            cov[0:3, 3:6] = cov[3:6, 0:3] = I3 * c12 * dt ** 3 * sc["acc_var"]
+            cov[3:6, 3:6] = I3 * n * dt ** 2 * sc["acc_var"]
+            cov[6:9, 6:9] = I3 * n * sc["acc_bias_var"]
+            W = np.linalg.inv(cov)
+            A = -np.eye(9)
+            A[0:3, 3:6] = -I3 * n * dt
+            A[0:3, 6:9] = Nij * dt * dt
+            A[3:6, 6:9] = Mij * dt
+            lo, hi = slice(9 * (h - 1), 9 * h), slice(9 * h, 9 * (h + 1))
+            Om[lo, lo] += A.T @ W @ A
+            Om[lo, hi] += A.T @ W
+            Om[hi, lo] += W @ A
+            Om[hi, hi] += W
+        Om[:9, :9] += np.eye(9)
+        assert rel(om[p], Om) < 1e-10
+        assert np.abs(om[p] - om[p].T).max() <= 1e-9 * np.abs(om[p]).max()
+
+
+def test_feature_information_matches_numpy(oracle):
+    """Pins calcInfoFromFeatures (feature_selector.cpp:239-365; PinholeCamera::spaceToPlane / distortion, inFOV, findNNDepth)
+    against an independent numpy statement, candidate by candidate: validity and the 3H x 3H position blocks of Delta."""
+    def q2R(q):  # x y z w
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    H = 5
+    pr = synth.make_fsel(2, horizon=H, n_cand=50, n_used=0, n_cloud=30, max_features=10)
+    om, dl, va = oracle.fsel_information(pr)
+    a, sc = pr.a, pr.scalars
+    Ric, tic = q2R(np.asarray(sc["q_ic"], float)), np.asarray(sc["t_ic"], float)
+    n_valid = 0
+    for p in range(2):
+        Rw = [q2R(a["hor_quat"][p, h]) for h in range(H + 1)]
+        tWC = [a["hor_pos"][p, h] + Rw[h] @ tic for h in range(H + 1)]
+        RWC = [Rw[h] @ Ric for h in range(H + 1)]
+        for c in range(int(a["n_cand"][p])):
+            x, y = a["cand_xy"][p, c]
+            d = 1.0
+            ncl = int(a["n_cloud"][p])
+            if ncl:
+                dist = ((a["cloud_xy"][p, :ncl] - [x, y]) ** 2).sum(1)
+                d = a["cloud_depth"][p, int(np.argmin(dist))]      # first minimum, like the strict '<' scan
+            fn = np.array([x, y, 1.0]) / np.linalg.norm([x, y, 1.0])
+            pell = tWC[1] + RWC[1] @ (fn * d)
+            Ch, EtE, nvis = {}, np.zeros((3, 3)), 1
+            for h in range(2, H + 1):
+                u = RWC[h].T @ (pell - tWC[h])
+                u = u / np.linalg.norm(u)
+                xu, yu = u[0] / u[2], u[1] / u[2]
+                r2 = xu * xu + yu * yu
+                rad = sc["k1"] * r2 + sc["k2"] * r2 * r2
+                dx = xu * rad + 2 * sc["p1"] * xu * yu + sc["p2"] * (r2 + 2 * xu * xu)
+                dy = yu * rad + 2 * sc["p2"] * xu * yu + sc["p1"] * (r2 + 2 * yu * yu)
+                px, py = sc["fx"] * (xu + dx) + sc["cx"], sc["fy"] * (yu + dy) + sc["cy"]
+                iu, iv = int(np.floor(abs(px) + 0.5) * np.sign(px)), int(np.floor(abs(py) + 0.5) * np.sign(py))   # std::round
+                if not (0 <= iu < sc["image_width"] and 0 <= iv < sc["image_height"]):
+                    continue
+                Bh = skew(u) @ (RWC[h] @ Ric).T          # (q_WC_h * q_IC)^-1: q_IC applied twice, as in the reference
+                Ch[h] = Bh.T @ Bh
+                EtE += Ch[h]
+                nvis += 1
+            assert bool(va[p, c]) == (nvis > 1), (p, c)
+            if nvis == 1:
+                continue
+            B1 = skew(fn) @ (RWC[1] @ Ric).T
+            Ch[1] = B1.T @ B1
+            EtE += Ch[1]
+            W = np.linalg.inv(EtE)
+            D = np.zeros((3 * H, 3 * H))
+            for j in range(1, H + 1):
+                for i in range(j, H + 1):
+                    Ci, Cj = Ch.get(i, np.zeros((3, 3))), Ch.get(j, np.zeros((3, 3)))
+                    Dij = Ci @ W @ Cj.T
+                    if i == j:
+                        D[3 * (i - 1):3 * i, 3 * (j - 1):3 * j] = Ci - Dij
+                    else:
+                        D[3 * (i - 1):3 * i, 3 * (j - 1):3 * j] = -Dij
+                        D[3 * (j - 1):3 * j, 3 * (i - 1):3 * i] = -Dij.T
+            assert np.abs(dl[p, c] - D).max() < 1e-9 * max(1.0, np.abs(D).max()), (p, c)
+            n_valid += 1
+    assert n_valid > 20
+
+
 def test_greedy_selection_matches_numpy_brute_force(oracle):
     """Pins selectInformativeFeatures (feature_selector.cpp:613-686) and the hoists of the restatement (reduced position
     system, Hadamard bound ordering) against a brute-force numpy greedy: every round, slogdet of the FULL 9(H+1) x 9(H+1)
