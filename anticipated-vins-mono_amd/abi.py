@@ -13,6 +13,8 @@ MAX_ITER_TRACE = 16
 
 AVM_OK = 0
 AVM_MEM_HOST, AVM_MEM_DEVICE = 0, 1
+# avm_status (include/avm.h)
+AVM_OK, AVM_ERR_INVALID, AVM_ERR_UNSUPPORTED, AVM_ERR_NO_DEVICE, AVM_ERR_HIP, AVM_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 BLK_POSE, BLK_SPEEDBIAS, BLK_EXPOSE = 0, 1, 2
 MARGIN_OLD, MARGIN_SECOND_NEW, MARGIN_NONE = 0, 1, 2
 TERM_NAMES = ["NO_CONVERGENCE", "GRADIENT_TOL", "PARAMETER_TOL", "FUNCTION_TOL", "MIN_RADIUS", "FAILURE"]

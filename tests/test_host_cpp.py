@@ -1,0 +1,354 @@
+"""include/avm_host.hpp - the C++ host side above the C ABI (avm_host::Estimator / avm_host::FeatureSelector with the
+reference's member names and call surfaces) - driven from pytest through the ctypes hooks of tests/host_cpp/host_shim.cpp.
+
+CPU tier: the marshalling (the inverse of the test's loader must give back the synthetic tables, features that fail the
+filter of estimator.cpp:715 are skipped in place), the selector's bookkeeping on the branches that need no device
+(feature_selector.cpp:74-120,172-202), and the loud failure without a GPU.
+GPU tier: optimization() / triangulate() / select() through the C++ objects against the CPU oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import abi, buffers, rel, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CAM_KEYS = ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")
+
+
+def _shim():
+    d = os.path.join(HERE, "host_cpp")
+    subprocess.check_call(["make", "-C", d, "-s"])
+    L = C.CDLL(os.path.join(d, "libavm_host_shim.so"))
+    L.hs_create.restype = C.c_void_p
+    L.hs_last_error.restype = C.c_char_p
+    return L
+
+
+class Host:
+    """One avm_host::Estimator (+ FeatureSelector) behind the shim."""
+
+    def __init__(self, device=0):
+        self.L = _shim()
+        self.h = C.c_void_p(self.L.hs_create(int(device)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.hs_destroy(self.h)
+            self.h = None
+
+    def err(self):
+        return self.L.hs_last_error().decode()
+
+    def load(self, win, w=0, feat_id=None, solve_flag=None, extras=()):
+        s = win.struct()
+        nf = int(win.a["n_feat"][w])
+        fid = np.ascontiguousarray(feat_id if feat_id is not None else np.arange(nf), np.int32)
+        sf = np.ascontiguousarray(solve_flag if solve_flag is not None else np.ones(nf), np.int32)
+        xb = np.ascontiguousarray([e[0] for e in extras], np.int32)
+        xs = np.ascontiguousarray([e[1] for e in extras], np.int32)
+        xn = np.ascontiguousarray([e[2] for e in extras], np.int32)
+        rc = self.L.hs_load_window(self.h, C.byref(s), int(w), abi.iptr(fid), abi.iptr(sf), len(extras), abi.iptr(xb), abi.iptr(xs), abi.iptr(xn))
+        assert rc == 0, self.err()
+
+    def marshal(self, max_samp):
+        out = dict(pose=np.zeros((11, 7)), speedbias=np.zeros((11, 9)), ex_pose=np.zeros(7), inv_depth=np.zeros(150), n_feat=np.zeros(1, np.int32),
+                   feat_start=np.zeros(150, np.int32), feat_nobs=np.zeros(150, np.int32), feat_obs_begin=np.zeros(150, np.int32),
+                   obs_xy=np.zeros((1650, 2)), imu_n=np.zeros(10, np.int32), imu_dt=np.zeros((10, max_samp)), imu_acc=np.zeros((10, max_samp + 1, 3)),
+                   imu_gyr=np.zeros((10, max_samp + 1, 3)), imu_lin_ba=np.zeros((10, 3)), imu_lin_bg=np.zeros((10, 3)), feat_id=np.full(150, -1, np.int32))
+        order = ("pose", "speedbias", "ex_pose", "inv_depth", "n_feat", "feat_start", "feat_nobs", "feat_obs_begin", "obs_xy", "imu_n", "imu_dt",
+                 "imu_acc", "imu_gyr", "imu_lin_ba", "imu_lin_bg", "feat_id")
+        args = [abi.iptr(out[k]) if out[k].dtype == np.int32 else abi.dptr(out[k]) for k in order]
+        rc = self.L.hs_marshal(self.h, int(max_samp), *args)
+        assert rc == 0, self.err()
+        return out
+
+    def set_flags(self, solver_flag=1, marginalization_flag=0, max_num_iterations=0):
+        self.L.hs_set_flags(self.h, int(solver_flag), int(marginalization_flag), int(max_num_iterations))
+
+    def optimization(self):
+        return self.L.hs_optimization(self.h)
+
+    def triangulate(self, init_depth=5.0):
+        return self.L.hs_triangulate(self.h, C.c_double(init_depth))
+
+    def state(self):
+        out = dict(pose=np.zeros((11, 7)), speedbias=np.zeros((11, 9)), ex_pose=np.zeros(7), depth=np.zeros(150), solve_flag=np.zeros(150, np.int32))
+        n = C.c_int32(0)
+        summ = buffers.summary_alloc(1)
+        self.L.hs_get_state(self.h, abi.dptr(out["pose"]), abi.dptr(out["speedbias"]), abi.dptr(out["ex_pose"]), C.byref(n), abi.dptr(out["depth"]),
+                            abi.iptr(out["solve_flag"]), buffers.summary_ptr(summ))
+        out["n_feat"], out["summary"] = n.value, summ
+        return out
+
+    def prior(self):
+        p = buffers.PriorOutArrays.alloc(1)
+        n, nb = C.c_int32(0), C.c_int32(0)
+        self.L.hs_get_prior(self.h, C.byref(n), C.byref(nb), abi.iptr(p.a["blk_kind"]), abi.iptr(p.a["blk_frame"]), abi.dptr(p.a["J"]), abi.dptr(p.a["r"]),
+                            abi.dptr(p.a["x0"]))
+        p.a["n"][0], p.a["nblk"][0] = n.value, nb.value
+        return p
+
+    # ---- selector
+    def sel_create(self, cam, horizon):
+        c = np.array([cam[k] for k in CAM_KEYS], float)
+        self.L.hs_sel_create(self.h, abi.dptr(c), int(cam["image_width"]), int(cam["image_height"]), int(horizon))
+
+    def sel_set_parameters(self, accVar, accBiasVar, enable, maxFeatures, initThresh, useGT=False):
+        self.L.hs_sel_set_parameters(self.h, C.c_double(accVar), C.c_double(accBiasVar), int(enable), int(maxFeatures), int(initThresh), int(useGT))
+
+    def sel_set_next_state(self, stamp, P, Q, V, a, w, Ba):
+        arrs = [np.ascontiguousarray(x, float) for x in (P, Q, V, a, w, Ba)]
+        self.L.hs_sel_set_next_state(self.h, C.c_double(stamp), *[abi.dptr(x) for x in arrs])
+
+    def select(self, image, stamp, nrImu):
+        """image: {id: 8-vector}. Returns (rc, image_ids_after, tracked, selected)."""
+        ids = np.ascontiguousarray(list(image.keys()), np.int32)
+        rows = np.ascontiguousarray([image[i] for i in image], float).reshape(-1, 8)
+        cap = 8192
+        io, tr, se = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        ni, nt = C.c_int32(0), C.c_int32(0)
+        rc = self.L.hs_sel_select(self.h, len(ids), abi.iptr(ids), abi.dptr(rows), C.c_double(stamp), int(nrImu), abi.iptr(io), C.byref(ni), abi.iptr(tr),
+                                  C.byref(nt), abi.iptr(se), cap)
+        if rc < 0:
+            return rc, None, None, None
+        return rc, io[:ni.value].tolist(), tr[:nt.value].tolist(), se[:rc].tolist()
+
+
+def _frame(rng, ids):
+    """image_t rows for the given ids: x y 1 u v vx vy prob (prob float32-rounded, as it arrives in the PointCloud channel)."""
+    cam = synth.CAM
+    img = {}
+    for i in ids:
+        u, v = rng.uniform(0, cam["image_width"]), rng.uniform(0, cam["image_height"])
+        p = float(np.float32(rng.uniform(0.05, 1.0)))
+        img[int(i)] = [(u - cam["cx"]) / cam["fx"], (v - cam["cy"]) / cam["fy"], 1.0, u, v, 0.0, 0.0, p]
+    return img
+
+
+# ------------------------------------------------------------------------------------------------ CPU tier
+def test_marshal_restores_the_tables_and_skips_filtered_features():
+    w = synth.make_windows(2, tracks="sparse", n_feat=70, max_feat=150, max_obs=1650, max_samp=24)
+    w.a["imu_n"][1, 3] = 17  # ragged sample counts
+    H = Host()
+    # features that fail used_num >= 2 && start_frame < WINDOW_SIZE - 2 sit between the others in the list
+    extras = [(0, 2, 1), (5, 9, 2), (5, 8, 3), (70, 0, 1)]
+    fid = 500 + 3 * np.arange(70)
+    H.load(w, 1, feat_id=fid, extras=extras)
+    m = H.marshal(24)
+    nf = int(w.a["n_feat"][1])
+    assert m["n_feat"][0] == nf
+    assert np.array_equal(m["feat_id"][:nf], fid[:nf])
+    for k in ("pose", "speedbias", "ex_pose", "imu_lin_ba", "imu_lin_bg"):
+        assert np.array_equal(m[k], w.a[k][1]), k
+    for k in ("feat_start", "feat_nobs", "inv_depth"):
+        assert rel(m[k][:nf], w.a[k][1, :nf]) < 1e-15, k
+    # observations are re-packed contiguously in list order: compare track by track
+    for e in range(nf):
+        n, b0, b1 = w.a["feat_nobs"][1, e], w.a["feat_obs_begin"][1, e], m["feat_obs_begin"][e]
+        assert np.array_equal(m["obs_xy"][b1:b1 + n], w.a["obs_xy"][1, b0:b0 + n])
+    assert np.array_equal(m["feat_obs_begin"][:nf], np.concatenate([[0], np.cumsum(w.a["feat_nobs"][1, :nf])[:-1]]))
+    assert np.array_equal(m["imu_n"], w.a["imu_n"][1])
+    for j in range(10):
+        n = w.a["imu_n"][1, j]
+        assert np.array_equal(m["imu_dt"][j, :n], w.a["imu_dt"][1, j, :n])
+        assert np.array_equal(m["imu_acc"][j, :n + 1], w.a["imu_acc"][1, j, :n + 1])
+        assert np.array_equal(m["imu_gyr"][j, :n + 1], w.a["imu_gyr"][1, j, :n + 1])
+
+
+def test_host_objects_fail_loudly_without_a_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    w = synth.make_windows(1, tracks="sparse", n_feat=20, max_feat=150, max_obs=1650)
+    H = Host()
+    H.load(w)
+    assert H.optimization() == abi.AVM_ERR_NO_DEVICE and "no CPU path" in H.err()
+    assert H.triangulate() == abi.AVM_ERR_NO_DEVICE
+    before = H.state()
+    assert np.array_equal(before["pose"], w.a["pose"][0])  # nothing was touched
+    H.sel_create(synth.CAM, 10)
+    H.sel_set_parameters(0.08, 0.004, True, 30, 10)
+    H.set_flags(solver_flag=1)
+    rng = np.random.default_rng(1)
+    H.sel_set_next_state(0.1, w.a["pose"][0, 10, :3], w.a["pose"][0, 10, 3:], np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3))
+    rc, *_ = H.select(_frame(rng, range(1, 20)), 0.1, 20)
+    assert rc == abi.AVM_ERR_NO_DEVICE
+
+
+def test_selector_bookkeeping_before_initialization():
+    """feature_selector.cpp:74-120,172-202 while solver_flag != NON_LINEAR: the first image is taken whole and tracked, later
+    images pass the tracked ids, and top up with everything left in `image` while fewer than initThresh are tracked."""
+    w = synth.make_windows(1, tracks="sparse", n_feat=20, max_feat=150, max_obs=1650)
+    H = Host()
+    H.load(w)
+    H.set_flags(solver_flag=0)
+    H.sel_create(synth.CAM, 10)
+    rng = np.random.default_rng(2)
+
+    H.sel_set_parameters(0.08, 0.004, False, 30, 10)
+    rc, img, tr, se = H.select(_frame(rng, [3, 5, 9]), 1.0, 20)
+    assert (rc, img, tr, se) == (0, [3, 5, 9], [], [])  # disabled: returns {} and leaves image alone
+
+    H.sel_set_parameters(0.08, 0.004, True, 30, 6)
+    rc, img, tr, se = H.select(_frame(rng, [3, 5, 9, 12]), 1.0, 20)
+    assert (rc, img, tr, se) == (0, [3, 5, 9, 12], [3, 5, 9, 12], [])
+    assert H.L.hs_sel_last_feature_id(H.h) == 12
+    # second image: 5 was lost, 14 and 20 are new.  Not initialized and not the first image: new ones are dropped,
+    # but 3 tracked < initThresh 6, so everything still in `image` (the old ids) is let through
+    rc, img, tr, se = H.select(_frame(rng, [3, 9, 12, 14, 20]), 1.1, 20)
+    assert (rc, img, tr, se) == (0, [3, 9, 12], [3, 5, 9, 12], [])
+    assert H.L.hs_sel_last_feature_id(H.h) == 20
+    # an old id that was never tracked (7 < lastFeatureId_) only passes through the initThresh top-up
+    rc, img, tr, se = H.select(_frame(rng, [3, 7, 9, 25]), 1.2, 20)
+    assert (rc, img, tr, se) == (0, [3, 7, 9], [3, 5, 9, 12], [])
+    H.sel_set_parameters(0.08, 0.004, True, 30, 2)
+    rc, img, tr, se = H.select(_frame(rng, [3, 7, 9, 30]), 1.3, 20)
+    assert (rc, img, tr, se) == (0, [3, 9], [3, 5, 9, 12], [])
+
+
+# ------------------------------------------------------------------------------------------------ GPU tier
+def _install_prior(win, p):
+    for k_w, k_p in (("prior_n", "n"), ("prior_nblk", "nblk"), ("prior_blk_kind", "blk_kind"), ("prior_blk_frame", "blk_frame"), ("prior_J", "J"),
+                     ("prior_r", "r"), ("prior_x0", "x0")):
+        win.a[k_w][:] = p.a[k_p]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", [0, 1])
+def test_cpp_estimator_optimization_matches_oracle_and_chains_the_prior(oracle, flag):
+    w = synth.make_windows(1, tracks="sparse", n_feat=60, max_feat=150, max_obs=1650)
+    H = Host()
+    H.load(w)
+    H.set_flags(solver_flag=1, marginalization_flag=flag)
+    assert H.optimization() == 0, H.err()
+    o = abi.default_options()
+    o.marginalization_flag = abi.MARGIN_OLD if flag == 0 else abi.MARGIN_SECOND_NEW
+    wo, po, so = w.copy(), buffers.PriorOutArrays.alloc(1), buffers.summary_alloc(1)
+    oracle.window_solve(o, wo, po, so)
+    s = H.state()
+    nf = int(w.a["n_feat"][0])
+    assert s["n_feat"] == nf
+    assert rel(s["pose"], wo.a["pose"][0]) < 1e-6 and rel(s["speedbias"], wo.a["speedbias"][0]) < 1e-6
+    assert rel(1.0 / s["depth"][:nf], wo.a["inv_depth"][0, :nf]) < 1e-6
+    assert np.array_equal(s["solve_flag"][:nf], np.where(wo.a["inv_depth"][0, :nf] < 0, 2, 1))
+    assert s["summary"]["accept_mask"][0] == so["accept_mask"][0] and s["summary"]["num_iterations"][0] == so["num_iterations"][0]
+    pg = H.prior()
+    assert pg.a["n"][0] == po.a["n"][0] and pg.a["nblk"][0] == po.a["nblk"][0]
+    nb = int(po.a["nblk"][0])
+    assert np.array_equal(pg.a["blk_kind"][0, :nb], po.a["blk_kind"][0, :nb]) and np.array_equal(pg.a["blk_frame"][0, :nb], po.a["blk_frame"][0, :nb])
+    # second optimization() on the same members: the prior left behind by the first one is the one that is used
+    assert H.optimization() == 0, H.err()
+    _install_prior(wo, po)
+    oracle.window_solve(o, wo, buffers.PriorOutArrays.alloc(1), so)
+    s2 = H.state()
+    assert rel(s2["pose"], wo.a["pose"][0]) < 1e-5 and rel(s2["speedbias"], wo.a["speedbias"][0]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_cpp_estimator_triangulate_matches_oracle(oracle):
+    w = synth.make_windows(1, tracks="sparse", n_feat=50, max_feat=150, max_obs=1650)
+    nf = int(w.a["n_feat"][0])
+    keep = w.a["inv_depth"][0].copy()
+    w.a["inv_depth"][0, :nf:2] = -1.0  # estimated_depth = -1: not triangulated yet
+    H = Host()
+    H.load(w)
+    assert H.triangulate(5.0) == 0, H.err()
+    wo = w.copy()
+    oracle.triangulate(wo, init_depth=5.0)
+    s = H.state()
+    assert rel(1.0 / s["depth"][:nf], wo.a["inv_depth"][0, :nf]) < 1e-9
+    assert np.array_equal(1.0 / s["depth"][1:nf:2], 1.0 / (1.0 / keep[1:nf:2]))  # features with a depth keep it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("horizon", [10, 5])
+def test_cpp_selector_select_over_frames_matches_oracle_composition(oracle, horizon):
+    """select() frame after frame through the C++ object against the same chain put together from the oracle's pieces
+    (HorizonGenerator::imu, initKDTree's cloud, the greedy) with the bookkeeping restated in Python."""
+    w = synth.make_windows(1, tracks="sparse", n_feat=80, max_feat=150, max_obs=1650)
+    nf = int(w.a["n_feat"][0])
+    flags = np.ones(nf, np.int32)
+    flags[::7] = 2  # some features failed in the last solve: they do not enter the depth cloud
+    H = Host()
+    H.load(w, solve_flag=flags)
+    cam = synth.CAM
+    H.sel_create(cam, horizon)
+    maxF, accVar, biasVar = 60, synth.ACC_N, synth.ACC_W
+    H.sel_set_parameters(accVar, biasVar, True, maxF, 10)
+    rng = np.random.default_rng(5)
+    pose10, sb10 = w.a["pose"][0, 10], w.a["speedbias"][0, 10]
+
+    tracked, last_id, first, n_selected = [], 0, True, 0
+    next_id = 1
+    stamp, t_prev = 10.0, None
+    alive = []
+    for k in range(5):
+        init = k >= 1
+        H.set_flags(solver_flag=int(init))
+        n_new = [30, 60, 40, 0, 50][k]
+        alive = [i for i in alive if rng.uniform() < 0.8] + list(range(next_id, next_id + n_new))
+        next_id += n_new
+        image = _frame(rng, alive)
+        P = pose10[:3] + rng.normal(0, 0.05, 3)
+        Q = pose10[3:] + rng.normal(0, 0.01, 4)
+        Q /= np.linalg.norm(Q)
+        V, a, gy = sb10[:3] + rng.normal(0, 0.05, 3), rng.normal(0, 0.5, 3) + [0, 0, 9.8], rng.normal(0, 0.1, 3)
+        H.sel_set_next_state(stamp, P, Q, V, a, gy, sb10[3:6])
+        rc, img_g, tr_g, se_g = H.select(dict(image), stamp, 20)
+        assert rc >= 0, H.err()
+
+        # ---- the same frame with the oracle's pieces
+        if t_prev is None:
+            t_prev = stamp
+        deltaF = stamp - t_prev
+        new = sorted(i for i in image if i > last_id)
+        old = sorted(i for i in image if i <= last_id)
+        if new:
+            last_id = new[-1]
+        subset = [f for f in sorted(set(tracked)) if f in old]
+        selected = []
+        if init:
+            hp, hq = oracle.fsel_horizon_imu(horizon, pose10[None, :3], pose10[None, 3:], sb10[None, 3:6], P[None], V[None], Q[None], a[None], gy[None],
+                                             np.array([20], np.int32), np.array([deltaF / 20]))
+            wc = w.copy()
+            wc.a["inv_depth"][0, :nf] = np.where(flags == 1, w.a["inv_depth"][0, :nf], -1.0)
+            ncl, cxy, cdep = oracle.fsel_build_cloud(wc, P[None], Q[None], 150)
+            nc, nu = max(len(new), 1), max(len(subset), 1)
+            arr = {
+                "hor_pos": hp, "hor_quat": hq, "nr_imu": np.array([20], np.int32), "delta_imu": np.array([deltaF / 20]),
+                "n_cand": np.array([len(new)], np.int32), "cand_id": np.zeros((1, nc), np.int32), "cand_xy": np.zeros((1, nc, 2)),
+                "cand_prob": np.zeros((1, nc)), "n_used": np.array([len(subset)], np.int32), "used_id": np.zeros((1, nu), np.int32),
+                "used_xy": np.zeros((1, nu, 2)), "n_cloud": ncl.astype(np.int32), "cloud_xy": cxy, "cloud_depth": cdep,
+            }
+            for j, i in enumerate(new):
+                arr["cand_id"][0, j], arr["cand_xy"][0, j], arr["cand_prob"][0, j] = i, image[i][:2], image[i][7]
+            for j, i in enumerate(subset):
+                arr["used_id"][0, j], arr["used_xy"][0, j] = i, image[i][:2]
+            dims = dict(n_problems=1, horizon=horizon, max_cand=nc, max_used=nu, max_cloud=150, max_features=maxF)
+            ex = w.a["ex_pose"][0]
+            sc = dict(acc_var=accVar, acc_bias_var=biasVar, q_ic=ex[3:], t_ic=ex[:3], **cam)
+            pr = buffers.FselArrays(dims, arr, sc)
+            out = buffers.FselOutArrays.alloc(1, maxF)
+            oracle.fsel_select(pr, out)
+            selected = out.a["selected_ids"][0, :out.a["n_selected"][0]].tolist()
+            image_out = sorted(subset + selected)
+        else:
+            if first:
+                subset, first = new, False
+                tracked = tracked + subset
+            if len(subset) < 10:
+                subset = sorted(set(subset) | set(old))
+            image_out = sorted(subset)
+        tracked = tracked + selected
+        n_selected += len(selected)
+        t_prev = stamp
+        assert se_g == selected, (k, se_g, selected)
+        assert img_g == image_out, k
+        assert tr_g == tracked, k
+        stamp += 0.1
+    assert n_selected >= 40, n_selected
