@@ -59,6 +59,66 @@ void* pool_get(avm_ctx* c, const std::string& name, size_t bytes) {
   return e.first;
 }
 
+const char* table_rule_text(int rule) {
+  switch (rule) {
+    case BAD_NFEAT: return "n_feat outside [0, max_feat]";
+    case BAD_TRACK: return "a feature track leaves the window (need start >= 0, nobs >= 1, start + nobs <= 11)";
+    case BAD_ORDER: return "feat_start must be non-decreasing in the feature index (std::list order)";
+    case BAD_OBS: return "feat_obs_begin + feat_nobs runs past max_obs";
+    case BAD_IMU: return "imu_n outside [0, max_samp]";
+    case BAD_PRIOR: return "prior tables inconsistent (prior_n / prior_nblk ranges, block kinds / frames, sizes must add up to prior_n)";
+    case BAD_FSEL: return "n_cand / n_used / n_cloud outside their strides, or nr_imu < 0";
+  }
+  return "bad table";
+}
+
+int report_bad(avm_ctx* c, int first_bad, const char* unit) {
+  c->err = std::string(unit) + " " + std::to_string(first_bad / 8) + ": " + table_rule_text(first_bad % 8);
+  return AVM_ERR_INVALID;
+}
+
+// Runs before any kernel indexes with the caller's tables: host tables are checked on the host, device-resident ones by a
+// one-thread-per-window kernel whose 4-byte verdict is read back (the only extra synchronization of a device-mode call).
+int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int what) {
+  if ((what & CHK_TRACKS) && (!b->n_feat || !b->feat_start || !b->feat_nobs || !b->feat_obs_begin)) return fail(c, AVM_ERR_INVALID, "null feature table");
+  if ((what & CHK_IMU) && !b->imu_n) return fail(c, AVM_ERR_INVALID, "null imu_n");
+  if ((what & CHK_PRIOR) && b->prior_n && (!b->prior_nblk || !b->prior_blk_kind || !b->prior_blk_frame)) return fail(c, AVM_ERR_INVALID, "null prior table");
+  if (mem == AVM_MEM_HOST) {
+    for (int w = 0; w < b->n_windows; w++) {
+      const int rule = check_window_tables(*b, w, what);
+      if (rule) return report_bad(c, w * 8 + rule, "window");
+    }
+    return AVM_OK;
+  }
+  int* flag = static_cast<int*>(pool_get(c, "v_flag", sizeof(int)));
+  if (!flag) return fail(c, AVM_ERR_HIP, "hipMalloc failed (validation flag)");
+  HIPCHK(c, hipMemsetAsync(flag, 0x7f, sizeof(int), c->stream));
+  HIPCHK(c, launch_validate_windows(*b, what, flag, c->stream));
+  int h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return h == 0x7f7f7f7f ? AVM_OK : report_bad(c, h, "window");
+}
+
+int validate_fsel(avm_ctx* c, avm_mem mem, const avm_fsel_batch* b) {
+  if (!b->n_cand || !b->nr_imu) return fail(c, AVM_ERR_INVALID, "null n_cand / nr_imu");
+  if (mem == AVM_MEM_HOST) {
+    for (int p = 0; p < b->n_problems; p++) {
+      const int rule = check_fsel_tables(*b, p);
+      if (rule) return report_bad(c, p * 8 + rule, "frame");
+    }
+    return AVM_OK;
+  }
+  int* flag = static_cast<int*>(pool_get(c, "v_flag", sizeof(int)));
+  if (!flag) return fail(c, AVM_ERR_HIP, "hipMalloc failed (validation flag)");
+  HIPCHK(c, hipMemsetAsync(flag, 0x7f, sizeof(int), c->stream));
+  HIPCHK(c, launch_validate_fsel(*b, flag, c->stream));
+  int h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return h == 0x7f7f7f7f ? AVM_OK : report_bad(c, h, "frame");
+}
+
 template <class T>
 int stage_in(avm_ctx* c, const char* name, const T* host, size_t count, const T** dev) {
   if (!host || count == 0) {
@@ -247,6 +307,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     if (prior_out->max_prior > MAXPRIOR || prior_out->max_prior < 1 || prior_out->max_pblk < 1) return fail(c, AVM_ERR_CAPACITY, "prior_out dims");
   }
   if (batch->n_windows == 0) return AVM_OK;
+  if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR)) != AVM_OK) return rc;
   if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
   avm_window_batch d;
   avm_solve_summary* d_sum = nullptr;
@@ -334,6 +395,7 @@ int avm_imu_preintegrate_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, 
   int rc = check_window_batch(c, opt, batch);
   if (rc != AVM_OK) return rc;
   if (batch->n_windows == 0) return AVM_OK;
+  if ((rc = validate_windows(c, mem, batch, CHK_IMU)) != AVM_OK) return rc;
   if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
   avm_window_batch d;
   if (mem == AVM_MEM_HOST) {
@@ -385,6 +447,10 @@ int avm_triangulate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, doub
   if (batch->max_feat > MAXE) return fail(c, AVM_ERR_CAPACITY, "max_feat > 150");
   if (batch->max_obs > MAXOBS) return fail(c, AVM_ERR_CAPACITY, "max_obs > 1650");
   if (batch->n_windows == 0) return AVM_OK;
+  {
+    const int vrc = validate_windows(c, mem, batch, CHK_TRACKS);
+    if (vrc != AVM_OK) return vrc;
+  }
   const size_t B = batch->n_windows;
   avm_window_batch d = *batch;
   if (mem == AVM_MEM_HOST) {
@@ -419,6 +485,10 @@ int avm_slide_window(avm_ctx* c, avm_mem mem, avm_window_batch* batch, int32_t f
   if (!batch || batch->n_windows < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
   if (flag != AVM_MARGIN_OLD && flag != AVM_MARGIN_SECOND_NEW) return fail(c, AVM_ERR_INVALID, "marginalization_flag must be MARGIN_OLD or MARGIN_SECOND_NEW");
   if (batch->n_windows == 0) return AVM_OK;
+  {
+    const int vrc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU);
+    if (vrc != AVM_OK) return vrc;
+  }
   const size_t B = batch->n_windows;
   avm_window_batch d = *batch;
   // (field, element type, elements) of everything the roll reads or rewrites
@@ -458,6 +528,10 @@ int avm_imu_propagate_batch(avm_ctx* c, avm_mem mem, avm_window_batch* batch, co
   (void)hipSetDevice(c->device);
   if (!batch || !g || batch->n_windows < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
   if (batch->n_windows == 0) return AVM_OK;
+  {
+    const int vrc = validate_windows(c, mem, batch, CHK_IMU);
+    if (vrc != AVM_OK) return vrc;
+  }
   const size_t B = batch->n_windows;
   avm_window_batch d = *batch;
   if (mem == AVM_MEM_HOST) {
@@ -517,6 +591,7 @@ int avm_window_eval_factors(avm_ctx* c, const avm_options* opt, avm_mem mem, con
   int rc = check_window_batch(c, opt, batch);
   if (rc != AVM_OK) return rc;
   if (batch->n_windows == 0) return AVM_OK;
+  if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR)) != AVM_OK) return rc;
   if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
   avm_window_batch d;
   const size_t B = batch->n_windows;
@@ -618,6 +693,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   if (rc != AVM_OK) return rc;
   if (!out || !out->n_selected || !out->selected_ids) return fail(c, AVM_ERR_INVALID, "null output");
   if (batch->n_problems == 0) return AVM_OK;
+  if ((rc = validate_fsel(c, mem, batch)) != AVM_OK) return rc;
   avm_fsel_batch d;
   avm_fsel_out dout;
   const size_t P = batch->n_problems, mf = batch->max_features;
@@ -692,6 +768,10 @@ int avm_fsel_build_cloud(avm_ctx* c, avm_mem mem, const avm_window_batch* window
   if (!windows || !k1_pos || !k1_quat || !n_cloud || !cloud_xy || !cloud_depth || windows->n_windows < 0 || max_cloud < 1)
     return fail(c, AVM_ERR_INVALID, "null/negative argument");
   if (windows->n_windows == 0) return AVM_OK;
+  {
+    const int vrc = validate_windows(c, mem, windows, CHK_TRACKS);
+    if (vrc != AVM_OK) return vrc;
+  }
   const size_t B = windows->n_windows;
   avm_window_batch d = *windows;
   const double *dp = k1_pos, *dq = k1_quat;
@@ -734,6 +814,7 @@ int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, d
   int rc = check_fsel(c, batch);
   if (rc != AVM_OK) return rc;
   if (batch->n_problems == 0) return AVM_OK;
+  if ((rc = validate_fsel(c, mem, batch)) != AVM_OK) return rc;
   avm_fsel_batch d;
   if (mem == AVM_MEM_HOST) {
     if ((rc = stage_fsel(c, batch, &d)) != AVM_OK) return rc;

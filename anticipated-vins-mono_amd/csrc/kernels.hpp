@@ -63,6 +63,61 @@ struct FselBuffers {
   int32_t *valid, *valid_u, *black, *nsel, *done;
 };
 
+// ---- table validation (every entry point that takes tables runs it before any kernel indexes with them) -----------
+// Which groups of an avm_window_batch an entry point reads.
+enum { CHK_TRACKS = 1, CHK_IMU = 2, CHK_PRIOR = 4 };
+// 0 = fine; otherwise the first violated rule (messages in avm_api.hip, table_rule_text)
+enum { BAD_NFEAT = 1, BAD_TRACK = 2, BAD_ORDER = 3, BAD_OBS = 4, BAD_IMU = 5, BAD_PRIOR = 6, BAD_FSEL = 7 };
+
+__host__ __device__ inline int check_window_tables(const avm_window_batch& B, int w, int what) {
+  if (what & CHK_TRACKS) {
+    const int nf = B.n_feat[w];
+    if (nf < 0 || nf > B.max_feat) return BAD_NFEAT;
+    int prev = 0;
+    for (int e = 0; e < nf; e++) {
+      const size_t k = (size_t)w * B.max_feat + e;
+      const int a = B.feat_start[k], no = B.feat_nobs[k], ob = B.feat_obs_begin[k];
+      if (a < 0 || no < 1 || a + no > AVM_NFRAMES) return BAD_TRACK;
+      if (a < prev) return BAD_ORDER;
+      prev = a;
+      if (ob < 0 || ob + no > B.max_obs) return BAD_OBS;
+    }
+  }
+  if (what & CHK_IMU)
+    for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
+      const int n = B.imu_n[(size_t)w * AVM_WINDOW_SIZE + j];
+      if (n < 0 || n > B.max_samp) return BAD_IMU;
+    }
+  if ((what & CHK_PRIOR) && B.prior_n) {
+    const int pn = B.prior_n[w];
+    if (pn < 0 || pn > B.max_prior) return BAD_PRIOR;
+    if (pn > 0) {
+      const int nb = B.prior_nblk[w];
+      if (nb < 1 || nb > B.max_pblk) return BAD_PRIOR;
+      int off = 0;
+      for (int k = 0; k < nb; k++) {
+        const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
+        if (kind < AVM_BLK_POSE || kind > AVM_BLK_EXPOSE || fr < 0 || fr >= AVM_NFRAMES) return BAD_PRIOR;
+        off += kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
+      }
+      if (off != pn) return BAD_PRIOR;
+    }
+  }
+  return 0;
+}
+
+__host__ __device__ inline int check_fsel_tables(const avm_fsel_batch& b, int p) {
+  if (b.n_cand[p] < 0 || b.n_cand[p] > b.max_cand) return BAD_FSEL;
+  if (b.n_used && (b.n_used[p] < 0 || b.n_used[p] > b.max_used)) return BAD_FSEL;
+  if (b.n_cloud && (b.n_cloud[p] < 0 || b.n_cloud[p] > b.max_cloud)) return BAD_FSEL;
+  if (b.nr_imu[p] < 0) return BAD_FSEL;
+  return 0;
+}
+
+// first_bad: one int, INT_MAX when every window / problem passes, else (index * 8 + rule) of the lowest failing index
+hipError_t launch_validate_windows(const avm_window_batch& b, int what, int* first_bad, hipStream_t stream);
+hipError_t launch_validate_fsel(const avm_fsel_batch& b, int* first_bad, hipStream_t stream);
+
 void launch_preint(const PreintArgs& a, hipStream_t stream);
 hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
                        hipStream_t stream);

@@ -278,6 +278,31 @@ hipError_t launch_slide_window(const avm_window_batch& b, int flag, int shift_de
   return hipGetLastError();
 }
 
+// ---- table validation: one thread per window / frame, the lowest failing index wins ------------------------------
+__global__ __launch_bounds__(64) void validate_windows_kernel(avm_window_batch B, int what, int* first_bad) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= B.n_windows) return;
+  const int rule = check_window_tables(B, w, what);
+  if (rule) atomicMin(first_bad, w * 8 + rule);
+}
+
+__global__ __launch_bounds__(64) void validate_fsel_kernel(avm_fsel_batch b, int* first_bad) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= b.n_problems) return;
+  const int rule = check_fsel_tables(b, p);
+  if (rule) atomicMin(first_bad, p * 8 + rule);
+}
+
+hipError_t launch_validate_windows(const avm_window_batch& b, int what, int* first_bad, hipStream_t stream) {
+  hipLaunchKernelGGL(validate_windows_kernel, dim3((b.n_windows + 63) / 64), dim3(64), 0, stream, b, what, first_bad);
+  return hipGetLastError();
+}
+
+hipError_t launch_validate_fsel(const avm_fsel_batch& b, int* first_bad, hipStream_t stream) {
+  hipLaunchKernelGGL(validate_fsel_kernel, dim3((b.n_problems + 63) / 64), dim3(64), 0, stream, b, first_bad);
+  return hipGetLastError();
+}
+
 // A7: ProjectionTdFactor::Evaluate (factor/projection_td_factor.cpp:34-141), one thread per factor.
 __global__ __launch_bounds__(TRI_NT) void projection_td_eval_kernel(avm_td_factor_batch f, double* residual, double* jac) {
   const int i = blockIdx.x * TRI_NT + threadIdx.x;

@@ -15,6 +15,11 @@
  * Conventions
  *   - plain pointers + sizes, FP64 everywhere, row-major, no exceptions cross
  *     the ABI; every function returns AVM_OK (0) or a negative avm_status.
+ *   - the index tables of a batch (feature tracks, IMU sample counts, prior block
+ *     tables, the selector's counts) are validated before any kernel indexes with
+ *     them - host tables on the host, device-resident ones by a one-thread-per-window
+ *     kernel: AVM_ERR_INVALID, avm_last_error() names the first bad window and the
+ *     rule, nothing has been modified.
  *   - all buffers are caller owned.  `mem` says whether the pointers are host
  *     pointers (the library stages them over PCIe) or device pointers already
  *     resident in HBM (what bench.py times).

@@ -304,6 +304,62 @@ def test_capacity_and_unsupported_errors(ctx, abi):
         est_m.Estimator(ctx=ctx, options=o).optimization(synth.make_windows(1, tracks="sparse", n_feat=5, max_feat=150))
 
 
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_malformed_tables_are_rejected_before_any_kernel_indexes_with_them(ctx, abi, selector, where):
+    """Every entry point validates the caller's tables first (host tables on the host, device-resident ones by a
+    one-thread-per-window kernel): AVM_ERR_INVALID naming the first bad window and the rule, states untouched."""
+    lib_m = __import__("importlib").import_module("anticipated-vins-mono_amd.lib")
+    est_m = __import__("importlib").import_module("anticipated-vins-mono_amd.estimator")
+    E = est_m.Estimator(ctx=ctx, options=abi.default_options())
+    good = synth.make_windows(3, tracks="sparse", n_feat=40, max_feat=150)
+    nf = int(good.a["n_feat"][1])
+
+    def broken(key, idx, value):
+        w = good.copy()
+        w.a[key][idx] = value
+        return w
+
+    cases = [
+        (broken("n_feat", 1, 151), "window 1: n_feat"),
+        (broken("n_feat", 2, -1), "window 2: n_feat"),
+        (broken("feat_nobs", (1, 3), 12), "window 1: a feature track leaves the window"),
+        (broken("feat_start", (1, nf - 1), 0) if good.a["feat_start"][1, nf - 1] > 0 else None, "window 1: feat_start must be non-decreasing"),
+        (broken("feat_obs_begin", (0, 2), good.dims["max_obs"] - 1), "window 0: feat_obs_begin"),
+        (broken("imu_n", (2, 4), good.dims["max_samp"] + 1), "window 2: imu_n"),
+        (broken("prior_nblk", 1, 3), "window 1: prior tables"),
+        (broken("prior_blk_frame", (0, 0), 11), "window 0: prior tables"),
+    ]
+    for w, msg in cases:
+        if w is None:
+            continue
+        before = w.a["pose"].copy()
+        x = w.to_device("cuda:0") if where == "device" else w
+        with pytest.raises(lib_m.AvmError, match="status -1: " + msg):
+            E.optimization(x)
+        after = x.a["pose"].cpu().numpy() if where == "device" else x.a["pose"]
+        assert np.array_equal(after, before)
+    # the other entry points share the check
+    w = broken("feat_nobs", (1, 3), 12)
+    x = w.to_device("cuda:0") if where == "device" else w
+    with pytest.raises(lib_m.AvmError, match="window 1: a feature track"):
+        E.triangulate(x)
+    with pytest.raises(lib_m.AvmError, match="window 1: a feature track"):
+        E.slideWindow(x, abi.MARGIN_OLD)
+    w = broken("imu_n", (0, 9), -2)
+    x = w.to_device("cuda:0") if where == "device" else w
+    with pytest.raises(lib_m.AvmError, match="window 0: imu_n"):
+        E.imu_propagate(x)
+    # selector
+    pr = synth.make_fsel(2, horizon=5, n_cand=20, n_used=2, n_cloud=10, max_features=8)
+    pr.a["n_cand"][1] = 21
+    x = pr.to_device("cuda:0") if where == "device" else pr
+    with pytest.raises(lib_m.AvmError, match="frame 1: n_cand"):
+        selector.select_batch(x)
+    # and a well-formed batch still runs afterwards on the same ctx
+    ok = good.to_device("cuda:0") if where == "device" else good.copy()
+    E.optimization(ok)
+
+
 def _prior_quadratic(p, i):
     n = int(p.a["n"][i])
     J, r = p.a["J"][i, :n, :n], p.a["r"][i, :n]
