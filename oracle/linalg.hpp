@@ -391,7 +391,7 @@ inline void eig_sym(const Mat& A, std::vector<double>& d, Mat& V) {
   for (int l = 0; l < n; l++) {
     tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
     int m = l;
-    while (m < n) {
+    while (m < n - 1) {  // e[n-1] == 0 ends the scan for finite data; the bound keeps NaN input inside the arrays
       if (std::fabs(e[m]) <= eps * tst1) break;
       m++;
     }

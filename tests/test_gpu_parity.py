@@ -360,6 +360,36 @@ def test_malformed_tables_are_rejected_before_any_kernel_indexes_with_them(ctx, 
     E.optimization(ok)
 
 
+def _poisoned_windows():
+    w = synth.make_windows(6, tracks="sparse", n_feat=40, max_feat=150)
+    w.a["pose"][0, 3, 0] = np.nan          # a NaN state
+    w.a["obs_xy"][1, 5, 0] = np.inf        # an infinite measurement
+    w.a["imu_dt"][2, :, :] = 0.0           # zero-length IMU intervals: singular pre-integration covariance
+    w.a["inv_depth"][3, :10] = 0.0         # points at infinity
+    w.a["prior_J"][4] = np.nan             # a poisoned prior
+    return w
+
+
+def test_non_finite_inputs_terminate_like_the_oracle_and_do_not_leak_into_other_windows(ctx, oracle):
+    """NaN / Inf / singular inputs: the solve gives up after max_num_consecutive_invalid_steps like Ceres does (FAILURE),
+    the marginalization still runs, nothing hangs, and the healthy window of the same batch is solved as usual."""
+    est_m = __import__("importlib").import_module("anticipated-vins-mono_amd.estimator")
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    w = _poisoned_windows()
+    wg, wo = w.copy(), w.copy()
+    sg = E.optimization(wg)
+    so, po = buffers.summary_alloc(6), buffers.PriorOutArrays.alloc(6)
+    oracle.window_solve(o, wo, po, so)
+    assert sg["termination"].tolist() == so["termination"].tolist() == [abi.TERM_NAMES.index("FAILURE")] * 5 + [0]
+    assert sg["num_iterations"].tolist() == so["num_iterations"].tolist()
+    assert rel(wg.a["pose"][5], wo.a["pose"][5]) < STATE_TOL
+    assert np.array_equal(E.last_marginalization_info.a["n"], po.a["n"])
+    for k in range(5):  # a failed solve leaves the states where they were (Ceres returns the initial point)
+        same = (wg.a["pose"][k] == w.a["pose"][k]) | (np.isnan(wg.a["pose"][k]) & np.isnan(w.a["pose"][k]))
+        assert same.all() == ((wo.a["pose"][k] == w.a["pose"][k]) | (np.isnan(wo.a["pose"][k]) & np.isnan(w.a["pose"][k]))).all()
+
+
 def _prior_quadratic(p, i):
     n = int(p.a["n"][i])
     J, r = p.a["J"][i, :n, :n], p.a["r"][i, :n]

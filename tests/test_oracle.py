@@ -146,6 +146,24 @@ def test_solver_decreases_cost_and_is_deterministic(oracle, opt, tracks, nf):
     assert np.abs(a.a["pose"] - w.a["pose"]).max() > 1e-3
 
 
+def test_non_finite_inputs_do_not_break_the_oracle(oracle, opt):
+    """NaN / Inf / singular inputs end in FAILURE after max_num_consecutive_invalid_steps attempts; the dense eigen solver
+    of the marginalization stays inside its arrays (the QL scan is bounded by n - 1 also when no comparison is true)."""
+    w = synth.make_windows(3, tracks="sparse", n_feat=30, max_feat=150)
+    w.a["pose"][0, 3, 0] = np.nan
+    w.a["imu_dt"][1, :, :] = 0.0
+    o = abi.default_options()
+    so, po = buffers.summary_alloc(3), buffers.PriorOutArrays.alloc(3)
+    oracle.window_solve(o, w, po, so)
+    assert so["termination"].tolist() == [5, 5, 0]
+    assert so["num_iterations"].tolist() == [5, 5, 8]
+    A = np.full((7, 7), np.nan)
+    wv, V = np.zeros(7), np.zeros((7, 7))
+    oracle.lib().avmo_eig_sym.argtypes = [C.c_int, abi.c_dp, abi.c_dp, abi.c_dp]
+    oracle.lib().avmo_eig_sym(7, abi.dptr(A), abi.dptr(wv), abi.dptr(V))
+    assert np.isnan(wv).all()
+
+
 def test_first_iteration_step_matches_dense_numpy_normal_equations(oracle):
     """Pins the oracle's linear path (Jacobi scaling, LM diagonal, Schur elimination of the inverse depths, Cholesky, the
     Gauss-Newton branch of the dogleg, Plus) against a dense numpy statement of Ceres' first trust-region iteration built
