@@ -140,7 +140,9 @@ AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, do
     const double dyy = yu * rad + 2.0 * b.p2 * mxy + b.p1 * (rho2 + 2.0 * my2);
     const double pu = b.fx * (xu + dxx) + b.cx, pv = b.fy * (yu + dyy) + b.cy;
     const int iu = (int)round(pu), ivv = (int)round(pv);  // std::round: half away from zero
-    if (!((0 <= iu && iu < b.image_width) && (0 <= ivv && ivv < b.image_height))) continue;
+    // a NaN pixel is outside the image: the reference's double -> int conversion yields INT_MIN for it (x86 cvttsd2si),
+    // v_cvt_i32_f64 would yield 0
+    if (!(pu == pu && pv == pv && (0 <= iu && iu < b.image_width) && (0 <= ivv && ivv < b.image_height))) continue;
     addC(h - 1, ue, ch + 12);
     ++numVisible;
   }

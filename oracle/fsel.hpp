@@ -30,6 +30,9 @@ struct FselCamera {
     v = fy * (yu + dy) + cy;
   }
   bool inFOV(double pu, double pv) const {  // feature_selector.cpp:369-376
+    // NaN or out-of-range doubles convert to INT_MIN on the reference's platform (x86 cvttsd2si): outside the image.
+    // Stated explicitly so that the restatement does not depend on the conversion's undefined behaviour.
+    if (!(std::fabs(pu) < 2147483647.0 && std::fabs(pv) < 2147483647.0)) return false;
     int u = (int)std::round(pu), v = (int)std::round(pv);
     return (0 <= u && u < width) && (0 <= v && v < height);
   }

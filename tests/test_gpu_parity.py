@@ -526,6 +526,26 @@ def test_selector_ids_over_many_frames(selector, oracle):
         assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
 
 
+def _poisoned_frames():
+    pr = synth.make_fsel(6, horizon=5, n_cand=40, n_used=3, n_cloud=20, max_features=12)
+    pr.a["delta_imu"][0] = 0.0        # the reference's very first call: deltaF = 0 (feature_selector.cpp:85-91), Omega is not finite
+    pr.a["hor_pos"][1, 2, 0] = np.nan  # one horizon frame is NaN: that frame sees nothing, the others still count
+    pr.a["cand_xy"][2, 3] = np.nan     # one NaN candidate
+    pr.a["cand_prob"][3, :] = 0.0      # no candidate adds information
+    pr.a["cloud_depth"][4, :] = np.inf
+    return pr
+
+
+def test_selector_non_finite_inputs_match_the_oracle(selector, oracle):
+    pr = _poisoned_frames()
+    og = selector.select_batch(pr).to_host()
+    oo = buffers.FselOutArrays.alloc(6, 12)
+    oracle.fsel_select(pr, oo)
+    assert oo.a["n_selected"].tolist() == [0, 9, 9, 9, 0, 9]
+    assert np.array_equal(og.a["n_selected"], oo.a["n_selected"])
+    assert np.array_equal(og.a["selected_ids"], oo.a["selected_ids"])
+
+
 def test_depth_cloud_matches_oracle(selector, oracle):
     """B8 (first half): FeatureSelector::initKDTree's cloud on device; it then feeds select() unchanged."""
     B = 5

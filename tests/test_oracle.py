@@ -597,6 +597,21 @@ def _numpy_triangulate(win, b, e):
     return A, v[2] / v[3]
 
 
+def test_selector_with_non_finite_inputs(oracle):
+    """deltaImu = 0 (the reference's first call), a NaN horizon frame, a NaN candidate, zero probabilities, infinite depths:
+    a NaN pixel is outside the image (the reference's double -> int conversion gives INT_MIN), NaN f values never win."""
+    pr = synth.make_fsel(6, horizon=5, n_cand=40, n_used=3, n_cloud=20, max_features=12)
+    pr.a["delta_imu"][0] = 0.0
+    pr.a["hor_pos"][1, 2, 0] = np.nan
+    pr.a["cand_xy"][2, 3] = np.nan
+    pr.a["cand_prob"][3, :] = 0.0
+    pr.a["cloud_depth"][4, :] = np.inf
+    out = buffers.FselOutArrays.alloc(6, 12)
+    oracle.fsel_select(pr, out)
+    assert out.a["n_selected"].tolist() == [0, 9, 9, 9, 0, 9]
+    assert int(pr.a["cand_id"][2, 3]) not in out.a["selected_ids"][2].tolist()
+
+
 def test_triangulate_matches_numpy_svd(oracle):
     """SURVEY 8(f)1: FeatureManager::triangulate. Pins the oracle's one-sided Jacobi SVD and its construction of the
     (2 nobs) x 4 system against numpy.linalg.svd / an independent numpy statement."""
