@@ -390,6 +390,43 @@ def test_non_finite_inputs_terminate_like_the_oracle_and_do_not_leak_into_other_
         assert same.all() == ((wo.a["pose"][k] == w.a["pose"][k]) | (np.isnan(wo.a["pose"][k]) & np.isnan(w.a["pose"][k]))).all()
 
 
+def test_non_finite_inputs_through_the_callers_either_side(ctx, oracle):
+    """triangulate / dead-reckoning / window roll on NaN states, infinite measurements, zero-length IMU intervals and zero
+    quaternions: same finite-ness pattern and same finite values as the oracle, nothing hangs."""
+    est_m = __import__("importlib").import_module("anticipated-vins-mono_amd.estimator")
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+
+    def poisoned(depth):
+        w = synth.make_windows(5, tracks="sparse", n_feat=40, max_feat=150)
+        w.a["pose"][0, 3, 0] = np.nan
+        w.a["obs_xy"][1, 5, 0] = np.inf
+        w.a["imu_dt"][2, :, :] = 0.0
+        w.a["pose"][3, :, 3:] = 0.0
+        w.a["inv_depth"][:, :] = depth
+        return w
+
+    def agree(a, b, tol):
+        assert np.array_equal(np.isfinite(a), np.isfinite(b))
+        m = np.isfinite(a)
+        assert rel(a[m], b[m]) < tol
+
+    wg, wo = poisoned(-1.0), poisoned(-1.0)
+    E.triangulate(wg, 5.0)
+    oracle.triangulate(wo, 5.0)
+    agree(wg.a["inv_depth"], wo.a["inv_depth"], 1e-9)
+    wg, wo = poisoned(0.3), poisoned(0.3)
+    E.imu_propagate(wg)
+    oracle.imu_propagate(wo, [o.g[0], o.g[1], o.g[2]])
+    agree(wg.a["pose"], wo.a["pose"], 1e-9)
+    agree(wg.a["speedbias"], wo.a["speedbias"], 1e-9)
+    wg, wo = poisoned(0.3), poisoned(0.3)
+    E.slideWindow(wg, abi.MARGIN_OLD, True, 5.0)
+    oracle.slide_window(wo, abi.MARGIN_OLD, True, 5.0)
+    assert np.array_equal(wg.a["n_feat"], wo.a["n_feat"])
+    agree(wg.a["inv_depth"], wo.a["inv_depth"], 1e-9)
+
+
 def _prior_quadratic(p, i):
     n = int(p.a["n"][i])
     J, r = p.a["J"][i, :n, :n], p.a["r"][i, :n]
