@@ -648,6 +648,19 @@ def test_selector_non_finite_inputs_match_the_oracle(selector, oracle):
     assert np.array_equal(og.a["selected_ids"], oo.a["selected_ids"])
 
 
+def test_selector_reference_horizon_at_scale(selector, oracle):
+    """HORIZON = 13 (state_defs.h:8, the value the reference is compiled with), 800 candidates, 20 already tracked,
+    maxFeatures 170: 150 greedy rounds on 39 x 39 position blocks - identical ids in identical order."""
+    pr = synth.make_fsel(1, first_id=77, horizon=13, n_cand=800, n_used=20, n_cloud=150, max_features=170)
+    og = selector.select_batch(pr).to_host()
+    oo = buffers.FselOutArrays.alloc(1, 170)
+    oracle.fsel_select(pr, oo)
+    assert oo.a["n_selected"][0] == 150
+    assert np.array_equal(og.a["n_selected"], oo.a["n_selected"])
+    assert np.array_equal(og.a["selected_ids"], oo.a["selected_ids"])
+    assert rel(og.a["fvalues"][0, :150], oo.a["fvalues"][0, :150]) < 1e-9
+
+
 def test_depth_cloud_matches_oracle(selector, oracle):
     """B8 (first half): FeatureSelector::initKDTree's cloud on device; it then feeds select() unchanged."""
     B = 5
