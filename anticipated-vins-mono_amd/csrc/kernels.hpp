@@ -69,41 +69,47 @@ enum { CHK_TRACKS = 1, CHK_IMU = 2, CHK_PRIOR = 4 };
 // 0 = fine; otherwise the first violated rule (messages in avm_api.hip, table_rule_text)
 enum { BAD_NFEAT = 1, BAD_TRACK = 2, BAD_ORDER = 3, BAD_OBS = 4, BAD_IMU = 5, BAD_PRIOR = 6, BAD_FSEL = 7 };
 
-__host__ __device__ inline int check_window_tables(const avm_window_batch& B, int w, int what) {
+// The lowest-numbered violated rule of window w (0 = fine), looking at features e = first, first + stride, ... only, so
+// that the host (first 0, stride 1) and a wavefront (first = lane, stride 64, then a min over the lanes) agree.
+__host__ __device__ inline int check_window_tables(const avm_window_batch& B, int w, int what, int first = 0, int stride = 1) {
+  int bad = 1 << 30;
+  auto rule = [&](int r) { bad = r < bad ? r : bad; };
   if (what & CHK_TRACKS) {
     const int nf = B.n_feat[w];
     if (nf < 0 || nf > B.max_feat) return BAD_NFEAT;
-    int prev = 0;
-    for (int e = 0; e < nf; e++) {
+    for (int e = first; e < nf; e += stride) {
       const size_t k = (size_t)w * B.max_feat + e;
       const int a = B.feat_start[k], no = B.feat_nobs[k], ob = B.feat_obs_begin[k];
-      if (a < 0 || no < 1 || a + no > AVM_NFRAMES) return BAD_TRACK;
-      if (a < prev) return BAD_ORDER;
-      prev = a;
-      if (ob < 0 || ob + no > B.max_obs) return BAD_OBS;
+      if (a < 0 || no < 1 || a + no > AVM_NFRAMES) rule(BAD_TRACK);
+      if (e > 0 && a < B.feat_start[k - 1]) rule(BAD_ORDER);
+      if (ob < 0 || ob + no > B.max_obs) rule(BAD_OBS);
     }
   }
-  if (what & CHK_IMU)
-    for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
-      const int n = B.imu_n[(size_t)w * AVM_WINDOW_SIZE + j];
-      if (n < 0 || n > B.max_samp) return BAD_IMU;
-    }
-  if ((what & CHK_PRIOR) && B.prior_n) {
-    const int pn = B.prior_n[w];
-    if (pn < 0 || pn > B.max_prior) return BAD_PRIOR;
-    if (pn > 0) {
-      const int nb = B.prior_nblk[w];
-      if (nb < 1 || nb > B.max_pblk) return BAD_PRIOR;
-      int off = 0;
-      for (int k = 0; k < nb; k++) {
-        const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
-        if (kind < AVM_BLK_POSE || kind > AVM_BLK_EXPOSE || fr < 0 || fr >= AVM_NFRAMES) return BAD_PRIOR;
-        off += kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
+  if (first == 0) {
+    if (what & CHK_IMU)
+      for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
+        const int n = B.imu_n[(size_t)w * AVM_WINDOW_SIZE + j];
+        if (n < 0 || n > B.max_samp) rule(BAD_IMU);
       }
-      if (off != pn) return BAD_PRIOR;
+    if ((what & CHK_PRIOR) && B.prior_n) {
+      const int pn = B.prior_n[w];
+      if (pn < 0 || pn > B.max_prior) rule(BAD_PRIOR);
+      else if (pn > 0) {
+        const int nb = B.prior_nblk[w];
+        if (nb < 1 || nb > B.max_pblk) rule(BAD_PRIOR);
+        else {
+          int off = 0;
+          for (int k = 0; k < nb; k++) {
+            const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
+            if (kind < AVM_BLK_POSE || kind > AVM_BLK_EXPOSE || fr < 0 || fr >= AVM_NFRAMES) rule(BAD_PRIOR);
+            off += kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
+          }
+          if (off != pn) rule(BAD_PRIOR);
+        }
+      }
     }
   }
-  return 0;
+  return bad == (1 << 30) ? 0 : bad;
 }
 
 __host__ __device__ inline int check_fsel_tables(const avm_fsel_batch& b, int p) {

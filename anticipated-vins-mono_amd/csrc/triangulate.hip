@@ -278,12 +278,13 @@ hipError_t launch_slide_window(const avm_window_batch& b, int flag, int shift_de
   return hipGetLastError();
 }
 
-// ---- table validation: one thread per window / frame, the lowest failing index wins ------------------------------
+// ---- table validation: one wavefront per window (one thread per selector frame), the lowest failing index wins ------------------------------
 __global__ __launch_bounds__(64) void validate_windows_kernel(avm_window_batch B, int what, int* first_bad) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
-  if (w >= B.n_windows) return;
-  const int rule = check_window_tables(B, w, what);
-  if (rule) atomicMin(first_bad, w * 8 + rule);
+  const int w = blockIdx.x, lane = threadIdx.x;  // one wavefront per window, lane = feature (mod 64)
+  int rule = check_window_tables(B, w, what, lane, 64);
+  rule = rule ? rule : 1 << 30;
+  for (int o = 32; o > 0; o >>= 1) rule = min(rule, __shfl_xor(rule, o, 64));
+  if (lane == 0 && rule != 1 << 30) atomicMin(first_bad, w * 8 + rule);
 }
 
 __global__ __launch_bounds__(64) void validate_fsel_kernel(avm_fsel_batch b, int* first_bad) {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(64) void validate_fsel_kernel(avm_fsel_batch b, int
 }
 
 hipError_t launch_validate_windows(const avm_window_batch& b, int what, int* first_bad, hipStream_t stream) {
-  hipLaunchKernelGGL(validate_windows_kernel, dim3((b.n_windows + 63) / 64), dim3(64), 0, stream, b, what, first_bad);
+  hipLaunchKernelGGL(validate_windows_kernel, dim3(b.n_windows), dim3(64), 0, stream, b, what, first_bad);
   return hipGetLastError();
 }
 
