@@ -26,6 +26,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <iterator>
 #include <list>
 #include <map>
 #include <stdexcept>
@@ -288,24 +289,7 @@ class Estimator {
     t.n_feat = e;
     size_t S = 1;
     for (int j = 0; j < AVM_WINDOW_SIZE; j++) S = std::max(S, pre_integrations[j + 1].dt_buf.size());
-    t.max_samp = (int)S;
-    t.imu_n.assign(AVM_WINDOW_SIZE, 0);
-    t.imu_dt.assign(AVM_WINDOW_SIZE * S, 0.0);
-    t.imu_acc.assign(AVM_WINDOW_SIZE * (S + 1) * 3, 0.0), t.imu_gyr.assign(AVM_WINDOW_SIZE * (S + 1) * 3, 0.0);
-    t.imu_lin_ba.assign(AVM_WINDOW_SIZE * 3, 0.0), t.imu_lin_bg.assign(AVM_WINDOW_SIZE * 3, 0.0);
-    for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
-      const IntegrationBase& p = pre_integrations[j + 1];
-      const size_t n = p.dt_buf.size(), row0 = (size_t)j * (S + 1);
-      t.imu_n[j] = (int32_t)n;
-      for (int k = 0; k < 3; k++) {
-        t.imu_acc[row0 * 3 + k] = p.linearized_acc[k], t.imu_gyr[row0 * 3 + k] = p.linearized_gyr[k];  // row 0 = the constructor's sample
-        t.imu_lin_ba[j * 3 + k] = p.linearized_ba[k], t.imu_lin_bg[j * 3 + k] = p.linearized_bg[k];
-      }
-      for (size_t s = 0; s < n; s++) {
-        t.imu_dt[j * S + s] = p.dt_buf[s];
-        for (int k = 0; k < 3; k++) t.imu_acc[(row0 + s + 1) * 3 + k] = p.acc_buf[s][k], t.imu_gyr[(row0 + s + 1) * 3 + k] = p.gyr_buf[s][k];
-      }
-    }
+    fill_imu(t, S);
   }
 
   // FeatureManager::triangulate(Ps, tic, ric) (feature_manager.cpp:202-257; call site estimator.cpp:470)
@@ -354,9 +338,107 @@ class Estimator {
     }
   }
 
+  // Estimator::slideWindow (estimator.cpp:996-1107) with slideWindowOld / slideWindowNew and the three FeatureManager
+  // remove* methods (feature_manager.cpp:275-352), for frame_count == WINDOW_SIZE: the states, the IMU buffers and EVERY
+  // feature of f_manager (not only the ones that pass the solve's filter) go through avm_slide_window() and come back.
+  // Headers / all_image_frame bookkeeping is the caller's.
+  void slideWindow(double init_depth = 5.0) {
+    vector2double();
+    WindowTables t;
+    t.pose.assign(&para_Pose[0][0], &para_Pose[0][0] + AVM_NFRAMES * 7);
+    t.speedbias.assign(&para_SpeedBias[0][0], &para_SpeedBias[0][0] + AVM_NFRAMES * 9);
+    t.ex_pose.assign(&para_Ex_Pose[0][0], &para_Ex_Pose[0][0] + 7);
+    const int nf = (int)f_manager.feature.size();
+    size_t n_obs = 0;
+    for (const auto& f : f_manager.feature) n_obs += f.feature_per_frame.size();
+    const int max_feat = std::max(1, nf), max_obs = (int)std::max<size_t>(1, n_obs);
+    t.inv_depth.assign(max_feat, 0.0);
+    t.feat_start.assign(max_feat, 0), t.feat_nobs.assign(max_feat, 0), t.feat_obs_begin.assign(max_feat, 0);
+    t.obs_xy.assign((size_t)max_obs * 2, 0.0);
+    {
+      int e = 0, o = 0;
+      for (auto it = f_manager.feature.begin(); it != f_manager.feature.end(); ++it, ++e) {
+        t.feat_start[e] = it->start_frame, t.feat_nobs[e] = (int)it->feature_per_frame.size(), t.feat_obs_begin[e] = o;
+        t.inv_depth[e] = 1.0 / it->estimated_depth;
+        for (const auto& pf : it->feature_per_frame) t.obs_xy[2 * o] = pf.point[0], t.obs_xy[2 * o + 1] = pf.point[1], o++;
+      }
+      t.n_feat = nf;
+    }
+    // second-new appends interval 10's samples to interval 9: leave room for them
+    size_t S = 1;
+    for (int j = 0; j < AVM_WINDOW_SIZE; j++) S = std::max(S, pre_integrations[j + 1].dt_buf.size());
+    S = std::max(S, pre_integrations[AVM_WINDOW_SIZE - 1].dt_buf.size() + pre_integrations[AVM_WINDOW_SIZE].dt_buf.size());
+    fill_imu(t, S);
+    avm_window_batch b = t.batch(nullptr);
+    b.max_feat = max_feat, b.max_obs = max_obs;
+    const int flag = marginalization_flag == MARGIN_OLD ? AVM_MARGIN_OLD : AVM_MARGIN_SECOND_NEW;
+    ctx_.check(avm_slide_window(ctx_.get(), AVM_MEM_HOST, &b, flag, solver_flag == NON_LINEAR ? 1 : 0, init_depth), "avm_slide_window");
+
+    std::copy(t.pose.begin(), t.pose.end(), &para_Pose[0][0]);
+    std::copy(t.speedbias.begin(), t.speedbias.end(), &para_SpeedBias[0][0]);
+    double2vector();
+    for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
+      const size_t row0 = (size_t)j * (S + 1);
+      auto v3 = [](const double* p) { return Vector3d{p[0], p[1], p[2]}; };
+      IntegrationBase p(v3(&t.imu_acc[row0 * 3]), v3(&t.imu_gyr[row0 * 3]), v3(&t.imu_lin_ba[j * 3]), v3(&t.imu_lin_bg[j * 3]));
+      for (int s2 = 0; s2 < t.imu_n[j]; s2++) p.push_back(t.imu_dt[j * S + s2], v3(&t.imu_acc[(row0 + s2 + 1) * 3]), v3(&t.imu_gyr[(row0 + s2 + 1) * 3]));
+      pre_integrations[j + 1] = std::move(p);
+    }
+    // features: the roll compacts the tables in list order and never moves an observation to another feature's slots
+    std::vector<char> kept(nf, 0);
+    std::vector<std::list<FeaturePerId>::iterator> all;
+    for (auto it = f_manager.feature.begin(); it != f_manager.feature.end(); ++it) all.push_back(it);
+    {
+      std::vector<int> index_of(max_obs, -1), first_slot(nf + 1, 0);  // observation slot -> feature, feature -> first slot
+      int e = 0, o = 0;
+      for (auto it = f_manager.feature.begin(); it != f_manager.feature.end(); ++it, ++e) {
+        first_slot[e] = o;
+        for (size_t k = 0; k < it->feature_per_frame.size(); k++) index_of[o++] = e;
+      }
+      for (int k = 0; k < t.n_feat; k++) {
+        const int ob = t.feat_obs_begin[k], e0 = index_of[ob];
+        FeaturePerId& f = *all[e0];
+        kept[e0] = 1;
+        auto& v = f.feature_per_frame;
+        if (flag == AVM_MARGIN_OLD) {
+          if (ob == first_slot[e0] + 1) v.erase(v.begin());                    // lost its first observation
+        } else if ((int)v.size() != t.feat_nobs[k]) {
+          v.erase(v.begin() + (AVM_WINDOW_SIZE - 1 - f.start_frame));          // lost its observation in frame 9
+        }
+        f.start_frame = t.feat_start[k];
+        f.estimated_depth = 1.0 / t.inv_depth[k];
+      }
+    }
+    {
+      int e = 0;
+      for (auto it = f_manager.feature.begin(); it != f_manager.feature.end(); ++e) it = kept[e] ? std::next(it) : f_manager.feature.erase(it);
+    }
+  }
+
   Context& context() { return ctx_; }
 
  private:
+  void fill_imu(WindowTables& t, size_t S) const {
+    t.max_samp = (int)S;
+    t.imu_n.assign(AVM_WINDOW_SIZE, 0);
+    t.imu_dt.assign(AVM_WINDOW_SIZE * S, 0.0);
+    t.imu_acc.assign(AVM_WINDOW_SIZE * (S + 1) * 3, 0.0), t.imu_gyr.assign(AVM_WINDOW_SIZE * (S + 1) * 3, 0.0);
+    t.imu_lin_ba.assign(AVM_WINDOW_SIZE * 3, 0.0), t.imu_lin_bg.assign(AVM_WINDOW_SIZE * 3, 0.0);
+    for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
+      const IntegrationBase& p = pre_integrations[j + 1];
+      const size_t n = p.dt_buf.size(), row0 = (size_t)j * (S + 1);
+      t.imu_n[j] = (int32_t)n;
+      for (int k = 0; k < 3; k++) {
+        t.imu_acc[row0 * 3 + k] = p.linearized_acc[k], t.imu_gyr[row0 * 3 + k] = p.linearized_gyr[k];  // row 0 = the constructor's sample
+        t.imu_lin_ba[j * 3 + k] = p.linearized_ba[k], t.imu_lin_bg[j * 3 + k] = p.linearized_bg[k];
+      }
+      for (size_t s = 0; s < n; s++) {
+        t.imu_dt[j * S + s] = p.dt_buf[s];
+        for (int k = 0; k < 3; k++) t.imu_acc[(row0 + s + 1) * 3 + k] = p.acc_buf[s][k], t.imu_gyr[(row0 + s + 1) * 3 + k] = p.gyr_buf[s][k];
+      }
+    }
+  }
+
   Context& ctx_;
 };
 

@@ -190,6 +190,38 @@ int hs_get_prior(void* hp, int32_t* n, int32_t* nblk, int32_t* kind, int32_t* fr
   return 0;
 }
 
+int hs_slide_window(void* hp, double init_depth) {
+  Host& H = *static_cast<Host*>(hp);
+  return guarded([&] { H.est.slideWindow(init_depth); });
+}
+
+// every feature of f_manager in list order: id, start_frame, number of observations, estimated_depth, first / last point
+int hs_dump_features(void* hp, int cap, int32_t* id, int32_t* start, int32_t* nobs, double* depth, double* first_xy, double* last_xy) {
+  Host& H = *static_cast<Host*>(hp);
+  int k = 0;
+  for (const auto& f : H.est.f_manager.feature) {
+    if (k >= cap) return -1;
+    id[k] = f.feature_id, start[k] = f.start_frame, nobs[k] = (int)f.feature_per_frame.size(), depth[k] = f.estimated_depth;
+    first_xy[2 * k] = f.feature_per_frame.front().point[0], first_xy[2 * k + 1] = f.feature_per_frame.front().point[1];
+    last_xy[2 * k] = f.feature_per_frame.back().point[0], last_xy[2 * k + 1] = f.feature_per_frame.back().point[1];
+    k++;
+  }
+  return k;
+}
+
+// the raw IMU buffers of interval j (pre_integrations[j + 1]): returns the sample count
+int hs_dump_imu(void* hp, int j, int cap, double* dt, double* acc, double* gyr, double* lin) {
+  const IntegrationBase& p = static_cast<Host*>(hp)->est.pre_integrations[j + 1];
+  const int n = (int)p.dt_buf.size();
+  if (n > cap) return -1;
+  for (int k = 0; k < 3; k++) acc[k] = p.linearized_acc[k], gyr[k] = p.linearized_gyr[k], lin[k] = p.linearized_ba[k], lin[3 + k] = p.linearized_bg[k];
+  for (int s = 0; s < n; s++) {
+    dt[s] = p.dt_buf[s];
+    for (int k = 0; k < 3; k++) acc[(s + 1) * 3 + k] = p.acc_buf[s][k], gyr[(s + 1) * 3 + k] = p.gyr_buf[s][k];
+  }
+  return n;
+}
+
 // ---- selector ----------------------------------------------------------------------------------------------------
 // cam = fx fy cx cy k1 k2 p1 p2
 int hs_sel_create(void* hp, const double* cam, int width, int height, int horizon) {

@@ -75,6 +75,24 @@ class Host:
     def triangulate(self, init_depth=5.0):
         return self.L.hs_triangulate(self.h, C.c_double(init_depth))
 
+    def slide_window(self, init_depth=5.0):
+        return self.L.hs_slide_window(self.h, C.c_double(init_depth))
+
+    def features(self):
+        cap = 512
+        out = dict(id=np.zeros(cap, np.int32), start=np.zeros(cap, np.int32), nobs=np.zeros(cap, np.int32), depth=np.zeros(cap),
+                   first=np.zeros((cap, 2)), last=np.zeros((cap, 2)))
+        n = self.L.hs_dump_features(self.h, cap, abi.iptr(out["id"]), abi.iptr(out["start"]), abi.iptr(out["nobs"]), abi.dptr(out["depth"]),
+                                    abi.dptr(out["first"]), abi.dptr(out["last"]))
+        assert n >= 0
+        return {k: v[:n] for k, v in out.items()}
+
+    def imu(self, j, cap=256):
+        dt, acc, gyr, lin = np.zeros(cap), np.zeros((cap + 1, 3)), np.zeros((cap + 1, 3)), np.zeros(6)
+        n = self.L.hs_dump_imu(self.h, int(j), cap, abi.dptr(dt), abi.dptr(acc), abi.dptr(gyr), abi.dptr(lin))
+        assert n >= 0
+        return n, dt[:n], acc[:n + 1], gyr[:n + 1], lin
+
     def state(self):
         out = dict(pose=np.zeros((11, 7)), speedbias=np.zeros((11, 9)), ex_pose=np.zeros(7), depth=np.zeros(150), solve_flag=np.zeros(150, np.int32))
         n = C.c_int32(0)
@@ -352,3 +370,54 @@ def test_cpp_selector_select_over_frames_matches_oracle_composition(oracle, hori
         assert tr_g == tracked, k
         stamp += 0.1
     assert n_selected >= 40, n_selected
+
+
+def _insert_feature_rows(w, rows):
+    """rows: (row index, start_frame, nobs) - features that fail the solve's filter, spliced into window 0's tables."""
+    a = w.a
+    for pos, start, nobs in sorted(rows):
+        nf = int(a["n_feat"][0])
+        ob = int((a["feat_obs_begin"][0, :nf] + a["feat_nobs"][0, :nf]).max()) if nf else 0
+        for k in ("feat_start", "feat_nobs", "feat_obs_begin", "inv_depth"):
+            a[k][0, pos + 1:nf + 1] = a[k][0, pos:nf].copy()
+        a["feat_start"][0, pos], a["feat_nobs"][0, pos], a["feat_obs_begin"][0, pos], a["inv_depth"][0, pos] = start, nobs, ob, 1.0 / 3.0
+        a["obs_xy"][0, ob:ob + nobs] = 0.01 * (1 + np.arange(2 * nobs).reshape(nobs, 2)) + 0.001 * pos
+        a["n_feat"][0] = nf + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", [0, 1])
+def test_cpp_estimator_slide_window_matches_oracle(oracle, flag):
+    """slideWindow() on the C++ object - every feature of f_manager goes through the roll, also the ones the solve never
+    sees (one observation, late start) - against the oracle's list-based restatement on the same tables."""
+    w = synth.make_windows(1, first_id=3, tracks="sparse", n_feat=60, max_feat=150, max_obs=1650, max_samp=48)
+    w.a["imu_n"][0, 8], w.a["imu_n"][0, 9] = 20, 17
+    nf0 = int(w.a["n_feat"][0])
+    n0 = int((w.a["feat_start"][0, :nf0] == 0).sum())
+    _insert_feature_rows(w, [(0, 0, 1), (n0 + 1, 0, 2), (nf0 + 2, 9, 1), (nf0 + 3, 9, 2), (nf0 + 4, 10, 1)])
+    nf = int(w.a["n_feat"][0])
+    assert nf == nf0 + 5 and np.all(np.diff(w.a["feat_start"][0, :nf]) >= 0)
+    H = Host()
+    H.load(w, feat_id=100 + np.arange(nf))
+    H.set_flags(solver_flag=1, marginalization_flag=flag)
+    assert H.slide_window(5.0) == 0, H.err()
+    wo = w.copy()
+    oracle.slide_window(wo, abi.MARGIN_OLD if flag == 0 else abi.MARGIN_SECOND_NEW, True, 5.0)
+    s, f = H.state(), H.features()
+    assert np.array_equal(s["pose"], wo.a["pose"][0]) and np.array_equal(s["speedbias"], wo.a["speedbias"][0])
+    n = int(wo.a["n_feat"][0])
+    assert len(f["id"]) == n and n < nf
+    st, no, ob = wo.a["feat_start"][0, :n], wo.a["feat_nobs"][0, :n], wo.a["feat_obs_begin"][0, :n]
+    assert np.array_equal(f["start"], st) and np.array_equal(f["nobs"], no)
+    assert rel(1.0 / f["depth"], wo.a["inv_depth"][0, :n]) < 1e-12
+    assert np.array_equal(f["first"], wo.a["obs_xy"][0, ob]) and np.array_equal(f["last"], wo.a["obs_xy"][0, ob + no - 1])
+    assert np.all(np.diff(f["id"]) > 0)  # list order survives
+    for j in range(10):
+        k, dt, acc, gyr, lin = H.imu(j)
+        assert k == wo.a["imu_n"][0, j]
+        assert np.array_equal(dt, wo.a["imu_dt"][0, j, :k])
+        assert np.array_equal(acc, wo.a["imu_acc"][0, j, :k + 1]) and np.array_equal(gyr, wo.a["imu_gyr"][0, j, :k + 1])
+        assert np.array_equal(lin[:3], wo.a["imu_lin_ba"][0, j]) and np.array_equal(lin[3:], wo.a["imu_lin_bg"][0, j])
+    # and the rolled members solve: optimization() right after, against the oracle on the rolled tables
+    H.set_flags(solver_flag=1, marginalization_flag=0)
+    assert H.optimization() == 0, H.err()
