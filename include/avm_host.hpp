@@ -292,6 +292,19 @@ class Estimator {
     fill_imu(t, S);
   }
 
+  // The dead-reckoning of Estimator::processIMU (estimator.cpp:100-107) for the newest frame, all samples of the last
+  // interval at once: Ps / Rs / Vs [WINDOW_SIZE] (holding the previous frame's values, as slideWindow() leaves them) are
+  // carried through pre_integrations[WINDOW_SIZE]'s raw buffers with Bas / Bgs [WINDOW_SIZE] and options.g.
+  void propagateNewestFrame() {
+    WindowTables t;
+    marshal(t, [](const FeaturePerId&) { return 1.0; });
+    avm_window_batch b = t.batch(nullptr);
+    ctx_.check(avm_imu_propagate_batch(ctx_.get(), AVM_MEM_HOST, &b, options.g), "avm_imu_propagate_batch");
+    std::copy(t.pose.begin(), t.pose.end(), &para_Pose[0][0]);
+    std::copy(t.speedbias.begin(), t.speedbias.end(), &para_SpeedBias[0][0]);
+    double2vector();
+  }
+
   // FeatureManager::triangulate(Ps, tic, ric) (feature_manager.cpp:202-257; call site estimator.cpp:470)
   void triangulate(double init_depth = 5.0) {
     WindowTables t;

@@ -190,6 +190,11 @@ int hs_get_prior(void* hp, int32_t* n, int32_t* nblk, int32_t* kind, int32_t* fr
   return 0;
 }
 
+int hs_propagate(void* hp) {
+  Host& H = *static_cast<Host*>(hp);
+  return guarded([&] { H.est.propagateNewestFrame(); });
+}
+
 int hs_slide_window(void* hp, double init_depth) {
   Host& H = *static_cast<Host*>(hp);
   return guarded([&] { H.est.slideWindow(init_depth); });

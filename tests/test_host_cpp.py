@@ -421,3 +421,20 @@ def test_cpp_estimator_slide_window_matches_oracle(oracle, flag):
     # and the rolled members solve: optimization() right after, against the oracle on the rolled tables
     H.set_flags(solver_flag=1, marginalization_flag=0)
     assert H.optimization() == 0, H.err()
+
+
+@pytest.mark.gpu
+def test_cpp_estimator_newest_frame_dead_reckoning_matches_oracle(oracle):
+    w = synth.make_windows(1, first_id=9, tracks="sparse", n_feat=30, max_feat=150, max_obs=1650)
+    w.a["pose"][0, 10] = w.a["pose"][0, 9]
+    w.a["speedbias"][0, 10] = w.a["speedbias"][0, 9]
+    H = Host()
+    H.load(w)
+    assert H.L.hs_propagate(H.h) == 0, H.err()
+    wo = w.copy()
+    o = abi.default_options()
+    oracle.imu_propagate(wo, [o.g[0], o.g[1], o.g[2]])
+    s = H.state()
+    assert rel(s["pose"][10], wo.a["pose"][0, 10]) < 1e-12 and rel(s["speedbias"][10], wo.a["speedbias"][0, 10]) < 1e-12
+    assert np.array_equal(s["pose"][:10], w.a["pose"][0, :10])
+    assert np.abs(s["pose"][10] - w.a["pose"][0, 9]).max() > 1e-3
