@@ -438,3 +438,28 @@ def test_cpp_estimator_newest_frame_dead_reckoning_matches_oracle(oracle):
     assert rel(s["pose"][10], wo.a["pose"][0, 10]) < 1e-12 and rel(s["speedbias"][10], wo.a["speedbias"][0, 10]) < 1e-12
     assert np.array_equal(s["pose"][:10], w.a["pose"][0, :10])
     assert np.abs(s["pose"][10] - w.a["pose"][0, 9]).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_cpp_estimator_solve_roll_solve_chain_matches_oracle(oracle):
+    """optimization() -> slideWindow() -> optimization() on one C++ object (the prior of the first solve feeds the second,
+    the tables are re-marshalled from the rolled members) against the same chain on the oracle."""
+    w = synth.make_windows(1, first_id=21, tracks="sparse", n_feat=70, max_feat=150, max_obs=1650)
+    H = Host()
+    H.load(w)
+    H.set_flags(solver_flag=1, marginalization_flag=0)
+    assert H.optimization() == 0, H.err()
+    assert H.slide_window(5.0) == 0, H.err()
+    assert H.optimization() == 0, H.err()
+    o = abi.default_options()
+    wo, po, so = w.copy(), buffers.PriorOutArrays.alloc(1), buffers.summary_alloc(1)
+    oracle.window_solve(o, wo, po, so)
+    oracle.slide_window(wo, abi.MARGIN_OLD, True, 5.0)
+    _install_prior(wo, po)
+    oracle.window_solve(o, wo, buffers.PriorOutArrays.alloc(1), so)
+    s = H.state()
+    n = int(wo.a["n_feat"][0])
+    assert s["n_feat"] == n
+    assert rel(s["pose"], wo.a["pose"][0]) < 1e-5 and rel(s["speedbias"], wo.a["speedbias"][0]) < 1e-5
+    assert rel(1.0 / s["depth"][:n], wo.a["inv_depth"][0, :n]) < 1e-5
+    assert s["summary"]["num_iterations"][0] == so["num_iterations"][0]
