@@ -50,10 +50,11 @@ def test_no_cpu_fallback_without_device():
 
 def test_product_package_never_touches_the_oracle():
     """No file of the shipped package may import, include, link or call anything under oracle/."""
-    pk = os.path.join(ROOT, PKG)
     banned = re.compile(r"oracle_py|libavm_oracle|avmo_|#include\s+\"[^\"]*oracle|import\s+oracle|from\s+oracle")
-    for dirpath, _, files in os.walk(pk):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
-                txt = open(os.path.join(dirpath, f)).read()
-                assert not banned.search(txt), (dirpath, f, banned.search(txt).group(0))
+    # the package, the public headers (C ABI + the C++ host side) and the measurement / profiling scripts
+    for top in (os.path.join(ROOT, PKG), os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts")):
+        for dirpath, _, files in os.walk(top):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".sh", "Makefile")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert not banned.search(txt), (dirpath, f, banned.search(txt).group(0))
