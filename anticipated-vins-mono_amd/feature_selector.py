@@ -66,23 +66,39 @@ class FeatureSelector:
         self.ctx.check(rc, "avm_fsel_information")
         return om, dl, va
 
-    def select(self, image: dict, problem_builder, header_stamp=None, nrImuMeasurements=None):
-        """Single-frame convenience with the reference's bookkeeping: `image` maps feature id ->
-        8-vector (x y 1 u v vx vy prob); `problem_builder(new_ids, used_ids)` returns a 1-problem
-        FselArrays for those ids.  Returns (trackedFeatures_, selectedIds) and mutates `image`."""
+    def setParameters(self, enable=True, maxFeatures=150, initThresh=0):
+        """The bookkeeping half of FeatureSelector::setParameters (feature_selector.cpp:24-34); the noise parameters and
+        the horizon mode travel with the FselArrays the problem_builder returns."""
+        self.enable_, self.maxFeatures_, self.initThresh_ = bool(enable), int(maxFeatures), int(initThresh)
+
+    def select(self, image: dict, problem_builder, initialized: bool = True):
+        """Single-frame select() with the reference's bookkeeping (feature_selector.cpp:74-202): `image` maps feature id ->
+        8-vector (x y 1 u v vx vy prob) and is replaced by the subset handed to the back end; `problem_builder(new_ids,
+        used_ids)` returns a 1-problem FselArrays for those ids (only called when `initialized`, i.e. solver_flag ==
+        NON_LINEAR).  Returns (trackedFeatures_, selectedIds); () when disabled.  include/avm_host.hpp holds the C++
+        statement of the same function, including the horizon / depth-cloud marshalling."""
+        if not getattr(self, "enable_", True):
+            return ()
         ids = sorted(image)
         new_ids = [i for i in ids if i > self.lastFeatureId_]  # splitOnFeatureId
         old = {i: image[i] for i in ids if i <= self.lastFeatureId_}
         if new_ids:
             self.lastFeatureId_ = new_ids[-1]
-        used_ids = [f for f in self.trackedFeatures_ if f in old]
-        prob = problem_builder(new_ids, used_ids)
-        out = self.select_batch(prob).to_host()
-        n = int(out.a["n_selected"][0])
-        selected = [int(v) for v in out.a["selected_ids"][0, :n]]
-        subset = {f: old[f] for f in used_ids}
-        for f in selected:
-            subset[f] = image[f]
+        subset = {f: old[f] for f in self.trackedFeatures_ if f in old}
+        selected = []
+        if initialized:
+            prob = problem_builder(new_ids, sorted(subset))
+            out = self.select_batch(prob).to_host()
+            n = int(out.a["n_selected"][0])
+            selected = [int(v) for v in out.a["selected_ids"][0, :n]]
+            for f in selected:
+                subset[f] = image[f]
+        elif getattr(self, "firstImage_", True):
+            subset = {f: image[f] for f in new_ids}  # the whole first image initializes the back end
+            self.trackedFeatures_.extend(new_ids)
+            self.firstImage_ = False
+        if not initialized and len(subset) < getattr(self, "initThresh_", 0):
+            subset.update(old)
         image.clear()
         image.update(subset)
         self.trackedFeatures_.extend(selected)
