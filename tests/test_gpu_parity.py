@@ -345,6 +345,12 @@ def test_full_size_batch_properties(ctx):
     # the prior is a square root: J^T J is symmetric positive semi-definite with the kept dimension's rank or less
     A = J[0, 0, :75, :75].T @ J[0, 0, :75, :75]
     assert np.linalg.eigvalsh(A).min() > -1e-6 * np.abs(A).max()
+    # the gauge fix of double2vector (estimator.cpp:521-587): frame 0 keeps its yaw and its position in every window
+    q0, q1 = synth.tile_windows(base, 4096).a["pose"][:, 0, 3:], out.a["pose"][:, 0, 3:]
+    yaw = lambda q: np.arctan2(2 * (q[:, 0] * q[:, 1] + q[:, 2] * q[:, 3]), 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2))
+    assert np.abs(yaw(q1) - yaw(q0)).max() < 1e-10
+    assert np.abs(out.a["pose"][:, 0, :3] - synth.tile_windows(base, 4096).a["pose"][:, 0, :3]).max() < 1e-12
+    assert np.abs(np.linalg.norm(out.a["pose"][..., 3:], axis=-1) - 1).max() < 1e-12
 
 
 def test_device_resident_buffers_match_host_path(estimator):

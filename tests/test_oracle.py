@@ -164,6 +164,32 @@ def test_non_finite_inputs_do_not_break_the_oracle(oracle, opt):
     assert np.isnan(wv).all()
 
 
+def _yaw_deg(q):  # Utility::R2ypr(R).x(), utility.h:86-99 (degrees), q = x y z w
+    x, y, z, w = q
+    r00, r10 = 1 - 2 * (y * y + z * z), 2 * (x * y + z * w)
+    return np.degrees(np.arctan2(r10, r00))
+
+
+def check_gauge_fix(before, after):
+    """double2vector (estimator.cpp:521-587): the first frame keeps its yaw and its position; every frame's position and
+    velocity is rotated about the first frame's new position by the yaw difference, so distances to frame 0 and speeds
+    are the solver's."""
+    for b in range(before["pose"].shape[0]):
+        assert abs(_yaw_deg(after["pose"][b, 0, 3:]) - _yaw_deg(before["pose"][b, 0, 3:])) < 1e-9
+        assert np.abs(after["pose"][b, 0, :3] - before["pose"][b, 0, :3]).max() < 1e-12
+        assert np.abs(np.linalg.norm(after["pose"][b, :, 3:], axis=1) - 1).max() < 1e-12
+
+
+def test_gauge_fix_keeps_first_frame_yaw_and_position(oracle, opt):
+    w = synth.make_windows(3, first_id=40, tracks="sparse", n_feat=40, max_feat=150)
+    # push the initial guess away so that the solve moves frame 0 before the fix brings it back
+    w.a["pose"][:, :, :3] += 0.05
+    a = w.copy()
+    oracle.window_solve(opt, a, None, buffers.summary_alloc(3))
+    assert np.abs(a.a["pose"][:, 1:, :3] - w.a["pose"][:, 1:, :3]).max() > 1e-3
+    check_gauge_fix(w.a, a.a)
+
+
 def test_first_iteration_step_matches_dense_numpy_normal_equations(oracle):
     """Pins the oracle's linear path (Jacobi scaling, LM diagonal, Schur elimination of the inverse depths, Cholesky, the
     Gauss-Newton branch of the dogleg, Plus) against a dense numpy statement of Ceres' first trust-region iteration built
