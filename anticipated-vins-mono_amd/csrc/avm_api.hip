@@ -28,6 +28,9 @@ struct avm_ctx {
   size_t summary_cap = 0;
   // staging pool for AVM_MEM_HOST calls: name -> (ptr, bytes)
   std::map<std::string, std::pair<void*, size_t>> pool;
+  // pinned host staging (small AVM_MEM_HOST batches travel as one packed copy each way): name -> (ptr, bytes)
+  std::map<std::string, std::pair<void*, size_t>> pinned;
+  bool packed_in = false;  // the last stage_window_batch took the packed path (states are contiguous on the device)
   hipEvent_t ev[8];
   std::map<std::string, float> last_ms;
 };
@@ -54,6 +57,17 @@ void* pool_get(avm_ctx* c, const std::string& name, size_t bytes) {
     if (e.first) (void)hipFree(e.first);
     e.first = nullptr;
     if (hipMalloc(&e.first, bytes ? bytes : 8) != hipSuccess) return nullptr;
+    e.second = bytes;
+  }
+  return e.first;
+}
+
+void* pinned_get(avm_ctx* c, const std::string& name, size_t bytes) {
+  auto& e = c->pinned[name];
+  if (e.second < bytes || e.first == nullptr) {
+    if (e.first) (void)hipHostFree(e.first);
+    e.first = nullptr;
+    if (hipHostMalloc(&e.first, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) return nullptr;
     e.second = bytes;
   }
   return e.first;
@@ -165,36 +179,85 @@ int check_window_batch(avm_ctx* c, const avm_options* opt, const avm_window_batc
 }
 
 // copy a host batch to the device; out = batch with device pointers
+// (field, element type, elements) of every table of an avm_window_batch; the four state arrays come first so that
+// the packed path can bring them back with one copy
+#define AVM_WINDOW_FIELDS(X, B, h)                                                                                        \
+  X(pose, double, (B) * 77) X(speedbias, double, (B) * 99) X(ex_pose, double, (B) * 7) X(inv_depth, double, (B) * (h)->max_feat) \
+  X(n_feat, int32_t, (B)) X(feat_start, int32_t, (B) * (h)->max_feat) X(feat_nobs, int32_t, (B) * (h)->max_feat)           \
+  X(feat_obs_begin, int32_t, (B) * (h)->max_feat) X(obs_xy, double, (B) * (h)->max_obs * 2) X(imu_n, int32_t, (B) * 10)    \
+  X(imu_dt, double, (B) * 10 * (h)->max_samp) X(imu_acc, double, (B) * 10 * ((h)->max_samp + 1) * 3)                       \
+  X(imu_gyr, double, (B) * 10 * ((h)->max_samp + 1) * 3) X(imu_lin_ba, double, (B) * 30) X(imu_lin_bg, double, (B) * 30)   \
+  X(prior_n, int32_t, (B)) X(prior_nblk, int32_t, (B)) X(prior_blk_kind, int32_t, (B) * (h)->max_pblk)                     \
+  X(prior_blk_frame, int32_t, (B) * (h)->max_pblk) X(prior_J, double, (B) * (h)->max_prior * (h)->max_prior)               \
+  X(prior_r, double, (B) * (h)->max_prior) X(prior_x0, double, (B) * (h)->max_pblk * 9)
+
+constexpr size_t PACK_LIMIT = 4u << 20;  // batches below 4 MiB (a few windows: the real-time use) travel packed
+inline size_t pack_up(size_t n) { return (n + 63) & ~size_t(63); }
+
+// copy a host batch to the device; out = batch with device pointers.  Small batches go through one pinned buffer and
+// one copy (22 pageable copies of a few hundred bytes each cost more than the solve's pre-integration kernel).
 int stage_window_batch(avm_ctx* c, const avm_window_batch* h, avm_window_batch* d) {
   *d = *h;
   const size_t B = h->n_windows;
   int rc;
-#define ST(field, type, count)                                                       \
+  size_t total = 0;
+#define SZ(field, type, count) total += h->field ? pack_up(sizeof(type) * (count)) : 0;
+  AVM_WINDOW_FIELDS(SZ, B, h)
+#undef SZ
+  c->packed_in = total <= PACK_LIMIT && h->pose && h->speedbias && h->ex_pose && h->inv_depth;
+  if (c->packed_in) {
+    char* hp = static_cast<char*>(pinned_get(c, "w_pack", total));
+    char* dp = static_cast<char*>(pool_get(c, "w_pack", total));
+    if (!hp || !dp) return fail(c, AVM_ERR_HIP, "allocation failed (packed staging)");
+    size_t off = 0;
+#define PK(field, type, count)                                             \
+  if (h->field) {                                                          \
+    std::memcpy(hp + off, h->field, sizeof(type) * (count));               \
+    *(const type**)&d->field = reinterpret_cast<const type*>(dp + off);    \
+    off += pack_up(sizeof(type) * (count));                                \
+  }
+    AVM_WINDOW_FIELDS(PK, B, h)
+#undef PK
+    HIPCHK(c, hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, c->stream));
+    return AVM_OK;
+  }
+#define ST(field, type, count) \
   if ((rc = stage_in<type>(c, "w_" #field, h->field, (count), (const type**)&d->field)) != AVM_OK) return rc;
-  ST(pose, double, B * 77)
-  ST(speedbias, double, B * 99)
-  ST(ex_pose, double, B * 7)
-  ST(inv_depth, double, B * h->max_feat)
-  ST(n_feat, int32_t, B)
-  ST(feat_start, int32_t, B * h->max_feat)
-  ST(feat_nobs, int32_t, B * h->max_feat)
-  ST(feat_obs_begin, int32_t, B * h->max_feat)
-  ST(obs_xy, double, B * h->max_obs * 2)
-  ST(imu_n, int32_t, B * 10)
-  ST(imu_dt, double, B * 10 * h->max_samp)
-  ST(imu_acc, double, B * 10 * (h->max_samp + 1) * 3)
-  ST(imu_gyr, double, B * 10 * (h->max_samp + 1) * 3)
-  ST(imu_lin_ba, double, B * 30)
-  ST(imu_lin_bg, double, B * 30)
-  ST(prior_n, int32_t, B)
-  ST(prior_nblk, int32_t, B)
-  ST(prior_blk_kind, int32_t, B * h->max_pblk)
-  ST(prior_blk_frame, int32_t, B * h->max_pblk)
-  ST(prior_J, double, B * h->max_prior * h->max_prior)
-  ST(prior_r, double, B * h->max_prior)
-  ST(prior_x0, double, B * h->max_pblk * 9)
+  AVM_WINDOW_FIELDS(ST, B, h)
 #undef ST
   return AVM_OK;
+}
+
+// the four state arrays back to the caller (after the kernels, before the final synchronize)
+int unstage_window_states(avm_ctx* c, const avm_window_batch* h, const avm_window_batch* d, char** pinned_states) {
+  const size_t B = h->n_windows;
+  *pinned_states = nullptr;
+  if (c->packed_in) {
+    // pose | speedbias | ex_pose | inv_depth are the first four blocks of the packed buffer
+    const size_t bytes = pack_up(sizeof(double) * B * 77) + pack_up(sizeof(double) * B * 99) + pack_up(sizeof(double) * B * 7) +
+                         pack_up(sizeof(double) * B * h->max_feat);
+    char* hp = static_cast<char*>(pinned_get(c, "w_states", bytes));
+    if (!hp) return fail(c, AVM_ERR_HIP, "allocation failed (packed states)");
+    HIPCHK(c, hipMemcpyAsync(hp, d->pose, bytes, hipMemcpyDeviceToHost, c->stream));
+    *pinned_states = hp;
+    return AVM_OK;
+  }
+  HIPCHK(c, hipMemcpyAsync(h->pose, d->pose, sizeof(double) * B * 77, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h->speedbias, d->speedbias, sizeof(double) * B * 99, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h->ex_pose, d->ex_pose, sizeof(double) * B * 7, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h->inv_depth, d->inv_depth, sizeof(double) * B * h->max_feat, hipMemcpyDeviceToHost, c->stream));
+  return AVM_OK;
+}
+
+// after the synchronize: scatter the packed states into the caller's arrays
+void finish_window_states(const avm_window_batch* h, const char* pinned_states) {
+  if (!pinned_states) return;
+  const size_t B = h->n_windows;
+  size_t off = 0;
+  std::memcpy(h->pose, pinned_states + off, sizeof(double) * B * 77), off += pack_up(sizeof(double) * B * 77);
+  std::memcpy(h->speedbias, pinned_states + off, sizeof(double) * B * 99), off += pack_up(sizeof(double) * B * 99);
+  std::memcpy(h->ex_pose, pinned_states + off, sizeof(double) * B * 7), off += pack_up(sizeof(double) * B * 7);
+  std::memcpy(h->inv_depth, pinned_states + off, sizeof(double) * B * h->max_feat);
 }
 
 int run_preint(avm_ctx* c, const avm_options* opt, const avm_window_batch* d) {
@@ -277,6 +340,8 @@ void avm_destroy(avm_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& kv : c->pool)
     if (kv.second.first) (void)hipFree(kv.second.first);
+  for (auto& kv : c->pinned)
+    if (kv.second.first) (void)hipHostFree(kv.second.first);
   for (void* p : {(void*)c->scratch, (void*)c->iscratch, (void*)c->pre_delta, (void*)c->pre_jac, (void*)c->pre_cov, (void*)c->pre_sqrt,
                   (void*)c->pre_sum, (void*)c->d_summary})
     if (p) (void)hipFree(p);
@@ -337,23 +402,25 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   HIPCHK(c, launch_window_solve(sa, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   avm_prior_out dpo;
+  char* po_pinned = nullptr;
+  size_t po_offsets[7] = {0, 0, 0, 0, 0, 0, 0};
   if (marg) {
     const size_t B = batch->n_windows, mp = prior_out->max_prior, mb = prior_out->max_pblk;
     dpo = *prior_out;
+    char* po_dev = nullptr;
+    size_t po_bytes = 0, po_off[7] = {0, 0, 0, 0, 0, 0, 0};
     if (mem == AVM_MEM_HOST) {
-      dpo.n = static_cast<int32_t*>(pool_get(c, "po_n", sizeof(int32_t) * B));
-      dpo.nblk = static_cast<int32_t*>(pool_get(c, "po_nblk", sizeof(int32_t) * B));
-      dpo.blk_kind = static_cast<int32_t*>(pool_get(c, "po_kind", sizeof(int32_t) * B * mb));
-      dpo.blk_frame = static_cast<int32_t*>(pool_get(c, "po_frame", sizeof(int32_t) * B * mb));
-      dpo.J = static_cast<double*>(pool_get(c, "po_J", sizeof(double) * B * mp * mp));
-      dpo.r = static_cast<double*>(pool_get(c, "po_r", sizeof(double) * B * mp));
-      dpo.x0 = static_cast<double*>(pool_get(c, "po_x0", sizeof(double) * B * mb * 9));
-      if (!dpo.n || !dpo.nblk || !dpo.blk_kind || !dpo.blk_frame || !dpo.J || !dpo.r || !dpo.x0) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior out)");
-      HIPCHK(c, hipMemsetAsync(dpo.J, 0, sizeof(double) * B * mp * mp, c->stream));
-      HIPCHK(c, hipMemsetAsync(dpo.r, 0, sizeof(double) * B * mp, c->stream));
-      HIPCHK(c, hipMemsetAsync(dpo.x0, 0, sizeof(double) * B * mb * 9, c->stream));
-      HIPCHK(c, hipMemsetAsync(dpo.blk_kind, 0, sizeof(int32_t) * B * mb, c->stream));
-      HIPCHK(c, hipMemsetAsync(dpo.blk_frame, 0, sizeof(int32_t) * B * mb, c->stream));
+      // one device block n | nblk | blk_kind | blk_frame | J | r | x0: one memset, and (small batches) one copy back
+      const size_t sz[7] = {sizeof(int32_t) * B, sizeof(int32_t) * B, sizeof(int32_t) * B * mb, sizeof(int32_t) * B * mb,
+                            sizeof(double) * B * mp * mp, sizeof(double) * B * mp, sizeof(double) * B * mb * 9};
+      for (int k = 0; k < 7; k++) po_off[k] = po_bytes, po_bytes += pack_up(sz[k]);
+      po_dev = static_cast<char*>(pool_get(c, "po_pack", po_bytes));
+      if (!po_dev) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior out)");
+      dpo.n = reinterpret_cast<int32_t*>(po_dev + po_off[0]), dpo.nblk = reinterpret_cast<int32_t*>(po_dev + po_off[1]);
+      dpo.blk_kind = reinterpret_cast<int32_t*>(po_dev + po_off[2]), dpo.blk_frame = reinterpret_cast<int32_t*>(po_dev + po_off[3]);
+      dpo.J = reinterpret_cast<double*>(po_dev + po_off[4]), dpo.r = reinterpret_cast<double*>(po_dev + po_off[5]);
+      dpo.x0 = reinterpret_cast<double*>(po_dev + po_off[6]);
+      HIPCHK(c, hipMemsetAsync(po_dev, 0, po_bytes, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_marginalize(sa, dpo, c->stream));
@@ -361,24 +428,40 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, c->prof, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     if (mem == AVM_MEM_HOST) {
-      HIPCHK(c, hipMemcpyAsync(prior_out->n, dpo.n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(prior_out->nblk, dpo.nblk, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(prior_out->blk_kind, dpo.blk_kind, sizeof(int32_t) * B * mb, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(prior_out->blk_frame, dpo.blk_frame, sizeof(int32_t) * B * mb, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(prior_out->J, dpo.J, sizeof(double) * B * mp * mp, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(prior_out->r, dpo.r, sizeof(double) * B * mp, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(prior_out->x0, dpo.x0, sizeof(double) * B * mb * 9, hipMemcpyDeviceToHost, c->stream));
+      if (po_bytes <= PACK_LIMIT) {
+        po_pinned = static_cast<char*>(pinned_get(c, "po_pack", po_bytes));
+        if (!po_pinned) return fail(c, AVM_ERR_HIP, "allocation failed (packed prior out)");
+        HIPCHK(c, hipMemcpyAsync(po_pinned, po_dev, po_bytes, hipMemcpyDeviceToHost, c->stream));
+        for (int k = 0; k < 7; k++) po_offsets[k] = po_off[k];
+      } else {
+        HIPCHK(c, hipMemcpyAsync(prior_out->n, dpo.n, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(prior_out->nblk, dpo.nblk, sizeof(int32_t) * B, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(prior_out->blk_kind, dpo.blk_kind, sizeof(int32_t) * B * mb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(prior_out->blk_frame, dpo.blk_frame, sizeof(int32_t) * B * mb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(prior_out->J, dpo.J, sizeof(double) * B * mp * mp, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(prior_out->r, dpo.r, sizeof(double) * B * mp, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(prior_out->x0, dpo.x0, sizeof(double) * B * mb * 9, hipMemcpyDeviceToHost, c->stream));
+      }
     }
   }
+  char* pinned_states = nullptr;
   if (mem == AVM_MEM_HOST) {
     const size_t B = batch->n_windows;
-    HIPCHK(c, hipMemcpyAsync(batch->pose, d.pose, sizeof(double) * B * 77, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(batch->speedbias, d.speedbias, sizeof(double) * B * 99, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(batch->ex_pose, d.ex_pose, sizeof(double) * B * 7, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(batch->inv_depth, d.inv_depth, sizeof(double) * B * batch->max_feat, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = unstage_window_states(c, batch, &d, &pinned_states)) != AVM_OK) return rc;
     if (summary) HIPCHK(c, hipMemcpyAsync(summary, d_sum, sizeof(avm_solve_summary) * B, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (mem == AVM_MEM_HOST) finish_window_states(batch, pinned_states);
+  if (po_pinned) {
+    const size_t B = batch->n_windows, mp = prior_out->max_prior, mb = prior_out->max_pblk;
+    std::memcpy(prior_out->n, po_pinned + po_offsets[0], sizeof(int32_t) * B);
+    std::memcpy(prior_out->nblk, po_pinned + po_offsets[1], sizeof(int32_t) * B);
+    std::memcpy(prior_out->blk_kind, po_pinned + po_offsets[2], sizeof(int32_t) * B * mb);
+    std::memcpy(prior_out->blk_frame, po_pinned + po_offsets[3], sizeof(int32_t) * B * mb);
+    std::memcpy(prior_out->J, po_pinned + po_offsets[4], sizeof(double) * B * mp * mp);
+    std::memcpy(prior_out->r, po_pinned + po_offsets[5], sizeof(double) * B * mp);
+    std::memcpy(prior_out->x0, po_pinned + po_offsets[6], sizeof(double) * B * mb * 9);
+  }
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->last_ms["preint"] = ms;
   if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->last_ms["window_solve"] = ms;

@@ -32,6 +32,14 @@ def lib():
                 f"{_LIB_PATH} is missing: build it with __graft_entry__.build() "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        # PyTorch-ROCm ships its own copy of the HIP / HSA runtime under the same sonames.  Whichever is loaded first serves
+        # the whole process, and torch cannot find the GPU on top of /opt/rocm's: load torch's first when it is installed,
+        # so that `import torch` after this module keeps working (device tensors are how the tests and bench.py hand over
+        # HBM-resident buffers).  A C++ host (include/avm_host.hpp) has no such concern.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIB_PATH)
         vp = C.c_void_p
         L.avm_version.restype = C.c_char_p
