@@ -722,26 +722,41 @@ int check_fsel(avm_ctx* c, const avm_fsel_batch* b) {
   return AVM_OK;
 }
 
+#define AVM_FSEL_FIELDS(X, P, H1, h)                                                                                  \
+  X(hor_pos, double, (P) * (H1) * 3) X(hor_quat, double, (P) * (H1) * 4) X(nr_imu, int32_t, (P)) X(delta_imu, double, (P))   \
+  X(n_cand, int32_t, (P)) X(cand_id, int32_t, (P) * (h)->max_cand) X(cand_xy, double, (P) * (h)->max_cand * 2)            \
+  X(cand_prob, double, (P) * (h)->max_cand) X(n_used, int32_t, (P)) X(used_id, int32_t, (P) * (h)->max_used)              \
+  X(used_xy, double, (P) * (h)->max_used * 2) X(n_cloud, int32_t, (P)) X(cloud_xy, double, (P) * (h)->max_cloud * 2)      \
+  X(cloud_depth, double, (P) * (h)->max_cloud)
+
+// like stage_window_batch: a frame or a few travel as one pinned copy
 int stage_fsel(avm_ctx* c, const avm_fsel_batch* h, avm_fsel_batch* d) {
   *d = *h;
   const size_t P = h->n_problems, H1 = h->horizon + 1;
   int rc;
+  size_t total = 0;
+#define SZ(field, type, count) total += h->field ? pack_up(sizeof(type) * (count)) : 0;
+  AVM_FSEL_FIELDS(SZ, P, H1, h)
+#undef SZ
+  if (total <= PACK_LIMIT) {
+    char* hp = static_cast<char*>(pinned_get(c, "f_pack", total));
+    char* dp = static_cast<char*>(pool_get(c, "f_pack", total));
+    if (!hp || !dp) return fail(c, AVM_ERR_HIP, "allocation failed (packed staging)");
+    size_t off = 0;
+#define PK(field, type, count)                                             \
+  if (h->field) {                                                          \
+    std::memcpy(hp + off, h->field, sizeof(type) * (count));               \
+    *(const type**)&d->field = reinterpret_cast<const type*>(dp + off);    \
+    off += pack_up(sizeof(type) * (count));                                \
+  }
+    AVM_FSEL_FIELDS(PK, P, H1, h)
+#undef PK
+    HIPCHK(c, hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, c->stream));
+    return AVM_OK;
+  }
 #define ST(field, type, count) \
   if ((rc = stage_in<type>(c, "f_" #field, h->field, (count), (const type**)&d->field)) != AVM_OK) return rc;
-  ST(hor_pos, double, P * H1 * 3)
-  ST(hor_quat, double, P * H1 * 4)
-  ST(nr_imu, int32_t, P)
-  ST(delta_imu, double, P)
-  ST(n_cand, int32_t, P)
-  ST(cand_id, int32_t, P * h->max_cand)
-  ST(cand_xy, double, P * h->max_cand * 2)
-  ST(cand_prob, double, P * h->max_cand)
-  ST(n_used, int32_t, P)
-  ST(used_id, int32_t, P * h->max_used)
-  ST(used_xy, double, P * h->max_used * 2)
-  ST(n_cloud, int32_t, P)
-  ST(cloud_xy, double, P * h->max_cloud * 2)
-  ST(cloud_depth, double, P * h->max_cloud)
+  AVM_FSEL_FIELDS(ST, P, H1, h)
 #undef ST
   return AVM_OK;
 }
