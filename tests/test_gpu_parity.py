@@ -498,6 +498,47 @@ def test_non_finite_inputs_through_the_callers_either_side(ctx, oracle):
     agree(wg.a["inv_depth"], wo.a["inv_depth"], 1e-9)
 
 
+def test_two_contexts_on_two_host_threads_are_independent(ctx, abi):
+    """include/avm.h: one avm_ctx per host thread, re-entrant, no statics.  Two contexts driven concurrently from two
+    threads (ctypes releases the GIL) give the bits of a serial run."""
+    import threading
+
+    lib_m = __import__("importlib").import_module("anticipated-vins-mono_amd.lib")
+    est_m = importlib_est()
+    fs_m = __import__("importlib").import_module("anticipated-vins-mono_amd.feature_selector")
+    wa = synth.make_windows(24, first_id=300, tracks="dense", n_feat=120, max_feat=150)
+    wb = synth.make_windows(24, first_id=400, tracks="sparse", n_feat=90, max_feat=150)
+    pr = synth.make_fsel(2, first_id=9, horizon=5, n_cand=60, n_used=3, n_cloud=30, max_features=20)
+    serial = {}
+    E = est_m.Estimator(ctx=ctx, options=abi.default_options())
+    for k, w in (("a", wa), ("b", wb)):
+        x = w.copy()
+        E.optimization(x)
+        serial[k] = (x.a["pose"].copy(), E.last_marginalization_info.a["J"].copy())
+    serial["f"] = fs_m.FeatureSelector(ctx=ctx).select_batch(pr).to_host().a["selected_ids"].copy()
+    got, errs = {}, []
+
+    def work(key, w):
+        try:
+            c = lib_m.Context(0)
+            Ek = est_m.Estimator(ctx=c, options=abi.default_options())
+            for _ in range(3):
+                x = w.copy()
+                Ek.optimization(x)
+                got[key] = (x.a["pose"].copy(), Ek.last_marginalization_info.a["J"].copy())
+                got["f" + key] = fs_m.FeatureSelector(ctx=c).select_batch(pr).to_host().a["selected_ids"].copy()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=("a", wa)), threading.Thread(target=work, args=("b", wb))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for k in ("a", "b"):
+        assert np.array_equal(got[k][0], serial[k][0]) and np.array_equal(got[k][1], serial[k][1]), k
+        assert np.array_equal(got["f" + k], serial["f"])
+
+
 def _prior_quadratic(p, i):
     n = int(p.a["n"][i])
     J, r = p.a["J"][i, :n, :n], p.a["r"][i, :n]
