@@ -20,6 +20,8 @@ CAM_KEYS = ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")
 
 
 def _shim():
+    import torch  # noqa: F401  (its bundled HIP runtime has to be the first one in the process, see lib.py)
+
     d = os.path.join(HERE, "host_cpp")
     subprocess.check_call(["make", "-C", d, "-s"])
     L = C.CDLL(os.path.join(d, "libavm_host_shim.so"))
