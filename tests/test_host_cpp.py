@@ -260,6 +260,21 @@ def test_python_and_cpp_select_bookkeeping_agree_before_initialization():
     assert len(tr_c) > 0
 
 
+def test_cpp_host_capacity_and_unsupported_errors_are_raised_before_any_device_work():
+    """More features than the device tables hold (150 / 1650 observations) and the option combinations that are not built
+    surface as avm_host::Error with the ABI's status codes - on a box without a GPU too, i.e. before the device is touched."""
+    w = synth.make_windows(1, tracks="dense", n_feat=150, max_feat=150, max_obs=1650)
+    H = Host()
+    H.load(w, extras=[(150, 0, 3)])  # a 151st feature that passes the filter of estimator.cpp:715
+    assert H.optimization() == abi.AVM_ERR_CAPACITY and "150 features" in H.err()
+    assert H.triangulate() == abi.AVM_ERR_CAPACITY
+    H.load(w)
+    o = abi.default_options()
+    o.estimate_td = 1
+    H.L.hs_set_options(H.h, C.byref(o))
+    assert H.optimization() == abi.AVM_ERR_UNSUPPORTED and "ESTIMATE_TD" in H.err()
+
+
 # ------------------------------------------------------------------------------------------------ GPU tier
 def _install_prior(win, p):
     for k_w, k_p in (("prior_n", "n"), ("prior_nblk", "nblk"), ("prior_blk_kind", "blk_kind"), ("prior_blk_frame", "blk_frame"), ("prior_J", "J"),
