@@ -499,6 +499,7 @@ class FeatureSelector {
   ~FeatureSelector() {
     if (gt_) avm_gt_free(gt_);
   }
+  int groundTruthSeek() const { return gt_ ? avm_gt_seek(gt_) : -1; }  // HorizonGenerator::seek_idx_
   FeatureSelector(const FeatureSelector&) = delete;
   FeatureSelector& operator=(const FeatureSelector&) = delete;
 

@@ -282,6 +282,8 @@ int hs_sel_select(void* hp, int n, const int32_t* ids, const double* rows8, doub
   return rc < 0 ? rc : n_sel;
 }
 
+int hs_sel_gt_seek(void* hp) { return static_cast<Host*>(hp)->sel->groundTruthSeek(); }
+
 int hs_sel_last_feature_id(void* hp) { return static_cast<Host*>(hp)->sel->lastFeatureId_; }
 
 }  // extern "C"

@@ -275,6 +275,40 @@ def test_cpp_host_capacity_and_unsupported_errors_are_raised_before_any_device_w
     assert H.optimization() == abi.AVM_ERR_UNSUPPORTED and "ESTIMATE_TD" in H.err()
 
 
+def test_cpp_selector_ground_truth_horizon_moves_its_cursor_on_every_call(oracle):
+    """useGT: the reference builds the horizon on every select() call, initialized or not (feature_selector.cpp:131), and
+    HorizonGenerator::groundTruth moves its seek cursor each time.  Host-only work: runs without a GPU.  The cursor of the
+    C++ object follows the oracle's GroundTruth driven with the same state_k_ / deltaF sequence."""
+    w = synth.make_windows(1, tracks="sparse", n_feat=20, max_feat=150, max_obs=1650)
+    n = 400
+    t = 1403636580.0 + 0.005 * np.arange(n)
+    rows = np.zeros((n, 17))
+    rows[:, 0] = t * 1e9
+    rows[:, 1:4] = np.stack([np.sin(0.3 * (t - t[0])), np.cos(0.2 * (t - t[0])), 0.1 * (t - t[0])], 1)
+    ang = 0.4 * (t - t[0])
+    rows[:, 4], rows[:, 7] = np.cos(ang / 2), np.sin(ang / 2)  # w x y z
+    H = Host()
+    H.load(w)
+    H.set_flags(solver_flag=0)
+    H.sel_create(synth.CAM, 5)
+    H.sel_set_parameters(0.08, 0.004, True, 30, 0, useGT=True)
+    assert H.L.hs_sel_set_ground_truth(H.h, abi.dptr(np.ascontiguousarray(rows)), n) == 0, H.err()
+    gt = oracle.GroundTruth(rows)
+    rng = np.random.default_rng(4)
+    pose10 = w.a["pose"][0, 10]
+    prev_stamp, frame_time = 0.0, None
+    for k in range(4):
+        stamp = t[0] + 0.1 * (k + 1)
+        H.sel_set_next_state(stamp, pose10[:3], pose10[3:], np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3))
+        rc, *_ = H.select(_frame(rng, range(1 + 5 * k, 6 + 5 * k)), stamp, 20)
+        assert rc == 0, H.err()
+        frame_time = stamp if frame_time is None else frame_time
+        gt.horizon(5, prev_stamp, pose10[:3], pose10[3:], stamp - frame_time)   # state_k_ carries the previous image's stamp
+        assert H.L.hs_sel_gt_seek(H.h) == gt.seek_idx, k
+        prev_stamp, frame_time = stamp, stamp
+    assert gt.seek_idx > 0
+
+
 # ------------------------------------------------------------------------------------------------ GPU tier
 def _install_prior(win, p):
     for k_w, k_p in (("prior_n", "n"), ("prior_nblk", "nblk"), ("prior_blk_kind", "blk_kind"), ("prior_blk_frame", "blk_frame"), ("prior_J", "J"),
