@@ -154,6 +154,7 @@ int ensure_window_buffers(avm_ctx* c, int n_windows) {
     HIPCHK(c, hipMemsetAsync(c->iscratch, 0, sizeof(int32_t) * ISCRATCH * c->n_slots, c->stream));
   }
   if ((size_t)n_windows > c->pre_cap) {
+    c->pre_cap = 0;  // a failed hipMalloc below must not leave the old capacity next to freed / partial buffers
     for (double** p : {&c->pre_delta, &c->pre_jac, &c->pre_cov, &c->pre_sqrt, &c->pre_sum})
       if (*p) (void)hipFree(*p), *p = nullptr;
     const size_t iv = (size_t)n_windows * 10;
@@ -316,7 +317,11 @@ int avm_create(const avm_config* cfg, avm_ctx** out) {
   if (hipSetDevice(dev) != hipSuccess) return AVM_ERR_HIP;
   avm_ctx* c = new avm_ctx();
   c->device = dev;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  // A BLOCKING stream (not hipStreamNonBlocking): device-resident buffers are usually produced on the legacy default
+  // stream (PyTorch's current stream, plain hipMemcpy), and a blocking stream is ordered after that work and before
+  // whatever the default stream does next - AVM_MEM_DEVICE calls need no extra synchronization from such callers.
+  // Producers on other streams order themselves against avm_ctx_stream() (see avm.h).
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) {
     delete c;
     return AVM_ERR_HIP;
   }
@@ -352,6 +357,12 @@ void avm_destroy(avm_ctx* c) {
 
 const char* avm_last_error(const avm_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
+int avm_ctx_stream(const avm_ctx* c, void** stream) {
+  if (!c || !stream) return AVM_ERR_INVALID;
+  *stream = reinterpret_cast<void*>(c->stream);
+  return AVM_OK;
+}
+
 int avm_last_kernel_ms(const avm_ctx* c, const char* which, float* ms) {
   if (!c || !which || !ms) return AVM_ERR_INVALID;
   auto it = c->last_ms.find(which);
@@ -368,7 +379,9 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   if (rc != AVM_OK) return rc;
   const bool marg = opt->marginalization_flag != AVM_MARGIN_NONE;
   if (marg) {
-    if (!prior_out || !prior_out->n || !prior_out->J) return fail(c, AVM_ERR_INVALID, "prior_out is NULL but marginalization_flag != AVM_MARGIN_NONE");
+    if (!prior_out || !prior_out->n || !prior_out->nblk || !prior_out->blk_kind || !prior_out->blk_frame || !prior_out->J || !prior_out->r ||
+        !prior_out->x0)
+      return fail(c, AVM_ERR_INVALID, "prior_out (or one of its arrays) is NULL but marginalization_flag != AVM_MARGIN_NONE");
     if (prior_out->max_prior > MAXPRIOR || prior_out->max_prior < 1 || prior_out->max_pblk < 1) return fail(c, AVM_ERR_CAPACITY, "prior_out dims");
   }
   if (batch->n_windows == 0) return AVM_OK;
@@ -402,6 +415,8 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   HIPCHK(c, launch_window_solve(sa, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   avm_prior_out dpo;
+  int* marg_err = nullptr;
+  int marg_err_host = 0;
   char* po_pinned = nullptr;
   size_t po_offsets[7] = {0, 0, 0, 0, 0, 0, 0};
   if (marg) {
@@ -422,8 +437,13 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
       dpo.x0 = reinterpret_cast<double*>(po_dev + po_off[6]);
       HIPCHK(c, hipMemsetAsync(po_dev, 0, po_bytes, c->stream));
     }
+    // raised by the kernel when a window's kept set does not fit (prior_out->max_prior / max_pblk, or the 76 rows /
+    // 16 blocks the eigen-solver holds): the call then fails with AVM_ERR_CAPACITY instead of returning a truncated prior
+    marg_err = static_cast<int*>(pool_get(c, "marg_err", sizeof(int)));
+    if (!marg_err) return fail(c, AVM_ERR_HIP, "hipMalloc failed (marginalization flag)");
+    HIPCHK(c, hipMemsetAsync(marg_err, 0, sizeof(int), c->stream));
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    HIPCHK(c, launch_marginalize(sa, dpo, c->stream));
+    HIPCHK(c, launch_marginalize(sa, dpo, marg_err, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, c->prof, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
@@ -450,7 +470,14 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     if ((rc = unstage_window_states(c, batch, &d, &pinned_states)) != AVM_OK) return rc;
     if (summary) HIPCHK(c, hipMemcpyAsync(summary, d_sum, sizeof(avm_solve_summary) * B, hipMemcpyDeviceToHost, c->stream));
   }
+  if (marg_err) HIPCHK(c, hipMemcpyAsync(&marg_err_host, marg_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (marg_err_host) {
+    c->err = "window " + std::to_string(marg_err_host - 1) +
+             ": the new prior does not fit (prior_out->max_prior / max_pblk too small, or more than 76 rows / 16 blocks to keep); "
+             "the states were solved, prior_out is not valid";
+    return AVM_ERR_CAPACITY;
+  }
   if (mem == AVM_MEM_HOST) finish_window_states(batch, pinned_states);
   if (po_pinned) {
     const size_t B = batch->n_windows, mp = prior_out->max_prior, mb = prior_out->max_pblk;

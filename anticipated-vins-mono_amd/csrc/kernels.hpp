@@ -137,7 +137,7 @@ hipError_t launch_slide_window(const avm_window_batch& b, int flag, int shift_de
 hipError_t launch_projection_td_eval(const avm_td_factor_batch& f, double* residual, double* jac, hipStream_t stream);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
-hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipStream_t stream);
+hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream);
 // second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior
 hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, hipStream_t stream);
 int window_solve_lds_bytes();

@@ -2396,7 +2396,7 @@ AVM_DEV bool pinv16_cholesky(double* EA, double* EV, int m, double eps) {
   return fast;
 }
 
-__global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO) {
+__global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO, int* err) {
   lds_base_check();
   using namespace mg;
   double* lds = LDS();
@@ -2668,7 +2668,10 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         if (!(present & (1 << id))) continue;
         const int base = id < 11 ? 6 * id : (id < 22 ? SB0 + 9 * (id - 11) : MEX0);
         const int sz = (id >= 11 && id < 22) ? 9 : 6;
-        if (n + sz > MAXKEEP || n + sz > PO.max_prior || nb >= MAXPBLK) break;
+        if (n + sz > MAXKEEP || n + sz > PO.max_prior || nb >= MAXPBLK || nb >= PO.max_pblk) {
+          atomicMax(err, w + 1);  // the host turns this into AVM_ERR_CAPACITY: a truncated kept set would silently lose information
+          break;
+        }
         kblk[nb++] = id;
         for (int q = 0; q < sz; q++) kidx[n++] = base + q;
       }
@@ -2881,7 +2884,7 @@ hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream) {
 }
 
 
-hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipStream_t stream) {
+hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(marginalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 8);
@@ -2889,7 +2892,7 @@ hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, hipSt
     attr_set = true;
   }
   const int grid = a.b.n_windows < a.n_slots ? a.b.n_windows : a.n_slots;
-  hipLaunchKernelGGL(marginalize_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a, po);
+  hipLaunchKernelGGL(marginalize_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a, po, err);
   return hipGetLastError();
 }
 

@@ -40,8 +40,32 @@ class Estimator:
                                       buffers.summary_ptr(summ) if summ is not None else None)
         self.ctx.check(rc, "avm_window_solve_batch")
         self.last_summary = summ
+        if prior is not None and self.options.marginalization_flag == abi.MARGIN_SECOND_NEW:
+            self._keep_old_prior_where_nothing_was_dropped(prior, windows)
         self.last_marginalization_info = prior
         return summ
+
+    @staticmethod
+    def _keep_old_prior_where_nothing_was_dropped(prior, windows):
+        """MARGIN_SECOND_NEW leaves last_marginalization_info untouched when pose[WINDOW_SIZE - 1] is not in the old prior
+        (or there is none): estimator.cpp:926-927.  The library reports that as n == -1; those windows keep the prior
+        they were solved with (the batch's prior_* tables), so that the returned slots can always be chained."""
+        n = prior.a["n"]
+        keep = (n < 0)
+        if not bool(keep.any()):
+            return
+        pa, wa = prior.a, windows.a
+        mp = min(prior.dims["max_prior"], windows.dims["max_prior"])
+        mb = min(prior.dims["max_pblk"], windows.dims["max_pblk"])
+        idx = keep.nonzero()[0] if isinstance(n, np.ndarray) else keep.nonzero().flatten()
+        for i in idx.tolist():
+            pa["n"][i] = wa["prior_n"][i]
+            pa["nblk"][i] = wa["prior_nblk"][i]
+            pa["blk_kind"][i, :mb] = wa["prior_blk_kind"][i, :mb]
+            pa["blk_frame"][i, :mb] = wa["prior_blk_frame"][i, :mb]
+            pa["J"][i, :mp, :mp] = wa["prior_J"][i, :mp, :mp]
+            pa["r"][i, :mp] = wa["prior_r"][i, :mp]
+            pa["x0"][i, :mb] = wa["prior_x0"][i, :mb]
 
     def triangulate(self, windows: buffers.WindowArrays, init_depth: float = 5.0):
         """FeatureManager::triangulate (feature_manager.cpp:202-257), the step before optimization() in solveOdometry():

@@ -80,7 +80,7 @@ EXPORTS = [
     "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
     "avm_window_solve_batch", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
     "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
-    "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
+    "avm_ctx_stream", "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
 ]
 
 

@@ -259,6 +259,29 @@ def make_windows(n_windows, first_id=0, tracks="dense", n_feat=150, with_prior=T
     return WindowArrays(dims, out)
 
 
+def _make_chunk(args):
+    kw, first, n = args
+    return make_windows(n, first_id=first, **kw).a
+
+
+def make_windows_parallel(n_windows, first_id=0, procs=1, **kw) -> WindowArrays:
+    """make_windows() on `procs` forked worker processes (window w only depends on (seed, w), so the result is identical to
+    the serial call).  Call it before the HIP runtime is initialised in this process: the workers are plain forks."""
+    procs = max(1, min(int(procs), (n_windows + 7) // 8))
+    if procs == 1:
+        return make_windows(n_windows, first_id=first_id, **kw)
+    import multiprocessing as mp
+
+    per = (n_windows + procs - 1) // procs
+    jobs = [(kw, first_id + lo, min(per, n_windows - lo)) for lo in range(0, n_windows, per)]
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        parts = pool.map(_make_chunk, jobs)
+    ref = make_windows(1, first_id=first_id, **kw)
+    d = dict(ref.dims)
+    d["n_windows"] = n_windows
+    return WindowArrays(d, {k: np.concatenate([p[k] for p in parts]) for k in ref.a})
+
+
 def tile_windows(base: WindowArrays, n_windows: int) -> WindowArrays:
     """Repeat a set of generated windows cyclically up to n_windows (bench uses it to fill 4096
     windows quickly from a few hundred distinct ones; stated in bench output as `distinct`)."""

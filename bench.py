@@ -4,19 +4,26 @@
 A "step" is one pass of the hot path over one batch of synthetic EuRoC-shaped inputs that are
 already resident in HBM: avm_window_solve_batch() over `--windows` independent 11-frame windows
 per GPU (BASELINE.json configs[3]: 4096 windows / GPU; configs[4]: 8 x 4096 = 32768 over 8 GPUs).
-Windows shard embarrassingly: rank r owns window ids [r*W, (r+1)*W); the only collective is one
-RCCL all-gather of the final poses per step ("weak" scaling: per-GPU work fixed).
+Every window of the batch is a DIFFERENT synthetic trajectory (`--distinct` < `--windows` tiles a
+smaller set; it is an option, not the default).  Windows shard embarrassingly: rank r owns window ids
+[r*W, (r+1)*W); the only collective is one RCCL all-gather of the final poses per step ("weak"
+scaling: per-GPU work fixed), issued by the library itself (avm_gather_states, raw rccl.h).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with
   roofline     : FP64 FLOP model of the window-solve kernel / its HIP-event duration vs the
                  78.6 TFLOP/s FP64 peak (vector == matrix rate on MI355X); model in DESIGN.md
-  cpu_baseline : the CPU oracle ("port" of the reference algorithm) timed on the host cores
+  cpu_baseline : the CPU oracle ("port" of the reference algorithm, compiled -O3 -march=native on this host)
+                 timed on the host cores this process may use: median of >= 5 passes, 1 core and all cores
+  feature_select: ms/frame + its own roofline and CPU baseline
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,21 +31,75 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 PKG = "anticipated-vins-mono_amd"
 
-FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 vector == FP64 matrix; FP32 vector 157.3 / 2
+FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet FP64 vector == FP64 matrix; measured: scripts/ubench/peak.hip, profiles/r02_fp64_peak.json
 HBM_PEAK_GBS = 8000.0
 
 
 def flop_model(n_fac, n_feat, summ):
-    """Algorithmic FP64 FLOPs of the solves in `summ` (numpy structured summaries). See DESIGN.md §Roofline."""
+    """Algorithmic FP64 FLOPs of the solves in `summ` (numpy structured summaries). See DESIGN.md §Roofline.
+    Jacobian evaluations and linear solves: one at the start + one per successful step (a rejected step re-uses the
+    factorization: DoglegStrategy `reuse`); residual-only evaluations: one per step attempt."""
     import numpy as np
 
     it = summ["num_iterations"].astype(np.float64)
     ns = summ["num_successful"].astype(np.float64)
+    # the step after the last accepted one is never computed when the iteration limit ends the solve
+    lin_solves = np.minimum(1.0 + ns, np.maximum(it, 1.0))
     jac_evals = 1.0 + ns
     per_jac = 1800.0 * n_fac + 5.0e5                       # factor r/J + J^T J blocks, 10 IMU factors + prior
     per_lin = 66.0 * 67.0 * n_feat + 165.0**3 / 3.0 + 2.0 * 165.0**2  # Schur rank-150 update + Cholesky + solves
     per_cand = 230.0 * n_fac + 3.0e4                       # residual-only evaluation
-    return float((jac_evals * (per_jac + per_lin) + it * per_cand).sum())
+    return float((jac_evals * per_jac + lin_solves * per_lin + it * per_cand).sum())
+
+
+def host_cpus():
+    """(threads this process may run on, description): scheduler affinity, capped by the cgroup CPU quota."""
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    n = n_aff if quota is None else max(1, min(n_aff, int(quota)))
+    return n, {"model": model, "os_cpu_count": os.cpu_count(), "sched_affinity": n_aff, "cgroup_cpu_quota": quota}
+
+
+def native_oracle():
+    """The oracle compiled for THIS host's cores (-O3 -march=native); falls back to the portable prebuilt library."""
+    import oracle_py
+
+    out = os.path.join(tempfile.gettempdir(), f"libavm_oracle_native_{os.getpid()}.so")
+    cmd = ["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-pthread", "-shared", "-o", out, os.path.join(ROOT, "oracle", "avm_oracle.cpp")]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        oracle_py.use_library(out)
+        return "g++ -O3 -march=native, compiled on this host"
+    except Exception:  # no compiler on the box: the prebuilt x86-64-v3 build
+        oracle_py.lib()
+        return "prebuilt g++ -O3 -march=x86-64-v3"
+
+
+def median_rate(fn, units, passes=5, budget_s=12.0):
+    """units / median wall time of fn() over >= 3 (normally `passes`) passes, bounded by budget_s of total time."""
+    times = []
+    t_all = time.perf_counter()
+    for k in range(passes):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+        if k >= 2 and time.perf_counter() - t_all > budget_s:
+            break
+    return units / statistics.median(times), len(times)
 
 
 def main():
@@ -47,65 +108,89 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=4096, help="windows per GPU per step")
-    ap.add_argument("--distinct", type=int, default=128, help="distinct generated windows per rank (tiled up to --windows)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct generated windows per rank, tiled up to --windows (0 = all distinct)")
     ap.add_argument("--tracks", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--fsel-problems", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fsel", action="store_true")
+    ap.add_argument("--gather", default="library", choices=["library", "torch"], help="who issues the all-gather of the final poses (N > 1)")
     args = ap.parse_args()
 
     import numpy as np
-    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    ncpu, cpu_info = host_cpus()
+
+    abi = importlib.import_module(PKG + ".abi")
+    synth = importlib.import_module(PKG + ".synth")
+    buffers = importlib.import_module(PKG + ".buffers")
+
+    # ---- inputs: generated on-rank from (seed, window id) on the host cores (worker processes are forked BEFORE the HIP
+    #      runtime is initialised), then resident in HBM
+    W = args.windows
+    n_distinct = W if args.distinct <= 0 else min(args.distinct, W)
+    t_gen = time.perf_counter()
+    base = synth.make_windows_parallel(n_distinct, first_id=rank * W, tracks=args.tracks, procs=max(1, min(64, ncpu // max(world, 1))))
+    host = base if n_distinct == W else synth.tile_windows(base, W)
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
-    abi = importlib.import_module(PKG + ".abi")
-    synth = importlib.import_module(PKG + ".synth")
-    buffers = importlib.import_module(PKG + ".buffers")
     est_m = importlib.import_module(PKG + ".estimator")
     fs_m = importlib.import_module(PKG + ".feature_selector")
     lib_m = importlib.import_module(PKG + ".lib")
 
-    W = args.windows
     opt = abi.default_options()
     opt.marginalization_flag = abi.MARGIN_NONE if os.environ.get("AVM_BENCH_NO_MARG") else opt.marginalization_flag
     ctx = lib_m.Context(local_rank)
     E = est_m.Estimator(ctx=ctx, options=opt)
 
-    # ---- inputs: generated on-rank from (seed, window id), then resident in HBM
-    base = synth.make_windows(min(args.distinct, W), first_id=rank * W, tracks=args.tracks)
-    host = synth.tile_windows(base, W)
     n_fac = float((host.a["feat_nobs"] - 1).clip(min=0).sum(1).mean())
     n_feat = float(host.a["n_feat"].mean())
     win = host.to_device(dev)
     pristine = {k: win.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
     gathered = torch.empty((world * W, 11, 7), dtype=torch.float64, device=dev) if world > 1 else None
+    use_lib_gather = world > 1 and args.gather == "library" and hasattr(ctx, "gather_states")
+    if use_lib_gather:
+        # the library's own communicator (raw rccl.h, avm_comm_*): the 128-byte unique id travels over torch.distributed
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).clone()
+        uid = uid.to(dev)
+        dist.broadcast(uid, 0)
+        ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
 
     marg = opt.marginalization_flag != abi.MARGIN_NONE
     prior_slots = buffers.PriorOutArrays.alloc(W, win.dims["max_prior"], win.dims["max_pblk"], dev) if marg else None
 
     def step():
+        # (torch's copies run on the legacy default stream; the ctx stream is a blocking stream, so the solve is ordered
+        #  after them and the next step's copies after the solve: include/avm.h "stream ordering")
         for k, v in pristine.items():
             win.a[k].copy_(v)
         summ = E.optimization(win, want_summary=True, prior_out=prior_slots)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, win.a["pose"])
+            if use_lib_gather:
+                ctx.gather_states(win.a["pose"], gathered, W * 77)
+            else:
+                dist.all_gather_into_tensor(gathered, win.a["pose"])
         return summ
 
-    kernel_ms, summ = [], None
+    kernel_ms, all_ms, summ = [], {k: [] for k in ("preint", "window_solve", "marginalize", "prior_eig")}, None
     for _ in range(args.warmup):
         summ = step()
     torch.cuda.synchronize()
@@ -116,6 +201,8 @@ def main():
     for _ in range(args.steps):
         summ = step()
         kernel_ms.append(ctx.kernel_ms("window_solve"))
+        for k in all_ms:
+            all_ms[k].append(ctx.kernel_ms(k))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -142,6 +229,10 @@ def main():
             traffic = tj["traffic_bytes_per_launch"]
             traffic_src = f"profiles/{os.path.basename(tp)}: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes"
         alg_bytes = W * (44.0 * n_fac + 23.0e3 + 45.6e3 + 3.0e3 + 2.6e3)  # ~140 KB / solve at K=1500
+        peak_meas = None
+        pm = os.path.join(ROOT, "profiles", "r02_fp64_peak.json")
+        if os.path.exists(pm):
+            peak_meas = json.load(open(pm))
         result = {
             "metric": "sliding-window solves/sec (10 KF, 150 feats)",
             "value": value,
@@ -164,6 +255,9 @@ def main():
                 "marginalization": "MARGIN_OLD" if opt.marginalization_flag == abi.MARGIN_OLD else "none",
                 "mean_iterations": float(s["num_iterations"].mean()),
                 "mean_successful_steps": float(s["num_successful"].mean()),
+                "iterations_histogram": {int(k): int(v) for k, v in zip(*np.unique(s["num_iterations"], return_counts=True))},
+                "pose_gather": (("avm_gather_states (library, raw rccl.h)" if use_lib_gather else "torch.distributed all_gather") if world > 1 else "none (1 GPU)"),
+                "input_generation_s": t_gen,
             },
             "roofline": {
                 "bound": "mfma",
@@ -176,24 +270,29 @@ def main():
                 "kernel": "window_solve_kernel",
                 "kernel_ms": k_ms,
                 "flops_per_launch": flops,
+                "peak_measured": peak_meas,
                 "hbm_secondary": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBs": alg_bytes / (k_ms * 1e-3) / 1e9,
                                   "peak_GBs": HBM_PEAK_GBS},
             },
-            "kernel_ms": {k: ctx.kernel_ms(k) for k in ("preint", "window_solve", "marginalize", "prior_eig")},
+            "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
         }
 
-    # ---- feature selector: ms/frame (batch throughput) and single-frame latency
+    # ---- feature selector: ms/frame (batch throughput), single-frame latency, FLOP/s of the scoring loop
+    fsel_host = None
     if not args.no_fsel:
         FS = fs_m.FeatureSelector(ctx=ctx)
         P = args.fsel_problems
-        fp = synth.make_fsel(P, first_id=rank * P).to_device(dev)
+        fsel_host = synth.make_fsel(P, first_id=rank * P)
+        fp = fsel_host.to_device(dev)
         f1 = synth.make_fsel(1, first_id=rank * P).to_device(dev)
-        FS.select_batch(fp)
+        out_b = FS.select_batch(fp)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         reps = 3
+        fsel_ms = []
         for _ in range(reps):
             FS.select_batch(fp)
+            fsel_ms.append(ctx.kernel_ms("fsel_select"))
         torch.cuda.synchronize()
         tb = (time.perf_counter() - t1) / reps
         FS.select_batch(f1)
@@ -203,40 +302,76 @@ def main():
         torch.cuda.synchronize()
         tl = (time.perf_counter() - t1) / reps
         if rank == 0:
+            # FLOPs of the scoring loop after the exact hoist: every round scores every live candidate with a
+            # T x T (T = 3 H) Cholesky: T^3/3 + 2 T^2 FLOP per evaluation (forming C + p Delta, the factorization, log diag)
+            _, _, valid = FS.information(fsel_host)
+            nsel = out_b.to_host().a["n_selected"].astype(np.int64)
+            nvalid = (valid != 0).sum(1).astype(np.int64)
+            evals = float(sum(int(nv) * int(k) - int(k) * (int(k) - 1) // 2 for nv, k in zip(nvalid, nsel)))
+            T = 3.0 * fsel_host.dims["horizon"]
+            fl = evals * (T**3 / 3.0 + 2.0 * T * T)
+            k_ms_f = float(np.mean(fsel_ms))
             result["feature_select"] = {
                 "workload": "500 candidates -> 150 selected, horizon 10 (BASELINE.json configs[2])",
                 "ms_per_frame_batched": tb / P * 1e3,
                 "batch": P,
                 "ms_per_frame_single": tl * 1e3,
+                "roofline": {
+                    "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "achieved": fl / (k_ms_f * 1e-3) / 1e12,
+                    "frac": fl / (k_ms_f * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "kernel": "fsel_setup + 150 x (fsel_round + fsel_pick), HIP events around the whole select",
+                    "kernel_ms": k_ms_f, "flops_per_launch": fl, "candidate_evaluations": evals,
+                    "reference_flops_unhoisted": evals * ((9.0 * (fsel_host.dims["horizon"] + 1)) ** 3 / 3.0),
+                },
             }
 
     # ---- CPU baseline (oracle = port of the reference algorithm), rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_py
 
-        cores = os.cpu_count() or 1
-        nsamp = min(W, max(8 * cores, 64))
-        sample = host.slice(0, nsamp).copy()
+        build = native_oracle()
         o2 = abi.default_options()
         o2.marginalization_flag = opt.marginalization_flag
-        po = buffers.PriorOutArrays.alloc(nsamp) if o2.marginalization_flag != abi.MARGIN_NONE else None
-        t2 = time.perf_counter()
-        oracle_py.window_solve(o2, sample, po, buffers.summary_alloc(nsamp), n_threads=cores)
-        tc = time.perf_counter() - t2
-        s1 = host.slice(0, min(4, nsamp)).copy()
-        po1 = buffers.PriorOutArrays.alloc(s1.n_windows) if po is not None else None
-        t2 = time.perf_counter()
-        oracle_py.window_solve(o2, s1, po1, buffers.summary_alloc(s1.n_windows), n_threads=1)
-        t1c = (time.perf_counter() - t2) / s1.n_windows
+
+        def solve_sample(n, threads):
+            smp = host.slice(0, n).copy()
+            po = buffers.PriorOutArrays.alloc(n) if o2.marginalization_flag != abi.MARGIN_NONE else None
+            sm = buffers.summary_alloc(n)
+            return lambda: oracle_py.window_solve(o2, smp.copy(), po, sm, n_threads=threads)
+
+        n1 = min(W, 6)
+        r1, p1 = median_rate(solve_sample(n1, 1), n1, passes=5, budget_s=6.0)
+        nall = min(W, max(2 * ncpu, 16))
+        rall, pall = median_rate(solve_sample(nall, ncpu), nall, passes=5, budget_s=12.0)
+        scaling = {}
+        for th in sorted({max(1, ncpu // 4), max(1, ncpu // 2)} - {1, ncpu}):
+            nn = min(W, max(2 * th, 16))
+            scaling[str(th)] = median_rate(solve_sample(nn, th), nn, passes=3, budget_s=5.0)[0]
         result["cpu_baseline"] = {
-            "value": nsamp / tc,
+            "value": rall,
             "unit": "solves/s",
-            "cores": cores,
+            "cores": ncpu,
             "kind": "port",
-            "sample": f"{nsamp} of the same windows, one single-threaded solve per host thread ({cores} threads); "
-                      f"1-thread rate {1.0 / t1c:.1f} solves/s",
+            "sample": f"{nall} of the same windows per pass, one single-threaded solve per host thread ({ncpu} threads = every CPU this process "
+                      f"may run on), median of {pall} passes; 1 thread: {n1} windows per pass, median of {p1} passes",
+            "value_1_core": r1,
+            "threads_scaling": scaling,
+            "build": build,
+            "cpu": cpu_info,
         }
-        result["gpu_over_cpu"] = value / (nsamp / tc)
+        result["gpu_over_cpu"] = value / rall
+        result["gpu_over_cpu_1_core"] = value / r1
+        if fsel_host is not None:
+            nf = min(fsel_host.n_problems, 2)
+            f_smp = synth.make_fsel(nf, first_id=0)
+            oo = buffers.FselOutArrays.alloc(nf, 150)
+            rf1, pf1 = median_rate(lambda: oracle_py.fsel_select(f_smp, oo, n_threads=1), nf, passes=3, budget_s=8.0)
+            result["feature_select"]["cpu_baseline"] = {
+                "value": 1e3 / rf1, "unit": "ms/frame", "cores": 1, "kind": "port",
+                "sample": f"{nf} frames of the same workload per pass on one host thread (the reference selects on one thread), median of {pf1} passes; "
+                          "the oracle follows feature_selector.cpp:613-728 literally (dense 9(H+1) x 9(H+1) Cholesky per evaluation, lazy upper-bound break)",
+                "build": build,
+            }
+            result["feature_select"]["gpu_over_cpu_1_core_batched"] = (1e3 / rf1) / result["feature_select"]["ms_per_frame_batched"]
 
     if rank == 0:
         print(json.dumps(result))

@@ -26,6 +26,13 @@
  *   - one avm_ctx per host thread (re-entrant, no statics — the reference's
  *     function-local statics at feature_selector.cpp:85,383,424 are NOT
  *     reproduced); the ctx owns device scratch + one HIP stream.
+ *   - stream ordering of AVM_MEM_DEVICE buffers: the ctx stream is a BLOCKING stream,
+ *     i.e. it is ordered after everything submitted to the legacy default (NULL) stream
+ *     before the call (PyTorch's default current stream, plain hipMemcpy), and every
+ *     entry point returns only after its own work has finished.  A caller that fills
+ *     device buffers on some other non-blocking stream must order that stream itself
+ *     before calling in (synchronize it, or record an event and hipStreamWaitEvent on
+ *     avm_ctx_stream()).
  *   - quaternions are stored (x,y,z,w) exactly like para_Pose
  *     (estimator.cpp:484-488).
  *
@@ -386,6 +393,10 @@ int avm_fsel_select_batch(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch
  * [P][max_cand][3H][3H] (+ valid flag [P][max_cand]); for parity tests. */
 int avm_fsel_information(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, double* omega,
                          double* delta_cand, int32_t* cand_valid);
+
+/* the HIP stream (hipStream_t) every call on this ctx is enqueued on, for callers that produce device-resident inputs
+ * on streams of their own (see "stream ordering" above) */
+int avm_ctx_stream(const avm_ctx* ctx, void** stream);
 
 /* ---- timing of the last call on the ctx stream (HIP events), milliseconds ---- */
 int avm_last_kernel_ms(const avm_ctx* ctx, const char* which, float* ms);

@@ -25,6 +25,13 @@ def lib():
     return _LIB
 
 
+def use_library(path):
+    """Switch to another build of the same oracle (bench.py compiles one with -march=native on the host it times)."""
+    global _LIB
+    _LIB = C.CDLL(path)
+    return _LIB
+
+
 def _pkg():
     return importlib.import_module("anticipated-vins-mono_amd")
 

@@ -12,6 +12,13 @@ adapters = importlib.import_module(PKG + ".adapters")
 lib_m = importlib.import_module(PKG + ".lib")
 
 
+@pytest.fixture(autouse=True, params=["cpu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def tier(request):
+    """Every case of this file runs in BOTH tiers: unmarked on the CPU (the adapters are host code) and, marked `gpu`, on the
+    GPU box next to the kernels they feed - there through the same libavm_hip.so the parity tests have loaded."""
+    return request.param
+
+
 def _gt_rows(n=700, seed=3):
     """A smooth synthetic trajectory in the EuRoC state_groundtruth_estimate0/data.csv layout, 200 Hz."""
     rng = np.random.default_rng(seed)

@@ -358,12 +358,15 @@ def test_device_resident_buffers_match_host_path(estimator):
 
     w = synth.make_windows(4, tracks="dense", n_feat=60, max_feat=150)
     h = w.copy()
-    estimator.optimization(h)
+    host_summary = buffers.summary_to_numpy(estimator.optimization(h)).copy()
     d = w.to_device("cuda:0")
     s = estimator.optimization(d)
     torch.cuda.synchronize()
     assert np.array_equal(d.a["pose"].cpu().numpy(), h.a["pose"])
-    assert buffers.summary_to_numpy(s)["num_iterations"].tolist() == [8] * 4 or True
+    sh = buffers.summary_to_numpy(s)
+    for k in ("num_iterations", "num_successful", "accept_mask", "termination", "cost_trace", "radius_trace"):
+        assert np.array_equal(sh[k], host_summary[k]), k
+    assert (sh["num_iterations"] >= 1).all() and (sh["num_iterations"] <= estimator.options.max_num_iterations).all()
 
 
 def test_capacity_and_unsupported_errors(ctx, abi):
@@ -373,6 +376,18 @@ def test_capacity_and_unsupported_errors(ctx, abi):
     o.estimate_extrinsic = 1
     with pytest.raises(lib_m.AvmError, match="-2"):
         est_m.Estimator(ctx=ctx, options=o).optimization(synth.make_windows(1, tracks="sparse", n_feat=5, max_feat=150))
+    # a prior_out that cannot hold the kept set (75 rows / 12 blocks here): AVM_ERR_CAPACITY, never a silently truncated prior
+    E = est_m.Estimator(ctx=ctx, options=abi.default_options())
+    w = synth.make_windows(2, tracks="sparse", n_feat=20, max_feat=150)
+    for mp, mb in ((40, 16), (96, 8)):
+        with pytest.raises(lib_m.AvmError, match="status -5.*window 0"):
+            E.optimization(w.copy(), prior_out=buffers.PriorOutArrays.alloc(2, max_prior=mp, max_pblk=mb))
+    E.optimization(w.copy(), prior_out=buffers.PriorOutArrays.alloc(2, max_prior=75, max_pblk=12))   # exactly enough
+    # a prior_out with a missing array is refused before anything runs
+    po = buffers.PriorOutArrays.alloc(2)
+    del po.a["x0"]
+    with pytest.raises(lib_m.AvmError, match="-1"):
+        E.optimization(w.copy(), prior_out=po)
 
 
 @pytest.mark.parametrize("where", ["host", "device"])
@@ -607,8 +622,36 @@ def test_marginalization_keeps_old_prior_when_second_new_has_nothing_to_drop(ctx
     o.marginalization_flag = abi.MARGIN_SECOND_NEW
     E = est_m.Estimator(ctx=ctx, options=o)
     w = synth.make_windows(2, tracks="sparse", n_feat=30, max_feat=150, with_prior=False)
+    wo = w.copy()
     E.optimization(w)
-    assert (E.last_marginalization_info.a["n"] == -1).all()
+    # no prior before, none after (estimator.cpp:926-927 leaves last_marginalization_info alone); the raw ABI says n == -1
+    assert (E.last_marginalization_info.a["n"] == 0).all()
+    po = buffers.PriorOutArrays.alloc(2)
+    oracle.window_solve(o, wo, po, buffers.summary_alloc(2))
+    assert (po.a["n"] == -1).all()
+    # a prior that does not contain pose[WINDOW_SIZE - 1]: the mirror hands the SAME prior back, and it chains into the next solve
+    w = synth.make_windows(2, first_id=40, tracks="sparse", n_feat=30, max_feat=150)
+    for b in range(2):  # drop the pose-9 block from the synthetic prior: rows / columns 54..59
+        keep = [i for i in range(75) if not 54 <= i < 60]
+        J = w.a["prior_J"][b][np.ix_(keep, keep)].copy()
+        w.a["prior_J"][b] = 0
+        w.a["prior_J"][b, :69, :69] = J
+        w.a["prior_r"][b, :69] = w.a["prior_r"][b, keep]
+        w.a["prior_r"][b, 69:] = 0
+        kinds, frames, x0 = w.a["prior_blk_kind"][b], w.a["prior_blk_frame"][b], w.a["prior_x0"][b]
+        kinds[9:11], frames[9:11], x0[9:11] = kinds[10:12].copy(), frames[10:12].copy(), x0[10:12].copy()
+        w.a["prior_n"][b], w.a["prior_nblk"][b] = 69, 11
+    before = w.copy()
+    E.optimization(w)
+    p = E.last_marginalization_info
+    assert (p.a["n"] == 69).all() and (p.a["nblk"] == 11).all()
+    assert np.array_equal(p.a["J"][:, :69, :69], before.a["prior_J"][:, :69, :69]) and np.array_equal(p.a["r"][:, :69], before.a["prior_r"][:, :69])
+    assert np.array_equal(p.a["blk_kind"][:, :11], before.a["prior_blk_kind"][:, :11]) and np.array_equal(p.a["x0"][:, :11], before.a["prior_x0"][:, :11])
+    for k, v in (("prior_n", "n"), ("prior_nblk", "nblk"), ("prior_blk_kind", "blk_kind"), ("prior_blk_frame", "blk_frame"), ("prior_J", "J"),
+                 ("prior_r", "r"), ("prior_x0", "x0")):
+        w.a[k][:] = p.a[v]
+    E.optimization(w)   # chained SECOND_NEW solve: the tables validate (no BAD_PRIOR) and the solve runs
+    assert np.isfinite(w.a["pose"]).all()
 
 
 def test_chained_solves_through_the_new_prior(ctx, oracle):
