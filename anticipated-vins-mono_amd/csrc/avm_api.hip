@@ -416,7 +416,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   avm_prior_out dpo;
   int* marg_err = nullptr;
-  int marg_err_host = 0;
+  int marg_err_host = 0x7f7f7f7f;
   char* po_pinned = nullptr;
   size_t po_offsets[7] = {0, 0, 0, 0, 0, 0, 0};
   if (marg) {
@@ -441,7 +441,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     // 16 blocks the eigen-solver holds): the call then fails with AVM_ERR_CAPACITY instead of returning a truncated prior
     marg_err = static_cast<int*>(pool_get(c, "marg_err", sizeof(int)));
     if (!marg_err) return fail(c, AVM_ERR_HIP, "hipMalloc failed (marginalization flag)");
-    HIPCHK(c, hipMemsetAsync(marg_err, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(marg_err, 0x7f, sizeof(int), c->stream));
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_marginalize(sa, dpo, marg_err, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
@@ -472,8 +472,8 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   }
   if (marg_err) HIPCHK(c, hipMemcpyAsync(&marg_err_host, marg_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (marg_err_host) {
-    c->err = "window " + std::to_string(marg_err_host - 1) +
+  if (marg_err_host != 0x7f7f7f7f) {
+    c->err = "window " + std::to_string(marg_err_host) +
              ": the new prior does not fit (prior_out->max_prior / max_pblk too small, or more than 76 rows / 16 blocks to keep); "
              "the states were solved, prior_out is not valid";
     return AVM_ERR_CAPACITY;

@@ -2669,7 +2669,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         const int base = id < 11 ? 6 * id : (id < 22 ? SB0 + 9 * (id - 11) : MEX0);
         const int sz = (id >= 11 && id < 22) ? 9 : 6;
         if (n + sz > MAXKEEP || n + sz > PO.max_prior || nb >= MAXPBLK || nb >= PO.max_pblk) {
-          atomicMax(err, w + 1);  // the host turns this into AVM_ERR_CAPACITY: a truncated kept set would silently lose information
+          atomicMin(err, w);  // (lowest failing window) the host turns this into AVM_ERR_CAPACITY: a truncated kept set would silently lose information
           break;
         }
         kblk[nb++] = id;

@@ -338,3 +338,123 @@ def make_fsel(n_problems, first_id=0, horizon=10, n_cand=500, n_used=0, n_cloud=
     dims = dict(n_problems=P, horizon=H, max_cand=max_cand, max_used=max_used, max_cloud=max_cloud, max_features=max_features)
     sc = dict(acc_var=ACC_N, acc_bias_var=ACC_W, q_ic=quat_from_R(RIC), t_ic=TIC, **CAM)
     return FselArrays(dims, a, sc)
+
+
+class Sequence:
+    """A synthetic image sequence for streaming tests (solve -> roll -> solve ...): one smooth trajectory sampled at
+    10 Hz, landmarks that are born and lost along the way, 200 Hz IMU.  Only the bookkeeping the reference does on the
+    host per image lives here (FeatureManager::addFeatureCheckParallax: append the new frame's observations, admit tracks
+    that now pass used_num >= 2 && start_frame < WINDOW_SIZE - 2); solving, marginalizing, rolling, triangulating and the
+    dead-reckoning of the newest frame are the library's (or the oracle's) job."""
+
+    def __init__(self, sid, n_frames=24, n_landmarks=420, max_feat=150, max_samp=20):
+        rng = np.random.Generator(np.random.Philox(key=SEED_WINDOW + 0x01000000 + sid))
+        self.tr, self.n_frames, self.max_feat, self.max_samp = _Trajectory(rng), n_frames, max_feat, max_samp
+        self.ba, self.bg = rng.normal(0, 0.02, 3), rng.normal(0, 0.002, 3)
+        tk = np.arange(n_frames) * 0.1
+        self.Rw, self.Pw, self.Vw = [self.tr.R(t) for t in tk], [self.tr.pos(t) for t in tk], [self.tr.vel(t) for t in tk]
+        sig = 1.5 / 460.0
+        self.tracks = []  # (birth frame, {frame: xy}, true inverse depth in the birth frame)
+        for _ in range(n_landmarks):
+            s = int(rng.integers(0, n_frames - 2))
+            life = int(rng.integers(3, 14))
+            xy = np.array([rng.uniform(-0.7, 0.7), rng.uniform(-0.45, 0.45)])
+            depth = rng.uniform(2.0, 15.0)
+            pw = self.Rw[s] @ (RIC @ (np.array([xy[0], xy[1], 1.0]) * depth) + TIC) + self.Pw[s]
+            obs = {}
+            for f in range(s, min(s + life, n_frames)):
+                pc = RIC.T @ (self.Rw[f].T @ (pw - self.Pw[f]) - TIC)
+                if pc[2] < 0.5 or abs(pc[0] / pc[2]) > 0.9 or abs(pc[1] / pc[2]) > 0.6:
+                    break
+                obs[f] = pc[:2] / pc[2] + rng.normal(0, sig, 2)
+            if len(obs) >= 2:
+                self.tracks.append((s, obs, pw))
+        self.tracks.sort(key=lambda t: t[0])
+        self._imu_seed = SEED_WINDOW + 0x02000000 + sid
+
+    def imu_interval(self, j):
+        """Raw samples between absolute frames j and j + 1: dt [20], acc / gyr [21, 3] (row 0 = the sample at frame j)."""
+        rng = np.random.Generator(np.random.Philox(key=self._imu_seed + 1000 * j))
+        ns, dt, G = 20, 0.005, np.array([0, 0, G_NORM])
+        acc, gyr = np.zeros((ns + 1, 3)), np.zeros((ns + 1, 3))
+        for s in range(ns + 1):
+            t = 0.1 * j + s * dt
+            acc[s] = self.tr.R(t).T @ (self.tr.acc(t) + G) + self.ba + rng.normal(0, ACC_N, 3)
+            gyr[s] = self.tr.omega_body(t) + self.bg + rng.normal(0, GYR_N, 3)
+        return np.full(ns, dt), acc, gyr
+
+    def _admissible(self, k, li):
+        """(start frame in window k, observations inside the window) of landmark li, or None if it fails the filter."""
+        s, obs, _ = self.tracks[li]
+        fr = [f for f in sorted(obs) if k <= f <= k + abi.WINDOW_SIZE]
+        if len(fr) < 2 or fr[0] - k >= abi.WINDOW_SIZE - 2:
+            return None
+        return fr[0] - k, [obs[f] for f in fr]
+
+    def _write_tracks(self, a, b, k, ids, lam):
+        o = 0
+        a["n_feat"][b] = len(ids)
+        for e, li in enumerate(ids):
+            st, ob = self._admissible(k, li) if not isinstance(li, tuple) else li
+            a["feat_start"][b, e], a["feat_nobs"][b, e], a["feat_obs_begin"][b, e] = st, len(ob), o
+            a["obs_xy"][b, o:o + len(ob)] = ob
+            a["inv_depth"][b, e] = lam[e]
+            o += len(ob)
+
+    def first_window(self, rng_seed=0):
+        """Window 0 (frames 0..10) as a one-window batch, no prior; returns (WindowArrays, landmark ids of its features)."""
+        rng = np.random.Generator(np.random.Philox(key=self._imu_seed + 7 + rng_seed))
+        w = make_windows(1, tracks="sparse", n_feat=1, with_prior=False, max_feat=self.max_feat, max_samp=self.max_samp)
+        a = w.a
+        ids = [li for li in range(len(self.tracks)) if self._admissible(0, li)][: self.max_feat]
+        lam = []
+        for li in ids:
+            s, _, pw = self.tracks[li]
+            f0 = max(s, 0)
+            pc = RIC.T @ (self.Rw[f0].T @ (pw - self.Pw[f0]) - TIC)
+            lam.append(1.0 / pc[2] * (1.0 + rng.normal(0, 0.10)))
+        a["obs_xy"][:] = 0
+        self._write_tracks(a, 0, 0, ids, lam)
+        ba0, bg0 = self.ba + rng.normal(0, 0.01, 3), self.bg + rng.normal(0, 0.001, 3)
+        for f in range(abi.NFRAMES):
+            a["pose"][0, f, :3] = self.Pw[f] + rng.normal(0, 0.05, 3)
+            a["pose"][0, f, 3:] = quat_from_R(self.Rw[f] @ _expm_so3(rng.normal(0, np.deg2rad(1.0), 3)))
+            a["speedbias"][0, f] = np.concatenate([self.Vw[f] + rng.normal(0, 0.05, 3), ba0, bg0])
+        for j in range(abi.WINDOW_SIZE):
+            dt, acc, gyr = self.imu_interval(j)
+            a["imu_n"][0, j], a["imu_dt"][0, j, :20], a["imu_acc"][0, j, :21], a["imu_gyr"][0, j, :21] = 20, dt, acc, gyr
+            a["imu_lin_ba"][0, j], a["imu_lin_bg"][0, j] = ba0, bg0
+        return w, ids
+
+    def next_image(self, w, ids, k):
+        """After the library rolled window k (MARGIN_OLD, shift_depth) in `w`: the host's per-image bookkeeping for window
+        k + 1.  `ids` are the landmark ids of the features of window k BEFORE the roll.  Appends the observations of the new
+        frame, admits the tracks that now pass the filter (inverse depth -1: to be triangulated), installs the new IMU
+        interval.  Returns the landmark ids of window k + 1's features."""
+        a = w.a
+        n_after = int(a["n_feat"][0])
+        # survivors of removeBackShiftDepth: everything except tracks that started in frame 0 with <= 2 observations
+        before = [self._admissible(k, li) for li in ids]
+        keep = [li for li, (st, ob) in zip(ids, before) if not (st == 0 and len(ob) <= 2)]
+        assert len(keep) == n_after, (len(keep), n_after)
+        lam = [float(a["inv_depth"][0, e]) for e in range(n_after)]
+        rows = []
+        for e, li in enumerate(keep):
+            st, no, ob0 = int(a["feat_start"][0, e]), int(a["feat_nobs"][0, e]), int(a["feat_obs_begin"][0, e])
+            ob = [a["obs_xy"][0, ob0 + i].copy() for i in range(no)]
+            newf = k + 1 + abi.WINDOW_SIZE
+            if st + no == abi.WINDOW_SIZE and newf in self.tracks[li][1]:  # tracked up to the previous newest frame
+                ob.append(self.tracks[li][1][newf])
+            rows.append((st, ob))
+        tracked = set(ids)
+        entrants = [li for li in range(len(self.tracks)) if li not in tracked and self.tracks[li][0] == k + 1 + abi.WINDOW_SIZE - 3
+                    and self._admissible(k + 1, li)]
+        entrants = entrants[: max(0, self.max_feat - len(keep))]
+        for li in entrants:
+            rows.append(self._admissible(k + 1, li))
+            lam.append(-1.0)
+        a["obs_xy"][:] = 0
+        self._write_tracks(a, 0, k + 1, rows, lam)
+        dt, acc, gyr = self.imu_interval(k + 1 + abi.WINDOW_SIZE - 1)
+        a["imu_n"][0, 9], a["imu_dt"][0, 9, :20], a["imu_acc"][0, 9, :21], a["imu_gyr"][0, 9, :21] = 20, dt, acc, gyr
+        return keep + entrants

@@ -13,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../include/avm.h"
 #include "factors.hpp"
@@ -130,18 +131,29 @@ struct Problem {
 
   // ceres ResidualBlock::Evaluate + ProgramEvaluator: cost = sum 1/2 rho(|r|^2); with jacobians the
   // blocks hold corrected residuals and corrected local Jacobians.
+  // A cost-only evaluation (the candidate point) must leave the stored residuals / Jacobians of the current point alone:
+  // Ceres keeps residuals_ and jacobian_ at x and evaluates the candidate into nothing (TrustRegionMinimizer::
+  // ComputeCandidatePointAndEvaluateCost passes NULL for residuals), and model_cost_change of a retried step after a
+  // rejection is computed from residuals_ at x.
   double evaluate(const State& x, bool want_jac) {
     const Window& win = *w;
     double cost = 0.0;
     const double sq = opt->focal_length / 1.5;
     V3 G(opt->g[0], opt->g[1], opt->g[2]);
-    for (auto& b : blocks) {
+    std::vector<double> scratch_r;
+    for (auto& blk : blocks) {
+      RBlock& b = blk;
+      double* br = b.r.data();
+      if (!want_jac) {
+        scratch_r.assign(b.nres, 0.0);
+        br = scratch_r.data();
+      }
       if (b.type == 0) {
         std::vector<const double*> ps(b.nb);
         for (int k = 0; k < b.nb; k++) ps[k] = param(x, b.ids[k]);
         std::vector<double> dx;
         prior_dx(win.prior, ps, dx);
-        prior_residual(win.prior, dx, b.r.data());
+        prior_residual(win.prior, dx, br);
         if (want_jac) {
           for (int k = 0; k < b.nb; k++) {
             if (!b.lsz[k]) continue;
@@ -151,13 +163,13 @@ struct Problem {
           }
         }
         double s = 0;
-        for (int i = 0; i < b.nres; i++) s += b.r[i] * b.r[i];
+        for (int i = 0; i < b.nres; i++) s += br[i] * br[i];
         cost += 0.5 * s;
       } else if (b.type == 1) {
         int i = b.aux0;
         double j0[15 * 7], j1[15 * 9], j2[15 * 7], j3[15 * 9];
         double* jac[4] = {j0, j1, j2, j3};
-        imu_factor_evaluate(win.pre[i], win.sqrt_info[i], G, x.pose[i], x.sb[i], x.pose[i + 1], x.sb[i + 1], b.r.data(),
+        imu_factor_evaluate(win.pre[i], win.sqrt_info[i], G, x.pose[i], x.sb[i], x.pose[i + 1], x.sb[i + 1], br,
                             want_jac ? jac : nullptr);
         if (want_jac) {
           const int gs[4] = {7, 9, 7, 9};
@@ -166,14 +178,14 @@ struct Problem {
               for (int c = 0; c < b.lsz[k]; c++) b.J[(size_t)r * b.ncols + b.coff[k] + c] = jac[k][r * gs[k] + c];
         }
         double s = 0;
-        for (int r = 0; r < 15; r++) s += b.r[r] * b.r[r];
+        for (int r = 0; r < 15; r++) s += br[r] * br[r];
         cost += 0.5 * s;
       } else {
         int e = b.aux0, slot = b.aux1, s0 = win.obs_begin[e];
         V3 pts_i(win.obs_xy[2 * s0], win.obs_xy[2 * s0 + 1], 1.0), pts_j(win.obs_xy[2 * slot], win.obs_xy[2 * slot + 1], 1.0);
         double j0[14], j1[14], j2[14], j3[2];
         double* jac[4] = {j0, j1, j2, j3};
-        projection_factor_evaluate(pts_i, pts_j, sq, x.pose[b.ids[0]], x.pose[b.ids[1]], x.ex, x.lam[e], b.r.data(),
+        projection_factor_evaluate(pts_i, pts_j, sq, x.pose[b.ids[0]], x.pose[b.ids[1]], x.ex, x.lam[e], br,
                                    want_jac ? jac : nullptr);
         if (want_jac) {
           const int gs[4] = {7, 7, 7, 1};
@@ -181,14 +193,14 @@ struct Problem {
             for (int r = 0; r < 2; r++)
               for (int c = 0; c < b.lsz[k]; c++) b.J[(size_t)r * b.ncols + b.coff[k] + c] = jac[k][r * gs[k] + c];
         }
-        double sn = b.r[0] * b.r[0] + b.r[1] * b.r[1];
+        double sn = br[0] * br[0] + br[1] * br[1];
         double rho[3];
         cauchy_loss(opt->cauchy_a, sn, rho);
         cost += 0.5 * rho[0];
         if (want_jac) {
           Corrector corr(sn, rho);
-          corr.correctJacobian(2, b.ncols, b.r.data(), b.J.data());
-          corr.correctResiduals(2, b.r.data());
+          corr.correctJacobian(2, b.ncols, br, b.J.data());
+          corr.correctResiduals(2, br);
         }
       }
     }
@@ -550,6 +562,16 @@ inline SolveResult trust_region_solve(Problem& P, const State& x0) {
       for (size_t bi = 0; bi < mr.size(); bi++)
         for (int r = 0; r < P.blocks[bi].nres; r++) s += mr[bi][r] * (P.blocks[bi].r[r] + mr[bi][r] / 2.0);
       model_cost_change = -s;
+      if (std::getenv("AVMO_TRACE")) {
+        // the same quantity through the identity the GPU kernel uses: -step^T g - 1/2 step^T H step with H y = g - mu D^2 y
+        double sg = 0, gg = 0;
+        for (int i = 0; i < n; i++) sg += step[i] * dgrad[i] * diagonal[i], gg += dgrad[i] * dgrad[i];
+        double q = 0;
+        for (size_t bi = 0; bi < mr.size(); bi++)
+          for (int r = 0; r < P.blocks[bi].nres; r++) q += mr[bi][r] * mr[bi][r];
+        std::fprintf(stderr, "[oracle it %d] radius %.10g mu %.3g alpha %.10g |g/D| %.10g model_cost_change %.12g (-s^T g %.12g, 1/2 |J s|^2 %.12g) step_norm %.10g\n",
+                     iteration, radius, mu, alpha, std::sqrt(gg), model_cost_change, -sg, 0.5 * q, dogleg_step_norm);
+      }
       step_is_valid = model_cost_change > 0.0;
       if (step_is_valid) {
         for (int i = 0; i < n; i++) delta[i] = step[i] * scale[i];
@@ -583,6 +605,7 @@ inline SolveResult trust_region_solve(Problem& P, const State& x0) {
     }
     // IsStepSuccessful (monotonic TrustRegionStepEvaluator)
     double relative_decrease = (ref_cost - cand_cost) / model_cost_change;
+    if (std::getenv("AVMO_TRACE")) std::fprintf(stderr, "[oracle it %d] x_cost %.12g cand_cost %.12g rho %.12g\n", iteration, x_cost, cand_cost, relative_decrease);
     if (relative_decrease > o.min_relative_decrease) {
       // HandleSuccessfulStep
       x = cand;

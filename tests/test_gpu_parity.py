@@ -301,12 +301,16 @@ def test_speculative_evaluation_is_exact_including_rejected_steps(estimator, ora
     assert (s1["accept_mask"] == s2["accept_mask"]).all() and (s1["termination"] == s2["termination"]).all()
     assert (np.isfinite(g2.a["pose"]).all(axis=(1, 2)) == np.isfinite(g1.a["pose"]).all(axis=(1, 2))).all()
     assert rel(g1.a["pose"][fin], g2.a["pose"][fin]) < 1e-9
-    # and both follow the oracle (starting points this far off are chaotic: rounding flips a borderline accept/reject
-    # decision in a few windows whichever way the evaluations are ordered, so: most windows, looser state tolerance)
-    same = fin & (s1["accept_mask"] == so["accept_mask"])
-    assert same.sum() >= 0.9 * fin.sum() and (rejected & same).sum() >= 2
+    # and both follow the oracle through every rejected step: same accept / reject decisions, same radii, same states
+    same = fin & (s1["accept_mask"] == so["accept_mask"]) & (s1["termination"] == so["termination"])
     per_window = np.array([rel(g1.a["pose"][i], wo.a["pose"][i]) for i in np.flatnonzero(same)])
-    assert np.median(per_window) < STATE_TOL and (per_window < 1e-4).mean() >= 0.8
+    print("\n[speculation] finite", int(fin.sum()), "same decisions", int(same.sum()), "with rejected steps", int((rejected & same).sum()),
+          "worst pose gap", float(per_window.max()), "median", float(np.median(per_window)))
+    assert same.sum() >= fin.sum() - 1 and (rejected & same).sum() >= 2     # (one borderline rho in 64 wild windows is rounding)
+    assert np.median(per_window) < 1e-9 and (per_window < STATE_TOL).mean() >= 0.95
+    for i in np.flatnonzero(same & rejected)[:8]:
+        n = int(s1["num_iterations"][i])
+        assert rel(s1["radius_trace"][i][:n], so["radius_trace"][i][:n]) < 1e-6, i
 
 
 def test_solve_is_bit_reproducible_and_shard_invariant(estimator):
@@ -685,8 +689,9 @@ def test_chained_solves_through_the_new_prior(ctx, oracle):
     sg = E2.optimization(wg)
     so = buffers.summary_alloc(2)
     oracle.window_solve(o2, wo, None, so)
+    assert np.array_equal(buffers.summary_to_numpy(sg)["accept_mask"], so["accept_mask"])
     for k in ("pose", "speedbias"):
-        assert rel(wg.a[k], wo.a[k]) < 1e-5, (k, rel(wg.a[k], wo.a[k]))
+        assert rel(wg.a[k], wo.a[k]) < 1e-6, (k, rel(wg.a[k], wo.a[k]))   # north-star tolerance (measured 1e-7; see test_prior_parity.py)
 
 
 # ---------------------------------------------------------------- HP-B
@@ -892,4 +897,4 @@ def test_window_roll_matches_oracle_and_chains_solves(ctx, oracle):
     E2.optimization(wg)
     oracle.window_solve(o2, wo, None, buffers.summary_alloc(3))
     for k in ("pose", "speedbias"):
-        assert rel(wg.a[k], wo.a[k]) < 1e-5, (k, rel(wg.a[k], wo.a[k]))
+        assert rel(wg.a[k], wo.a[k]) < 1e-6, (k, rel(wg.a[k], wo.a[k]))   # north-star tolerance; the 10-frame stream is in test_prior_parity.py
