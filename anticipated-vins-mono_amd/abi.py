@@ -15,7 +15,7 @@ AVM_OK = 0
 AVM_MEM_HOST, AVM_MEM_DEVICE = 0, 1
 # avm_status (include/avm.h)
 AVM_OK, AVM_ERR_INVALID, AVM_ERR_UNSUPPORTED, AVM_ERR_NO_DEVICE, AVM_ERR_HIP, AVM_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
-BLK_POSE, BLK_SPEEDBIAS, BLK_EXPOSE = 0, 1, 2
+BLK_POSE, BLK_SPEEDBIAS, BLK_EXPOSE, BLK_TD = 0, 1, 2, 3
 MARGIN_OLD, MARGIN_SECOND_NEW, MARGIN_NONE = 0, 1, 2
 TERM_NAMES = ["NO_CONVERGENCE", "GRADIENT_TOL", "PARAMETER_TOL", "FUNCTION_TOL", "MIN_RADIUS", "FAILURE"]
 
@@ -49,6 +49,8 @@ class Options(C.Structure):
         ("max_num_consecutive_invalid_steps", C.c_int32),
         ("jacobi_scaling", C.c_int32),
         ("marg_eps", C.c_double),
+        ("tr", C.c_double),
+        ("row", C.c_double),
     ]
 
 
@@ -82,6 +84,15 @@ class WindowBatch(C.Structure):
         ("prior_J", c_dp),
         ("prior_r", c_dp),
         ("prior_x0", c_dp),
+        ("obs_vel_td", c_dp),
+        ("td", c_dp),
+        ("relo_n", c_ip),
+        ("relo_frame", c_ip),
+        ("relo_feat", c_ip),
+        ("relo_xy", c_dp),
+        ("relo_pose", c_dp),
+        ("failure_occur", c_ip),
+        ("last_pose0", c_dp),
     ]
 
 
@@ -256,6 +267,7 @@ def default_options() -> Options:
     o.max_num_consecutive_invalid_steps = 5
     o.jacobi_scaling = 1
     o.marg_eps = 1e-8
+    o.tr, o.row = 0.0, 480.0  # global shutter (euroc_config.yaml:66), image_height 480
     return o
 
 

@@ -13,10 +13,12 @@ from . import abi
 _WINDOW_F64 = [
     "pose", "speedbias", "ex_pose", "inv_depth", "obs_xy", "imu_dt", "imu_acc", "imu_gyr",
     "imu_lin_ba", "imu_lin_bg", "prior_J", "prior_r", "prior_x0",
+    "obs_vel_td", "td", "relo_xy", "relo_pose", "last_pose0",   # optional members (absent key -> NULL)
 ]
 _WINDOW_I32 = [
     "n_feat", "feat_start", "feat_nobs", "feat_obs_begin", "imu_n", "prior_n", "prior_nblk",
     "prior_blk_kind", "prior_blk_frame",
+    "relo_n", "relo_frame", "relo_feat", "failure_occur",       # optional members
 ]
 
 

@@ -170,8 +170,12 @@ int ensure_window_buffers(avm_ctx* c, int n_windows) {
 
 int check_window_batch(avm_ctx* c, const avm_options* opt, const avm_window_batch* b) {
   if (!opt || !b || b->n_windows < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
-  if (opt->estimate_extrinsic) return fail(c, AVM_ERR_UNSUPPORTED, "estimate_extrinsic != 0 is not built (ex_pose is held constant)");
-  if (opt->estimate_td) return fail(c, AVM_ERR_UNSUPPORTED, "estimate_td != 0 is not built (ProjectionTdFactor)");
+  if (opt->estimate_td && (!b->obs_vel_td || !b->td))
+    return fail(c, AVM_ERR_INVALID, "estimate_td != 0 needs obs_vel_td (velocity, cur_td, uv.y per observation) and td");
+  if (opt->estimate_td && !(opt->row > 0.0)) return fail(c, AVM_ERR_INVALID, "estimate_td != 0 needs opt->row (image height) > 0");
+  if (b->relo_n && (!b->relo_feat || !b->relo_xy || !b->relo_pose))
+    return fail(c, AVM_ERR_INVALID, "relo_n is set but relo_feat / relo_xy / relo_pose is NULL");
+  if (b->failure_occur && !b->last_pose0) return fail(c, AVM_ERR_INVALID, "failure_occur is set but last_pose0 is NULL");
   if (b->max_feat > MAXE) return fail(c, AVM_ERR_CAPACITY, "max_feat > 150");
   if (b->max_obs > MAXOBS) return fail(c, AVM_ERR_CAPACITY, "max_obs > 1650");
   if (b->max_prior > MAXPRIOR || b->max_pblk > MAXPBLK) return fail(c, AVM_ERR_CAPACITY, "prior larger than 96 / 16 blocks");
@@ -190,7 +194,10 @@ int check_window_batch(avm_ctx* c, const avm_options* opt, const avm_window_batc
   X(imu_gyr, double, (B) * 10 * ((h)->max_samp + 1) * 3) X(imu_lin_ba, double, (B) * 30) X(imu_lin_bg, double, (B) * 30)   \
   X(prior_n, int32_t, (B)) X(prior_nblk, int32_t, (B)) X(prior_blk_kind, int32_t, (B) * (h)->max_pblk)                     \
   X(prior_blk_frame, int32_t, (B) * (h)->max_pblk) X(prior_J, double, (B) * (h)->max_prior * (h)->max_prior)               \
-  X(prior_r, double, (B) * (h)->max_prior) X(prior_x0, double, (B) * (h)->max_pblk * 9)
+  X(prior_r, double, (B) * (h)->max_prior) X(prior_x0, double, (B) * (h)->max_pblk * 9)                                        \
+  X(obs_vel_td, double, (B) * (h)->max_obs * 4) X(td, double, (B)) X(relo_n, int32_t, (B)) X(relo_frame, int32_t, (B))            \
+  X(relo_feat, int32_t, (B) * (h)->max_feat) X(relo_xy, double, (B) * (h)->max_feat * 2) X(relo_pose, double, (B) * 7)           \
+  X(failure_occur, int32_t, (B)) X(last_pose0, double, (B) * 7)
 
 constexpr size_t PACK_LIMIT = 4u << 20;  // batches below 4 MiB (a few windows: the real-time use) travel packed
 inline size_t pack_up(size_t n) { return (n + 63) & ~size_t(63); }
@@ -250,6 +257,14 @@ int unstage_window_states(avm_ctx* c, const avm_window_batch* h, const avm_windo
   return AVM_OK;
 }
 
+// the optional in/out members (para_Td, relo_Pose) back to the caller
+int unstage_window_extras(avm_ctx* c, const avm_window_batch* h, const avm_window_batch* d) {
+  const size_t B = h->n_windows;
+  if (h->td && d->td) HIPCHK(c, hipMemcpyAsync(h->td, d->td, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+  if (h->relo_pose && d->relo_pose) HIPCHK(c, hipMemcpyAsync(h->relo_pose, d->relo_pose, sizeof(double) * B * 7, hipMemcpyDeviceToHost, c->stream));
+  return AVM_OK;
+}
+
 // after the synchronize: scatter the packed states into the caller's arrays
 void finish_window_states(const avm_window_batch* h, const char* pinned_states) {
   if (!pinned_states) return;
@@ -304,6 +319,7 @@ int avm_default_options(avm_options* o) {
   o->max_num_consecutive_invalid_steps = 5;
   o->jacobi_scaling = 1;
   o->marg_eps = 1e-8;
+  o->tr = 0.0, o->row = 480.0;  // global shutter (config/euroc/euroc_config.yaml:66), image_height
   return AVM_OK;
 }
 
@@ -412,7 +428,9 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     sa.speculate = (ns && ns[0] == '1') ? 0 : 1;
   }
   if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * 32 * c->n_slots, c->stream));
-  HIPCHK(c, launch_window_solve(sa, c->stream));
+  // ex_pose / td as variables, relocalization factors: the build of the solve kernel with the wider dense block
+  const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || d.relo_n != nullptr;
+  HIPCHK(c, extended ? launch_window_solve_x(sa, c->stream) : launch_window_solve(sa, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   avm_prior_out dpo;
   int* marg_err = nullptr;
@@ -468,6 +486,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   if (mem == AVM_MEM_HOST) {
     const size_t B = batch->n_windows;
     if ((rc = unstage_window_states(c, batch, &d, &pinned_states)) != AVM_OK) return rc;
+    if ((rc = unstage_window_extras(c, batch, &d)) != AVM_OK) return rc;
     if (summary) HIPCHK(c, hipMemcpyAsync(summary, d_sum, sizeof(avm_solve_summary) * B, hipMemcpyDeviceToHost, c->stream));
   }
   if (marg_err) HIPCHK(c, hipMemcpyAsync(&marg_err_host, marg_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -8,11 +8,25 @@ namespace avm {
 
 // compile-time problem limits of the window-solve kernel (WINDOW_SIZE = 10 => 11 frames)
 constexpr int NFR = AVM_NFRAMES;       // 11
+// The solve kernel is compiled twice from the same source (csrc/Makefile):
+//   window_solve.o    the reference's default configuration (ESTIMATE_EXTRINSIC = 0, ESTIMATE_TD = 0, no relocalization frame):
+//                     f-block = pose 66 | speed-bias 99 = 165 columns
+//   window_solve_x.o  (-DAVM_X) every optional member of the problem: the dense "pose-like" part grows to
+//                     pose 66 | relo_Pose 6 | ex_pose 6 | td 1 = 79 columns (relo_Pose is treated as a 12th frame), then
+//                     speed-bias 99 = 178 columns; members that are switched off keep a unit diagonal
+#ifdef AVM_X
+constexpr int NFRP = NFR + 1;          // pose-like frames of the projection factors: 11 window frames + relo_Pose
+constexpr int NPOSE = NFRP * 6 + 7;    // 79 dense columns in front of the speed-biases
+constexpr int XC_EX = NFRP * 6;        // 72: first ex_pose column
+constexpr int XC_TD = XC_EX + 6;       // 78: the td column
+#else
+constexpr int NFRP = NFR;
 constexpr int NPOSE = NFR * 6;         // 66 pose columns (local)
-constexpr int NF = NFR * 15;           // 165 f-block columns: poses first, then speed-bias
+#endif
+constexpr int NF = NPOSE + NFR * 9;    // 165 (178) f-block columns: poses (+ relo, ex, td) first, then speed-bias
 constexpr int SB0 = NPOSE;             // column of speedbias[0]
 constexpr int MAXE = 150;              // inverse depths (e-blocks)
-constexpr int NCOL = NF + MAXE;        // 315
+constexpr int NCOL = NF + MAXE;        // 315 (328)
 constexpr int MAXOBS = MAXE * NFR;     // 1650 observation slots
 constexpr int MAXPRIOR = 96;           // prior residual dimension limit
 constexpr int MAXKEEP = 76;            // rows a marginalization may keep (prior_eig.hip holds A' and V in half a CU's LDS); this problem keeps <= 75
@@ -27,15 +41,16 @@ struct PreintArgs {
 };
 
 // per-slot global scratch layout (doubles), one slot per resident workgroup (stays L2 resident)
+// (one layout for both builds of the solve kernel and the marginalization kernel: the slots are shared)
 struct Scratch {
-  static constexpr size_t PF = 0;                               // [14][MAXOBS] per-factor Ji^T Je (6), Je^T Je, Je^T r, Jex^T Je (6, marginalization)
-  static constexpr size_t PART = PF + 14 * (size_t)MAXOBS;       // [11][11][27] sum_b Ji^T Ji (21) and Ji^T r (6) per (frame b, start a)
-  static constexpr size_t IJRAW = PART + 3272;                  // [10][15][31] IMU residual + Jacobian before sqrt_info
-  static constexpr size_t W = IJRAW + 4656;                     // [MAXE][NPOSE] E^T F ([MAXE][72] in the marginalization kernel)
-  static constexpr size_t HP = W + (size_t)MAXE * 72;        // [MAXPRIOR][MAXPRIOR] J0^T J0
+  static constexpr size_t PF = 0;                               // per-factor products: [14..15 quantities][frames][152] feature-major (solve), [15][MAXOBS] (marginalization)
+  static constexpr size_t PART = PF + 17 * (size_t)MAXOBS;       // per (frame b, start a) partial blocks: [12][11][69] + [12][35]
+  static constexpr size_t IJRAW = PART + 9600;                  // [10][15][31] IMU residual + Jacobian before sqrt_info
+  static constexpr size_t W = IJRAW + 4656;                     // E^T F: Wt[80][152] (solve), [MAXE][80] (marginalization)
+  static constexpr size_t HP = W + (size_t)80 * 152;            // [MAXPRIOR][MAXPRIOR] J0^T J0
   static constexpr size_t TOTAL = HP + (size_t)MAXPRIOR * MAXPRIOR;
 };
-constexpr int ISCRATCH = MAXOBS + NFR * MAXE;  // ints per slot: observation slot -> feature, then cov[11][150]
+constexpr int ISCRATCH = MAXOBS + (NFR + 1) * MAXE;  // ints per slot: observation slot -> feature, then cov[12][150] (row 11: the relocalization frame)
 
 struct SolveArgs {
   avm_window_batch b;  // device pointers
@@ -101,8 +116,8 @@ __host__ __device__ inline int check_window_tables(const avm_window_batch& B, in
           int off = 0;
           for (int k = 0; k < nb; k++) {
             const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
-            if (kind < AVM_BLK_POSE || kind > AVM_BLK_EXPOSE || fr < 0 || fr >= AVM_NFRAMES) rule(BAD_PRIOR);
-            off += kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
+            if (kind < AVM_BLK_POSE || kind > AVM_BLK_TD || fr < 0 || fr >= AVM_NFRAMES) rule(BAD_PRIOR);
+            off += kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
           }
           if (off != pn) rule(BAD_PRIOR);
         }
@@ -136,6 +151,8 @@ hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipS
 hipError_t launch_slide_window(const avm_window_batch& b, int flag, int shift_depth, double init_depth, int* err, hipStream_t stream);
 hipError_t launch_projection_td_eval(const avm_td_factor_batch& f, double* residual, double* jac, hipStream_t stream);
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
+hipError_t launch_window_solve_x(const SolveArgs& a, hipStream_t stream);  // window_solve_x.o: estimate_extrinsic / estimate_td / relocalization
+int window_solve_x_lds_bytes();
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream);
 // second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior

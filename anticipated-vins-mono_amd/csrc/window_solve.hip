@@ -51,50 +51,74 @@ AVM_DEV void lds_base_check() {
 #define PROF(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pt__; pt__ = n__; } } while (0)
 
 constexpr int NT = 512;          // threads per workgroup (8 wavefronts)
-constexpr int SROWS = 13944;     // padded packed lower triangle of a 165x165 matrix + one augmented row (the RHS): roff(166)
-constexpr int VEC = 320;         // padded NCOL
-constexpr int XN = 328;          // pose 77 | speedbias 99 | inv depth 150 (+2 pad)
-constexpr int XSB = 77, XLAM = 176;
+constexpr int croff(int i) { return 2 * ((i >> 1) + 1) * ((i >> 1) + (i & 1)); }  // roff() at compile time
+constexpr int SROWS = croff(NF + 1);  // padded packed lower triangle of the NF x NF matrix + one augmented row (the RHS): 13944 (16200)
+constexpr int VEC = (NCOL + 7) & ~7;  // padded NCOL: 320 (328)
+constexpr int XSB = 7 * NFRP, XLAM = XSB + 99;  // state vector: poses (relo_Pose as frame 11) | speedbias 99 | inv depth 150 [| ex_pose 7 | td]
+#ifdef AVM_X
+constexpr int XEX = XLAM + MAXE, XTD = XEX + 7;
+constexpr int XN = (XTD + 2) & ~1;  // 342
+#else
+constexpr int XN = XLAM + MAXE + 2;  // 328
+#endif
 
 // LDS carve (offsets in doubles).  Everything between L_S + SPP (end of the pose-pose rows of S) and
 // L_G is dead while the projection factors are being assembled, so that range doubles as the per-wave
 // staging area of the MFMA X^T X products (ASM_WAVES x XSTG doubles).
-constexpr int SPP = 2244;          // roff(66): packed rows 0..65 = pose-pose block
-constexpr int WCH = 32;            // rows of the scratch tile at L_WCH (x 80 columns): diag-block temporaries, back-substitution vector
+constexpr int SPP = croff(NPOSE);  // packed rows 0..NPOSE-1 = the dense pose(-like) block: 2244 (3200)
 constexpr int WLD = 80;
-constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r (+1 pad)
 constexpr int XRS = 132;           // column stride of the frame tasks' column-major staging tile: 128 rows + 4 (bank spread)
+#ifdef AVM_X
+constexpr int WCH = 8;             // rows of the scratch tile at L_WCH (x 80 columns): diag-block temporaries, back-substitution vector
+constexpr int XCOLS = 20;          // staged factor row: Jj(6) | Ji(6) | r | Jex(6) | Jtd
+constexpr int XSTG = XCOLS * XRS;
+constexpr int ASM_WAVES = 5;       // wavefronts assembling projection factors
+#else
+constexpr int WCH = 32;
+constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r (+1 pad)
 constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows (>= 13 * XRS)
 static_assert(13 * XRS <= XSTG, "column-major staging tile fits");
-constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diagonal block); trailing tiles stay 16x16
 constexpr int ASM_WAVES = 7;       // wavefronts assembling projection factors (the 8th does the IMU factors)
+#endif
+constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diagonal block); trailing tiles stay 16x16
+constexpr int TLAST = NF / 16;     // last 16-row tile of the packed matrix incl. the augmented row NF: 10 (11)
+constexpr int FRS = 18 * NFRP;     // one frames slot: R (NFRP x 9) then A = ric^T R^T (NFRP x 9)
 constexpr int L_S = 0;
 constexpr int L_Y = L_S + SROWS;   // Gauss-Newton solution y of (H + mu D^2) y = g
 constexpr int L_ST = L_Y + VEC;    // trust region step (scaled space)
 constexpr int L_XC = L_ST + VEC;   // candidate state
-constexpr int L_WCH = L_XC + XN;   // [32][80] scratch tile
+constexpr int L_WCH = L_XC + XN;   // [WCH][80] scratch tile
 constexpr int L_G = L_WCH + WCH * WLD;  // scaled gradient g (f | e)
+#ifdef AVM_X
+constexpr int L_DD = L_G + VEC;    // D   (g / D is recomputed where it is needed: no room for a fourth vector next to the 178 x 178 system)
+#else
 constexpr int L_DG = L_G + VEC;    // g / D
 constexpr int L_DD = L_DG + VEC;   // D
+#endif
 constexpr int L_SC = L_DD + VEC;   // Jacobi scaling
 constexpr int L_X = L_SC + VEC;
-constexpr int L_FR = L_X + XN;     // [2][198]: R (11x9) then A = ric^T R^T (11x9)
-constexpr int L_RIC = L_FR + 396;  // ric 9, tic 3, current ex_pose 7 (+1 pad)
-constexpr int L_HEE = L_RIC + 20;  // E^T E (150) padded
+constexpr int L_FR = L_X + XN;     // [2][FRS]
+#ifdef AVM_X
+constexpr int L_RIC = L_FR + 2 * FRS;  // [2][12]: ric 9, tic 3 of the current point / of the candidate
+constexpr int L_HEE = L_RIC + 24;      // E^T E (150) padded
+#else
+constexpr int L_RIC = L_FR + 2 * FRS;  // ric 9, tic 3, current ex_pose 7 (+1 pad)
+constexpr int L_HEE = L_RIC + 20;      // E^T E (150) padded
+#endif
 constexpr int L_DXP = L_HEE + 152;
 constexpr int L_RP = L_DXP + MAXPRIOR;
 constexpr int L_RED = L_RP + MAXPRIOR;
 constexpr int L_INT = L_RED + 32;  // int region (as doubles): 360 doubles = 720 ints
 constexpr int L_SUM = L_INT + 360;  // cost_trace[16], radius_trace[16]
-constexpr int L_CTX = L_SUM + 32;   // WinCtx of the window being solved (24 doubles)
-constexpr int L_OPT = L_CTX + 24;   // avm_options (copied from the kernel arguments)
+constexpr int L_CTX = L_SUM + 32;   // WinCtx of the window being solved (32 doubles)
+constexpr int L_OPT = L_CTX + 32;   // avm_options (copied from the kernel arguments)
 constexpr int L_END = L_OPT + (int)((sizeof(avm_options) + 7) / 8);
 static_assert(L_END * 8 <= 163840, "LDS budget exceeded");
 static_assert(L_S + SPP + ASM_WAVES * XSTG <= L_G, "assembly staging overlaps live data");
 // int carve (offsets in ints from L_INT)
 constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 546, I_PBLK = 560 /* kind,frame,off x16 */, I_FAIL = 620,
-              I_NCOV = 624 /* [11] factors observed in frame b */, I_FRW = 636 /* [11] assembling wave of frame b */,
-              I_PMASK = 648 /* [11] start frames flushed by frame b */, I_END = 660;
+              I_NCOV = 624 /* [12] factors observed in frame b */, I_FRW = 636 /* [12] assembling wave of frame b */,
+              I_PMASK = 648 /* [12] start frames flushed by frame b */, I_END = 660;
 static_assert(I_END <= 720, "int carve");
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -119,7 +143,8 @@ struct Frames {
 template <bool WANT_J>
 AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const double* tic, double pix, double piy, double pjx,
                          double pjy, double lam, int fa, int fb, double sqi, double cauchy_a, bool apply_loss, double* r,
-                         double* Ji, double* Jj, double* Je, double* Jex = nullptr) {
+                         double* Ji, double* Jj, double* Je, double* Jex = nullptr, double* Jtd = nullptr, double vix = 0.0,
+                         double viy = 0.0, double vjx = 0.0, double vjy = 0.0) {
   const double* Ra = fr.R + fa * 9;
   const double* Rb = fr.R + fb * 9;
   const v3 Pa = mk3(x[fa * 7], x[fa * 7 + 1], x[fa * 7 + 2]);
@@ -176,6 +201,9 @@ AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const do
       Jj[rr * 6 + 0] = -m.x, Jj[rr * 6 + 1] = -m.y, Jj[rr * 6 + 2] = -m.z;
       Jj[rr * 6 + 3] = cj.x, Jj[rr * 6 + 4] = cj.y, Jj[rr * 6 + 5] = cj.z;
       Je[rr] = dot(mr, u) * il2;
+      // ProjectionTdFactor (projection_td_factor.cpp:131-136): d r / d td = reduce ric^T Rj^T Ri ric velocity_i (-1 / lambda) +
+      // sqrt_info velocity_j; (pix, piy) / (pjx, pjy) are the td-shifted observations then (the caller shifts them)
+      if (Jtd) Jtd[rr] = dot(mr, Rmul(ric, mk3(vix, viy, 0.0))) * -il + (srho * sqi) * (rr == 0 ? vjx : vjy);
       if (Jex) {
         // jaco_ex (projection_factor.cpp:97-107): left = ric^T (Rj^T Ri - I); right = -tmp_r [pc_i]x + [tmp_r pc_i]x + [q]x,
         // and tmp_r pc_i + q is the point in camera j, so the two skew terms collapse to [pc_j]x
@@ -295,6 +323,8 @@ AVM_DEV int imu_col(int i, int c) {
 AVM_DEV void prior_block_dx(int kind, const double* xb, const double* x0, double* dx) {
   if (kind == AVM_BLK_SPEEDBIAS) {
     for (int k = 0; k < 9; k++) dx[k] = xb[k] - x0[k];
+  } else if (kind == AVM_BLK_TD) {
+    dx[0] = xb[0] - x0[0];
   } else {
     for (int k = 0; k < 3; k++) dx[k] = xb[k] - x0[k];
     const quat q0{x0[6], x0[3], x0[4], x0[5]}, q{xb[6], xb[3], xb[4], xb[5]};
@@ -335,9 +365,14 @@ struct WinCtx {
   gcdouble *lba, *lbg;
   gcdouble *pJ, *pr, *px0;  // prior
   int ldp;
+  // optional members of the problem (the solve reads them in the AVM_X build only, the marginalization in both)
+  gcdouble* aux;      // [max_obs][4] velocity.x, velocity.y, cur_td, uv.y per observation slot (null unless estimate_td)
+  gcdouble* relo_xy;  // [relo_n][2] match points
+  int relo_n;         // > 0: the relocalization frame takes part (frame 11)
+  int est_ex, est_td;
 };
 
-static_assert(sizeof(WinCtx) <= 24 * 8, "WinCtx outgrew its LDS slot");
+static_assert(sizeof(WinCtx) <= 32 * 8, "WinCtx outgrew its LDS slot");
 // The per-window context and the options live in LDS: handed to the outlined phases by reference they would sit in
 // the caller's private (scratch) memory and every field access would be a flat load from it.
 AVM_DEV const WinCtx& lds_ctx() { return *reinterpret_cast<const WinCtx*>(LDS() + L_CTX); }
@@ -355,10 +390,22 @@ AVM_DEV void build_frames(int xs_off, int which) {
   double* lds = LDS();
   const double* xs = lds + xs_off;
   const int t = threadIdx.x;
-  double* R = lds + L_FR + which * 198;
-  double* A = R + 99;
+  double* R = lds + L_FR + which * FRS;
+  double* A = R + 9 * NFRP;
+#ifdef AVM_X
+  // ex_pose is part of the state here: every thread that needs ric recomputes it (thread NFRP publishes it for the factors)
+  double ricv[9];
+  q2R(quat{xs[XEX + 6], xs[XEX + 3], xs[XEX + 4], xs[XEX + 5]}, ricv);
+  const double* ric = ricv;
+  if (t == NFRP) {
+    double* dst = lds + L_RIC + which * 12;
+    for (int k = 0; k < 9; k++) dst[k] = ricv[k];
+    for (int k = 0; k < 3; k++) dst[9 + k] = xs[XEX + k];
+  }
+#else
   const double* ric = lds + L_RIC;
-  if (t < NFR) {
+#endif
+  if (t < NFRP) {
     quat q{xs[t * 7 + 6], xs[t * 7 + 3], xs[t * 7 + 4], xs[t * 7 + 5]};
     double Rm[9];
     q2R(q, Rm);
@@ -366,6 +413,23 @@ AVM_DEV void build_frames(int xs_off, int which) {
     for (int a = 0; a < 3; a++)
       for (int b = 0; b < 3; b++) A[t * 9 + a * 3 + b] = ric[0 * 3 + a] * Rm[b * 3 + 0] + ric[1 * 3 + a] * Rm[b * 3 + 1] + ric[2 * 3 + a] * Rm[b * 3 + 2];
   }
+}
+
+// ric / tic the factors of frames slot `which` are evaluated with
+AVM_DEV const double* ric_of(int which) {
+#ifdef AVM_X
+  return LDS() + L_RIC + which * 12;
+#else
+  (void)which;
+  return LDS() + L_RIC;
+#endif
+}
+
+// the td-shifted pair of observations of one ProjectionTdFactor (projection_td_factor.cpp:50-52) and the two velocities:
+// ob = {pts_i.x, pts_i.y, pts_j.x, pts_j.y}, ai / aj = {velocity.x, velocity.y, cur_td, uv.y} of the two observations
+AVM_DEV void td_shift(double* ob, const double* ai, const double* aj, double td, double tr, double row) {
+  const double si = td - ai[2] + tr / row * (ai[3] - row / 2), sj = td - aj[2] + tr / row * (aj[3] - row / 2);
+  ob[0] -= si * ai[0], ob[1] -= si * ai[1], ob[2] -= sj * aj[0], ob[3] -= sj * aj[1];
 }
 
 // prior residual r_p = r0 + J0 * dx(xs) into lds[L_RP]; returns (to all threads) nothing; needs syncs by caller
@@ -378,11 +442,15 @@ AVM_NOINL void prior_residual_dev(const WinCtx&, int xs_off) {
   const int t = threadIdx.x;
   if (t < c.pnblk) {
     const int kind = ids[I_PBLK + t * 3], fr = ids[I_PBLK + t * 3 + 1], off = ids[I_PBLK + t * 3 + 2];
+#ifdef AVM_X
+    const double* xb = kind == AVM_BLK_POSE ? xs + fr * 7 : (kind == AVM_BLK_SPEEDBIAS ? xs + XSB + fr * 9 : (kind == AVM_BLK_TD ? xs + XTD : xs + XEX));
+#else
     // ex_pose is constant in the solve; its current value sits behind ric/tic
-    const double* xb = kind == AVM_BLK_POSE ? xs + fr * 7 : (kind == AVM_BLK_SPEEDBIAS ? xs + XSB + fr * 9 : lds + L_RIC + 12);
+    const double* xb = kind == AVM_BLK_POSE ? xs + fr * 7 : (kind == AVM_BLK_SPEEDBIAS ? xs + XSB + fr * 9 : lds + L_RIC + (kind == AVM_BLK_TD ? 19 : 12));
+#endif
     double dx[9];
     prior_block_dx(kind, xb, c.px0 + t * 9, dx);
-    const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
+    const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
     for (int k = 0; k < n; k++) lds[L_DXP + off + k] = dx[k];
   }
   __syncthreads();
@@ -416,7 +484,8 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   (void)ids;
   const int t = threadIdx.x;
-  Frames fr{lds + L_FR + which * 198, lds + L_FR + which * 198 + 99};
+  Frames fr{lds + L_FR + which * FRS, lds + L_FR + which * FRS + 9 * NFRP};
+  const double* ric = ric_of(which);
   const double sqi = o.focal_length / 1.5;
   double acc = 0;
   // IMU raw residuals by threads of the last wave (so they overlap with projection work of the others)
@@ -449,10 +518,27 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
       const int e = es[u];
       const int fa = ids[I_FSTART + e], fb = fa + (s - s0s[u]);
       double r[2];
-      acc += proj_eval<false>(xs, fr, lds + L_RIC, lds + L_RIC + 9, ob[u][0], ob[u][1], ob[u][2], ob[u][3], xs[XLAM + e], fa, fb, sqi,
+#ifdef AVM_X
+      if (c.est_td) {
+        double ai[4], aj[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) ai[k] = c.aux[4 * s0s[u] + k], aj[k] = c.aux[4 * s + k];
+        td_shift(ob[u], ai, aj, xs[XTD], o.tr, o.row);
+      }
+#endif
+      acc += proj_eval<false>(xs, fr, ric, ric + 9, ob[u][0], ob[u][1], ob[u][2], ob[u][3], xs[XLAM + e], fa, fb, sqi,
                               o.cauchy_a, true, r, nullptr, nullptr, nullptr);
     }
   }
+#ifdef AVM_X
+  // relocalization factors (estimator.cpp:760-792): plain ProjectionFactors against relo_Pose = frame 11
+  for (int k = t; k < c.relo_n; k += NT) {
+    const int e = c.cov[(NFRP - 1) * MAXE + k], s0 = ids[I_FOBS + e];
+    double r[2];
+    acc += proj_eval<false>(xs, fr, ric, ric + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.relo_xy[2 * k], c.relo_xy[2 * k + 1], xs[XLAM + e],
+                            ids[I_FSTART + e], NFRP - 1, sqi, o.cauchy_a, true, r, nullptr, nullptr, nullptr);
+  }
+#endif
   __syncthreads();
   if (t < 150) {
     const int i = t / 15, r = t % 15;
@@ -514,7 +600,17 @@ AVM_NOINL void prior_jtj_add_lds(gcdouble* pJ, int ldp, int pn, int s_off) {
 //   Wt [NPOSE][WLE]       E^T F transposed: Wt[c][e] = (E^T F)[e][c]
 //   PFt[8][NFR][WLE]      per (quantity q, observing frame b, feature e): Ji^T Je (q < 6), Je^T Je, Je^T r
 constexpr int WLE = 152;
-static_assert(NPOSE * WLE <= MAXE * 72 && 8 * NFR * WLE <= 14 * MAXOBS, "transposed layouts fit the W / PF regions");
+#ifdef AVM_X
+constexpr int NQ = 15;      // per-factor quantities: Ji^T Je (6), Je^T Je, Je^T r, Jex^T Je (6), Jtd^T Je
+constexpr int SPARTW = 69;   // per (frame b, start a): Ji^T Ji (21) | Ji^T r (6) | [Jex; Jtd]^T Ji (7 x 6)
+constexpr int PARTX = 35;   // per frame b: [Jex; Jtd]^T [Jex; Jtd] lower (28) | [Jex; Jtd]^T r (7)
+constexpr int PARTX0 = NFRP * NFR * SPARTW;
+static_assert(PARTX0 + NFRP * PARTX <= 9600, "partial blocks fit the PART region");
+#else
+constexpr int NQ = 8;
+constexpr int SPARTW = 27;
+#endif
+static_assert(NPOSE * WLE <= 80 * 152 && NQ * NFRP * WLE <= 17 * MAXOBS, "transposed layouts fit the W / PF regions");
 constexpr int HPK_MAX = MAXPRIOR * (MAXPRIOR + 1) / 2;  // 4656 doubles, followed by 4656 ints (fits the [96][96] slot)
 static_assert(HPK_MAX + HPK_MAX / 2 <= MAXPRIOR * MAXPRIOR, "packed Hp + destinations fit the HP scratch region");
 AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gint* dst) {
@@ -565,6 +661,7 @@ AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gin
 // are consecutive; the B operand is masked per a-run to keep the (b,a)/(a,a) blocks separate.
 // Blocks (b,b), (b,a) and g_b belong to this frame only and are written straight into LDS; the (a,a)
 // contributions go to PART[b][a] in the scratch slot and are summed in a fixed order afterwards.
+#ifndef AVM_X
 AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
   const WinCtx& c = lds_ctx();
   const avm_options& o = lds_opt();
@@ -695,6 +792,166 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
   if (lane == 0) ids[I_PMASK + b] = pmask;
   return cost;
 }
+#else
+// The same task with every optional member of the problem: staged row [Jj | Ji | r | Jex | Jtd] (20 columns, two 16-wide
+// operand tiles), frame 11 = the relocalization frame (its "observations" are the match points, its pose relo_Pose).
+// X^T X now has three tiles: D00 = [Jj Ji r]^2 as before, D10 = [Jex Jtd]^T [Jj Ji r] and D11 = [Jex Jtd]^2.
+//   D00, per start-frame run a:  (b,a), (a,a) -> PART[b][a], g_a;        total: (b,b), g_b
+//   D10, per run:  [Jex Jtd]^T Ji -> PART[b][a][27..68];                 total: [Jex Jtd]^T Jj -> S rows 72..78 x cols 6b.. (owned by
+//        this frame), [Jex Jtd]^T r -> PARTX[b][28..34]
+//   D11, total: -> PARTX[b][0..27]
+// Members that are switched off (estimate_extrinsic / estimate_td == 0) stage exact zeros, so their blocks come out zero.
+AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
+  const WinCtx& c = lds_ctx();
+  const avm_options& o = lds_opt();
+  double* lds = LDS();
+  double* stage = lds + stage_off;
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  const int lane = threadIdx.x & 63;
+  const int ncov = ids[I_NCOV + b];
+  const int32_t* cov = c.cov + b * MAXE;
+  Frames fr{lds + L_FR, lds + L_FR + 9 * NFRP};
+  const double* ric = ric_of(0);
+  const double* xs = lds + L_X;
+  const double sqi = o.focal_length / 1.5;
+  const bool relo = b == NFRP - 1;
+  const bool use_td = c.est_td && !relo;  // the relocalization factors are plain ProjectionFactors (estimator.cpp:783)
+  const double exm = c.est_ex ? 1.0 : 0.0;
+  const double td = xs[XTD];
+  double* W = c.sc + Scratch::W;
+  double* PF = c.sc + Scratch::PF;
+  double* PART = c.sc + Scratch::PART + (size_t)b * NFR * SPARTW;
+  double* PX = c.sc + Scratch::PART + PARTX0 + (size_t)b * PARTX;
+  d4 Dtot = {0, 0, 0, 0}, D00 = {0, 0, 0, 0}, E00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, E10 = {0, 0, 0, 0}, D10tot = {0, 0, 0, 0},
+     D11 = {0, 0, 0, 0}, E11 = {0, 0, 0, 0};
+  int a_run = -1, pmask = 0;
+  double cost = 0;
+  const int drow = lane >> 4, dcol = lane & 15;
+  auto flush = [&]() {
+    if (a_run < 0) return;
+    D00 += E00, D10 += E10;
+    E00 = E10 = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = drow + 4 * r;
+      const double v = D00[r];
+      if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + 6 * a_run + (dcol - 6)] = v;  // Jj^T Ji
+      if (row >= 6 && row < 12) {
+        const int i = row - 6;
+        if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[a_run * SPARTW + i * (i + 1) / 2 + (dcol - 6)] = v;  // Ji^T Ji (lower)
+        if (dcol == 12) PART[a_run * SPARTW + 21 + i] = v;                                                    // Ji^T r
+      }
+      if (row < 7 && dcol >= 6 && dcol < 12) PART[a_run * SPARTW + 27 + row * 6 + (dcol - 6)] = D10[r];         // [Jex Jtd]^T Ji
+    }
+    pmask |= 1 << a_run;
+    Dtot += D00, D10tot += D10;
+    D00 = D10 = d4{0, 0, 0, 0};
+  };
+  for (int chunk0 = 0; chunk0 < ncov; chunk0 += 64) {
+    const int idx = chunk0 + lane;
+    const bool act = idx < ncov;
+    const int e = cov[min(idx, ncov - 1)];
+    const int fa = ids[I_FSTART + e];
+    const int s0 = ids[I_FOBS + e], s = s0 + (b - fa);
+    double ob[4];
+    ob[0] = c.obs[2 * s0], ob[1] = c.obs[2 * s0 + 1];
+    if (relo)
+      ob[2] = c.relo_xy[2 * min(idx, ncov - 1)], ob[3] = c.relo_xy[2 * min(idx, ncov - 1) + 1];
+    else
+      ob[2] = c.obs[2 * s], ob[3] = c.obs[2 * s + 1];
+    double ai[4] = {0, 0, 0, 0}, aj[4] = {0, 0, 0, 0};
+    if (use_td) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) ai[k] = c.aux[4 * s0 + k], aj[k] = c.aux[4 * s + k];
+      td_shift(ob, ai, aj, td, o.tr, o.row);
+    }
+    double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0}, Jx[12], Jt[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 12; k++) Ji[k] = 0, Jj[k] = 0, Jx[k] = 0;
+    if (act) {
+      cost += proj_eval<true>(xs, fr, ric, ric + 9, ob[0], ob[1], ob[2], ob[3], xs[XLAM + e], fa, b, sqi, o.cauchy_a, true, r, Ji, Jj, Je, Jx,
+                              Jt, ai[0], ai[1], aj[0], aj[1]);
+#pragma unroll
+      for (int k = 0; k < 12; k++) Jx[k] *= exm;
+      if (!use_td) Jt[0] = Jt[1] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        W[(6 * b + k) * WLE + e] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
+        PF[(k * NFRP + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+        PF[((8 + k) * NFRP + b) * WLE + e] = Jx[k] * Je[0] + Jx[6 + k] * Je[1];
+      }
+      PF[(6 * NFRP + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
+      PF[(7 * NFRP + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
+      PF[(14 * NFRP + b) * WLE + e] = Jt[0] * Je[0] + Jt[1] * Je[1];
+    }
+    {
+      dv2* st = reinterpret_cast<dv2*>(stage) + lane;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        st[k * (XRS / 2)] = dv2{Jj[k], Jj[6 + k]};
+        st[(6 + k) * (XRS / 2)] = dv2{Ji[k], Ji[6 + k]};
+        st[(13 + k) * (XRS / 2)] = dv2{Jx[k], Jx[6 + k]};
+      }
+      st[12 * (XRS / 2)] = dv2{r[0], r[1]};
+      st[19 * (XRS / 2)] = dv2{Jt[0], Jt[1]};
+    }
+    wave_lds_sync();
+    const int nact = min(64, ncov - chunk0);
+    const int fav = act ? fa : -1;
+    int l = 0;
+    while (l < nact) {
+      const int a_cur = __shfl(fav, l, 64);
+      const int cnt = __popcll(__ballot(act && fa == a_cur));
+      const int l_end = l + cnt;
+      if (a_cur != a_run) {
+        flush();
+        a_run = a_cur;
+      }
+      const int j_end = (l_end + 3) >> 2;
+#pragma unroll 1
+      for (int j0 = l >> 2; j0 < j_end; j0 += 4) {
+        dv2 u0[4], u1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int ro = 8 * min(j0 + u, 15) + 2 * drow;
+          u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS + ro);
+          u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * XRS + ro);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int f = 4 * (j0 + u) + drow;
+          const bool in = f >= l && f < l_end;
+          const double a0 = (in && dcol < 13) ? u0[u][0] : 0.0, a1 = (in && dcol < 13) ? u0[u][1] : 0.0;
+          const double x0 = (in && dcol < 7) ? u1[u][0] : 0.0, x1 = (in && dcol < 7) ? u1[u][1] : 0.0;
+          D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
+          D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
+          D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
+          E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
+          E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
+          E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+        }
+      }
+      l = l_end;
+    }
+    wave_lds_sync();
+  }
+  flush();
+  D11 += E11;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = drow + 4 * r;
+    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r];   // (b,b) lower
+    if (row < 6 && dcol == 12) lds[L_G + 6 * b + row] = Dtot[r];                         // g_b
+    if (row < 7) {
+      if (dcol < 6) lds[L_S + roff(XC_EX + row) + 6 * b + dcol] = D10tot[r];             // ([ex td], pose b)
+      if (dcol == 12) PX[28 + row] = D10tot[r];                                          // [Jex Jtd]^T r
+      if (dcol <= row) PX[row * (row + 1) / 2 + dcol] = D11[r];                          // ([ex td], [ex td]) lower
+    }
+  }
+  if (lane == 0) ids[I_PMASK + b] = pmask;
+  return cost;
+}
+#endif
 
 // One wavefront, one IMU factor i: J = sqrt_info * [r | J_raw] (15 x 31) and its Gram matrix on v_mfma_f64_16x16x4,
 // then S += J^T J (lower), g += J^T r; returns 0.5 r^T r on lane 0 (0 elsewhere).
@@ -794,16 +1051,16 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   build_frames(L_X, 0);
   for (int i = t; i < SPP; i += NT) lds[L_S + i] = 0.0;
   for (int i = t; i < VEC; i += NT) lds[L_G + i] = 0.0;
-  if (t < NFR) ids[I_PMASK + t] = 0;
+  if (t < NFRP) ids[I_PMASK + t] = 0;
   double* IJR = c.sc + Scratch::IJRAW;  // (zeroed once per window: imu_raw rewrites the same entries every time)
   __syncthreads();
-  Frames fr{lds + L_FR, lds + L_FR + 99};
+  Frames fr{lds + L_FR, lds + L_FR + 9 * NFRP};
   double acc = 0;
-  // ---- phase A: projection factors (waves 0..6, one frame at a time) || IMU raw Jacobians (wave 7)
+  // ---- phase A: projection factors (waves 0..ASM_WAVES-1, one frame at a time) || IMU raw Jacobians (the next wave)
   if (wv < ASM_WAVES) {
-    for (int b = 1; b < NFR; b++)
+    for (int b = 1; b < NFRP; b++)
       if (ids[I_FRW + b] == wv) acc += frame_task(c, o, b, L_S + SPP + wv * XSTG);
-  } else if (lane < 10) {
+  } else if (wv == ASM_WAVES && lane < 10) {
     const int i = lane;
     if (c.psum[i] <= o.max_sum_dt)
       imu_raw<true>(xs, fr.R, o, c.pdelta + i * 10, c.pjac + i * 225, c.psum[i], c.lba + i * 3, c.lbg + i * 3, i, IJR + i * 465);
@@ -816,10 +1073,10 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     const double* PF = c.sc + Scratch::PF;
     // sums over the feature's own factors: one thread per (quantity, feature), features along the lanes
     // (the W blocks of frames that do not observe a feature were zeroed once, at window load)
-    for (int idx = t; idx < c.nf * 8; idx += NT) {
+    for (int idx = t; idx < c.nf * NQ; idx += NT) {
       const int q = idx / c.nf, e = idx - q * c.nf;
       const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
-      const double* P = PF + (q * NFR + a) * WLE + e;  // + k * WLE : the factor observed in frame a + k
+      const double* P = PF + (q * NFRP + a) * WLE + e;  // + k * WLE : the factor observed in frame a + k
       // all (<= 10) loads in flight, clamped to the feature's last observation and masked; same pairing of the
       // partial sums as a sequential two-accumulator loop
       double pv[NFR - 1];
@@ -831,6 +1088,18 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
         const double v = k < no ? pv[k - 1] : 0.0;
         if (k & 1) s0a += v; else s1a += v;
       }
+#ifdef AVM_X
+      // + the feature's relocalization factor (frame 11; its slots were zeroed at window load for unmatched features)
+      const double sacc = (s0a + s1a) + (c.relo_n > 0 ? PF[(q * NFRP + (NFRP - 1)) * WLE + e] : 0.0);
+      if (q < 6)
+        W[(6 * a + q) * WLE + e] = sacc;
+      else if (q == 6)
+        lds[L_HEE + e] = sacc;
+      else if (q == 7)
+        lds[L_G + NF + e] = sacc;
+      else
+        W[(XC_EX + (q - 8)) * WLE + e] = sacc;  // E^T F of the ex_pose (6) and td (1) columns
+#else
       const double sacc = s0a + s1a;
       if (q < 6)
         W[(6 * a + q) * WLE + e] = sacc;
@@ -838,8 +1107,52 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
         lds[L_HEE + e] = sacc;
       else
         lds[L_G + NF + e] = sacc;
+#endif
     }
     const double* PART = c.sc + Scratch::PART;
+#ifdef AVM_X
+    __syncthreads();  // (the sums below add to blocks other frames' tasks have written: all of phase A is behind the barrier above)
+    for (int tt = t; tt < NFR * SPARTW + PARTX; tt += NT) {
+      if (tt < NFR * SPARTW) {
+        const int f = tt / SPARTW, q = tt % SPARTW;
+        double sacc = 0;
+        double pp[NFRP - 1];
+#pragma unroll
+        for (int b = 1; b < NFRP; b++) pp[b - 1] = PART[((size_t)b * NFR + f) * SPARTW + q];
+#pragma unroll
+        for (int b = 1; b < NFRP; b++)
+          if (b > f && (ids[I_PMASK + b] & (1 << f))) sacc += pp[b - 1];
+        if (q < 21) {
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= q) i++;
+          const int j = q - i * (i + 1) / 2;
+          lds[L_S + roff(6 * f + i) + 6 * f + j] += sacc;
+        } else if (q < 27) {
+          lds[L_G + 6 * f + (q - 21)] += sacc;
+        } else {
+          lds[L_S + roff(XC_EX + (q - 27) / 6) + 6 * f + (q - 27) % 6] += sacc;  // ([ex td], start pose f)
+        }
+      } else {
+        const int q = tt - NFR * SPARTW;
+        double sacc = 0;
+        for (int b = 1; b < NFRP; b++) sacc += PART[PARTX0 + (size_t)b * PARTX + q];  // (a frame without factors wrote zeros)
+        if (q < 28) {
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= q) i++;
+          lds[L_S + roff(XC_EX + i) + XC_EX + (q - i * (i + 1) / 2)] = sacc;
+        } else {
+          lds[L_G + XC_EX + (q - 28)] = sacc;
+        }
+      }
+    }
+    __syncthreads();
+    // members that are switched off: unit diagonal, nothing else (their rows / columns stay zero), so their step is exactly 0
+    if (t < 13) {
+      const int col = NFR * 6 + t;  // relo 66..71 | ex 72..77 | td 78
+      const bool on = t < 6 ? c.relo_n > 0 : (t < 12 ? c.est_ex != 0 : c.est_td != 0);
+      if (!on) lds[L_S + roff(col) + col] = 1.0;
+    }
+#else
     if (t < NFR * 27) {
       const int f = t / 27, q = t % 27;
       double sacc = 0;
@@ -858,6 +1171,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
         lds[L_G + 6 * f + (q - 21)] += sacc;
       }
     }
+#endif
   }
   PROF(c, 1);
   // prior residual (uses L_DXP/L_RP; includes syncs)
@@ -941,16 +1255,53 @@ AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
   const double* u = lds + L_ST;
   const double* scl = lds + L_SC;
   const double* xs = lds + L_X;
-  Frames fr{lds + L_FR, lds + L_FR + 99};
+  Frames fr{lds + L_FR, lds + L_FR + 9 * NFRP};
+  const double* ric = ric_of(0);
   const double sqi = o.focal_length / 1.5;
   double acc = 0;
+#ifdef AVM_X
+  // regular factors, then the relocalization factors (slot index >= nobs_tot: match k against frame 11)
+  for (int s = t; s < c.nobs_tot + c.relo_n; s += NT) {
+    const bool relo = s >= c.nobs_tot;
+    const int e = relo ? c.cov[(NFRP - 1) * MAXE + (s - c.nobs_tot)] : c.osf[s];
+    const int s0 = ids[I_FOBS + e];
+    if (!relo && s == s0) continue;
+    const int fa = ids[I_FSTART + e], fb = relo ? NFRP - 1 : fa + (s - s0);
+    double ob[4] = {c.obs[2 * s0], c.obs[2 * s0 + 1], 0, 0}, ai[4] = {0, 0, 0, 0}, aj[4] = {0, 0, 0, 0};
+    if (relo)
+      ob[2] = c.relo_xy[2 * (s - c.nobs_tot)], ob[3] = c.relo_xy[2 * (s - c.nobs_tot) + 1];
+    else
+      ob[2] = c.obs[2 * s], ob[3] = c.obs[2 * s + 1];
+    const bool use_td = c.est_td && !relo;
+    if (use_td) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) ai[k] = c.aux[4 * s0 + k], aj[k] = c.aux[4 * s + k];
+      td_shift(ob, ai, aj, xs[XTD], o.tr, o.row);
+    }
+    double r[2], Ji[12], Jj[12], Je[2], Jx[12], Jt[2];
+    proj_eval<true>(xs, fr, ric, ric + 9, ob[0], ob[1], ob[2], ob[3], xs[XLAM + e], fa, fb, sqi, o.cauchy_a, true, r, Ji, Jj, Je, Jx, Jt,
+                    ai[0], ai[1], aj[0], aj[1]);
+    double y0 = 0, y1 = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double va = u[fa * 6 + k] * scl[fa * 6 + k], vb = u[fb * 6 + k] * scl[fb * 6 + k];
+      const double vx = c.est_ex ? u[XC_EX + k] * scl[XC_EX + k] : 0.0;
+      y0 += Ji[k] * va + Jj[k] * vb + Jx[k] * vx;
+      y1 += Ji[6 + k] * va + Jj[6 + k] * vb + Jx[6 + k] * vx;
+    }
+    const double ve = u[NF + e] * scl[NF + e], vt = use_td ? u[XC_TD] * scl[XC_TD] : 0.0;
+    y0 += Je[0] * ve + Jt[0] * vt;
+    y1 += Je[1] * ve + Jt[1] * vt;
+    acc += y0 * y0 + y1 * y1;
+  }
+#else
   for (int s = t; s < c.nobs_tot; s += NT) {
     const int e = c.osf[s];
     const int s0 = ids[I_FOBS + e];
     if (s == s0) continue;
     const int fa = ids[I_FSTART + e], fb = fa + (s - s0);
     double r[2], Ji[12], Jj[12], Je[2];
-    proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1], xs[XLAM + e],
+    proj_eval<true>(xs, fr, ric, ric + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1], xs[XLAM + e],
                     fa, fb, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
     double y0 = 0, y1 = 0;
 #pragma unroll
@@ -964,6 +1315,7 @@ AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
     y1 += Je[1] * ve;
     acc += y0 * y0 + y1 * y1;
   }
+#endif
   if (t < 150) {  // IMU: y = sqrt_info * (raw_J * v), raw Jacobians of the last eval_jac are still in the scratch slot
     const int i = t / 15, r = t % 15;
     if (c.psum[i] <= o.max_sum_dt) {
@@ -1162,7 +1514,7 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
       const double isq = fast_rsqrt(dc);  // applied to the product's columns below: its latency hides under the loads and MFMAs
 #pragma unroll
       for (int m = 0; m < NB / 4; m++) bop[m] = (lk + 4 * m < nb && lr < nb) ? bop[m] : 0.0;
-      for (int ti = (c1 >> 4) + wv; ti <= 10; ti += NT / 64) {
+      for (int ti = (c1 >> 4) + wv; ti <= TLAST; ti += NT / 64) {
         const int row = 16 * ti + lr;
         const double* pa = S + roff(min(row, NR - 1)) + c0 + lk;
         const bool va = row < NR && row >= c1;
@@ -1201,9 +1553,9 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
         const long long q0 = clock64();
         // items: tiles (tm + 1 .. 10, tm), then the early part of the NEXT diagonal tile (tm + 1, tm + 1): all panels solved
         // so far, so that wavefront 0 only has to add one panel to it before it factors the block
-        const int nitem = (10 - tm) + (tm + 1 <= 10 ? 1 : 0);
+        const int nitem = (TLAST - tm) + (tm + 1 <= TLAST ? 1 : 0);
         for (int k = wv - 1; k < nitem; k += NT / 64 - 1) {
-          if (k < 10 - tm)
+          if (k < TLAST - tm)
             chol_left_tile(tm + 1 + k, tm, 0, tm);
           else
             chol_left_tile(tm + 1, tm + 1, 0, tm);
@@ -1422,8 +1774,9 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
   gcdouble* W = c.sc + Scratch::W;
   const double* scl = lds + L_SC;
   double* ys = lds + L_WCH;  // s_c y_c
+  constexpr int NQ4 = (NPOSE + 3) / 4;  // W rows dealt to the 4 lanes of a feature, a quarter each: 17 (20)
   if (t < NPOSE) ys[t] = scl[t] * lds[L_Y + t];
-  if (t >= NPOSE && t < NPOSE + 6) ys[t] = 0.0;
+  if (t >= NPOSE && t < 4 * NQ4 + 4) ys[t] = 0.0;
   __syncthreads();
   const int part = t & 3;
 #pragma unroll
@@ -1432,11 +1785,11 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
     double sacc = 0;
     if (e < c.nf) {
       gcdouble* We = W + e;  // Wt[c][e]
-      double v[17];
+      double v[NQ4];
 #pragma unroll
-      for (int j = 0; j < 17; j++) v[j] = (part + 4 * j < NPOSE) ? We[(size_t)(part + 4 * j) * WLE] : 0.0;
+      for (int j = 0; j < NQ4; j++) v[j] = (part + 4 * j < NPOSE) ? We[(size_t)(part + 4 * j) * WLE] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 17; j++) sacc += v[j] * ys[part + 4 * j];
+      for (int j = 0; j < NQ4; j++) sacc += v[j] * ys[part + 4 * j];
     }
     sacc += __shfl_xor(sacc, 1, 64);
     sacc += __shfl_xor(sacc, 2, 64);
@@ -1492,11 +1845,33 @@ AVM_DEV void state_plus() {
     const int e = t - 192;
     xc[XLAM + e] = x[XLAM + e] + st[NF + e] * scl[NF + e];
   }
+#ifdef AVM_X
+  // relo_Pose (frame 11) / ex_pose: PoseLocalParameterization::Plus when they are variables, else carried over untouched
+  const WinCtx& c = lds_ctx();
+  if (t >= 384 && t < 386) {
+    const bool ex = t == 385;
+    const int xo = ex ? XEX : 7 * NFR, o = ex ? XC_EX : 6 * NFR;
+    if (ex ? c.est_ex != 0 : c.relo_n > 0) {
+      for (int k = 0; k < 3; k++) xc[xo + k] = x[xo + k] + st[o + k] * scl[o + k];
+      quat q{x[xo + 6], x[xo + 3], x[xo + 4], x[xo + 5]};
+      quat r = qnormalized(qmul(q, deltaQ(mk3(st[o + 3] * scl[o + 3], st[o + 4] * scl[o + 4], st[o + 5] * scl[o + 5]))));
+      xc[xo + 3] = r.x, xc[xo + 4] = r.y, xc[xo + 5] = r.z, xc[xo + 6] = r.w;
+    } else {
+      for (int k = 0; k < 7; k++) xc[xo + k] = x[xo + k];
+    }
+  }
+  if (t == 386) xc[XTD] = c.est_td ? x[XTD] + st[XC_TD] * scl[XC_TD] : x[XTD];
+#endif
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
+#ifdef AVM_X
+#define AVM_SOLVE_KERNEL window_solve_x_kernel
+#else
+#define AVM_SOLVE_KERNEL window_solve_kernel
+#endif
+__global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
   lds_base_check();
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
@@ -1527,6 +1902,13 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       if (cl.nf > 0) tot = B.feat_obs_begin[(size_t)w * B.max_feat + cl.nf - 1] + B.feat_nobs[(size_t)w * B.max_feat + cl.nf - 1];
       cl.nobs_tot = tot;
     }
+#ifdef AVM_X
+    cl.est_ex = A.opt.estimate_extrinsic != 0, cl.est_td = A.opt.estimate_td != 0;
+    cl.aux = (cl.est_td && B.obs_vel_td) ? as_global(B.obs_vel_td + (size_t)w * B.max_obs * 4) : nullptr;
+    if (!cl.aux) cl.est_td = 0;  // (the host refuses estimate_td without the per-observation data)
+    cl.relo_n = (B.relo_n && B.relo_feat && B.relo_xy && B.relo_pose) ? min(max(B.relo_n[w], 0), cl.nf) : 0;
+    cl.relo_xy = cl.relo_n > 0 ? as_global(B.relo_xy + (size_t)w * B.max_feat * 2) : nullptr;
+#endif
     __syncthreads();  // the previous window's readers of the LDS context are done
     lds_store_ctx(cl, A.opt);
     const WinCtx& c = lds_ctx();
@@ -1536,13 +1918,25 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
     for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
     for (int i = t; i < MAXE; i += NT) lds[L_X + XLAM + i] = i < c.nf ? B.inv_depth[(size_t)w * B.max_feat + i] : 1.0;
+#ifdef AVM_X
+    for (int i = t; i < VEC; i += NT) lds[L_SC + i] = 1.0, lds[L_ST + i] = 0.0, lds[L_Y + i] = 0.0, lds[L_DD + i] = 1.0;
+    if (t < 7) {
+      lds[L_X + XEX + t] = B.ex_pose[(size_t)w * 7 + t];
+      // relo_Pose is frame 11 of the state; without a relocalization frame it mirrors pose 0 (never read by a factor)
+      lds[L_X + 7 * NFR + t] = c.relo_n > 0 ? B.relo_pose[(size_t)w * 7 + t] : B.pose[(size_t)w * 77 + t];
+    }
+    if (t == 7) lds[L_X + XTD] = (c.est_td && B.td) ? B.td[w] : 0.0;
+    if (t == 8) lds[L_X + XTD + 1] = 0.0;
+#else
     for (int i = t; i < VEC; i += NT) lds[L_SC + i] = 1.0, lds[L_ST + i] = 0.0, lds[L_Y + i] = 0.0, lds[L_DG + i] = 0.0, lds[L_DD + i] = 1.0;
+#endif
     for (int i = t; i < MAXPRIOR; i += NT) lds[L_DXP + i] = 0.0, lds[L_RP + i] = 0.0;
     if (t < c.nf) {
       ids[I_FSTART + t] = B.feat_start[(size_t)w * B.max_feat + t];
       ids[I_FNOBS + t] = B.feat_nobs[(size_t)w * B.max_feat + t];
       ids[I_FOBS + t] = B.feat_obs_begin[(size_t)w * B.max_feat + t];
     }
+#ifndef AVM_X
     if (t == 0) {
       const double* ex = B.ex_pose + (size_t)w * 7;
       double R[9];
@@ -1550,8 +1944,12 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       for (int k = 0; k < 9; k++) lds[L_RIC + k] = R[k];
       for (int k = 0; k < 3; k++) lds[L_RIC + 9 + k] = ex[k];
     }
+#endif
     __syncthreads();
+#ifndef AVM_X
     if (t < 7) lds[L_RIC + 12 + t] = B.ex_pose[(size_t)w * 7 + t];  // current ex_pose for the prior's dx
+    if (t == 7) lds[L_RIC + 19] = B.td ? B.td[w] : 0.0;             // ... and para_Td (a constant here)
+#endif
     if (t < c.nf) {
       const int s0 = ids[I_FOBS + t], no = ids[I_FNOBS + t];
       for (int k = 0; k < no; k++) c.osf[s0 + k] = t;
@@ -1566,8 +1964,15 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       for (int k = 0; k < c.pnblk; k++) {
         const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
         ids[I_PBLK + k * 3] = kind, ids[I_PBLK + k * 3 + 1] = fr, ids[I_PBLK + k * 3 + 2] = off;
-        const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
+        const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
+#ifdef AVM_X
+        for (int q = 0; q < n; q++)
+          ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q
+                                  : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q
+                                     : (kind == AVM_BLK_TD ? (c.est_td ? XC_TD : -1) : (c.est_ex ? XC_EX + q : -1)));
+#else
         for (int q = 0; q < n; q++) ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q : -1);
+#endif
         off += n;
       }
     }
@@ -1580,15 +1985,20 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       ids[I_NCOV + t] = n;
     }
     if (t == 0) ids[I_NCOV] = 0;
+#ifdef AVM_X
+    // frame 11: the features matched in the relocalization frame (the host's list, in its order)
+    for (int k = t; k < c.relo_n; k += NT) c.cov[(NFRP - 1) * MAXE + k] = min(max(B.relo_feat[(size_t)w * B.max_feat + k], 0), max(c.nf - 1, 0));
+    if (t == 64) ids[I_NCOV + NFRP - 1] = c.relo_n;
+#endif
     __syncthreads();
-    if (t == 0) {  // longest-processing-time assignment of the 10 frames to the assembling wavefronts
+    if (t == 0) {  // longest-processing-time assignment of the frames to the assembling wavefronts
       int load[ASM_WAVES];
       for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
       int done = 0;
       ids[I_FRW] = -1;
-      for (int k = 1; k < NFR; k++) {
+      for (int k = 1; k < NFRP; k++) {
         int bb = -1, bn = -1;
-        for (int f = 1; f < NFR; f++)
+        for (int f = 1; f < NFRP; f++)
           if (!(done & (1 << f)) && ids[I_NCOV + f] > bn) bn = ids[I_NCOV + f], bb = f;
         int bw = 0;
         for (int q = 1; q < ASM_WAVES; q++)
@@ -1613,6 +2023,13 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
           for (int q = 0; q < 6; q++) Wt[(6 * f + q) * WLE + e] = 0.0;
         }
       }
+#ifdef AVM_X
+      // relocalization frame: E^T F rows 66..71 and the per-factor products of frame 11 are zero except for the matched
+      // features, whose entries frame task 11 rewrites at every evaluation
+      gdouble* PF = c.sc + Scratch::PF;
+      for (int idx = t; idx < MAXE * 6; idx += NT) Wt[(6 * NFR + idx / MAXE) * WLE + idx % MAXE] = 0.0;
+      for (int idx = t; idx < MAXE * NQ; idx += NT) PF[((idx / MAXE) * NFRP + (NFRP - 1)) * WLE + idx % MAXE] = 0.0;
+#endif
     }
     // Hp = J0^T J0 (constant during the solve: hoisted out of the per-iteration J^T J)
     if (c.pn > 0) prior_jtj_packed(c.pJ, c.ldp, c.pn, c.sc + Scratch::HP, reinterpret_cast<gint*>(c.sc + Scratch::HP + HPK_MAX));
@@ -1626,6 +2043,11 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     double radius = o.initial_trust_region_radius, mu = 1e-8;
     const double min_mu = 1e-8, max_mu = 1.0, mu_inc = 10.0;
     bool reuse = false, first = true, have_alpha = false;
+#ifdef AVM_X
+    auto DG = [&](int i) { return lds[L_G + i] / lds[L_DD + i]; };  // g / D, recomputed (the same division every time)
+#else
+    auto DG = [&](int i) { return lds[L_DG + i]; };
+#endif
     double alpha = 0, dogleg_step_norm = 0;
     double gnorm = 0, gn_norm = 0, ytg = 0, jusq = 0;  // |g/D|, |D y|, y^T g, |J u|^2
     double k1 = 0, k2 = 0;                             // step = -(k1 * g/D^2 + k2 * y)
@@ -1633,11 +2055,29 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     int iteration = 0, num_invalid = 0, termination = AVM_TERM_NO_CONVERGENCE;
     bool step_ok = true;
 
+    // squared ambient norm over the variable parameter blocks (Ceres' reduced program: constant blocks are not in it)
+#ifdef AVM_X
+    auto amb_sq = [&](const double* xa, const double* xb) {  // |xa - xb|^2, xb == nullptr: |xa|^2
+      double s = 0;
+      auto term = [&](int i) {
+        const double d = xb ? xa[i] - xb[i] : xa[i];
+        s += d * d;
+      };
+      for (int i = t; i < 7 * NFR; i += NT) term(i);                                 // poses
+      if (c.relo_n > 0 && t >= 128 && t < 135) term(7 * NFR + t - 128);             // relo_Pose
+      for (int i = t; i < 99 + c.nf; i += NT) term(XSB + i);                          // speed-biases, inverse depths
+      if (c.est_ex && t >= 192 && t < 199) term(XEX + t - 192);
+      if (c.est_td && t == 200) term(XTD);
+      return block_sum<NT>(s, lds + L_RED);
+    };
+    auto amb_norm = [&](const double* xs) { return sqrt(amb_sq(xs, nullptr)); };
+#else
     auto amb_norm = [&](const double* xs) {
       double s = 0;
       for (int i = t; i < 176 + c.nf; i += NT) s += xs[i] * xs[i];
       return sqrt(block_sum<NT>(s, lds + L_RED));
     };
+#endif
     // evaluate + scaling + gradient max norm at lds[L_X]
     // what follows a Jacobian evaluation at lds[L_X]: scaling, gradient max norm
     auto post_evaluate = [&]() {
@@ -1663,6 +2103,16 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
         }
         if (t >= 64 && t < 64 + 99) gm = fmax(gm, fabs(g[SB0 + t - 64]));
         if (t >= 192 && t < 192 + c.nf) gm = fmax(gm, fabs(g[NF + t - 192]));
+#ifdef AVM_X
+        if ((t == 400 && c.relo_n > 0) || (t == 401 && c.est_ex)) {  // relo_Pose / ex_pose: pose blocks like the others
+          const int xo = t == 401 ? XEX : 7 * NFR, go = t == 401 ? XC_EX : 6 * NFR;
+          for (int k = 0; k < 3; k++) gm = fmax(gm, fabs(g[go + k]));
+          quat q{x[xo + 6], x[xo + 3], x[xo + 4], x[xo + 5]};
+          quat r = qnormalized(qmul(q, deltaQ(mk3(-g[go + 3], -g[go + 4], -g[go + 5]))));
+          gm = fmax(gm, fmax(fmax(fabs(q.x - r.x), fabs(q.y - r.y)), fmax(fabs(q.z - r.z), fabs(q.w - r.w))));
+        }
+        if (t == 402 && c.est_td) gm = fmax(gm, fabs(g[XC_TD]));
+#endif
       }
       gradient_max_norm = block_max<NT>(gm, lds + L_RED);
       __syncthreads();
@@ -1743,7 +2193,9 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
         double g2 = 0;
         for (int i = t; i < NF + c.nf; i += NT) {
           const double v = lds[L_G + i] / lds[L_DD + i];
+#ifndef AVM_X
           lds[L_DG + i] = v;
+#endif
           g2 += v * v;
         }
         gnorm = sqrt(block_sum<NT>(g2, lds + L_RED));
@@ -1797,7 +2249,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
           dogleg_step_norm = gn_norm;
         } else {
           if (!have_alpha) {  // Cauchy point, needed only when the GN step leaves the trust region
-            for (int i = t; i < VEC; i += NT) lds[L_ST + i] = i < NF + c.nf ? lds[L_DG + i] / lds[L_DD + i] : 0.0;
+            for (int i = t; i < VEC; i += NT) lds[L_ST + i] = i < NF + c.nf ? DG(i) / lds[L_DD + i] : 0.0;
             __syncthreads();
             jusq = jac_times_vec_sq(c, o);
             alpha = gnorm * gnorm / jusq;
@@ -1818,14 +2270,14 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
             k1 = alpha * (1.0 - beta), k2 = beta;
             double s2 = 0;
             for (int i = t; i < NF + c.nf; i += NT) {
-              const double v = -k1 * lds[L_DG + i] - k2 * lds[L_DD + i] * lds[L_Y + i];
+              const double v = -k1 * DG(i) - k2 * lds[L_DD + i] * lds[L_Y + i];
               s2 += v * v;
             }
             dogleg_step_norm = sqrt(block_sum<NT>(s2, lds + L_RED));
           }
         }
         for (int i = t; i < VEC; i += NT)
-          lds[L_ST + i] = i < NF + c.nf ? -(k1 * lds[L_DG + i] / lds[L_DD + i] + k2 * lds[L_Y + i]) : 0.0;
+          lds[L_ST + i] = i < NF + c.nf ? -(k1 * DG(i) / lds[L_DD + i] + k2 * lds[L_Y + i]) : 0.0;
         // model_cost_change = -step^T g - 1/2 step^T H step, with H y = g - mu D^2 y
         {
           const double utg = gnorm * gnorm;                     // u^T g, u = g/D^2
@@ -1853,12 +2305,16 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
       PROF_T0();
       state_plus();
       __syncthreads();
+#ifdef AVM_X
+      const double step_norm = sqrt(amb_sq(lds + L_X, lds + L_XC));
+#else
       double d2 = 0;
       for (int i = t; i < 176 + c.nf; i += NT) {
         const double d = lds[L_X + i] - lds[L_XC + i];
         d2 += d * d;
       }
       const double step_norm = sqrt(block_sum<NT>(d2, lds + L_RED));
+#endif
       const bool spec = speculate;
       double cand_cost;
       if (spec) {
@@ -1918,7 +2374,12 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
     __syncthreads();
     // ---------------- double2vector + vector2double (estimator.cpp:521-587, 477-519) ----------------
     {
-      // rot_diff from yaw of frame 0 before / after ; stored in lds[L_DG..+9], origin_P0 in +9..12
+      // rot_diff from yaw of frame 0 before / after ; stored in lds[L_GF..+9], origin_P0 in +9..12
+#ifdef AVM_X
+      constexpr int L_GF = L_Y;  // (the Gauss-Newton step is dead after the loop)
+#else
+      constexpr int L_GF = L_DG;
+#endif
       if (t == 0) {
         const double* p0 = B.pose + (size_t)w * 77;
         double Rs0[9], R00[9];
@@ -1930,8 +2391,17 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
           const double r = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
           out[0] = y / M_PI * 180.0, out[1] = p / M_PI * 180.0, out[2] = r / M_PI * 180.0;
         };
-        double a0[3], a1[3];
+        double a0[3], a1[3], P0[3] = {p0[0], p0[1], p0[2]};
         ypr(Rs0, a0);
+        if (B.failure_occur && B.last_pose0 && B.failure_occur[w]) {
+          // failure_occur (estimator.cpp:526-531): the yaw / position anchor is last_R0 / last_P0; Rs[0] itself (the
+          // pitch-singular branch below) stays what it was
+          const double* lp = B.last_pose0 + (size_t)w * 7;
+          double Rl[9];
+          q2R(quat{lp[6], lp[3], lp[4], lp[5]}, Rl);
+          ypr(Rl, a0);
+          P0[0] = lp[0], P0[1] = lp[1], P0[2] = lp[2];
+        }
         ypr(R00, a1);
         const double yd = (a0[0] - a1[0]) / 180.0 * M_PI;
         double rd[9] = {cos(yd), -sin(yd), 0, sin(yd), cos(yd), 0, 0, 0, 1};
@@ -1939,34 +2409,51 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
           for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) rd[a * 3 + b] = Rs0[a * 3] * R00[b * 3] + Rs0[a * 3 + 1] * R00[b * 3 + 1] + Rs0[a * 3 + 2] * R00[b * 3 + 2];
         }
-        for (int k = 0; k < 9; k++) lds[L_DG + k] = rd[k];
-        for (int k = 0; k < 3; k++) lds[L_DG + 9 + k] = p0[k], lds[L_DG + 12 + k] = lds[L_X + k];
+        for (int k = 0; k < 9; k++) lds[L_GF + k] = rd[k];
+        for (int k = 0; k < 3; k++) lds[L_GF + 9 + k] = P0[k], lds[L_GF + 12 + k] = lds[L_X + k];
       }
       __syncthreads();
-      if (t < NFR) {
-        const double* rd = lds + L_DG;
+      if (t < NFRP) {
+        const double* rd = lds + L_GF;
         const double* x = lds + L_X;
         quat q = qnormalized(quat{x[t * 7 + 6], x[t * 7 + 3], x[t * 7 + 4], x[t * 7 + 5]});
         double Rq[9], Rs[9];
         q2R(q, Rq);
         mat3mul(rd, Rq, Rs);
-        const v3 P = Rmul(rd, mk3(x[t * 7] - lds[L_DG + 12], x[t * 7 + 1] - lds[L_DG + 13], x[t * 7 + 2] - lds[L_DG + 14])) +
-                     mk3(lds[L_DG + 9], lds[L_DG + 10], lds[L_DG + 11]);
-        const v3 V = Rmul(rd, mk3(x[XSB + t * 9], x[XSB + t * 9 + 1], x[XSB + t * 9 + 2]));
+        const v3 P = Rmul(rd, mk3(x[t * 7] - lds[L_GF + 12], x[t * 7 + 1] - lds[L_GF + 13], x[t * 7 + 2] - lds[L_GF + 14])) +
+                     mk3(lds[L_GF + 9], lds[L_GF + 10], lds[L_GF + 11]);
         const quat qo = R2q(Rs);
-        double* po = B.pose + (size_t)w * 77 + t * 7;
-        po[0] = P.x, po[1] = P.y, po[2] = P.z, po[3] = qo.x, po[4] = qo.y, po[5] = qo.z, po[6] = qo.w;
-        double* so = B.speedbias + (size_t)w * 99 + t * 9;
-        so[0] = V.x, so[1] = V.y, so[2] = V.z;
-        for (int k = 3; k < 9; k++) so[k] = x[XSB + t * 9 + k];
+        if (t < NFR) {
+          const v3 V = Rmul(rd, mk3(x[XSB + t * 9], x[XSB + t * 9 + 1], x[XSB + t * 9 + 2]));
+          double* po = B.pose + (size_t)w * 77 + t * 7;
+          po[0] = P.x, po[1] = P.y, po[2] = P.z, po[3] = qo.x, po[4] = qo.y, po[5] = qo.z, po[6] = qo.w;
+          double* so = B.speedbias + (size_t)w * 99 + t * 9;
+          so[0] = V.x, so[1] = V.y, so[2] = V.z;
+          for (int k = 3; k < 9; k++) so[k] = x[XSB + t * 9 + k];
+        }
+#ifdef AVM_X
+        else if (c.relo_n > 0) {  // relo_t / relo_r of estimator.cpp:590-596 (frame 11 went through the same transformation)
+          double* po = B.relo_pose + (size_t)w * 7;
+          po[0] = P.x, po[1] = P.y, po[2] = P.z, po[3] = qo.x, po[4] = qo.y, po[5] = qo.z, po[6] = qo.w;
+        }
+#endif
       }
       if (t == 64) {
         double* ex = B.ex_pose + (size_t)w * 7;
         double R[9];
+#ifdef AVM_X
+        const double* exs = lds + L_X + XEX;  // tic / ric come back from para_Ex_Pose (estimator.cpp:569-579)
+        for (int k = 0; k < 3; k++) ex[k] = exs[k];
+        q2R(quat{exs[6], exs[3], exs[4], exs[5]}, R);
+#else
         q2R(quat{ex[6], ex[3], ex[4], ex[5]}, R);
+#endif
         const quat qo = R2q(R);
         ex[3] = qo.x, ex[4] = qo.y, ex[5] = qo.z, ex[6] = qo.w;
       }
+#ifdef AVM_X
+      if (t == 65 && c.est_td && B.td) B.td[w] = lds[L_X + XTD];
+#endif
       if (t >= 128 && t < 128 + c.nf) {
         const int e = t - 128;
         B.inv_depth[(size_t)w * B.max_feat + e] = 1.0 / (1.0 / lds[L_X + XLAM + e]);
@@ -1987,6 +2474,7 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
   }
 }
 
+#ifndef AVM_X
 // =====================================================================================
 // Post-solve marginalization: MarginalizationInfo::addResidualBlockInfo / preMarginalize /
 // marginalize / getParameterBlocks (vins_estimator/src/factor/marginalization_factor.cpp:89-319)
@@ -2003,8 +2491,8 @@ __global__ __launch_bounds__(NT) void window_solve_kernel(SolveArgs A) {
 // Deterministic block order (the reference's is address-hash order): kept = poses by frame,
 // speed-bias by frame, ex_pose.
 namespace mg {
-constexpr int MEX0 = 165, MROWS = 14792;  // 171 variables: MROWS = roff(171)
-constexpr int MXSTG = 19 * XRS;                       // column-major staging tile: Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18, XRS rows each
+constexpr int MEX0 = 165, MTD = 171, MROWS = croff(172);  // 172 variables: poses | speed-biases | ex_pose | td
+constexpr int MXSTG = 20 * XRS;                       // column-major staging tile: Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18 | Jtd 19, XRS rows each
 constexpr int MASM = 4;                               // assembling wavefronts (staging must stay below row 165)
 constexpr int M_G = MROWS;                            // b over the 171 variables (176)
 constexpr int M_GE = M_G + 176;                       // g_e (152)
@@ -2012,11 +2500,13 @@ constexpr int M_WCH = M_GE + 152;                     // [24][80] Schur staging 
 constexpr int MWCH = 24;
 static_assert(M_WCH + MWCH * WLD <= L_G, "marg layout");
 static_assert(SPP + MASM * MXSTG <= 13778, "marg staging must not reach the ex_pose rows (roff(165))");
-constexpr int PARTW = 126;  // aa 21 | g_a 6 | ex.pose0 36 | ex.ex 21 | g_ex 6 | ex.pose_b 36
+constexpr int PARTW = 146;  // aa 21 | g_a 6 | [ex td].pose0 42 | [ex td]^2 28 | g_[ex td] 7 | [ex td].pose_b 42
+constexpr int MNW = 73;     // columns of W = E^T F here: 66 pose | 6 ex_pose | 1 td
+constexpr int MWS = 80;     // row stride of W[e][.]
 }  // namespace mg
 
 // column of the joint system for W column c (0..71): poses, then ex_pose
-AVM_DEV int mg_col(int c) { return c < NPOSE ? c : mg::MEX0 + (c - NPOSE); }
+AVM_DEV int mg_col(int c) { return c < NPOSE ? c : mg::MEX0 + (c - NPOSE); }  // (td: W column 72 -> variable 171)
 
 // One wavefront's share of the elimination of the start-0 inverse depths (marginalization): the tiles (R, C),
 // R in {R0, R1}, C in {C0, C1}, C <= R, of  W^T diag(1 / E^T E) W  over the 72 (padded 80) columns of W = E^T F
@@ -2033,14 +2523,14 @@ AVM_DEV void marg_schur_macro_tile(int nf0) {
   constexpr int NR = R1 >= 0 ? 2 : 1, NC = C1 >= 0 ? 2 : 1;
   constexpr int RB[2] = {R0, R1}, CB[2] = {C0, C1};
   constexpr bool SAME = R0 == C0 && R1 == C1;
-  constexpr int KB = 8, NW = 72;
+  constexpr int KB = 8, NW = MNW;
   d4 D[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
   for (int e0 = 0; e0 < nf0; e0 += 4 * KB) {
     double vr[2][KB], vc[2][KB], fe[KB], xe[KB];
 #pragma unroll
     for (int m = 0; m < KB; m++) {
       const int e = e0 + 4 * m + lk, ec = min(e, nf0 - 1);
-      gcdouble* We = W + (size_t)ec * NW;
+      gcdouble* We = W + (size_t)ec * MWS;
 #pragma unroll
       for (int a = 0; a < NR; a++) vr[a][m] = We[min(16 * RB[a] + li, NW - 1)];
       if (!SAME) {
@@ -2102,9 +2592,10 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
   Frames fr{lds + L_FR, lds + L_FR + 99};
   const double* xs = lds + L_X;
   const double sqi = o.focal_length / 1.5;
-  double* W = c.sc + Scratch::W;       // [MAXE][72] here
-  double* PF = c.sc + Scratch::PF;     // 8 rows here + 6 more in IJRAW's tail (see MPF2)
-  double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;  // [6][MAXOBS] Jex^T Je
+  double* W = c.sc + Scratch::W;       // [MAXE][MWS] here
+  double* PF = c.sc + Scratch::PF;     // [8][MAXOBS] Ji^T Je (6), Je^T Je, Je^T r per observation slot
+  double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;  // [7][MAXOBS] Jex^T Je (6), Jtd^T Je
+  const double td = lds[L_RIC + 19];   // para_Td (0 unless estimate_td)
   double* PART = c.sc + Scratch::PART + (size_t)b * PARTW;
   d4 D00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, D11 = {0, 0, 0, 0}, E00 = {0, 0, 0, 0}, E10 = {0, 0, 0, 0}, E11 = {0, 0, 0, 0};
   const int drow = lane >> 4, dcol = lane & 15;
@@ -2114,20 +2605,28 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
     const int e = act ? cov[idx] : 0;
     const int s0 = ids[I_FOBS + e];
     const int s = s0 + b;
-    double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0}, Jx[12];
+    double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0}, Jx[12], Jt[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < 12; k++) Ji[k] = 0, Jj[k] = 0, Jx[k] = 0;
     if (act) {
-      proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1], xs[XLAM + e], 0, b,
-                      sqi, o.cauchy_a, true, r, Ji, Jj, Je, Jx);
+      double ob[4] = {c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1]}, ai[4] = {0, 0, 0, 0}, aj[4] = {0, 0, 0, 0};
+      if (c.est_td) {  // ProjectionTdFactor (estimator.cpp:874-885)
+#pragma unroll
+        for (int k = 0; k < 4; k++) ai[k] = c.aux[4 * s0 + k], aj[k] = c.aux[4 * s + k];
+        td_shift(ob, ai, aj, td, o.tr, o.row);
+      }
+      proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, ob[0], ob[1], ob[2], ob[3], xs[XLAM + e], 0, b, sqi, o.cauchy_a, true, r, Ji, Jj,
+                      Je, Jx, Jt, ai[0], ai[1], aj[0], aj[1]);
+      if (!c.est_td) Jt[0] = Jt[1] = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        W[(size_t)e * 72 + 6 * b + k] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
+        W[(size_t)e * MWS + 6 * b + k] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
         PF[k * MAXOBS + s] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
         PF2[k * MAXOBS + s] = Jx[k] * Je[0] + Jx[6 + k] * Je[1];
       }
       PF[6 * MAXOBS + s] = Je[0] * Je[0] + Je[1] * Je[1];
       PF[7 * MAXOBS + s] = Je[0] * r[0] + Je[1] * r[1];
+      PF2[6 * MAXOBS + s] = Jt[0] * Je[0] + Jt[1] * Je[1];
     }
     // staged column-major like the solve kernel's frame tasks (Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18): one 16-byte store
     // per column, contiguous across the lanes; inactive lanes stage zeros, so no row needs masking
@@ -2140,6 +2639,7 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
         st[(13 + k) * (XRS / 2)] = dv2{Jx[k], Jx[6 + k]};
       }
       st[12 * (XRS / 2)] = dv2{r[0], r[1]};
+      st[19 * (XRS / 2)] = dv2{Jt[0], Jt[1]};
     }
     wave_lds_sync();
     const int nact = min(64, ncov - chunk0);
@@ -2153,13 +2653,13 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
       for (int u = 0; u < 4; u++) {
         const int ro = 8 * min(j0 + u, 15) + 2 * drow;
         u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS + ro);
-        u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 5)) * XRS + ro);
+        u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * XRS + ro);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const bool on = j0 + u < j_end;
         const double a0 = (on && dcol < 13) ? u0[u][0] : 0.0, a1 = (on && dcol < 13) ? u0[u][1] : 0.0;
-        const double x0 = (on && dcol < 6) ? u1[u][0] : 0.0, x1 = (on && dcol < 6) ? u1[u][1] : 0.0;
+        const double x0 = (on && dcol < 7) ? u1[u][0] : 0.0, x1 = (on && dcol < 7) ? u1[u][1] : 0.0;
         D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
         D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
         D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
@@ -2183,12 +2683,12 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
       if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[i * (i + 1) / 2 + (dcol - 6)] = D00[r];         // (0,0)
       if (dcol == 12) PART[21 + i] = D00[r];                                                            // g_0
     }
-    // D10: rows = Jex, cols = [Jj | Ji | r]
-    if (row < 6) {
-      if (dcol < 6) PART[90 + row * 6 + dcol] = D10[r];                       // (ex, pose b)
-      if (dcol >= 6 && dcol < 12) PART[27 + row * 6 + (dcol - 6)] = D10[r];   // (ex, pose 0)
-      if (dcol == 12) PART[84 + row] = D10[r];                                // g_ex
-      if (dcol <= row) PART[63 + row * (row + 1) / 2 + dcol] = D11[r];        // (ex, ex)
+    // D10: rows = [Jex | Jtd] (7), cols = [Jj | Ji | r]
+    if (row < 7) {
+      if (dcol < 6) PART[104 + row * 6 + dcol] = D10[r];                      // ([ex td], pose b)
+      if (dcol >= 6 && dcol < 12) PART[27 + row * 6 + (dcol - 6)] = D10[r];   // ([ex td], pose 0)
+      if (dcol == 12) PART[97 + row] = D10[r];                                // g_[ex td]
+      if (dcol <= row) PART[69 + row * (row + 1) / 2 + dcol] = D11[r];        // ([ex td], [ex td])
     }
   }
 }
@@ -2424,6 +2924,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     cl.pr = as_global(B.prior_r + (size_t)w * B.max_prior);
     cl.px0 = as_global(B.prior_x0 + (size_t)w * B.max_pblk * 9);
     cl.nobs_tot = 0;
+    cl.est_ex = 0, cl.est_td = (A.opt.estimate_td != 0 && B.obs_vel_td && B.td) ? 1 : 0;
+    cl.aux = cl.est_td ? as_global(B.obs_vel_td + (size_t)w * B.max_obs * 4) : nullptr;
+    cl.relo_n = 0, cl.relo_xy = nullptr;  // (the relocalization factors take no part in the marginalization)
     __syncthreads();  // the previous window's readers of the LDS context are done
     lds_store_ctx(cl, A.opt);
     const WinCtx& c = lds_ctx();
@@ -2442,6 +2945,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       ids[I_FOBS + t] = B.feat_obs_begin[(size_t)w * B.max_feat + t];
     }
     if (t < 7) lds[L_RIC + 12 + t] = B.ex_pose[(size_t)w * 7 + t];
+    if (t == 7) lds[L_RIC + 19] = c.est_td ? B.td[w] : 0.0;  // para_Td
     if (t == 0) {
       const double* ex = B.ex_pose + (size_t)w * 7;
       double R[9];
@@ -2452,8 +2956,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       for (int k = 0; k < c.pnblk; k++) {
         const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
         ids[I_PBLK + k * 3] = kind, ids[I_PBLK + k * 3 + 1] = fr, ids[I_PBLK + k * 3 + 2] = off;
-        const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : 6;
-        for (int q = 0; q < n; q++) ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q : MEX0 + q);
+        const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
+        for (int q = 0; q < n; q++)
+          ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q : (kind == AVM_BLK_TD ? MTD : MEX0 + q));
         off += n;
       }
     }
@@ -2505,18 +3010,20 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         if (f == 0 || f == 11) {
           const double* P = f == 0 ? PF : PF2;
           // all loads of the feature's (<= 10) factors in flight at once, clamped to its last observation and masked
-          double pv[6][NFR - 1];
+          // (f == 11: the six ex_pose columns and the td column, W columns 66..72)
+          double pv[7][NFR - 1];
 #pragma unroll
           for (int k = 1; k < NFR; k++)
 #pragma unroll
-            for (int q = 0; q < 6; q++) pv[q][k - 1] = P[q * MAXOBS + s0 + min(k, max(no - 1, 0))];
-          double sacc[6] = {0, 0, 0, 0, 0, 0};
+            for (int q = 0; q < 7; q++) pv[q][k - 1] = P[min(q, f == 0 ? 5 : 6) * MAXOBS + s0 + min(k, max(no - 1, 0))];
+          double sacc[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int k = 1; k < NFR; k++)
 #pragma unroll
-            for (int q = 0; q < 6; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
+            for (int q = 0; q < 7; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
 #pragma unroll
-          for (int q = 0; q < 6; q++) W[(size_t)e * 72 + 6 * f + q] = sacc[q];
+          for (int q = 0; q < 6; q++) W[(size_t)e * MWS + 6 * f + q] = sacc[q];
+          if (f == 11) W[(size_t)e * MWS + 72] = sacc[6];
           if (f == 0) {
             double hv[2][NFR - 1];
 #pragma unroll
@@ -2532,7 +3039,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
           }
         } else if (f >= no) {
 #pragma unroll
-          for (int q = 0; q < 6; q++) W[(size_t)e * 72 + 6 * f + q] = 0.0;
+          for (int q = 0; q < 6; q++) W[(size_t)e * MWS + 6 * f + q] = 0.0;
         }
       }
     }
@@ -2541,8 +3048,8 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     __syncthreads();
     if (flag == AVM_MARGIN_OLD && t < PARTW) {
       const double* PART = c.sc + Scratch::PART;
-      const int q = t;
-      if (q < 90) {
+      const int q = t;  // (rows MEX0 .. MEX0 + 6 = the six ex_pose variables and td)
+      if (q < 104) {
         double sacc = 0;
         for (int b = 1; b < NFR; b++)
           if (ids[I_NCOV + b] > 0) sacc += PART[(size_t)b * PARTW + q];
@@ -2552,18 +3059,18 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
           lds[L_S + roff(i) + (q - i * (i + 1) / 2)] = sacc;
         } else if (q < 27) {
           lds[M_G + (q - 21)] = sacc;
-        } else if (q < 63) {
+        } else if (q < 69) {
           lds[L_S + roff(MEX0 + (q - 27) / 6) + (q - 27) % 6] = sacc;
-        } else if (q < 84) {
-          const int k = q - 63;
+        } else if (q < 97) {
+          const int k = q - 69;
           int i = 0;
           while ((i + 1) * (i + 2) / 2 <= k) i++;
           lds[L_S + roff(MEX0 + i) + MEX0 + (k - i * (i + 1) / 2)] = sacc;
         } else {
-          lds[M_G + MEX0 + (q - 84)] = sacc;
+          lds[M_G + MEX0 + (q - 97)] = sacc;
         }
       } else {
-        const int k = q - 90;
+        const int k = q - 104;
         for (int b = 1; b < NFR; b++)
           if (ids[I_NCOV + b] > 0) lds[L_S + roff(MEX0 + k / 6) + 6 * b + k % 6] = PART[(size_t)b * PARTW + q];
       }
@@ -2641,20 +3148,20 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     // ---- phase G: dropped / kept variable lists (ints at I_FSTART.. are dead now)
     int* midx = ids + 0;       // [<=16]
     int* kidx = ids + 16;      // [<=96]
-    int* kblk = ids + 120;     // [<=16] id of kept block k : pose f -> f, speedbias f -> 11+f, ex -> 22
+    int* kblk = ids + 120;     // [<=16] id of kept block k : pose f -> f, speedbias f -> 11+f, ex -> 22, td -> 23
     int* cnts = ids + 140;     // m, n, nblk
     __syncthreads();
     if (t == 0) {
       int present = 0;  // bit id
       for (int k = 0; k < c.pnblk; k++) {
         const int kind = ids[I_PBLK + k * 3], fr = ids[I_PBLK + k * 3 + 1];
-        present |= 1 << (kind == AVM_BLK_POSE ? fr : (kind == AVM_BLK_SPEEDBIAS ? 11 + fr : 22));
+        present |= 1 << (kind == AVM_BLK_POSE ? fr : (kind == AVM_BLK_SPEEDBIAS ? 11 + fr : (kind == AVM_BLK_TD ? 23 : 22)));
       }
       if (!use_prior) present = 0;
       int m = 0, n = 0, nb = 0;
       if (flag == AVM_MARGIN_OLD) {
         if (imu0) present |= (1 << 0) | (1 << 11) | (1 << 1) | (1 << 12);
-        if (nf0 > 0) present |= (1 << 0) | (1 << 22);
+        if (nf0 > 0) present |= (1 << 0) | (1 << 22) | (c.est_td ? 1 << 23 : 0);  // ProjectionTdFactor keeps para_Td (estimator.cpp:880-883)
         for (int b = 1; b < NFR; b++)
           if (ids[I_NCOV + b] > 0) present |= 1 << b;
         for (int q = 0; q < 6; q++) midx[m++] = q;
@@ -2664,10 +3171,10 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         for (int q = 0; q < 6; q++) midx[m++] = 6 * (AVM_WINDOW_SIZE - 1) + q;
         present &= ~(1 << (AVM_WINDOW_SIZE - 1));
       }
-      for (int id = 0; id < 23; id++) {
+      for (int id = 0; id < 24; id++) {
         if (!(present & (1 << id))) continue;
-        const int base = id < 11 ? 6 * id : (id < 22 ? SB0 + 9 * (id - 11) : MEX0);
-        const int sz = (id >= 11 && id < 22) ? 9 : 6;
+        const int base = id < 11 ? 6 * id : (id < 22 ? SB0 + 9 * (id - 11) : (id == 23 ? MTD : MEX0));
+        const int sz = (id >= 11 && id < 22) ? 9 : (id == 23 ? 1 : 6);
         if (n + sz > MAXKEEP || n + sz > PO.max_prior || nb >= MAXPBLK || nb >= PO.max_pblk) {
           atomicMin(err, w);  // (lowest failing window) the host turns this into AVM_ERR_CAPACITY: a truncated kept set would silently lose information
           break;
@@ -2750,9 +3257,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       PROF(c, 24);
       if (t < nblk) {
         const int id = kblk[t];
-        const int kind = id < 11 ? AVM_BLK_POSE : (id < 22 ? AVM_BLK_SPEEDBIAS : AVM_BLK_EXPOSE);
+        const int kind = id < 11 ? AVM_BLK_POSE : (id < 22 ? AVM_BLK_SPEEDBIAS : (id == 23 ? AVM_BLK_TD : AVM_BLK_EXPOSE));
         int fr = id < 11 ? id : (id < 22 ? id - 11 : 0);
-        if (kind != AVM_BLK_EXPOSE) {
+        if (kind == AVM_BLK_POSE || kind == AVM_BLK_SPEEDBIAS) {
           if (flag == AVM_MARGIN_OLD)
             fr -= 1;  // addr_shift, estimator.cpp:904-909
           else if (fr == AVM_WINDOW_SIZE)
@@ -2761,8 +3268,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         PO.blk_kind[(size_t)w * PO.max_pblk + t] = kind;
         PO.blk_frame[(size_t)w * PO.max_pblk + t] = fr;
         double* x0 = PO.x0 + ((size_t)w * PO.max_pblk + t) * 9;
-        const double* src = kind == AVM_BLK_POSE ? lds + L_X + id * 7 : (kind == AVM_BLK_SPEEDBIAS ? lds + L_X + XSB + (id - 11) * 9 : lds + L_RIC + 12);
-        const int gs = kind == AVM_BLK_SPEEDBIAS ? 9 : 7;
+        const double* src = kind == AVM_BLK_POSE ? lds + L_X + id * 7
+                            : (kind == AVM_BLK_SPEEDBIAS ? lds + L_X + XSB + (id - 11) * 9 : lds + L_RIC + (kind == AVM_BLK_TD ? 19 : 12));
+        const int gs = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 7);
         for (int q = 0; q < 9; q++) x0[q] = q < gs ? src[q] : 0.0;
       }
       if (t == 0) PO.n[w] = n, PO.nblk[w] = nblk;
@@ -2869,6 +3377,9 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
   if (t == 0 && A.cost) A.cost[w] = cost;
 }
 
+#endif  // !AVM_X (marginalization + per-factor evaluation kernels: base build only)
+
+#ifndef AVM_X
 int window_solve_lds_bytes() { return L_END * 8; }
 
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream) {
@@ -2882,7 +3393,6 @@ hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(window_solve_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a);
   return hipGetLastError();
 }
-
 
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream) {
   static bool attr_set = false;
@@ -2906,5 +3416,21 @@ hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(eval_factors_kernel, dim3(a.b.n_windows), dim3(NT), L_END * 8, stream, a);
   return hipGetLastError();
 }
+#else
+int window_solve_x_lds_bytes() { return L_END * 8; }
+
+// the solve with ex_pose / td / relo_Pose as (optional) variables: 178 x 178 reduced system
+hipError_t launch_window_solve_x(const SolveArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_solve_x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 8);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = a.b.n_windows < a.n_slots ? a.b.n_windows : a.n_slots;
+  hipLaunchKernelGGL(window_solve_x_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a);
+  return hipGetLastError();
+}
+#endif
 
 }  // namespace avm

@@ -126,8 +126,9 @@ class _Trajectory:
         )
 
 
-def _one_window(wid, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, max_prior, max_pblk, out, b):
+def _one_window(wid, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, max_prior, max_pblk, out, b, td_true=None, relo=False):
     rng = np.random.Generator(np.random.Philox(key=SEED_WINDOW + wid))
+    world_pts = []
     tr = _Trajectory(rng)
     G = np.array([0, 0, G_NORM])
     nF, ns, dt = abi.NFRAMES, 20, 0.005
@@ -181,6 +182,7 @@ def _one_window(wid, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, ma
         out["feat_obs_begin"][b, e] = o
         out["obs_xy"][b, o : o + L] = obs
         out["inv_depth"][b, e] = (1.0 / depth) * (1.0 + rng.normal(0, 0.10))
+        world_pts.append(pw)
         o += L
     assert o <= max_obs
     # ---- initial state = ground truth + perturbation
@@ -221,10 +223,47 @@ def _one_window(wid, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, ma
                 out["prior_x0"][b, k, :9] = out["speedbias"][b, fr] + rng.normal(0, 0.005, 9) * np.array([1] * 3 + [0.2] * 3 + [0.02] * 3)
             else:
                 out["prior_x0"][b, k, :7] = out["ex_pose"][b]
+    # ---- optional members (their own random stream: the tables above do not depend on them)
+    rx = np.random.Generator(np.random.Philox(key=SEED_WINDOW + 0x04000000 + wid))
+
+    def project(pw, t):
+        pc = RIC.T @ (tr.R(t).T @ (pw - tr.pos(t)) - TIC)
+        return pc[:2] / pc[2]
+
+    if td_true is not None:
+        # camera-IMU time offset (estimator.cpp:732-747): every observation carries the image velocity of its feature, the
+        # td its frame was stamped with (0 here) and its image row; the image was really taken td_true later than stamped,
+        # so the raw observation is the projection moved along the velocity by td_true
+        for e in range(n_feat):
+            s0, L, o0 = int(out["feat_start"][b, e]), int(out["feat_nobs"][b, e]), int(out["feat_obs_begin"][b, e])
+            for i in range(L):
+                t = tk[s0 + i]
+                vel = (project(world_pts[e], t + 1e-3) - project(world_pts[e], t - 1e-3)) / 2e-3
+                out["obs_xy"][b, o0 + i] += td_true * vel
+                out["obs_vel_td"][b, o0 + i] = [vel[0], vel[1], 0.0, CAM["fy"] * out["obs_xy"][b, o0 + i, 1] + CAM["cy"]]
+        out["td"][b] = 0.0
+    if relo:
+        # relocalization (estimator.cpp:760-792, setReloFrame :1120-1141): an old keyframe that saw the same landmarks from a
+        # pose near frame r; relo_Pose starts at the window's frame r
+        r = int(rx.integers(3, 8))
+        Rl = Rw[r] @ _expm_so3(rx.normal(0, np.deg2rad(4.0), 3))
+        Pl = Pw[r] + rx.normal(0, 0.25, 3)
+        k = 0
+        for e in range(n_feat):
+            if int(out["feat_start"][b, e]) > r or rx.uniform() < 0.4:
+                continue
+            pc = RIC.T @ (Rl.T @ (world_pts[e] - Pl) - TIC)
+            if pc[2] < 0.5:
+                continue
+            out["relo_feat"][b, k] = e
+            out["relo_xy"][b, k] = pc[:2] / pc[2] + rx.normal(0, sig_px, 2)
+            k += 1
+        out["relo_n"][b], out["relo_frame"][b] = k, r
+        out["relo_pose"][b] = out["pose"][b, r]
 
 
 def make_windows(n_windows, first_id=0, tracks="dense", n_feat=150, with_prior=True, max_feat=None, max_obs=None,
-                 max_samp=20, max_prior=96, max_pblk=16) -> WindowArrays:
+                 max_samp=20, max_prior=96, max_pblk=16, td_true=None, relo=False) -> WindowArrays:
     """B synthetic windows [first_id, first_id + n_windows). tracks: 'dense' (K=1500) or 'sparse' (ragged)."""
     max_feat = max_feat or max(n_feat, 1)
     max_obs = max_obs or max_feat * abi.NFRAMES
@@ -253,8 +292,13 @@ def make_windows(n_windows, first_id=0, tracks="dense", n_feat=150, with_prior=T
         "prior_r": np.zeros((B, max_prior)),
         "prior_x0": np.zeros((B, max_pblk, 9)),
     }
+    if td_true is not None:
+        out["obs_vel_td"], out["td"] = np.zeros((B, max_obs, 4)), np.zeros(B)
+    if relo:
+        out.update(relo_n=np.zeros(B, np.int32), relo_frame=np.zeros(B, np.int32), relo_feat=np.zeros((B, max_feat), np.int32),
+                   relo_xy=np.zeros((B, max_feat, 2)), relo_pose=np.zeros((B, 7)))
     for b in range(B):
-        _one_window(first_id + b, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, max_prior, max_pblk, out, b)
+        _one_window(first_id + b, tracks, n_feat, with_prior, max_feat, max_obs, max_samp, max_prior, max_pblk, out, b, td_true, relo)
     dims = dict(n_windows=B, max_feat=max_feat, max_obs=max_obs, max_samp=max_samp, max_prior=max_prior, max_pblk=max_pblk)
     return WindowArrays(dims, out)
 

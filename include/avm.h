@@ -66,7 +66,7 @@ typedef enum avm_status {
 typedef enum avm_mem { AVM_MEM_HOST = 0, AVM_MEM_DEVICE = 1 } avm_mem;
 
 /* prior block kinds (replaces the pointer-keyed addr_shift map, estimator.cpp:904-916) */
-enum { AVM_BLK_POSE = 0, AVM_BLK_SPEEDBIAS = 1, AVM_BLK_EXPOSE = 2 };
+enum { AVM_BLK_POSE = 0, AVM_BLK_SPEEDBIAS = 1, AVM_BLK_EXPOSE = 2, AVM_BLK_TD = 3 /* para_Td, 1 value */ };
 
 /* marginalization_flag, estimator.h:33-37 */
 enum { AVM_MARGIN_OLD = 0, AVM_MARGIN_SECOND_NEW = 1, AVM_MARGIN_NONE = 2 };
@@ -86,8 +86,8 @@ enum {
  * parameters.cpp:11, estimator.cpp:17, and the Ceres defaults listed in SURVEY.md §5.9. */
 typedef struct avm_options {
   int32_t max_num_iterations;        /* NUM_ITERATIONS = 8; wall-clock cap is NOT reproduced */
-  int32_t estimate_extrinsic;        /* 0: ex_pose constant (SetParameterBlockConstant, estimator.cpp:677-681) */
-  int32_t estimate_td;               /* 0 only (ProjectionTdFactor is a SURVEY §8 A7 follow-up) */
+  int32_t estimate_extrinsic;        /* 0: ex_pose constant (SetParameterBlockConstant, estimator.cpp:677-681); != 0: a variable of the solve */
+  int32_t estimate_td;               /* != 0: every vision factor is a ProjectionTdFactor and para_Td is a variable (estimator.cpp:684-688,732-747) */
   int32_t marginalization_flag;      /* AVM_MARGIN_* */
   double focal_length;               /* FOCAL_LENGTH 460; sqrt_info = focal/1.5 * I2 (estimator.cpp:17) */
   double g[3];                       /* G = (0,0,g_norm) parameters.cpp:11,127 */
@@ -107,6 +107,8 @@ typedef struct avm_options {
   int32_t max_num_consecutive_invalid_steps; /* 5 */
   int32_t jacobi_scaling;                    /* 1 */
   double marg_eps;                           /* 1e-8 marginalization_factor.h:70 */
+  double tr, row;                            /* TR (rolling-shutter read-out time, 0 for a global shutter) and ROW (image height), parameters.cpp:
+                                                only read by the td factor (projection_td_factor.cpp:19-20,50-52) */
 } avm_options;
 
 /* A batch of independent sliding windows, struct-of-arrays over the window index.
@@ -148,7 +150,25 @@ typedef struct avm_window_batch {
   const int32_t* prior_blk_frame; /* [B][max_pblk] frame index the block is applied to (already addr_shift'ed) */
   const double* prior_J;          /* [B][max_prior][max_prior] linearized_jacobians (n x n used) */
   const double* prior_r;          /* [B][max_prior] linearized_residuals */
-  const double* prior_x0;         /* [B][max_pblk][9] keep_block_data (pose uses 7, speedbias 9) */
+  const double* prior_x0;         /* [B][max_pblk][9] keep_block_data (pose uses 7, speedbias 9, td 1) */
+
+  /* ---- optional members of the problem; NULL = absent -------------------------------------------------------- */
+  /* time offset (opt->estimate_td != 0): per OBSERVATION slot FeaturePerFrame::velocity.x, .y, cur_td, uv.y()
+   * (estimator.cpp:734-736) and para_Td */
+  const double* obs_vel_td;      /* [B][max_obs][4] */
+  double* td;                    /* [B] in/out */
+  /* relocalization factors (estimator.cpp:760-792): relo_n[w] > 0 <=> relocalization_info.  The loop over
+   * f_manager.feature / match_points (ids ascending) is resolved by the host into feature INDICES of this batch
+   * (ascending, only features with start_frame <= relo_frame_local_index). */
+  const int32_t* relo_n;         /* [B] number of matched features */
+  const int32_t* relo_frame;     /* [B] relo_frame_local_index (only needed by the host for the outputs of :598-604) */
+  const int32_t* relo_feat;      /* [B][max_feat] feature index of match k */
+  const double* relo_xy;         /* [B][max_feat][2] match_points[k].x, .y */
+  double* relo_pose;             /* [B][7] relo_Pose, in: as set by setReloFrame (:1135-1141); out: relo_t | quaternion of
+                                    relo_r of double2vector (:590-596), i.e. the optimized loop-frame pose after the gauge fix */
+  /* failure_occur re-anchoring of double2vector (estimator.cpp:526-531) */
+  const int32_t* failure_occur;  /* [B] != 0: origin_R0 / origin_P0 come from last_pose0 instead of pose[0] */
+  const double* last_pose0;      /* [B][7] last_P0, last_R0 as a quaternion x y z w */
 } avm_window_batch;
 
 /* new prior produced by the post-solve marginalization (estimator.cpp:817-990) */
@@ -239,8 +259,8 @@ typedef struct avm_fsel_horizon_in {
 } avm_fsel_horizon_in;
 
 /* A7: inputs of ProjectionTdFactor (factor/projection_td_factor.cpp:6-32,34-141; call site estimator.cpp:732-747),
- * one entry per factor.  The solve itself does not take td as a variable yet (estimate_td must be 0); this is the
- * factor on its own, for hosts that assemble the td problem themselves and for the parity tests. */
+ * one entry per factor: the factor on its own (the solve uses it through avm_window_batch::obs_vel_td when
+ * opt->estimate_td != 0), for hosts that assemble problems themselves and for the parity tests. */
 typedef struct avm_td_factor_batch {
   int32_t n;
   const double* pose_i;    /* [n][7] x y z qx qy qz qw */

@@ -54,6 +54,23 @@ void load_window(const avm_options& o, const avm_window_batch& B, int w, Window&
     W.pre.push_back(p);
     W.sqrt_info.push_back(imu_sqrt_info(p));
   }
+  // optional members
+  W.obs_aux.clear();
+  W.x.td = 0.0;
+  if (o.estimate_td) {
+    if (B.obs_vel_td) W.obs_aux.assign(B.obs_vel_td + (size_t)w * B.max_obs * 4, B.obs_vel_td + ((size_t)w + 1) * B.max_obs * 4);
+    else W.obs_aux.assign((size_t)B.max_obs * 4, 0.0);
+    if (B.td) W.x.td = B.td[w];
+  }
+  W.relo_n = (B.relo_n && B.relo_feat && B.relo_xy && B.relo_pose) ? B.relo_n[w] : 0;
+  W.relo_frame = B.relo_frame ? B.relo_frame[w] : 0;
+  if (W.relo_n > 0) {
+    W.relo_feat.assign(B.relo_feat + (size_t)w * B.max_feat, B.relo_feat + (size_t)w * B.max_feat + W.relo_n);
+    W.relo_xy.assign(B.relo_xy + (size_t)w * B.max_feat * 2, B.relo_xy + ((size_t)w * B.max_feat + W.relo_n) * 2);
+    std::memcpy(W.x.relo, B.relo_pose + (size_t)w * 7, 7 * sizeof(double));
+  }
+  W.failure_occur = B.failure_occur && B.last_pose0 && B.failure_occur[w] != 0;
+  if (W.failure_occur) std::memcpy(W.last_pose0, B.last_pose0 + (size_t)w * 7, 7 * sizeof(double));
   W.has_prior = B.prior_n && B.prior_n[w] > 0;
   if (W.has_prior) {
     Prior& P = W.prior;
@@ -77,7 +94,9 @@ void load_window(const avm_options& o, const avm_window_batch& B, int w, Window&
   }
 }
 
-void store_state(const avm_window_batch& B, int w, const State& x) {
+void store_state(const avm_window_batch& B, int w, const State& x, bool td = false, bool relo = false) {
+  if (td && B.td) B.td[w] = x.td;
+  if (relo && B.relo_pose) std::memcpy(B.relo_pose + (size_t)w * 7, x.relo, 7 * sizeof(double));
   for (int f = 0; f < AVM_NFRAMES; f++) {
     std::memcpy(B.pose + ((size_t)w * AVM_NFRAMES + f) * 7, x.pose[f], 7 * sizeof(double));
     std::memcpy(B.speedbias + ((size_t)w * AVM_NFRAMES + f) * 9, x.sb[f], 9 * sizeof(double));
@@ -191,6 +210,7 @@ int avmo_default_options(avm_options* o) {
   o->max_num_consecutive_invalid_steps = 5;
   o->jacobi_scaling = 1;
   o->marg_eps = 1e-8;
+  o->tr = 0.0, o->row = 480.0;  // global shutter (config/euroc/euroc_config.yaml:66), image_height
   return 0;
 }
 
@@ -206,14 +226,14 @@ int avmo_window_solve_batch(const avm_options* opt, const avm_window_batch* batc
     SolveResult R = trust_region_solve(P, W.x);
     State out;
     out.lam = R.x.lam;
-    gauge_fix_roundtrip(W.x, R.x, out);
+    gauge_fix_roundtrip(W.x, R.x, out, W.failure_occur ? W.last_pose0 : nullptr, W.relo_n > 0);
     if (summary) summary[w] = R.sum;
     if (opt->marginalization_flag != AVM_MARGIN_NONE && prior_out) {
       Prior np;
       marginalize(W, out, *opt, np);
       store_prior(*prior_out, w, np);
     }
-    store_state(*batch, w, out);
+    store_state(*batch, w, out, opt->estimate_td != 0, W.relo_n > 0);
   });
   return 0;
 }

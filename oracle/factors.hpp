@@ -418,8 +418,8 @@ struct Prior {
   std::vector<std::vector<double>> x0;            // keep_block_data
   Mat J;                                          // linearized_jacobians n x n
   std::vector<double> r;                          // linearized_residuals
-  static int gsize(int kind) { return kind == 1 ? 9 : 7; }
-  static int lsize(int kind) { return kind == 1 ? 9 : 6; }
+  static int gsize(int kind) { return kind == 1 ? 9 : (kind == 3 ? 1 : 7); }  // AVM_BLK_TD: one value
+  static int lsize(int kind) { return kind == 1 ? 9 : (kind == 3 ? 1 : 6); }
 };
 
 // MarginalizationFactor::Evaluate (marginalization_factor.cpp:333-381); params[i] -> current block i

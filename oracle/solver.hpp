@@ -25,6 +25,8 @@ struct State {
   double sb[AVM_NFRAMES][9];
   double ex[7];
   std::vector<double> lam;
+  double td = 0.0;                          // para_Td[0][0]
+  double relo[7] = {0, 0, 0, 0, 0, 0, 1};   // relo_Pose
 };
 
 struct Window {
@@ -36,13 +38,21 @@ struct Window {
   std::vector<Mat> sqrt_info;
   bool has_prior = false;
   Prior prior;
+  // optional members of the problem (avm_window_batch)
+  std::vector<double> obs_aux;  // [obs slot][4] velocity.x, velocity.y, cur_td, uv.y  (estimate_td)
+  int relo_n = 0;               // relocalization_info: matched features (estimator.cpp:760-792)
+  int relo_frame = 0;
+  std::vector<int> relo_feat;
+  std::vector<double> relo_xy;
+  bool failure_occur = false;   // estimator.cpp:526-531
+  double last_pose0[7] = {0, 0, 0, 0, 0, 0, 1};
 };
 
-// parameter block ids: pose f -> f ; speedbias f -> 11+f ; ex_pose -> 22 ; feature e -> 23+e
-enum { ID_SB0 = AVM_NFRAMES, ID_EX = 2 * AVM_NFRAMES, ID_FEAT0 = 2 * AVM_NFRAMES + 1 };
+// parameter block ids: pose f -> f ; speedbias f -> 11+f ; ex_pose -> 22 ; td -> 23 ; relo_Pose -> 24 ; feature e -> 25+e
+enum { ID_SB0 = AVM_NFRAMES, ID_EX = 2 * AVM_NFRAMES, ID_TD = 2 * AVM_NFRAMES + 1, ID_RELO = 2 * AVM_NFRAMES + 2, ID_FEAT0 = 2 * AVM_NFRAMES + 3 };
 
 struct RBlock {
-  int type;  // 0 prior, 1 imu, 2 projection
+  int type;  // 0 prior, 1 imu, 2 projection (aux1 < 0: relocalization factor -aux1 - 1), 3 projection with td
   int nres;
   int nb;
   int ids[16];
@@ -72,6 +82,8 @@ struct Problem {
     for (int f = 0; f < AVM_NFRAMES; f++) loff[f] = off, lsize[f] = 6, off += 6;
     for (int f = 0; f < AVM_NFRAMES; f++) loff[ID_SB0 + f] = off, lsize[ID_SB0 + f] = 9, off += 9;
     if (o.estimate_extrinsic) loff[ID_EX] = off, lsize[ID_EX] = 6, off += 6;
+    if (o.estimate_td) loff[ID_TD] = off, lsize[ID_TD] = 1, off += 1;                 // estimator.cpp:684-688
+    if (win.relo_n > 0) loff[ID_RELO] = off, lsize[ID_RELO] = 6, off += 6;           // estimator.cpp:763-764
     n_f = off;
     for (int e = 0; e < win.nf; e++) loff[ID_FEAT0 + e] = off, lsize[ID_FEAT0 + e] = 1, off += 1;
     n_local = off;
@@ -93,7 +105,7 @@ struct Problem {
       b.type = 0, b.nres = win.prior.n, b.nb = (int)win.prior.blk_kind.size();
       for (int k = 0; k < b.nb; k++) {
         int kind = win.prior.blk_kind[k], fr = win.prior.blk_frame[k];
-        b.ids[k] = kind == AVM_BLK_POSE ? fr : (kind == AVM_BLK_SPEEDBIAS ? ID_SB0 + fr : ID_EX);
+        b.ids[k] = kind == AVM_BLK_POSE ? fr : (kind == AVM_BLK_SPEEDBIAS ? ID_SB0 + fr : (kind == AVM_BLK_TD ? (int)ID_TD : (int)ID_EX));
       }
       b.aux0 = b.aux1 = 0;
       finish(b);
@@ -113,12 +125,22 @@ struct Problem {
     for (int e = 0; e < win.nf; e++) {
       for (int t = 1; t < win.nobs[e]; t++) {
         RBlock b;
-        b.type = 2, b.nres = 2, b.nb = 4;
-        b.ids[0] = win.start[e], b.ids[1] = win.start[e] + t, b.ids[2] = ID_EX, b.ids[3] = ID_FEAT0 + e;
+        b.type = o.estimate_td ? 3 : 2, b.nres = 2, b.nb = o.estimate_td ? 5 : 4;
+        b.ids[0] = win.start[e], b.ids[1] = win.start[e] + t, b.ids[2] = ID_EX, b.ids[3] = ID_FEAT0 + e, b.ids[4] = ID_TD;
         b.aux0 = e, b.aux1 = win.obs_begin[e] + t;
         finish(b);
         blocks.push_back(b);
       }
+    }
+    // relocalization (estimator.cpp:760-792): plain ProjectionFactors between the start pose of a matched feature and relo_Pose
+    for (int k = 0; k < win.relo_n; k++) {
+      const int e = win.relo_feat[k];
+      RBlock b;
+      b.type = 2, b.nres = 2, b.nb = 4;
+      b.ids[0] = win.start[e], b.ids[1] = ID_RELO, b.ids[2] = ID_EX, b.ids[3] = ID_FEAT0 + e;
+      b.aux0 = e, b.aux1 = -(k + 1);
+      finish(b);
+      blocks.push_back(b);
     }
   }
 
@@ -126,6 +148,8 @@ struct Problem {
     if (id < ID_SB0) return x.pose[id];
     if (id < ID_EX) return x.sb[id - ID_SB0];
     if (id == ID_EX) return x.ex;
+    if (id == ID_TD) return &x.td;
+    if (id == ID_RELO) return x.relo;
     return &x.lam[id - ID_FEAT0];
   }
 
@@ -182,16 +206,32 @@ struct Problem {
         cost += 0.5 * s;
       } else {
         int e = b.aux0, slot = b.aux1, s0 = win.obs_begin[e];
-        V3 pts_i(win.obs_xy[2 * s0], win.obs_xy[2 * s0 + 1], 1.0), pts_j(win.obs_xy[2 * slot], win.obs_xy[2 * slot + 1], 1.0);
-        double j0[14], j1[14], j2[14], j3[2];
-        double* jac[4] = {j0, j1, j2, j3};
-        projection_factor_evaluate(pts_i, pts_j, sq, x.pose[b.ids[0]], x.pose[b.ids[1]], x.ex, x.lam[e], br,
-                                   want_jac ? jac : nullptr);
-        if (want_jac) {
-          const int gs[4] = {7, 7, 7, 1};
-          for (int k = 0; k < 4; k++)
-            for (int r = 0; r < 2; r++)
-              for (int c = 0; c < b.lsz[k]; c++) b.J[(size_t)r * b.ncols + b.coff[k] + c] = jac[k][r * gs[k] + c];
+        if (b.type == 3) {
+          // ProjectionTdFactor (estimator.cpp:732-747): velocity / cur_td / uv.y of the two observations
+          const double* ai = &win.obs_aux[4 * (size_t)s0];
+          const double* aj = &win.obs_aux[4 * (size_t)slot];
+          double j20[40];
+          projection_td_factor_evaluate(&win.obs_xy[2 * s0], &win.obs_xy[2 * slot], ai, aj, ai[2], aj[2], ai[3], aj[3], opt->tr, opt->row, sq,
+                                        x.pose[b.ids[0]], x.pose[b.ids[1]], x.ex, x.lam[e], x.td, br, want_jac ? j20 : nullptr);
+          if (want_jac) {
+            const int src[5] = {0, 6, 12, 18, 19};  // pose_i | pose_j | ex_pose | inv depth | td
+            for (int k = 0; k < 5; k++)
+              for (int r = 0; r < 2; r++)
+                for (int c = 0; c < b.lsz[k]; c++) b.J[(size_t)r * b.ncols + b.coff[k] + c] = j20[r * 20 + src[k] + c];
+          }
+        } else {
+          V3 pts_i(win.obs_xy[2 * s0], win.obs_xy[2 * s0 + 1], 1.0);
+          V3 pts_j = slot >= 0 ? V3(win.obs_xy[2 * slot], win.obs_xy[2 * slot + 1], 1.0)
+                               : V3(win.relo_xy[2 * (-slot - 1)], win.relo_xy[2 * (-slot - 1) + 1], 1.0);  // match_points (estimator.cpp:781)
+          double j0[14], j1[14], j2[14], j3[2];
+          double* jac[4] = {j0, j1, j2, j3};
+          projection_factor_evaluate(pts_i, pts_j, sq, x.pose[b.ids[0]], param(x, b.ids[1]), x.ex, x.lam[e], br, want_jac ? jac : nullptr);
+          if (want_jac) {
+            const int gs[4] = {7, 7, 7, 1};
+            for (int k = 0; k < 4; k++)
+              for (int r = 0; r < 2; r++)
+                for (int c = 0; c < b.lsz[k]; c++) b.J[(size_t)r * b.ncols + b.coff[k] + c] = jac[k][r * gs[k] + c];
+          }
         }
         double sn = br[0] * br[0] + br[1] * br[1];
         double rho[3];
@@ -370,6 +410,14 @@ struct Problem {
       Q r = normalized(q * deltaQ(V3(d[o + 3], d[o + 4], d[o + 5])));
       out.ex[3] = r.x, out.ex[4] = r.y, out.ex[5] = r.z, out.ex[6] = r.w;
     }
+    if (loff[ID_TD] >= 0) out.td = x.td + d[loff[ID_TD]];
+    if (loff[ID_RELO] >= 0) {
+      int o = loff[ID_RELO];
+      for (int k = 0; k < 3; k++) out.relo[k] = x.relo[k] + d[o + k];
+      Q q(x.relo[6], x.relo[3], x.relo[4], x.relo[5]);
+      Q r = normalized(q * deltaQ(V3(d[o + 3], d[o + 4], d[o + 5])));
+      out.relo[3] = r.x, out.relo[4] = r.y, out.relo[5] = r.z, out.relo[6] = r.w;
+    }
     for (int e = 0; e < w->nf; e++) out.lam[e] = x.lam[e] + d[loff[ID_FEAT0 + e]];
   }
   // ambient-space helpers over the non-constant blocks
@@ -381,6 +429,9 @@ struct Problem {
       for (int k = 0; k < 9; k++) f(a.sb[fr][k], b.sb[fr][k]);
     if (loff[ID_EX] >= 0)
       for (int k = 0; k < 7; k++) f(a.ex[k], b.ex[k]);
+    if (loff[ID_TD] >= 0) f(a.td, b.td);
+    if (loff[ID_RELO] >= 0)
+      for (int k = 0; k < 7; k++) f(a.relo[k], b.relo[k]);
     for (int e = 0; e < w->nf; e++) f(a.lam[e], b.lam[e]);
   }
 };
@@ -651,10 +702,15 @@ inline M3 ypr2R(V3 ypr) {
 // Estimator::double2vector (estimator.cpp:521-587) followed by vector2double (:477-519):
 // the state the host sees after optimization().  `before` = para_* before the solve
 // (Rs[0]/Ps[0] are reconstructed from it), `sol` = para_* after ceres::Solve.
-inline void gauge_fix_roundtrip(const State& before, const State& sol, State& out) {
+inline void gauge_fix_roundtrip(const State& before, const State& sol, State& out, const double* failure_anchor = nullptr,
+                                bool relo = false) {
   M3 Rs0 = toR(Q(before.pose[0][6], before.pose[0][3], before.pose[0][4], before.pose[0][5]));
   V3 origin_R0 = R2ypr(Rs0);
   V3 origin_P0(before.pose[0][0], before.pose[0][1], before.pose[0][2]);
+  if (failure_anchor) {  // failure_occur: last_R0 / last_P0 (estimator.cpp:526-531); Rs[0] itself stays what it was
+    origin_R0 = R2ypr(toR(Q(failure_anchor[6], failure_anchor[3], failure_anchor[4], failure_anchor[5])));
+    origin_P0 = V3(failure_anchor[0], failure_anchor[1], failure_anchor[2]);
+  }
   M3 R00 = toR(Q(sol.pose[0][6], sol.pose[0][3], sol.pose[0][4], sol.pose[0][5]));
   V3 origin_R00 = R2ypr(R00);
   double y_diff = origin_R0.x - origin_R00.x;
@@ -680,6 +736,14 @@ inline void gauge_fix_roundtrip(const State& before, const State& sol, State& ou
   }
   // setDepth: estimated_depth = 1/x ; getDepthVector: 1/estimated_depth
   for (size_t e = 0; e < sol.lam.size(); e++) out.lam[e] = 1.0 / (1.0 / sol.lam[e]);
+  if (relo) {  // relo_r / relo_t of estimator.cpp:590-596 (the pose-graph outputs :597-604 are host arithmetic on them)
+    Q q(sol.relo[6], sol.relo[3], sol.relo[4], sol.relo[5]);
+    M3 relo_r = rot_diff * toR(normalized(q));
+    V3 relo_t = rot_diff * V3(sol.relo[0] - sol.pose[0][0], sol.relo[1] - sol.pose[0][1], sol.relo[2] - sol.pose[0][2]) + origin_P0;
+    Q qo = fromR(relo_r);
+    out.relo[0] = relo_t.x, out.relo[1] = relo_t.y, out.relo[2] = relo_t.z;
+    out.relo[3] = qo.x, out.relo[4] = qo.y, out.relo[5] = qo.z, out.relo[6] = qo.w;
+  }
 }
 
 // ---- MarginalizationInfo (marginalization_factor.cpp:89-319) -------------------------------
@@ -701,12 +765,13 @@ inline void marginalize(const Window& win, const State& x, const avm_options& o,
   V3 G(o.g[0], o.g[1], o.g[2]);
   auto idOfPrior = [&](int k) {
     int kind = win.prior.blk_kind[k], fr = win.prior.blk_frame[k];
-    return kind == AVM_BLK_POSE ? fr : (kind == AVM_BLK_SPEEDBIAS ? ID_SB0 + fr : (int)ID_EX);
+    return kind == AVM_BLK_POSE ? fr : (kind == AVM_BLK_SPEEDBIAS ? ID_SB0 + fr : (kind == AVM_BLK_TD ? (int)ID_TD : (int)ID_EX));
   };
   auto paramOf = [&](int id) -> const double* {
     if (id < ID_SB0) return x.pose[id];
     if (id < ID_EX) return x.sb[id - ID_SB0];
     if (id == ID_EX) return x.ex;
+    if (id == ID_TD) return &x.td;
     return &x.lam[id - ID_FEAT0];
   };
   auto gsOf = [&](int id) { return id < ID_SB0 ? 7 : (id < ID_EX ? 9 : (id == ID_EX ? 7 : 1)); };
@@ -779,8 +844,21 @@ inline void marginalize(const Window& win, const State& x, const avm_options& o,
         f.gs = {7, 7, 7, 1};
         f.J = {std::vector<double>(14), std::vector<double>(14), std::vector<double>(14), std::vector<double>(2)};
         f.r.assign(2, 0.0);
+        if (o.estimate_td) {  // estimator.cpp:874-885: ProjectionTdFactor, para_Td kept
+          f.ids.push_back(ID_TD), f.gs.push_back(1), f.J.push_back(std::vector<double>(2));
+          const double* ai = &win.obs_aux[4 * (size_t)s0];
+          const double* aj = &win.obs_aux[4 * (size_t)slot];
+          double j20[40];
+          projection_td_factor_evaluate(&win.obs_xy[2 * s0], &win.obs_xy[2 * slot], ai, aj, ai[2], aj[2], ai[3], aj[3], o.tr, o.row, sq, x.pose[0],
+                                        x.pose[t], x.ex, x.lam[e], x.td, f.r.data(), j20);
+          for (int r = 0; r < 2; r++) {
+            for (int c = 0; c < 6; c++) f.J[0][r * 7 + c] = j20[r * 20 + c], f.J[1][r * 7 + c] = j20[r * 20 + 6 + c], f.J[2][r * 7 + c] = j20[r * 20 + 12 + c];
+            f.J[3][r] = j20[r * 20 + 18], f.J[4][r] = j20[r * 20 + 19];
+          }
+        } else {
         double* jac[4] = {f.J[0].data(), f.J[1].data(), f.J[2].data(), f.J[3].data()};
         projection_factor_evaluate(pts_i, pts_j, sq, x.pose[0], x.pose[t], x.ex, x.lam[e], f.r.data(), jac);
+        }
         // ResidualBlockInfo::Evaluate loss correction (marginalization_factor.cpp:37-68)
         double sn = f.r[0] * f.r[0] + f.r[1] * f.r[1], rho[3];
         cauchy_loss(o.cauchy_a, sn, rho);
@@ -886,9 +964,9 @@ inline void marginalize(const Window& win, const State& x, const avm_options& o,
   }
   // getParameterBlocks + addr_shift (estimator.cpp:904-916 / :960-983)
   for (int id : kept) {
-    int kind = id < ID_SB0 ? AVM_BLK_POSE : (id < ID_EX ? AVM_BLK_SPEEDBIAS : AVM_BLK_EXPOSE);
+    int kind = id < ID_SB0 ? AVM_BLK_POSE : (id < ID_EX ? AVM_BLK_SPEEDBIAS : (id == ID_TD ? AVM_BLK_TD : AVM_BLK_EXPOSE));
     int fr = kind == AVM_BLK_POSE ? id : (kind == AVM_BLK_SPEEDBIAS ? id - ID_SB0 : 0);
-    if (kind != AVM_BLK_EXPOSE) {
+    if (kind == AVM_BLK_POSE || kind == AVM_BLK_SPEEDBIAS) {
       if (flag == AVM_MARGIN_OLD)
         fr = fr - 1;
       else if (fr == AVM_WINDOW_SIZE)
