@@ -43,6 +43,32 @@ struct Quaterniond {
   double x = 0, y = 0, z = 0, w = 1;
 };
 
+namespace detail {
+// the handful of rotation helpers double2vector's relocalization outputs need (utility/utility.h:66-108,124-141); unit quaternions
+inline Quaterniond conj(const Quaterniond& q) { return Quaterniond{-q.x, -q.y, -q.z, q.w}; }
+inline Quaterniond mul(const Quaterniond& a, const Quaterniond& b) {
+  return Quaterniond{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+                     a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+inline Vector3d rotate(const Quaterniond& q, const Vector3d& v) {  // Eigen: v + w t + u x t, t = 2 u x v
+  const double tx = 2 * (q.y * v[2] - q.z * v[1]), ty = 2 * (q.z * v[0] - q.x * v[2]), tz = 2 * (q.x * v[1] - q.y * v[0]);
+  return Vector3d{v[0] + q.w * tx + (q.y * tz - q.z * ty), v[1] + q.w * ty + (q.z * tx - q.x * tz), v[2] + q.w * tz + (q.x * ty - q.y * tx)};
+}
+inline double yaw_deg(const Quaterniond& q) {  // Utility::R2ypr(R).x(): atan2(R(1,0), R(0,0)) in degrees
+  const double r10 = 2 * (q.x * q.y + q.z * q.w), r00 = 1 - 2 * (q.y * q.y + q.z * q.z);
+  return std::atan2(r10, r00) / M_PI * 180.0;
+}
+inline Vector3d rotate_yaw(double yaw_degrees, const Vector3d& v) {  // Utility::ypr2R(Vector3d(yaw, 0, 0)) * v
+  const double y = yaw_degrees / 180.0 * M_PI, c = std::cos(y), s2 = std::sin(y);
+  return Vector3d{c * v[0] - s2 * v[1], s2 * v[0] + c * v[1], v[2]};
+}
+inline double normalize_angle(double a) {  // Utility::normalizeAngle (utility.h:124-141), degrees
+  const double two_pi = 360.0;
+  if (a > 0) return a - two_pi * std::floor((a + 180.0) / two_pi);
+  return a + two_pi * std::floor((-a + 180.0) / two_pi);
+}
+}  // namespace detail
+
 struct Error : std::runtime_error {
   int status;
   Error(int s, const std::string& what) : std::runtime_error(what), status(s) {}
@@ -170,8 +196,18 @@ struct WindowTables {
   std::vector<double> pose, speedbias, ex_pose, inv_depth, obs_xy, imu_dt, imu_acc, imu_gyr, imu_lin_ba, imu_lin_bg;
   std::vector<int32_t> feat_start, feat_nobs, feat_obs_begin, imu_n;
   std::vector<int32_t> feat_id;  // feature_id per table row (host side only)
+  // optional members of the problem (avm_window_batch): handed over only when the matching use_* flag is set
+  bool use_td = false, use_relo = false, use_failure = false;
+  std::vector<double> obs_vel_td, relo_xy;
+  std::vector<int32_t> relo_feat;
+  double td = 0;
+  int32_t relo_n = 0, relo_frame = 0, failure_occur = 0;
+  std::array<double, 7> relo_pose{{0, 0, 0, 0, 0, 0, 1}}, last_pose0{{0, 0, 0, 0, 0, 0, 1}};
   avm_window_batch batch(const MarginalizationInfo* prior) {
     avm_window_batch b{};
+    if (use_td) b.obs_vel_td = obs_vel_td.data(), b.td = &td;
+    if (use_relo) b.relo_n = &relo_n, b.relo_frame = &relo_frame, b.relo_feat = relo_feat.data(), b.relo_xy = relo_xy.data(), b.relo_pose = relo_pose.data();
+    if (use_failure) b.failure_occur = &failure_occur, b.last_pose0 = last_pose0.data();
     b.n_windows = 1, b.max_feat = MAX_FEAT, b.max_obs = MAX_OBS, b.max_samp = max_samp, b.max_prior = MAX_PRIOR, b.max_pblk = MAX_PBLK;
     b.pose = pose.data(), b.speedbias = speedbias.data(), b.ex_pose = ex_pose.data(), b.inv_depth = inv_depth.data();
     b.n_feat = &n_feat, b.feat_start = feat_start.data(), b.feat_nobs = feat_nobs.data(), b.feat_obs_begin = feat_obs_begin.data();
@@ -239,6 +275,24 @@ class Estimator {
   double para_Pose[AVM_NFRAMES][AVM_SIZE_POSE];
   double para_SpeedBias[AVM_NFRAMES][AVM_SIZE_SPEEDBIAS];
   double para_Ex_Pose[1][AVM_SIZE_POSE];
+  double para_Td[1][1] = {{0}};
+
+  // relocalization (estimator.h:117-131; setReloFrame estimator.cpp:1120-1141): match_points[k] = (x, y, feature_id)
+  bool relocalization_info = false;
+  int relo_frame_local_index = 0;
+  std::vector<Vector3d> match_points;
+  double relo_Pose[AVM_SIZE_POSE] = {0, 0, 0, 0, 0, 0, 1};
+  Vector3d prev_relo_t{0, 0, 0};
+  Quaterniond prev_relo_r{};
+  // ... and what double2vector leaves for the pose graph (estimator.cpp:588-604)
+  double drift_correct_yaw = 0;       // drift_correct_r = ypr2R(drift_correct_yaw, 0, 0)
+  Vector3d drift_correct_t{0, 0, 0}, relo_relative_t{0, 0, 0};
+  Quaterniond relo_relative_q{};
+  double relo_relative_yaw = 0;
+  // failure_occur re-anchoring of double2vector (estimator.cpp:526-531; last_R0 / last_P0 are set by processImage :170-171,207-208)
+  bool failure_occur = false;
+  Quaterniond last_R0{};
+  Vector3d last_P0{0, 0, 0};
 
   void vector2double() {  // estimator.cpp:477-519 (para_Feature is marshalled with the feature tables)
     for (int i = 0; i <= AVM_WINDOW_SIZE; i++) {
@@ -274,6 +328,7 @@ class Estimator {
     t.feat_start.assign(WindowTables::MAX_FEAT, 0), t.feat_nobs.assign(WindowTables::MAX_FEAT, 0), t.feat_obs_begin.assign(WindowTables::MAX_FEAT, 0);
     t.feat_id.clear();
     t.obs_xy.assign((size_t)WindowTables::MAX_OBS * 2, 0.0);
+    if (t.use_td) t.obs_vel_td.assign((size_t)WindowTables::MAX_OBS * 4, 0.0);
     int e = 0, o = 0;
     for (auto& f : f_manager.feature) {
       f.used_num = (int)f.feature_per_frame.size();
@@ -283,7 +338,14 @@ class Estimator {
       t.feat_start[e] = f.start_frame, t.feat_nobs[e] = f.used_num, t.feat_obs_begin[e] = o;
       t.inv_depth[e] = inv_depth_of(f);
       t.feat_id.push_back(f.feature_id);
-      for (const auto& pf : f.feature_per_frame) t.obs_xy[2 * o] = pf.point[0], t.obs_xy[2 * o + 1] = pf.point[1], o++;
+      for (const auto& pf : f.feature_per_frame) {
+        t.obs_xy[2 * o] = pf.point[0], t.obs_xy[2 * o + 1] = pf.point[1];
+        if (t.use_td) {  // what ProjectionTdFactor's constructor takes per observation (estimator.cpp:734-736)
+          double* a = &t.obs_vel_td[4 * (size_t)o];
+          a[0] = pf.velocity[0], a[1] = pf.velocity[1], a[2] = pf.cur_td, a[3] = pf.uv[1];
+        }
+        o++;
+      }
       e++;
     }
     t.n_feat = e;
@@ -321,10 +383,37 @@ class Estimator {
 
   // HP-A (estimator.cpp:661-994): solve the window in place, leave the new prior in last_marginalization_info.
   void optimization() {
-    if (options.estimate_extrinsic || options.estimate_td) throw Error(AVM_ERR_UNSUPPORTED, "ESTIMATE_EXTRINSIC / ESTIMATE_TD are not built on the device yet");
     options.marginalization_flag = marginalization_flag == MARGIN_OLD ? AVM_MARGIN_OLD : AVM_MARGIN_SECOND_NEW;
     WindowTables t;
+    t.use_td = options.estimate_td != 0, t.use_relo = relocalization_info, t.use_failure = failure_occur;
     marshal(t, [](const FeaturePerId& f) { return 1.0 / f.estimated_depth; });  // getDepthVector()
+    t.td = para_Td[0][0] = td;                                                  // vector2double, estimator.cpp:517-518
+    if (t.use_relo) {
+      // the loop of estimator.cpp:766-790 over f_manager.feature and match_points (both ascending in feature id), resolved
+      // into feature indices of the tables
+      t.relo_feat.assign(WindowTables::MAX_FEAT, 0), t.relo_xy.assign((size_t)WindowTables::MAX_FEAT * 2, 0.0);
+      size_t retrive_feature_index = 0;
+      int feature_index = -1, k = 0;
+      for (auto& it_per_id : f_manager.feature) {
+        if (!in_problem(it_per_id)) continue;
+        ++feature_index;
+        if (it_per_id.start_frame <= relo_frame_local_index) {
+          while (retrive_feature_index < match_points.size() && (int)match_points[retrive_feature_index][2] < it_per_id.feature_id) retrive_feature_index++;
+          if (retrive_feature_index < match_points.size() && (int)match_points[retrive_feature_index][2] == it_per_id.feature_id) {
+            t.relo_feat[k] = feature_index;
+            t.relo_xy[2 * k] = match_points[retrive_feature_index][0], t.relo_xy[2 * k + 1] = match_points[retrive_feature_index][1];
+            k++, retrive_feature_index++;
+          }
+        }
+      }
+      t.relo_n = k, t.relo_frame = relo_frame_local_index;
+      std::copy(relo_Pose, relo_Pose + 7, t.relo_pose.begin());
+      if (k == 0) t.use_relo = false;  // no factor references relo_Pose: Ceres would not move it either
+    }
+    if (t.use_failure) {
+      t.failure_occur = 1;
+      t.last_pose0 = {last_P0[0], last_P0[1], last_P0[2], last_R0.x, last_R0.y, last_R0.z, last_R0.w};
+    }
     avm_window_batch b = t.batch(&last_marginalization_info);
 
     MarginalizationInfo next;
@@ -345,6 +434,23 @@ class Estimator {
     std::copy(t.ex_pose.begin(), t.ex_pose.end(), &para_Ex_Pose[0][0]);
     double2vector();
     f_manager.setDepth(t.inv_depth.data());
+    if (options.estimate_td) td = para_Td[0][0] = t.td;  // estimator.cpp:585-586
+    failure_occur = false;                                 // estimator.cpp:530
+    if (relocalization_info) {
+      // estimator.cpp:588-604: relo_t / relo_r come back gauge-fixed from the device (the untouched relo_Pose when no feature
+      // matched); the relative pose of the loop frame and the drift correction are host arithmetic on them
+      if (t.use_relo) std::copy(t.relo_pose.begin(), t.relo_pose.end(), relo_Pose);
+      const Vector3d relo_t{relo_Pose[0], relo_Pose[1], relo_Pose[2]};
+      const Quaterniond relo_r{relo_Pose[3], relo_Pose[4], relo_Pose[5], relo_Pose[6]};
+      drift_correct_yaw = detail::yaw_deg(prev_relo_r) - detail::yaw_deg(relo_r);
+      const Vector3d rt = detail::rotate_yaw(drift_correct_yaw, relo_t);
+      drift_correct_t = {prev_relo_t[0] - rt[0], prev_relo_t[1] - rt[1], prev_relo_t[2] - rt[2]};
+      const int i = relo_frame_local_index;
+      relo_relative_t = detail::rotate(detail::conj(relo_r), Vector3d{Ps[i][0] - relo_t[0], Ps[i][1] - relo_t[1], Ps[i][2] - relo_t[2]});
+      relo_relative_q = detail::mul(detail::conj(relo_r), Rs[i]);
+      relo_relative_yaw = detail::normalize_angle(detail::yaw_deg(Rs[i]) - detail::yaw_deg(relo_r));
+      relocalization_info = false;
+    }
     if (out_n >= 0) {  // -1: MARGIN_SECOND_NEW had nothing to drop, the old prior stays (estimator.cpp:926-927)
       next.n = out_n, next.nblk = out_nblk;
       last_marginalization_info = std::move(next);

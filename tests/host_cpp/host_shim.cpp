@@ -80,9 +80,32 @@ int hs_load_window(void* hp, const avm_window_batch* b, int w, const int32_t* fe
         const double* o = b->obs_xy + ((size_t)w * b->max_obs + b->feat_obs_begin[fe] + t) * 2;
         FeaturePerFrame pf;
         pf.point = {o[0], o[1], 1.0};
+        if (b->obs_vel_td) {  // FeaturePerFrame::velocity / cur_td / uv.y of the td factor
+          const double* a = b->obs_vel_td + ((size_t)w * b->max_obs + b->feat_obs_begin[fe] + t) * 4;
+          pf.velocity = {a[0], a[1]}, pf.cur_td = a[2], pf.uv = {0.0, a[3]};
+        }
         f.feature_per_frame.push_back(pf);
       }
       E.f_manager.feature.push_back(f);
+    }
+    E.td = b->td ? b->td[w] : 0.0;
+    E.relocalization_info = b->relo_n && b->relo_n[w] > 0;
+    E.match_points.clear();
+    if (E.relocalization_info) {  // setReloFrame (estimator.cpp:1120-1141): match_points = (x, y, feature id), ascending ids
+      E.relo_frame_local_index = b->relo_frame[w];
+      for (int k = 0; k < b->relo_n[w]; k++) {
+        const int e = b->relo_feat[(size_t)w * b->max_feat + k];
+        const double* xy = b->relo_xy + ((size_t)w * b->max_feat + k) * 2;
+        E.match_points.push_back(Vector3d{xy[0], xy[1], (double)(feat_id ? feat_id[e] : e)});
+      }
+      std::copy(b->relo_pose + (size_t)w * 7, b->relo_pose + (size_t)w * 7 + 7, E.relo_Pose);
+      E.prev_relo_t = {E.relo_Pose[0] + 0.3, E.relo_Pose[1] - 0.2, E.relo_Pose[2] + 0.1};  // (any loop-frame pose: the outputs are checked against it)
+      E.prev_relo_r = Quaterniond{0.0, 0.0, std::sin(0.2), std::cos(0.2)};
+    }
+    E.failure_occur = b->failure_occur && b->failure_occur[w] != 0;
+    if (E.failure_occur) {
+      const double* lp = b->last_pose0 + (size_t)w * 7;
+      E.last_P0 = {lp[0], lp[1], lp[2]}, E.last_R0 = Quaterniond{lp[3], lp[4], lp[5], lp[6]};
     }
     const size_t S = b->max_samp;
     for (int j = 0; j < AVM_WINDOW_SIZE; j++) {
@@ -175,6 +198,20 @@ int hs_get_state(void* hp, double* pose, double* speedbias, double* ex_pose, int
   }
   *n_feat = k;
   if (summary) *summary = E.summary;
+  return 0;
+}
+
+// the optional members after optimization(): td, relo_Pose, and the pose-graph outputs of double2vector (estimator.cpp:588-604)
+// out[0] td | 1..7 relo_Pose | 8 drift_correct_yaw | 9..11 drift_correct_t | 12..14 relo_relative_t | 15..18 relo_relative_q | 19 relo_relative_yaw
+// | 20 relocalization_info | 21 failure_occur
+int hs_get_extras(void* hp, double* out) {
+  const Estimator& E = static_cast<Host*>(hp)->est;
+  out[0] = E.td;
+  std::copy(E.relo_Pose, E.relo_Pose + 7, out + 1);
+  out[8] = E.drift_correct_yaw;
+  for (int k = 0; k < 3; k++) out[9 + k] = E.drift_correct_t[k], out[12 + k] = E.relo_relative_t[k];
+  out[15] = E.relo_relative_q.x, out[16] = E.relo_relative_q.y, out[17] = E.relo_relative_q.z, out[18] = E.relo_relative_q.w;
+  out[19] = E.relo_relative_yaw, out[20] = E.relocalization_info ? 1.0 : 0.0, out[21] = E.failure_occur ? 1.0 : 0.0;
   return 0;
 }
 

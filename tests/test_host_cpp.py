@@ -104,6 +104,15 @@ class Host:
         out["n_feat"], out["summary"] = n.value, summ
         return out
 
+    def set_options(self, o):
+        self.L.hs_set_options(self.h, C.byref(o))
+
+    def extras(self):
+        v = np.zeros(22)
+        self.L.hs_get_extras(self.h, abi.dptr(v))
+        return dict(td=v[0], relo_pose=v[1:8], drift_correct_yaw=v[8], drift_correct_t=v[9:12], relo_relative_t=v[12:15], relo_relative_q=v[15:19],
+                    relo_relative_yaw=v[19], relocalization_info=bool(v[20]), failure_occur=bool(v[21]))
+
     def prior(self):
         p = buffers.PriorOutArrays.alloc(1)
         n, nb = C.c_int32(0), C.c_int32(0)
@@ -261,18 +270,21 @@ def test_python_and_cpp_select_bookkeeping_agree_before_initialization():
 
 
 def test_cpp_host_capacity_and_unsupported_errors_are_raised_before_any_device_work():
-    """More features than the device tables hold (150 / 1650 observations) and the option combinations that are not built
-    surface as avm_host::Error with the ABI's status codes - on a box without a GPU too, i.e. before the device is touched."""
+    """More features than the device tables hold (150 / 1650 observations) surface as avm_host::Error with the ABI's status
+    codes - on a box without a GPU too, i.e. before the device is touched."""
     w = synth.make_windows(1, tracks="dense", n_feat=150, max_feat=150, max_obs=1650)
     H = Host()
     H.load(w, extras=[(150, 0, 3)])  # a 151st feature that passes the filter of estimator.cpp:715
     assert H.optimization() == abi.AVM_ERR_CAPACITY and "150 features" in H.err()
     assert H.triangulate() == abi.AVM_ERR_CAPACITY
+    # ESTIMATE_TD / ESTIMATE_EXTRINSIC are built: without a GPU the call now gets as far as opening the device and fails there
     H.load(w)
     o = abi.default_options()
     o.estimate_td = 1
     H.L.hs_set_options(H.h, C.byref(o))
-    assert H.optimization() == abi.AVM_ERR_UNSUPPORTED and "ESTIMATE_TD" in H.err()
+    import torch
+    if not torch.cuda.is_available():
+        assert H.optimization() == abi.AVM_ERR_NO_DEVICE
 
 
 def test_cpp_selector_ground_truth_horizon_moves_its_cursor_on_every_call(oracle):
@@ -345,6 +357,50 @@ def test_cpp_estimator_optimization_matches_oracle_and_chains_the_prior(oracle, 
     oracle.window_solve(o, wo, buffers.PriorOutArrays.alloc(1), so)
     s2 = H.state()
     assert rel(s2["pose"], wo.a["pose"][0]) < 1e-5 and rel(s2["speedbias"], wo.a["speedbias"][0]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_cpp_estimator_optimization_with_extrinsic_td_relocalization_and_failure_anchor(oracle):
+    """ESTIMATE_EXTRINSIC, ESTIMATE_TD, relocalization_info and failure_occur through the C++ object: the members come back like
+    the reference leaves them (estimator.cpp:521-604): td, tic / ric, relo_Pose, the pose-graph outputs, both flags cleared."""
+    w = synth.make_windows(1, first_id=33, tracks="sparse", n_feat=90, max_feat=150, max_obs=1650, td_true=0.01, relo=True)
+    anchor = w.a["pose"][:, 0].copy()
+    anchor[:, :3] += np.array([0.5, 0.25, -0.125])
+    w.a["failure_occur"], w.a["last_pose0"] = np.array([1], np.int32), anchor
+    w.a["ex_pose"][:, :3] += 0.01
+    o = abi.default_options()
+    o.estimate_extrinsic, o.estimate_td = 1, 1
+    H = Host()
+    H.load(w, feat_id=1000 + 3 * np.arange(int(w.a["n_feat"][0])))
+    H.set_options(o)
+    H.set_flags(solver_flag=1, marginalization_flag=0)
+    assert H.optimization() == 0, H.err()
+    wo, po, so = w.copy(), buffers.PriorOutArrays.alloc(1), buffers.summary_alloc(1)
+    oracle.window_solve(o, wo, po, so)
+    s, x = H.state(), H.extras()
+    assert s["summary"]["accept_mask"][0] == so["accept_mask"][0]
+    assert rel(s["pose"], wo.a["pose"][0]) < 1e-6 and rel(s["speedbias"], wo.a["speedbias"][0]) < 1e-6 and rel(s["ex_pose"], wo.a["ex_pose"][0]) < 1e-6
+    assert abs(x["td"] - wo.a["td"][0]) < 1e-6 * abs(wo.a["td"][0]) and abs(x["td"]) > 1e-5
+    assert rel(x["relo_pose"], wo.a["relo_pose"][0]) < 1e-6
+    assert not x["relocalization_info"] and not x["failure_occur"]
+    assert np.abs(s["pose"][0, :3] - anchor[0, :3]).max() < 1e-12                       # re-anchored on last_P0
+    # the pose-graph outputs, restated with numpy from the oracle's relo_r / relo_t and Ps / Rs (estimator.cpp:597-604)
+    rp, r = wo.a["relo_pose"][0], int(w.a["relo_frame"][0])
+    Rr, Ri = synth.R_from_quat(rp[3:]), synth.R_from_quat(wo.a["pose"][0, r, 3:])
+    yaw = lambda R: np.degrees(np.arctan2(R[1, 0], R[0, 0]))
+    prev_t = w.a["relo_pose"][0, :3] + np.array([0.3, -0.2, 0.1])
+    prev_R = synth.R_from_quat(np.array([0.0, 0.0, np.sin(0.2), np.cos(0.2)]))
+    dyaw = yaw(prev_R) - yaw(Rr)
+    cy, sy = np.cos(np.radians(dyaw)), np.sin(np.radians(dyaw))
+    assert abs(x["drift_correct_yaw"] - dyaw) < 1e-6
+    assert rel(x["drift_correct_t"], prev_t - np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]]) @ rp[:3]) < 1e-6
+    assert rel(x["relo_relative_t"], Rr.T @ (wo.a["pose"][0, r, :3] - rp[:3])) < 1e-5
+    assert rel(synth.R_from_quat(x["relo_relative_q"]), Rr.T @ Ri) < 1e-6
+    assert abs(x["relo_relative_yaw"] - (yaw(Ri) - yaw(Rr))) < 1e-6
+    # the new prior carries td (n = 76) and chains into the next optimization()
+    pg = H.prior()
+    assert pg.a["n"][0] == po.a["n"][0] == 76 and (pg.a["blk_kind"][0, :13] == po.a["blk_kind"][0, :13]).all() and pg.a["blk_kind"][0, 12] == abi.BLK_TD
+    assert H.optimization() == 0, H.err()
 
 
 @pytest.mark.gpu
