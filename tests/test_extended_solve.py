@@ -196,5 +196,17 @@ def test_marginalization_carries_td_and_the_estimated_extrinsic(ctx, oracle, fla
     so2 = buffers.summary_alloc(3)
     oracle.window_solve(o2, co, None, so2)
     assert np.array_equal(s2["accept_mask"], so2["accept_mask"])
-    for k in ("pose", "speedbias", "td", "ex_pose"):
-        assert rel(cg.a[k], co.a[k]) < 5e-6, (k, rel(cg.a[k], co.a[k]))
+    # yardstick: the oracle's own chained solution when the inputs of its marginalization move by one ulp (td and the
+    # extrinsic translation are the weakly observable directions of a one-second window)
+    ref = wo.copy()
+    install_prior(ref, marginalize_only(wo, o))
+    oracle.window_solve(o2, ref, None, buffers.summary_alloc(3))
+    own = {k: 0.0 for k in ("pose", "speedbias", "td", "ex_pose")}
+    for sd in range(4):
+        ck = wo.copy()
+        install_prior(ck, marginalize_only(ulp_perturbed(wo, sd), o))
+        oracle.window_solve(o2, ck, None, buffers.summary_alloc(3))
+        for k in own:
+            own[k] = max(own[k], rel(ck.a[k], ref.a[k]))
+    for k in own:
+        assert rel(cg.a[k], co.a[k]) < max(1e-6, 2.0 * own[k]), (k, rel(cg.a[k], co.a[k]), own[k])
