@@ -9,9 +9,42 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen'ed (avm_comm_*), a single-GPU host never needs it
+
 #include "kernels.hpp"
 
 using namespace avm;
+
+namespace {
+// raw rccl.h entry points, resolved on first use
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load() {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);  // (a process that already maps an RCCL under this soname, e.g. PyTorch's, gets that one)
+      if (lib) break;
+    }
+    if (!lib) return false;
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    return GetUniqueId && CommInitRank && AllGather && CommDestroy && GetErrorString;
+  }
+};
+Rccl& rccl() {
+  static Rccl r;
+  return r;
+}
+}  // namespace
 
 struct avm_ctx {
   int device = 0;
@@ -33,6 +66,8 @@ struct avm_ctx {
   bool packed_in = false;  // the last stage_window_batch took the packed path (states are contiguous on the device)
   hipEvent_t ev[8];
   std::map<std::string, float> last_ms;
+  ncclComm_t comm = nullptr;  // avm_comm_init
+  int comm_ranks = 0, comm_rank = 0;
 };
 
 namespace {
@@ -359,6 +394,7 @@ void avm_destroy(avm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)avm_comm_destroy(c);
   for (auto& kv : c->pool)
     if (kv.second.first) (void)hipFree(kv.second.first);
   for (auto& kv : c->pinned)
@@ -372,6 +408,62 @@ void avm_destroy(avm_ctx* c) {
 }
 
 const char* avm_last_error(const avm_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+// ---- multi-GPU: raw RCCL (rccl.h) all-gather of the final states, one communicator per ctx ---------------------------------
+#define RCCLCHK(ctx, call)                                                                                  \
+  do {                                                                                                      \
+    ncclResult_t r__ = (call);                                                                              \
+    if (r__ != ncclSuccess) {                                                                               \
+      (ctx)->err = std::string(#call) + ": " + rccl().GetErrorString(r__);                                  \
+      return AVM_ERR_HIP;                                                                                   \
+    }                                                                                                       \
+  } while (0)
+
+int avm_comm_unique_id(avm_ctx* c, void* id) {
+  if (!c || !id) return AVM_ERR_INVALID;
+  if (!rccl().load()) return fail(c, AVM_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded (dlopen)");
+  static_assert(sizeof(ncclUniqueId) == AVM_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  RCCLCHK(c, rccl().GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof u);
+  return AVM_OK;
+}
+
+int avm_comm_init(avm_ctx* c, int32_t n_ranks, int32_t rank, const void* id) {
+  if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return c ? fail(c, AVM_ERR_INVALID, "bad rank / n_ranks / id") : AVM_ERR_INVALID;
+  if (c->comm) return fail(c, AVM_ERR_INVALID, "this ctx already has a communicator (avm_comm_destroy first)");
+  if (!rccl().load()) return fail(c, AVM_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded (dlopen)");
+  (void)hipSetDevice(c->device);
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  RCCLCHK(c, rccl().CommInitRank(&c->comm, n_ranks, u, rank));
+  c->comm_ranks = n_ranks, c->comm_rank = rank;
+  return AVM_OK;
+}
+
+int avm_gather_states(avm_ctx* c, const double* send, double* recv, size_t count) {
+  if (!c || !send || !recv) return c ? fail(c, AVM_ERR_INVALID, "null buffer") : AVM_ERR_INVALID;
+  if (!c->comm) return fail(c, AVM_ERR_INVALID, "avm_comm_init has not been called on this ctx");
+  (void)hipSetDevice(c->device);
+  if (count == 0) return AVM_OK;
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  RCCLCHK(c, rccl().AllGather(send, recv, count, ncclDouble, c->comm, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->last_ms["gather_states"] = ms;
+  return AVM_OK;
+}
+
+int avm_comm_destroy(avm_ctx* c) {
+  if (!c) return AVM_ERR_INVALID;
+  if (c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)rccl().CommDestroy(c->comm);
+    c->comm = nullptr, c->comm_ranks = 0;
+  }
+  return AVM_OK;
+}
 
 int avm_ctx_stream(const avm_ctx* c, void** stream) {
   if (!c || !stream) return AVM_ERR_INVALID;

@@ -63,6 +63,10 @@ def lib():
         L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
         L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
         L.avm_slide_window.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.c_int32, C.c_int32, C.c_double]
+        L.avm_comm_unique_id.argtypes = [vp, C.c_void_p]
+        L.avm_comm_init.argtypes = [vp, C.c_int32, C.c_int32, C.c_void_p]
+        L.avm_gather_states.argtypes = [vp, abi.c_dp, abi.c_dp, C.c_size_t]
+        L.avm_comm_destroy.argtypes = [vp]
         L.avm_gt_load_csv.restype = vp
         L.avm_gt_load_csv.argtypes = [C.c_char_p]
         L.avm_gt_from_rows.restype = vp
@@ -80,7 +84,7 @@ EXPORTS = [
     "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
     "avm_window_solve_batch", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
     "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
-    "avm_ctx_stream", "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
+    "avm_ctx_stream", "avm_comm_unique_id", "avm_comm_init", "avm_gather_states", "avm_comm_destroy", "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
 ]
 
 
@@ -112,6 +116,23 @@ class Context:
     def check(self, rc: int, what: str):
         if rc != abi.AVM_OK:
             raise AvmError(f"{what} failed: status {rc}: {self._L.avm_last_error(self.h).decode()}")
+
+    # ---- multi-GPU: the library's own RCCL communicator (include/avm.h)
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self.check(self._L.avm_comm_unique_id(self.h, buf), "avm_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, n_ranks: int, rank: int, uid: bytes):
+        assert len(uid) == 128
+        self.check(self._L.avm_comm_init(self.h, int(n_ranks), int(rank), C.create_string_buffer(uid, 128)), "avm_comm_init")
+
+    def gather_states(self, send, recv, count: int):
+        """ncclAllGather of `count` doubles per rank (device tensors): recv[r * count : (r + 1) * count] = rank r's send."""
+        self.check(self._L.avm_gather_states(self.h, abi.dptr(send), abi.dptr(recv), int(count)), "avm_gather_states")
+
+    def comm_destroy(self):
+        self.check(self._L.avm_comm_destroy(self.h), "avm_comm_destroy")
 
     def kernel_ms(self, which: str) -> float:
         ms = C.c_float(0)

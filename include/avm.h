@@ -42,6 +42,7 @@
 #ifndef AVM_H_
 #define AVM_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -413,6 +414,20 @@ int avm_fsel_select_batch(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch
  * [P][max_cand][3H][3H] (+ valid flag [P][max_cand]); for parity tests. */
 int avm_fsel_information(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, double* omega,
                          double* delta_cand, int32_t* cand_valid);
+
+/* ---- multi-GPU: windows and selector frames are independent, so a job is one process per GPU, each with its
+ * own ctx and a contiguous block of the work; the only exchange is a gather of the final states.  The library owns a raw
+ * RCCL communicator for it (rccl.h over xGMI; librccl.so.1 is dlopen'ed on first use, a single-GPU host never loads it).
+ *   avm_comm_unique_id   rank 0 creates the 128-byte ncclUniqueId; the caller carries it to the other ranks (any channel)
+ *   avm_comm_init        collective over all ranks: ncclCommInitRank on this ctx's device
+ *   avm_gather_states    ncclAllGather of `count` doubles per rank, device pointers, on the ctx stream; returns when done.
+ *                        recv is [n_ranks][count]; rank r's block lands at recv + r * count on every rank
+ *   avm_comm_destroy     (also done by avm_destroy) */
+#define AVM_COMM_ID_BYTES 128
+int avm_comm_unique_id(avm_ctx* ctx, void* id /* AVM_COMM_ID_BYTES */);
+int avm_comm_init(avm_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id);
+int avm_gather_states(avm_ctx* ctx, const double* send, double* recv, size_t count);
+int avm_comm_destroy(avm_ctx* ctx);
 
 /* the HIP stream (hipStream_t) every call on this ctx is enqueued on, for callers that produce device-resident inputs
  * on streams of their own (see "stream ordering" above) */
