@@ -172,7 +172,15 @@ def main():
             uid = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).clone()
         uid = uid.to(dev)
         dist.broadcast(uid, 0)
-        ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        ok = 1
+        try:
+            ctx.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        except Exception as e:  # keep the job alive: every rank falls back to torch.distributed together
+            ok = 0
+            print(f"[bench] rank {rank}: avm_comm_init failed ({e}); falling back to torch.distributed", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_lib_gather = bool(flag.item())
 
     marg = opt.marginalization_flag != abi.MARGIN_NONE
     prior_slots = buffers.PriorOutArrays.alloc(W, win.dims["max_prior"], win.dims["max_pblk"], dev) if marg else None
