@@ -337,7 +337,7 @@ def test_solve_is_bit_reproducible_and_shard_invariant(estimator):
         assert np.array_equal(np.concatenate([lo.a[k], hi.a[k]]), a.a[k])
 
 
-def test_full_size_batch_properties(ctx):
+def test_full_size_batch_properties(ctx, oracle):
     """BASELINE.json configs[3] size (4096 windows x 150 features x 1500 factors, MARGIN_OLD) through size-independent
     properties: every copy of a window gives bit-identical states / priors whichever workgroup slot solved it, costs
     decrease, everything is finite, and the new prior reproduces A' = J^T J of the oracle-checked small case shape."""
@@ -355,6 +355,13 @@ def test_full_size_batch_properties(ctx):
         assert (a == a[0]).all(), k                                   # 128 copies of each of the 32 windows
     J = prior.a["J"].reshape(128, 32, 96, 96)
     assert (J == J[0]).all()
+    # ... and the 32 distinct windows of the BASELINE-size batch against the oracle: same decisions, states within tolerance
+    wo, so, po = base.copy(), buffers.summary_alloc(32), buffers.PriorOutArrays.alloc(32)
+    oracle.window_solve(opt, wo, po, so, n_threads=8)
+    assert np.array_equal(summ["accept_mask"][:32], so["accept_mask"]) and np.array_equal(summ["termination"][:32], so["termination"])
+    for k in ("pose", "speedbias", "inv_depth"):
+        assert rel(out.a[k][:32], wo.a[k]) < STATE_TOL, (k, rel(out.a[k][:32], wo.a[k]))
+    assert np.array_equal(prior.a["n"][:32], po.a["n"]) and np.array_equal(prior.a["blk_kind"][:32], po.a["blk_kind"])
     # the prior is a square root: J^T J is symmetric positive semi-definite with the kept dimension's rank or less
     A = J[0, 0, :75, :75].T @ J[0, 0, :75, :75]
     assert np.linalg.eigvalsh(A).min() > -1e-6 * np.abs(A).max()
