@@ -16,6 +16,7 @@
 // This is the same Cholesky with the constant leading pivots factored once — the same kind of
 // hoist as IMUFactor's sqrt_info.  All FP64; selection order is deterministic.
 #include <cfloat>
+#include <cstdlib>
 
 #include "devmath.hpp"
 #include "kernels.hpp"
@@ -29,6 +30,7 @@ constexpr int FS_CPW = 4;  // candidates per wavefront in the Delta slices of th
 
 struct FselDev {
   avm_fsel_batch b;  // device pointers
+  int no_key_rule;   // test switch (AVM_FSEL_NO_KEY_RULE=1): skip the std::map equal-key rule of sortedlogDetUB
   // work buffers
   double* C;        // [P][T*T] current reduced position information (C0 + used + OmegaS)
   double* dpp;      // [P][T]   un-reduced diagonal of the position rows (for the Hadamard bound)
@@ -488,31 +490,65 @@ __global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) 
   const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
   if (round >= kappa || A.done[p]) return;
   const int nc = b.n_cand[p];
-  // lexicographic max of (fValue, ub, id) over live candidates with fValue > fMax0 = -1.0 (NaN never wins)
-  double bf = -1.0, bu = -DBL_MAX;
-  int bi = -1;
-  for (int l = t; l < nc; l += FS_NT) {
-    if (!A.valid[(size_t)p * b.max_cand + l] || A.black[(size_t)p * b.max_cand + l]) continue;
-    const double f = A.fval[(size_t)p * b.max_cand + l], u = A.ub[(size_t)p * b.max_cand + l];
-    if (!(f > -1.0)) continue;
-    if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
-  }
   auto better = [](double f, double u, int i, double f2, double u2, int i2) {
     if (i2 < 0) return false;
     if (i < 0) return true;
     return f2 > f || (f2 == f && (u2 > u || (u2 == u && i2 > i)));
   };
-  for (int o = 32; o > 0; o >>= 1) {
-    const double f2 = __shfl_xor(bf, o, 64), u2 = __shfl_xor(bu, o, 64);
-    const int i2 = __shfl_xor(bi, o, 64);
-    if (better(bf, bu, bi, f2, u2, i2)) bf = f2, bu = u2, bi = i2;
-  }
-  if ((t & 63) == 0) s_f[t >> 6] = bf, s_u[t >> 6] = bu, s_i[t >> 6] = bi;
+  // sortedlogDetUB keeps the upper bounds in a std::map<double, int> (feature_selector.cpp:724): of two live candidates
+  // with BIT-IDENTICAL upper bounds only the later (higher) id survives the round, the other one is never scored.  The
+  // argmax below therefore runs until its winner is not shadowed by a higher id with the same key; `shadowed` holds the
+  // (at most a handful of) candidates that were ruled out this way.  One extra pass over the bounds in the usual case.
+  constexpr int MAXSH = 8;
+  __shared__ int s_shadow[MAXSH];
+  __shared__ int s_nsh, s_hit;
+  if (t == 0) s_nsh = 0;
   __syncthreads();
+  double bf;
+  int bi;
+  for (;;) {
+    // lexicographic max of (fValue, ub, id) over live candidates with fValue > fMax0 = -1.0 (NaN never wins)
+    bf = -1.0;
+    double bu = -DBL_MAX;
+    bi = -1;
+    const int nsh = s_nsh;
+    for (int l = t; l < nc; l += FS_NT) {
+      if (!A.valid[(size_t)p * b.max_cand + l] || A.black[(size_t)p * b.max_cand + l]) continue;
+      bool sh = false;
+      for (int q = 0; q < nsh; q++) sh |= s_shadow[q] == l;
+      if (sh) continue;
+      const double f = A.fval[(size_t)p * b.max_cand + l], u = A.ub[(size_t)p * b.max_cand + l];
+      if (!(f > -1.0)) continue;
+      if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double f2 = __shfl_xor(bf, o, 64), u2 = __shfl_xor(bu, o, 64);
+      const int i2 = __shfl_xor(bi, o, 64);
+      if (better(bf, bu, bi, f2, u2, i2)) bf = f2, bu = u2, bi = i2;
+    }
+    if ((t & 63) == 0) s_f[t >> 6] = bf, s_u[t >> 6] = bu, s_i[t >> 6] = bi;
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < FS_NT / 64; w++)
+        if (better(bf, bu, bi, s_f[w], s_u[w], s_i[w])) bf = s_f[w], bu = s_u[w], bi = s_i[w];
+      s_win = bi, s_f[0] = bf, s_u[0] = bu, s_hit = 0;
+    }
+    __syncthreads();
+    const int cand = s_win;
+    if (cand < 0) break;
+    const double cu = s_u[0];
+    int hit = 0;
+    for (int l = cand + 1 + t; l < nc; l += FS_NT)  // a live candidate with a higher id and the same key?
+      if (A.valid[(size_t)p * b.max_cand + l] && !A.black[(size_t)p * b.max_cand + l] && A.ub[(size_t)p * b.max_cand + l] == cu) hit = 1;
+    if (hit) s_hit = 1;
+    __syncthreads();
+    if (!s_hit || s_nsh >= MAXSH || A.no_key_rule) break;  // (more than MAXSH chained collisions in one round: keep the last winner)
+    __syncthreads();
+    if (t == 0) s_shadow[s_nsh++] = cand;
+    __syncthreads();
+  }
   if (t == 0) {
-    for (int w = 1; w < FS_NT / 64; w++)
-      if (better(bf, bu, bi, s_f[w], s_u[w], s_i[w])) bf = s_f[w], bu = s_u[w], bi = s_i[w];
-    s_win = bi;
+    bi = s_win, bf = s_f[0];
     if (bi >= 0) {
       const int k = A.nsel[p];
       A.out.selected_ids[(size_t)p * b.max_features + k] = b.cand_id[(size_t)p * b.max_cand + bi];
@@ -552,6 +588,10 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
                        hipStream_t stream) {
   FselDev d;
   d.b = b;
+  {
+    const char* nk = getenv("AVM_FSEL_NO_KEY_RULE");
+    d.no_key_rule = (nk && nk[0] == '1') ? 1 : 0;
+  }
   d.C = w.C, d.dpp = w.dpp, d.consts = w.consts, d.delta = w.delta, d.delta_u = w.delta_u, d.valid = w.valid, d.valid_u = w.valid_u;
   d.black = w.black, d.fval = w.fval, d.ub = w.ub, d.nsel = w.nsel, d.done = w.done, d.omega_out = omega_out, d.out = out;
   const int H = b.horizon, T = 3 * H;

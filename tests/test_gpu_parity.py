@@ -274,6 +274,33 @@ def test_window_solve_degenerate_inputs(estimator, oracle):
     _assert_state_parity(wg, wo, sg, so)
 
 
+def test_gauge_fix_near_pitch_90_takes_the_full_rotation_branch(estimator, oracle):
+    """double2vector (estimator.cpp:536-546): within one degree of pitch +-90 the yaw-only correction is replaced by the full
+    rot_diff = Rs[0] * R00^T.  The whole synthetic world (poses, velocities, gravity) is turned so that frame 0 looks straight
+    up / down; observations and IMU samples are body-frame quantities and stay."""
+    for wid, target in ((60, 89.6), (61, -89.5), (62, 90.8)):
+        w = synth.make_windows(1, first_id=wid, tracks="sparse", n_feat=60, max_feat=150, with_prior=False)
+        R0 = synth.R_from_quat(w.a["pose"][0, 0, 3:])
+        s_, c_ = np.sin(np.radians(target)), np.cos(np.radians(target))
+        x, y = np.array([c_, 0.0, -s_]), np.array([0.0, 1.0, 0.0])       # R2ypr: pitch = atan2(-R[2,0], .) -> first column (c, 0, -s)
+        Rw = np.stack([x, y, np.cross(x, y)], 1) @ R0.T
+        for f in range(11):
+            w.a["pose"][0, f, :3] = Rw @ w.a["pose"][0, f, :3]
+            w.a["pose"][0, f, 3:] = synth.quat_from_R(Rw @ synth.R_from_quat(w.a["pose"][0, f, 3:]))
+            w.a["speedbias"][0, f, :3] = Rw @ w.a["speedbias"][0, f, :3]
+        o = abi.default_options()
+        o.marginalization_flag = abi.MARGIN_NONE
+        o.g[0], o.g[1], o.g[2] = Rw @ np.array([0, 0, 9.81007])
+        Rb = synth.R_from_quat(w.a["pose"][0, 0, 3:])
+        pitch = np.degrees(np.arctan2(-Rb[2, 0], Rb[0, 0] * np.cos(np.arctan2(Rb[1, 0], Rb[0, 0])) + Rb[1, 0] * np.sin(np.arctan2(Rb[1, 0], Rb[0, 0]))))
+        assert abs(abs(pitch) - 90) < 1.0
+        wg, wo, sg, so = _solve_both(estimator, oracle, w, o)
+        _assert_state_parity(wg, wo, sg, so)
+        assert (sg["final_cost"] < 1e-2 * sg["initial_cost"]).all()
+        # frame 0 keeps its WHOLE attitude in this branch, not just its yaw
+        assert rel(synth.R_from_quat(wg.a["pose"][0, 0, 3:]), Rb) < 1e-9
+
+
 def test_small_trust_region_dogleg_branches_parity(estimator, oracle):
     o = abi.default_options()
     o.marginalization_flag = abi.MARGIN_NONE
@@ -837,6 +864,54 @@ def test_selector_headline_500_to_150(selector, oracle):
     oracle.fsel_select(pr, oo)
     assert int(out.a["n_selected"][0]) == 150
     assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+
+
+def _mirror_frame(H=5, npairs=20, n_used=3, seed=0):
+    """A frame whose candidates come in mirror pairs (x, y) / (-x, y) of equal probability in front of a camera that moves
+    straight along its optical axis (identity attitudes, identity extrinsics): the DIAGONALS of the two Delta_l are
+    bit-identical (every x enters them squared), the off-diagonals are not - equal Hadamard upper bounds, different logdets.
+    Asymmetric already-tracked features make Omega asymmetric under the mirror."""
+    rng = np.random.default_rng(seed)
+    pr = synth.make_fsel(1, horizon=H, n_cand=2 * npairs, n_used=n_used, n_cloud=30, max_features=n_used + 12)
+    a = pr.a
+    a["hor_quat"][0, :] = [0, 0, 0, 1]
+    a["hor_pos"][0, :, :] = 0
+    a["hor_pos"][0, :, 2] = 0.15 * np.arange(H + 1)
+    pr.scalars["q_ic"], pr.scalars["t_ic"] = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    xy = np.stack([rng.uniform(0.05, 0.5, npairs), rng.uniform(-0.3, 0.3, npairs)], 1)
+    a["cand_xy"][0, 0:2 * npairs:2], a["cand_xy"][0, 1:2 * npairs:2] = xy, xy * np.array([-1, 1])
+    p = rng.uniform(0.3, 1.0, npairs).astype(np.float32).astype(float)
+    a["cand_prob"][0, 0:2 * npairs:2], a["cand_prob"][0, 1:2 * npairs:2] = p, p
+    a["n_cloud"][0], a["cloud_xy"][0, 0], a["cloud_depth"][0, 0] = 1, [0, 0], 6.0      # one cloud point: the same depth for everybody
+    a["used_xy"][0, :n_used] = np.stack([rng.uniform(0.1, 0.5, n_used), rng.uniform(-0.3, 0.3, n_used)], 1)
+    return pr
+
+
+def test_selector_equal_upper_bounds_follow_the_std_map_rule(selector, oracle, monkeypatch):
+    """sortedlogDetUB stores the bounds in a std::map<double, int> (feature_selector.cpp:724): of two live candidates with
+    bit-identical bounds only the higher id is scored in that round.  The oracle keeps the map; the device reproduces the
+    rule in its pick kernel.  With the rule switched off the same frame selects in a different order - i.e. the frame really
+    exercises it."""
+    for seed in (0, 1):
+        pr = _mirror_frame(seed=seed)
+        _, dl, va = oracle.fsel_information(pr)
+        assert va.all() and np.array_equal(np.diag(dl[0, 0]), np.diag(dl[0, 1])) and np.abs(dl[0, 0] - dl[0, 1]).max() > 1e-3
+        oo = buffers.FselOutArrays.alloc(1, pr.dims["max_features"])
+        oracle.fsel_select(pr, oo)
+        out = selector.select_batch(pr)
+        assert np.array_equal(out.a["n_selected"], oo.a["n_selected"]) and np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+        # in every pair the higher id goes first, whatever the two logdets are
+        ids = pr.a["cand_id"][0].tolist()
+        order = [ids.index(s) for s in oo.a["selected_ids"][0, : oo.a["n_selected"][0]]]
+        assert all(order[k] % 2 == 1 and order[k + 1] == order[k] - 1 for k in range(0, len(order) - 1, 2)), order
+    monkeypatch.setenv("AVM_FSEL_NO_KEY_RULE", "1")
+    differs = 0
+    for seed in (0, 1):
+        pr = _mirror_frame(seed=seed)
+        oo = buffers.FselOutArrays.alloc(1, pr.dims["max_features"])
+        oracle.fsel_select(pr, oo)
+        differs += int(not np.array_equal(selector.select_batch(pr).a["selected_ids"], oo.a["selected_ids"]))
+    assert differs >= 1
 
 
 def test_selector_edge_cases(selector, oracle):
