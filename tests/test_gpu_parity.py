@@ -903,7 +903,9 @@ def test_selector_equal_upper_bounds_follow_the_std_map_rule(selector, oracle, m
         # in every pair the higher id goes first, whatever the two logdets are
         ids = pr.a["cand_id"][0].tolist()
         order = [ids.index(s) for s in oo.a["selected_ids"][0, : oo.a["n_selected"][0]]]
-        assert all(order[k] % 2 == 1 and order[k + 1] == order[k] - 1 for k in range(0, len(order) - 1, 2)), order
+        for k in range(0, 2 * 20, 2):   # while both members of a pair are live the lower id is shadowed: the higher id always goes first
+            if k in order:
+                assert k + 1 in order and order.index(k + 1) < order.index(k), (k, order)
     monkeypatch.setenv("AVM_FSEL_NO_KEY_RULE", "1")
     differs = 0
     for seed in (0, 1):
