@@ -916,6 +916,9 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   GET(black, int32_t, P * mc)
   GET(nsel, int32_t, P)
   GET(done, int32_t, P)
+  GET(live, int32_t, P * mc)
+  GET(pos, int32_t, P * mc)
+  GET(nlive, int32_t, P)
 #undef GET
   return AVM_OK;
 }

@@ -44,6 +44,9 @@ struct FselDev {
   double* ub;       // [P][max_cand]
   int32_t* nsel;    // [P] number selected so far
   int32_t* done;    // [P] 1 when a round found no winner (state is then frozen)
+  int32_t* live;    // [P][max_cand] indices of the candidates still in the race (valid, not yet selected), any order
+  int32_t* pos;     // [P][max_cand] position of candidate l in live[]
+  int32_t* nlive;   // [P]
   double* omega_out;  // optional [P][N*N] (tests)
   avm_fsel_out out;
 };
@@ -410,69 +413,117 @@ AVM_DEV double fs_readlane_d(double v, int srclane) {  // srclane must be wave-u
   return __hiloint2double(hi, lo);
 }
 
-// One candidate per wavefront, lane = row of the T x T matrix, registers = columns.  The factorization is the same
-// register-resident, square-root-free pivot chain as the solve's diagonal blocks (window_solve.hip, chol_diag_block):
-// pivots and column entries are broadcast through SGPRs with v_readlane (the previous version packed two candidates into
-// a wavefront and had to go through the LDS crossbar, ~930 ds_bpermute per pair), column j is divided by its pivot with
-// v_rcp_f64 + two Newton steps, and the rank-1 update of pivot j-1 is software-pipelined into the latency shadows of pivot
-// j's reciprocal chain.  logdet = sum_j log(d_j) over the LDL^T pivots (Utility::logdet sums log(diag(L)) of L L^T:
-// diag(L)_j = sqrt(d_j)); the logarithms are taken afterwards by all lanes at once and added up in pivot order.
-template <int T>
+// FOUR candidates per wavefront: candidate g lives in the 16-lane DPP row g of the wave.  The T x T matrix is cut into NB block
+// rows of BS <= 16 rows (T = 30: 2 x 15, T = 39: 3 x 13); lane r of the row holds row r of EVERY block row in registers
+// (block row bi: columns 0 .. (bi + 1) BS - 1), so an entry A[gk][gj] is broadcast to the whole candidate with a DPP
+// row_newbcast of lane gk % BS (two 32-bit DPP moves; the 64-bit DPP forms are ~50x slower on gfx950, scripts/ubench/dpp.hip)
+// and one broadcast feeds the updates of all block rows.  The factorization is the same right-looking, square-root-free
+// LDL^T as before (column j divided by its pivot with v_rcp_f64 + two Newton steps; junk above the diagonal of the diagonal
+// blocks is computed and never read), only the lanes are used four times as densely and there are no SGPR round trips:
+// 2 DPP moves + 1-3 FMAs per (pivot, column) pair for four candidates instead of 2 v_readlane + 1 FMA for one.
+// logdet = sum_j log(d_j) in pivot order; the Hadamard bound (sortedlogDetUB) is summed the same way for every candidate, so
+// mirror-image candidates still get bit-identical bounds (the std::map rule of the pick kernel depends on that).
+template <int K>
+AVM_DEV double fs_rowbcast_k(double v) {  // lane K of every 16-lane row -> the whole row (row_newbcast:K = dpp_ctrl 0x150 + K)
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, true);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+AVM_DEV double fs_rowbcast(double v, int k) {  // k is a compile-time constant at every call site (fully unrolled loops)
+  switch (k) {
+    case 0: return fs_rowbcast_k<0>(v);
+    case 1: return fs_rowbcast_k<1>(v);
+    case 2: return fs_rowbcast_k<2>(v);
+    case 3: return fs_rowbcast_k<3>(v);
+    case 4: return fs_rowbcast_k<4>(v);
+    case 5: return fs_rowbcast_k<5>(v);
+    case 6: return fs_rowbcast_k<6>(v);
+    case 7: return fs_rowbcast_k<7>(v);
+    case 8: return fs_rowbcast_k<8>(v);
+    case 9: return fs_rowbcast_k<9>(v);
+    case 10: return fs_rowbcast_k<10>(v);
+    case 11: return fs_rowbcast_k<11>(v);
+    case 12: return fs_rowbcast_k<12>(v);
+    case 13: return fs_rowbcast_k<13>(v);
+    case 14: return fs_rowbcast_k<14>(v);
+    default: return fs_rowbcast_k<15>(v);
+  }
+}
+
+constexpr int FS_CPWG = (FS_NT / 64) * 4;  // candidates per workgroup of the round kernel
+
+template <int T, int BS, int NB>
 __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int round) {
+  static_assert(BS * NB == T && BS <= 16, "block rows of at most 16 lanes");
   const avm_fsel_batch& b = A.b;
   const int p = blockIdx.y;
   const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
   if (round >= kappa || A.done[p]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int l = blockIdx.x * (FS_NT / 64) + wv;  // (wave-uniform)
-  const int nc = b.n_cand[p];
-  if (!(l < nc && A.valid[(size_t)p * b.max_cand + l] && !A.black[(size_t)p * b.max_cand + l])) return;
-  const double pr = b.cand_prob[(size_t)p * b.max_cand + l];
+  const int g = lane >> 4, r = min(lane & 15, BS - 1);  // candidate slot of this lane, its row inside every block row
+  // the candidates still in the race are kept compact (fsel_pick_kernel swap-removes the winner), so late rounds do not pay for
+  // the slots of the features already selected
+  const int nl = A.nlive[p];
+  const int slot = (blockIdx.x * (FS_NT / 64) + wv) * 4 + g;
+  const bool live = slot < nl;
+  if (!__any(live)) return;  // (wave-uniform)
+  const int l = A.live[(size_t)p * b.max_cand + min(slot, max(nl - 1, 0))];
+  const int lc = l;  // a slot past the end factors the last live candidate's matrix again and throws the result away
+  const double pr = b.cand_prob[(size_t)p * b.max_cand + lc];
   const double* C = A.C + (size_t)p * T * T;
-  const double* D = A.delta + ((size_t)p * b.max_cand + l) * T * T;
-  const int r = lane < T ? lane : T - 1;
-  double a[T];
+  const double* D = A.delta + ((size_t)p * b.max_cand + lc) * T * T;
+  // m[bi][c] = (C + p Delta)[bi BS + r][c], c < (bi + 1) BS.  Both matrices are symmetric, so the entry is fetched as
+  // [c][bi BS + r]: the 15 lanes of a candidate then read 15 consecutive doubles instead of 15 different cache lines
+  double m[NB][T];
 #pragma unroll
-  for (int k = 0; k < T; k++) a[k] = C[r * T + k] + pr * D[r * T + k];
-  // Hadamard upper bound (sortedlogDetUB): sum of log of the diagonal of Omega + OmegaS + p Delta
-  double ubt = (lane < T) ? log(A.dpp[(size_t)p * T + r] + pr * D[r * T + r]) : 0.0;
+  for (int bi = 0; bi < NB; bi++)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ubt += __shfl_xor(ubt, o, 64);
-  double myd = 1.0, uprev = 0.0;  // lane j keeps the pivot d_jj
+    for (int c = 0; c < (bi + 1) * BS; c++) m[bi][c] = C[c * T + bi * BS + r] + pr * D[c * T + bi * BS + r];
+  // Hadamard upper bound: sum over the rows, block row by block row, then across the 16 lanes in lane order
+  double ubl = 0.0;
+#pragma unroll
+  for (int bi = 0; bi < NB; bi++) ubl += log(A.dpp[(size_t)p * T + bi * BS + r] + pr * D[(bi * BS + r) * T + bi * BS + r]);
+  double ubt = 0.0;
+#pragma unroll
+  for (int k = 0; k < BS; k++) ubt += fs_rowbcast(ubl, k);
+  double dkeep[NB];  // lane j keeps the pivot of row bj BS + j
   bool bad = false;
 #pragma unroll
-  for (int j = 0; j < T; j++) {
-    if (j > 0) a[j] = fma(-uprev, fs_readlane_d(a[j - 1], j), a[j]);
-    const double djj = fs_readlane_d(a[j], j);
-    if (!(djj > 0.0)) bad = true;
-    myd = lane == j ? djj : myd;
-    double y = __builtin_amdgcn_rcp(djj), e = 0;
-    constexpr int NS = (T + 3) / 5;  // tail elements per slot (5 slots)
-#define AVM_FS_TAIL(slot)                                                                                  \
-  if (j > 0) {                                                                                             \
-    double sk[NS];                                                                                         \
-    _Pragma("unroll") for (int q = 0; q < NS; q++) sk[q] = fs_readlane_d(a[j - 1], min(j + 1 + (slot) + 5 * q, T - 1)); \
-    _Pragma("unroll") for (int q = 0; q < NS; q++)                                                         \
-      if (j + 1 + (slot) + 5 * q < T) a[j + 1 + (slot) + 5 * q] = fma(-uprev, sk[q], a[j + 1 + (slot) + 5 * q]); \
+  for (int bj = 0; bj < NB; bj++) {
+    dkeep[bj] = 1.0;
+#pragma unroll
+    for (int j = 0; j < BS; j++) {
+      const int gj = bj * BS + j;
+      const double djj = fs_rowbcast(m[bj][gj], j);
+      if (!(djj > 0.0)) bad = true;
+      dkeep[bj] = (lane & 15) == j ? djj : dkeep[bj];
+      double y = __builtin_amdgcn_rcp(djj), e = fma(-djj, y, 1.0);
+      y = fma(y, e, y);
+      e = fma(-djj, y, 1.0);
+      y = fma(y, e, y);
+      double mult[NB];
+#pragma unroll
+      for (int bi = bj; bi < NB; bi++) mult[bi] = m[bi][gj] * y;
+#pragma unroll
+      for (int bk = bj; bk < NB; bk++)
+#pragma unroll
+        for (int k = (bk == bj ? j + 1 : 0); k < BS; k++) {
+          const int gk = bk * BS + k;
+          const double v = fs_rowbcast(m[bk][gj], k);  // A[gk][gj]
+#pragma unroll
+          for (int bi = bk; bi < NB; bi++) m[bi][gk] = fma(-mult[bi], v, m[bi][gk]);
+        }
+    }
   }
-    AVM_FS_TAIL(0)
-    e = fma(-djj, y, 1.0);
-    AVM_FS_TAIL(1)
-    y = fma(y, e, y);
-    AVM_FS_TAIL(2)
-    e = fma(-djj, y, 1.0);
-    AVM_FS_TAIL(3)
-    y = fma(y, e, y);
-    AVM_FS_TAIL(4)
-#undef AVM_FS_TAIL
-    uprev = a[j] * y;
-  }
-  // log(sqrt(d_jj)) per lane, then the sum in pivot order (same order as a sequential accumulation)
-  const double mylog = (lane < T && myd > 0.0) ? 0.5 * log(myd) : 0.0;
+  // log(sqrt(d)) per lane and block row, summed in pivot order
   double ld = 0;
 #pragma unroll
-  for (int j = 0; j < T; j++) ld += fs_readlane_d(mylog, j);
-  if (lane == 0) {
+  for (int bj = 0; bj < NB; bj++) {
+    const double mylog = dkeep[bj] > 0.0 ? 0.5 * log(dkeep[bj]) : 0.0;
+#pragma unroll
+    for (int j = 0; j < BS; j++) ld += fs_rowbcast(mylog, j);
+  }
+  if (live && (lane & 15) == 0) {
     const double f = bad ? __builtin_nan("") : (A.consts[(size_t)p * 4] + 2.0 * ld);
     A.fval[(size_t)p * b.max_cand + l] = f;
     A.ub[(size_t)p * b.max_cand + l] = A.consts[(size_t)p * 4 + 1] + ubt;
@@ -489,7 +540,8 @@ __global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) 
   const int T = 3 * b.horizon;
   const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
   if (round >= kappa || A.done[p]) return;
-  const int nc = b.n_cand[p];
+  int32_t* live = A.live + (size_t)p * b.max_cand;
+  const int nl = A.nlive[p];
   auto better = [](double f, double u, int i, double f2, double u2, int i2) {
     if (i2 < 0) return false;
     if (i < 0) return true;
@@ -512,8 +564,8 @@ __global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) 
     double bu = -DBL_MAX;
     bi = -1;
     const int nsh = s_nsh;
-    for (int l = t; l < nc; l += FS_NT) {
-      if (!A.valid[(size_t)p * b.max_cand + l] || A.black[(size_t)p * b.max_cand + l]) continue;
+    for (int s = t; s < nl; s += FS_NT) {
+      const int l = live[s];
       bool sh = false;
       for (int q = 0; q < nsh; q++) sh |= s_shadow[q] == l;
       if (sh) continue;
@@ -538,8 +590,8 @@ __global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) 
     if (cand < 0) break;
     const double cu = s_u[0];
     int hit = 0;
-    for (int l = cand + 1 + t; l < nc; l += FS_NT)  // a live candidate with a higher id and the same key?
-      if (A.valid[(size_t)p * b.max_cand + l] && !A.black[(size_t)p * b.max_cand + l] && A.ub[(size_t)p * b.max_cand + l] == cu) hit = 1;
+    for (int s = t; s < nl; s += FS_NT)  // a live candidate with a higher id and the same key?
+      if (live[s] > cand && A.ub[(size_t)p * b.max_cand + live[s]] == cu) hit = 1;
     if (hit) s_hit = 1;
     __syncthreads();
     if (!s_hit || s_nsh >= MAXSH || A.no_key_rule) break;  // (more than MAXSH chained collisions in one round: keep the last winner)
@@ -556,6 +608,9 @@ __global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) 
       A.nsel[p] = k + 1;
       A.out.n_selected[p] = k + 1;
       A.black[(size_t)p * b.max_cand + bi] = 1;
+      const int at = A.pos[(size_t)p * b.max_cand + bi], last = live[nl - 1];  // swap-remove the winner from the live list
+      live[at] = last, A.pos[(size_t)p * b.max_cand + last] = at;
+      A.nlive[p] = nl - 1;
     } else {
       A.done[p] = 1;  // lMax == -1: nothing is added; later rounds would repeat the same state
     }
@@ -570,6 +625,25 @@ __global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) 
     C[idx] += pr * D[idx];
     if (idx / T == idx % T) A.dpp[(size_t)p * T + idx / T] += pr * D[idx];
   }
+}
+
+// the compact list of the candidates that take part in the greedy rounds: the valid ones, in ascending index (= id) order
+__global__ __launch_bounds__(64) void fsel_live_init_kernel(FselDev A) {
+  const avm_fsel_batch& b = A.b;
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int nc = b.n_cand[p];
+  int n = 0;
+  for (int base = 0; base < nc; base += 64) {
+    const int l = base + lane;
+    const bool ok = l < nc && A.valid[(size_t)p * b.max_cand + l] != 0;
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+      const int at = n + __popcll(m & ((1ull << lane) - 1));
+      A.live[(size_t)p * b.max_cand + at] = l, A.pos[(size_t)p * b.max_cand + l] = at;
+    }
+    n += __popcll(m);
+  }
+  if (lane == 0) A.nlive[p] = n;
 }
 
 }  // namespace
@@ -594,6 +668,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   }
   d.C = w.C, d.dpp = w.dpp, d.consts = w.consts, d.delta = w.delta, d.delta_u = w.delta_u, d.valid = w.valid, d.valid_u = w.valid_u;
   d.black = w.black, d.fval = w.fval, d.ub = w.ub, d.nsel = w.nsel, d.done = w.done, d.omega_out = omega_out, d.out = out;
+  d.live = w.live, d.pos = w.pos, d.nlive = w.nlive;
   const int H = b.horizon, T = 3 * H;
   const size_t lds = fsel_setup_lds_bytes(H);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fsel_setup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -602,15 +677,16 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems, 1 + (b.max_cand + cand_per_wg - 1) / cand_per_wg), dim3(FS_NT), lds, stream, d);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (!run_rounds) return hipSuccess;
-  const int per_block = FS_NT / 64;  // one candidate per wavefront
+  hipLaunchKernelGGL(fsel_live_init_kernel, dim3(b.n_problems), dim3(64), 0, stream, d);
+  const int per_block = FS_CPWG;  // four candidates per wavefront
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
   for (int r = 0; r < b.max_features; r++) {
     switch (T) {
-      case 6: hipLaunchKernelGGL(fsel_round_kernel<6>, grid, dim3(FS_NT), 0, stream, d, r); break;
-      case 9: hipLaunchKernelGGL(fsel_round_kernel<9>, grid, dim3(FS_NT), 0, stream, d, r); break;
-      case 15: hipLaunchKernelGGL(fsel_round_kernel<15>, grid, dim3(FS_NT), 0, stream, d, r); break;
-      case 30: hipLaunchKernelGGL(fsel_round_kernel<30>, grid, dim3(FS_NT), 0, stream, d, r); break;
-      case 39: hipLaunchKernelGGL(fsel_round_kernel<39>, grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 6: hipLaunchKernelGGL((fsel_round_kernel<6, 6, 1>), grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 9: hipLaunchKernelGGL((fsel_round_kernel<9, 9, 1>), grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 15: hipLaunchKernelGGL((fsel_round_kernel<15, 15, 1>), grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 30: hipLaunchKernelGGL((fsel_round_kernel<30, 15, 2>), grid, dim3(FS_NT), 0, stream, d, r); break;
+      case 39: hipLaunchKernelGGL((fsel_round_kernel<39, 13, 3>), grid, dim3(FS_NT), 0, stream, d, r); break;
       default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(fsel_pick_kernel, dim3(b.n_problems), dim3(FS_NT), 0, stream, d, r);

@@ -75,7 +75,7 @@ struct EvalArgs {
 // device work buffers of the feature selector (owned by the ctx)
 struct FselBuffers {
   double *C, *dpp, *consts, *delta, *delta_u, *fval, *ub;
-  int32_t *valid, *valid_u, *black, *nsel, *done;
+  int32_t *valid, *valid_u, *black, *nsel, *done, *live, *pos, *nlive;
 };
 
 // ---- table validation (every entry point that takes tables runs it before any kernel indexes with them) -----------
