@@ -31,6 +31,7 @@
 //    are normalised to full precision.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace avm {
@@ -50,7 +51,8 @@ constexpr int PL = 40;                        // lanes that hold columns (np <= 
 constexpr int P_PART = P_A + NMAX * LD;       // [2 buffers][2 values][NW][PL] partial dot products
 constexpr int P_B = P_PART + 2 * 2 * NW * PL;
 constexpr int P_DG = P_B + NMAX;              // running diagonal of the Cholesky factorization
-constexpr int P_END = P_DG + NMAX;
+constexpr int P_PIV = P_DG + NMAX;            // pivot sequence of the Cholesky factorization (ints), then 4 doubles of verdicts
+constexpr int P_END = P_PIV + NMAX / 2 + 4;
 
 __device__ __forceinline__ double nrm_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -92,7 +94,26 @@ __device__ __forceinline__ double wave_max_pos(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-__global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof) {
+// sum over the wavefront, result uniform (same DPP ladder as wave_max_pos; the order of the additions is fixed)
+__device__ __forceinline__ double wave_sum(double v) {
+#define AVM_DPP_ADD(ctrl, rmask)                                                                \
+  {                                                                                             \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, true);   \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, true);   \
+    v += __hiloint2double(hi, lo);                                                              \
+  }
+  AVM_DPP_ADD(0x111, 0xf)
+  AVM_DPP_ADD(0x112, 0xf)
+  AVM_DPP_ADD(0x114, 0xf)
+  AVM_DPP_ADD(0x118, 0xf)
+  AVM_DPP_ADD(0x142, 0xa)
+  AVM_DPP_ADD(0x143, 0xc)
+#undef AVM_DPP_ADD
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// `literal` != 0 forces the eigen-decomposition even where the Cholesky factor would do (AVM_PRIOR_LITERAL=1, for A/B tests)
+__global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof, int literal) {
   extern __shared__ char pe_smem[];
   double* lds = reinterpret_cast<double*>(pe_smem);
   double* A = lds + P_A;
@@ -135,6 +156,8 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
   // that every thread tracks (pad indices start eliminated).
   unsigned long long done_lo = n >= 64 ? 0ull : ~0ull << n, done_hi = n >= 64 ? ~0ull << (n - 64) : ~0ull;
   double dmax0 = 0.0;
+  int* piv = reinterpret_cast<int*>(lds + P_PIV);
+  int rank = 0;
   for (int j = 0; j < n; j++) {
     // every wavefront finds the same pivot: largest remaining diagonal (lowest index among those equal in all but the
     // last 7 mantissa bits, which carry the index through the reduction)
@@ -164,6 +187,8 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
       if (col1 < NMAX) g[col1] = col1 == p ? bv * isq : (((done_hi >> lane) & 1ull) ? 0.0 : r1 * isq);
     }
     if (p < 64) done_lo |= 1ull << p; else done_hi |= 1ull << (p - 64);
+    if (t == 0) piv[j] = p;
+    rank = j + 1;
     __syncthreads();
     // A <- A - g g^T.  Eliminated rows / columns have g = 0; row and column p are left alone (g_p is zeroed for the update)
     {
@@ -186,6 +211,68 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
     __syncthreads();
   }
   __syncthreads();
+
+  // ---- The prior is a SQUARE ROOT of A' (marginalization_factor.cpp:283-301): linearized_jacobians = diag(sqrt S) V^T,
+  // linearized_residuals = diag(1 / sqrt S) V^T b'.  Every consumer - MarginalizationFactor::Evaluate in the next solve and in
+  // the next marginalization - sees it only as a residual block r0 + J dx without a loss function, i.e. through J^T J = A',
+  // J^T r0 = b' and |r0|^2 = b'^T A'^-1 b'; any J' = Q J, r0' = Q r0 with Q orthogonal is the same prior.  When NO eigenvalue
+  // is clamped (lambda_min(A') > eps), the transposed Cholesky factor is such a pair: J = G^T (rows = the columns g_p in pivot
+  // order), r0 = G^-1 b' - and it is already here.  The eigen-decomposition (7-8 Jacobi sweeps, ~10x the cost of everything
+  // above) is only needed when an eigenvalue may fall under the clamp.  That is decided rigorously and with a wide margin:
+  //   full rank reached, and  lambda_min(A') = 1 / |G^-1|_2^2 >= 1 / (|G^-1|_1 |G^-1|_inf) > 1000 eps,
+  // the two norms bounded from above by one triangular solve each with the comparison matrix M(G) (|diagonal|, -|off-diagonal|):
+  // |G^-1| e <= M(G)^-1 e elementwise (Higham, Accuracy and Stability of Numerical Algorithms, section 8.2).  Typical windows with a
+  // prior have lambda_min ~ 1e2 against the 1e-5 asked for.  Wavefront 0 solves for r0, wavefronts 1 and 2 for the two bounds.
+  double* verdict = lds + P_PIV + NMAX / 2;
+  if (!literal && rank == n) {
+    // entries of G in pivot order: G[p_j][i] = g_{p_i}[p_j] = A[p_i * LD + p_j], zero for i > j (p_j was eliminated before p_i)
+    if (wv < 3) {
+      const int i0 = lane, i1 = lane + 64;  // this lane's share of the dot products: pivots i0 and i1
+      const int pi0 = piv[min(i0, n - 1)], pi1 = piv[min(i1, n - 1)];
+      double y0 = 0.0, y1 = 0.0;  // solution entries of pivots i0, i1 (kept by their lanes)
+      if (wv < 2) {
+        // forward: y_j = (rhs_j -+ sum_{i < j} G[p_j][i] y_i) / G[p_j][j]   (wave 0: real entries and rhs = b'; wave 1: comparison matrix, rhs = 1)
+        for (int j = 0; j < n; j++) {
+          const int pj = piv[j];
+          const double a0 = i0 < j ? A[pi0 * LD + pj] : 0.0, a1 = i1 < j ? A[pi1 * LD + pj] : 0.0;
+          const double sacc = wv == 0 ? wave_sum(a0 * y0 + a1 * y1) : wave_sum(fabs(a0) * y0 + fabs(a1) * y1);
+          const double d = A[pj * LD + pj];
+          const double yj = wv == 0 ? (lds[P_B + pj] - sacc) / d : (1.0 + sacc) / fabs(d);
+          y0 = i0 == j ? yj : y0, y1 = i1 == j ? yj : y1;
+        }
+        if (wv == 0) {
+          if (i0 < n) gr[i0] = y0;
+          if (i1 < n) gr[i1] = y1;
+        } else {
+          const double m = wave_max_pos(fmax(i0 < n ? y0 : 0.0, i1 < n ? y1 : 0.0));  // >= |G^-1|_inf
+          if (lane == 0) verdict[0] = m;
+        }
+      } else {
+        // backward with the transposed comparison matrix: w_j = (1 + sum_{i > j} |G[p_i][j]| w_i) / |G[p_j][j]|, G[p_i][j] = A[p_j * LD + p_i]
+        for (int j = n - 1; j >= 0; j--) {
+          const int pj = piv[j];
+          const double a0 = (i0 > j && i0 < n) ? fabs(A[pj * LD + pi0]) : 0.0, a1 = (i1 > j && i1 < n) ? fabs(A[pj * LD + pi1]) : 0.0;
+          const double sacc = wave_sum(a0 * y0 + a1 * y1);
+          const double yj = (1.0 + sacc) / fabs(A[pj * LD + pj]);
+          y0 = i0 == j ? yj : y0, y1 = i1 == j ? yj : y1;
+        }
+        const double m = wave_max_pos(fmax(i0 < n ? y0 : 0.0, i1 < n ? y1 : 0.0));  // >= |G^-T|_inf = |G^-1|_1
+        if (lane == 0) verdict[1] = m;
+      }
+    }
+    __syncthreads();
+    const double inv_norm2_bound = verdict[0] * verdict[1];  // >= |G^-1|_2^2 = 1 / lambda_min(A')
+    if (inv_norm2_bound * (1000.0 * eps) < 1.0) {          // (NaN compares false)
+      // linearized_jacobians: row j = g_{p_j}^T
+      for (int e = t; e < n * n; e += NT) {
+        const int j = e / n, c = e - j * n;
+        gJ[(size_t)j * ldj + c] = A[piv[j] * LD + c];
+      }
+      if (prof && t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(prof + 25), (unsigned long long)((long long)__builtin_readcyclecounter() - t_start));
+      return;
+    }
+    __syncthreads();  // (wave 0 has overwritten b'-independent outputs only: gr is rewritten below, lds[P_B] is intact)
+  }
 
   // ---- one-sided Jacobi on the columns of G.  Lane k: X = column on position 2k, Y = column on position 2k+1.
   double X[RW], Y[RW];
@@ -330,6 +417,8 @@ __global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_w
 
 hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, hipStream_t stream) {
   static bool attr_set = false;
+  const char* lit = getenv("AVM_PRIOR_LITERAL");  // (read per call: the A/B test flips it inside one process)
+  const int literal = (lit && lit[0] == '1') ? 1 : 0;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe::prior_eig_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pe::P_END * 8);
     if (e != hipSuccess) return e;
@@ -340,7 +429,7 @@ hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, 
       fprintf(stderr, "[avm] prior_eig_kernel: %d workgroups / CU (LDS %d B)\n", nb, pe::P_END * 8);
     }
   }
-  hipLaunchKernelGGL(pe::prior_eig_kernel, dim3(n_windows), dim3(pe::NT), pe::P_END * 8, stream, po, n_windows, eps, prof);
+  hipLaunchKernelGGL(pe::prior_eig_kernel, dim3(n_windows), dim3(pe::NT), pe::P_END * 8, stream, po, n_windows, eps, prof, literal);
   return hipGetLastError();
 }
 

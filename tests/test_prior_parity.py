@@ -163,3 +163,48 @@ def test_ten_frame_solve_roll_solve_stream_matches_the_oracle(ctx, oracle, seq_i
             assert gap <= max(1e-6, 2.0 * own), (k, key, gap, own)
             worst = max(worst, gap)
     print(f"[stream {seq_id}] worst gpu-oracle gap over {n} frames: {worst:.2e}")
+
+
+def test_cholesky_square_root_is_the_same_prior_as_the_eigen_square_root(ctx, oracle, monkeypatch):
+    """prior_eig_kernel hands out the transposed Cholesky factor of A' whenever it can certify that no eigenvalue is near the
+    1e-8 clamp (the usual case once the window has a prior), and the reference's eigen form diag(sqrt S) V^T otherwise.  Both are
+    square roots of the same A' with the matching residual: identical J^T J, J^T r0 and |r0|^2, hence identical next solves.
+    Windows without any prior are rank deficient (gauge freedom): they must still take the eigen path."""
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    for tracks, nf, with_prior in (("sparse", 60, True), ("dense", 150, True), ("sparse", 80, False)):
+        w = synth.make_windows(3, first_id=500, tracks=tracks, n_feat=nf, max_feat=150, with_prior=with_prior)
+        wa, wb = w.copy(), w.copy()
+        monkeypatch.setenv("AVM_PRIOR_LITERAL", "1")
+        E.optimization(wa)
+        pa = E.last_marginalization_info
+        monkeypatch.setenv("AVM_PRIOR_LITERAL", "0")
+        E.optimization(wb)
+        pb = E.last_marginalization_info
+        assert np.array_equal(wa.a["pose"], wb.a["pose"]) and np.array_equal(pa.a["n"], pb.a["n"])
+        n_fast = 0
+        for i in range(3):
+            n = int(pa.a["n"][i])
+            Ja, Jb = pa.a["J"][i, :n, :n], pb.a["J"][i, :n, :n]
+            clamped = int((np.abs(Ja).max(1) == 0).sum())                 # eigenvalues the literal path zeroed (<= eps)
+            if clamped == 0:
+                assert np.count_nonzero(Jb) <= n * (n + 1) // 2, (i, "the certified Cholesky path was expected")   # a (permuted) triangle
+                assert np.count_nonzero(Ja) > n * (n + 1) // 2
+                n_fast += 1
+            else:   # an eigenvalue under the clamp: the eigen path either way, bit for bit
+                assert np.array_equal(Ja, Jb) and np.array_equal(pa.a["r"][i], pb.a["r"][i]), i
+        assert n_fast >= (2 if tracks == "dense" else 0) and (with_prior or n_fast == 0)
+        m = prior_metrics(pb, pa)
+        print("\n[cholesky vs eigen prior]", tracks, nf, with_prior, m)
+        assert m["H_rel"] < 1e-9 and m["g_scaled"] < 1e-7 and m["cost_rel"] < 1e-6, m
+        # and the next solve cannot tell them apart
+        o2 = abi.default_options()
+        o2.marginalization_flag = abi.MARGIN_NONE
+        E2 = est_m.Estimator(ctx=ctx, options=o2)
+        ca, cb = wa.copy(), wb.copy()
+        install_prior(ca, pa), install_prior(cb, pb)
+        sa = buffers.summary_to_numpy(E2.optimization(ca)).copy()
+        sb = buffers.summary_to_numpy(E2.optimization(cb))
+        assert np.array_equal(sa["accept_mask"], sb["accept_mask"])
+        for k in ("pose", "speedbias", "inv_depth"):
+            assert rel(ca.a[k], cb.a[k]) < 1e-8, (k, rel(ca.a[k], cb.a[k]))
