@@ -49,6 +49,10 @@ AVM_DEV void lds_base_check() {
 #define AVM_NOINL __device__ __noinline__
 #define PROF_T0() long long pt__ = clock64()
 #define PROF(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pt__; pt__ = n__; } } while (0)
+// second, independent stopwatch for the trust-region loop's own segments (slots 16.. are shared with the marginalization
+// kernel: read them from a run without marginalization)
+#define PROFQ_T0() pq__ = clock64()
+#define PROFQ(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pq__; pq__ = n__; } } while (0)
 
 constexpr int NT = 512;          // threads per workgroup (8 wavefronts)
 constexpr int croff(int i) { return 2 * ((i >> 1) + 1) * ((i >> 1) + (i & 1)); }  // roff() at compile time
@@ -504,7 +508,7 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
     int es[NSL], s0s[NSL];
     double ob[NSL][4];
 #pragma unroll
-    for (int u = 0; u < NSL; u++) es[u] = c.osf[min(t + u * NT, c.nobs_tot - 1)];
+    for (int u = 0; u < NSL; u++) es[u] = min(max(c.osf[min(t + u * NT, c.nobs_tot - 1)], 0), c.nf - 1);
 #pragma unroll
     for (int u = 0; u < NSL; u++) {
       const int s = min(t + u * NT, c.nobs_tot - 1);
@@ -514,8 +518,10 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
 #pragma unroll
     for (int u = 0; u < NSL; u++) {
       const int s = t + u * NT;
-      if (s >= c.nobs_tot || s == s0s[u]) continue;
       const int e = es[u];
+      // the observation table may have holes (avm_slide_window drops a feature's first observation in place): a slot
+      // belongs to the feature the slot map names only if it lies inside that feature's range of the CURRENT table
+      if (s >= c.nobs_tot || s <= s0s[u] || s >= s0s[u] + ids[I_FNOBS + e]) continue;
       const int fa = ids[I_FSTART + e], fb = fa + (s - s0s[u]);
       double r[2];
 #ifdef AVM_X
@@ -1263,9 +1269,9 @@ AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
   // regular factors, then the relocalization factors (slot index >= nobs_tot: match k against frame 11)
   for (int s = t; s < c.nobs_tot + c.relo_n; s += NT) {
     const bool relo = s >= c.nobs_tot;
-    const int e = relo ? c.cov[(NFRP - 1) * MAXE + (s - c.nobs_tot)] : c.osf[s];
+    const int e = relo ? c.cov[(NFRP - 1) * MAXE + (s - c.nobs_tot)] : min(max(c.osf[s], 0), c.nf - 1);
     const int s0 = ids[I_FOBS + e];
-    if (!relo && s == s0) continue;
+    if (!relo && (s <= s0 || s >= s0 + ids[I_FNOBS + e])) continue;  // first observation, or a hole of the table (see eval_cost)
     const int fa = ids[I_FSTART + e], fb = relo ? NFRP - 1 : fa + (s - s0);
     double ob[4] = {c.obs[2 * s0], c.obs[2 * s0 + 1], 0, 0}, ai[4] = {0, 0, 0, 0}, aj[4] = {0, 0, 0, 0};
     if (relo)
@@ -1296,9 +1302,9 @@ AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
   }
 #else
   for (int s = t; s < c.nobs_tot; s += NT) {
-    const int e = c.osf[s];
+    const int e = min(max(c.osf[s], 0), c.nf - 1);
     const int s0 = ids[I_FOBS + e];
-    if (s == s0) continue;
+    if (s <= s0 || s >= s0 + ids[I_FNOBS + e]) continue;  // first observation, or a hole of the table (see eval_cost)
     const int fa = ids[I_FSTART + e], fb = fa + (s - s0);
     double r[2], Ji[12], Jj[12], Je[2];
     proj_eval<true>(xs, fr, ric, ric + 9, c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1], xs[XLAM + e],
@@ -1811,11 +1817,31 @@ AVM_NOINL void scale_system(const WinCtx&) {
   double* lds = LDS();
   const int t = threadIdx.x;
   const double* scl = lds + L_SC;
-  for (int i2 = t; i2 < NF * 4; i2 += NT) {  // 4 lanes per row, interleaved columns
-    const int i = i2 >> 2, part = i2 & 3;
-    double* ri = lds + L_S + roff(i);
-    const double si = scl[i];
-    for (int j = part; j <= i; j += 4) ri[j] *= si * scl[j];
+  // 16x16 tiles of the packed lower triangle dealt to the wavefronts, 4 entries per lane and tile (the same lane <-> entry
+  // map as the accumulators of the factorization): every lane has the same amount of work, a round's loads are all in
+  // flight before its stores, and entries outside the matrix go to the lane's dump slot instead of a predicated store
+  {
+    const int lane = t & 63, wv = t >> 6, lr = lane & 15, lk = lane >> 4;
+    constexpr int NTR = (NF + 15) / 16, NTILE = NTR * (NTR + 1) / 2;
+    for (int tile = wv; tile < NTILE; tile += NT / 64) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+      const int tj = tile - ti * (ti + 1) / 2;
+      const int gj = 16 * tj + lr;
+      const double sj = scl[min(gj, NF - 1)];
+      int off[4];
+      double v[4], si[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = 16 * ti + lk + 4 * r;
+        const bool ok = gi < NF && gj <= gi;
+        off[r] = ok ? L_S + roff(gi) + gj : L_WCH + 512 + lane;
+        si[r] = scl[min(gi, NF - 1)];
+        v[r] = lds[off[r]];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) lds[off[r]] = v[r] * (si[r] * sj);
+    }
   }
   if (t < c.nf) lds[L_HEE + t] *= scl[NF + t] * scl[NF + t];
   for (int i = t; i < NF + c.nf; i += NT) lds[L_G + i] *= scl[i];
@@ -1914,6 +1940,9 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     const WinCtx& c = lds_ctx();
     __syncthreads();
     PROF_T0();
+    long long pq__ = 0;
+    (void)pq__;
+    PROFQ_T0();
     // ---------------- load ----------------
     for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
     for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
@@ -1936,6 +1965,10 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       ids[I_FNOBS + t] = B.feat_nobs[(size_t)w * B.max_feat + t];
       ids[I_FOBS + t] = B.feat_obs_begin[(size_t)w * B.max_feat + t];
     }
+    if (t >= 256 && t < 256 + c.pnblk) {  // the prior's block table (one round trip instead of one per block)
+      const int k = t - 256;
+      ids[I_PBLK + k * 3] = B.prior_blk_kind[(size_t)w * B.max_pblk + k], ids[I_PBLK + k * 3 + 1] = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
+    }
 #ifndef AVM_X
     if (t == 0) {
       const double* ex = B.ex_pose + (size_t)w * 7;
@@ -1946,6 +1979,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     }
 #endif
     __syncthreads();
+    PROFQ(c, 22);
 #ifndef AVM_X
     if (t < 7) lds[L_RIC + 12 + t] = B.ex_pose[(size_t)w * 7 + t];  // current ex_pose for the prior's dx
     if (t == 7) lds[L_RIC + 19] = B.td ? B.td[w] : 0.0;             // ... and para_Td (a constant here)
@@ -1962,8 +1996,8 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     if (t == 0) {
       int off = 0;
       for (int k = 0; k < c.pnblk; k++) {
-        const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
-        ids[I_PBLK + k * 3] = kind, ids[I_PBLK + k * 3 + 1] = fr, ids[I_PBLK + k * 3 + 2] = off;
+        const int kind = ids[I_PBLK + k * 3], fr = ids[I_PBLK + k * 3 + 1];  // (loaded by 16 lanes at once above)
+        ids[I_PBLK + k * 3 + 2] = off;
         const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
 #ifdef AVM_X
         for (int q = 0; q < n; q++)
@@ -1991,6 +2025,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     if (t == 64) ids[I_NCOV + NFRP - 1] = c.relo_n;
 #endif
     __syncthreads();
+    PROFQ(c, 23);
     if (t == 0) {  // longest-processing-time assignment of the frames to the assembling wavefronts
       int load[ASM_WAVES];
       for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
@@ -2031,9 +2066,11 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       for (int idx = t; idx < MAXE * NQ; idx += NT) PF[((idx / MAXE) * NFRP + (NFRP - 1)) * WLE + idx % MAXE] = 0.0;
 #endif
     }
+    PROFQ(c, 24);
     // Hp = J0^T J0 (constant during the solve: hoisted out of the per-iteration J^T J)
     if (c.pn > 0) prior_jtj_packed(c.pJ, c.ldp, c.pn, c.sc + Scratch::HP, reinterpret_cast<gint*>(c.sc + Scratch::HP + HPK_MAX));
     __syncthreads();
+    PROFQ(c, 25);
 
     PROF(c, 9);
     // ---------------- TrustRegionMinimizer ----------------
@@ -2160,6 +2197,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     double ref_cost = x_cost;
 
     while (true) {
+      PROFQ_T0();
       // FinalizeIterationAndCheckIfMinimizerCanContinue
       if (iteration > 0) {
         if (step_ok) n_successful++;
@@ -2202,6 +2240,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         // Gauss-Newton step with mu retry (DoglegStrategy::ComputeGaussNewtonStep)
         solver_ok = false;
         bool rebuilt = true;
+        PROFQ(c, 16);
         while (mu < max_mu) {
           if (!rebuilt) {  // S was destroyed by a failed factorisation: rebuild the normal equations
             evaluate_x();
@@ -2229,6 +2268,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           solver_ok = true;
           break;
         }
+        PROFQ_T0();
         if (solver_ok) {
           double a1 = 0, a2 = 0;
           for (int i = t; i < NF + c.nf; i += NT) {
@@ -2251,10 +2291,12 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           if (!have_alpha) {  // Cauchy point, needed only when the GN step leaves the trust region
             for (int i = t; i < VEC; i += NT) lds[L_ST + i] = i < NF + c.nf ? DG(i) / lds[L_DD + i] : 0.0;
             __syncthreads();
+            PROFQ(c, 17);
             jusq = jac_times_vec_sq(c, o);
             alpha = gnorm * gnorm / jusq;
             have_alpha = true;
             __syncthreads();
+            PROFQ(c, 18);
           }
           if (gnorm * alpha >= radius) {
             k1 = radius / gnorm, k2 = 0;
@@ -2302,6 +2344,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         continue;
       }
       // candidate
+      PROFQ(c, 17);
       PROF_T0();
       state_plus();
       __syncthreads();
@@ -2315,8 +2358,13 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       }
       const double step_norm = sqrt(block_sum<NT>(d2, lds + L_RED));
 #endif
-      const bool spec = speculate;
+      // the last iteration the options allow: the minimizer stops right after it (the iteration limit is checked before
+      // the gradient tolerance, trust_region_minimizer.cc FinalizeIterationAndCheckIfMinimizerCanContinue), so the
+      // Jacobian Ceres evaluates at the accepted point is never used: only the cost is computed there
+      const bool last_iteration = iteration >= o.max_num_iterations;
+      const bool spec = speculate && !last_iteration;
       double cand_cost;
+      PROFQ(c, 19);
       if (spec) {
         spec_enter();  // x <- candidate; the current point and the GN step are parked in the slot
         cand_cost = eval_jac(c, o);
@@ -2327,6 +2375,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         cand_cost = eval_cost(c, o, L_XC, 1);
         PROF(c, 15);
       }
+      PROFQ_T0();
       if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
         if (spec) spec_restore();  // the minimizer stops at the current point, not at the candidate
         termination = AVM_TERM_PARAMETER_TOL;
@@ -2350,7 +2399,10 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           for (int i = t; i < XN; i += NT) lds[L_X + i] = lds[L_XC + i];
           __syncthreads();
           x_norm = amb_norm(lds + L_X);
-          evaluate_x();
+          if (last_iteration)
+            x_cost = cand_cost;
+          else
+            evaluate_x();
         }
         speculate = A.speculate != 0 && rel > 0.75;
         step_ok = true;
@@ -2370,8 +2422,10 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         radius *= 0.5;
         reuse = true;
       }
+      PROFQ(c, 20);
     }
     __syncthreads();
+    PROFQ_T0();
     // ---------------- double2vector + vector2double (estimator.cpp:521-587, 477-519) ----------------
     {
       // rot_diff from yaw of frame 0 before / after ; stored in lds[L_GF..+9], origin_P0 in +9..12
@@ -2459,6 +2513,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         B.inv_depth[(size_t)w * B.max_feat + e] = 1.0 / (1.0 / lds[L_X + XLAM + e]);
       }
     }
+    PROFQ(c, 21);
     if (c.prof && t == 0) c.prof[31] += 1;
     if (t == 0 && A.summary) {
       avm_solve_summary* so = A.summary + w;

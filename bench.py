@@ -38,14 +38,14 @@ HBM_PEAK_GBS = 8000.0
 def flop_model(n_fac, n_feat, summ):
     """Algorithmic FP64 FLOPs of the solves in `summ` (numpy structured summaries). See DESIGN.md §Roofline.
     Jacobian evaluations and linear solves: one at the start + one per successful step (a rejected step re-uses the
-    factorization: DoglegStrategy `reuse`); residual-only evaluations: one per step attempt."""
+    factorization: DoglegStrategy `reuse`), except after a step accepted in the last iteration the options allow - the
+    minimizer stops there and neither is ever used; residual-only evaluations: one per step attempt."""
     import numpy as np
 
     it = summ["num_iterations"].astype(np.float64)
     ns = summ["num_successful"].astype(np.float64)
-    # the step after the last accepted one is never computed when the iteration limit ends the solve
     lin_solves = np.minimum(1.0 + ns, np.maximum(it, 1.0))
-    jac_evals = 1.0 + ns
+    jac_evals = lin_solves
     per_jac = 1800.0 * n_fac + 5.0e5                       # factor r/J + J^T J blocks, 10 IMU factors + prior
     per_lin = 66.0 * 67.0 * n_feat + 165.0**3 / 3.0 + 2.0 * 165.0**2  # Schur rank-150 update + Cholesky + solves
     per_cand = 230.0 * n_fac + 3.0e4                       # residual-only evaluation
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=4096, help="windows per GPU per step")
     ap.add_argument("--distinct", type=int, default=0, help="distinct generated windows per rank, tiled up to --windows (0 = all distinct)")
+    ap.add_argument("--gen-procs", type=int, default=0, help="worker processes generating the synthetic windows (0 = one per usable CPU; 1 = in-process, for runs under a profiler)")
     ap.add_argument("--tracks", default="dense", choices=["dense", "sparse"])
     ap.add_argument("--fsel-problems", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,7 +134,7 @@ def main():
     W = args.windows
     n_distinct = W if args.distinct <= 0 else min(args.distinct, W)
     t_gen = time.perf_counter()
-    base = synth.make_windows_parallel(n_distinct, first_id=rank * W, tracks=args.tracks, procs=max(1, min(64, ncpu // max(world, 1))))
+    base = synth.make_windows_parallel(n_distinct, first_id=rank * W, tracks=args.tracks, procs=args.gen_procs or max(1, min(64, ncpu // max(world, 1))))
     host = base if n_distinct == W else synth.tile_windows(base, W)
     t_gen = time.perf_counter() - t_gen
 

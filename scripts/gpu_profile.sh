@@ -5,11 +5,15 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fsel-problems 4"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- $CMD > /dev/null 2> $OUT/pmc_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- $CMD > /dev/null 2> $OUT/pmc_write.log
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY -d $OUT/pmc_sq -o run -- $CMD > /dev/null 2> $OUT/pmc_sq.log
+# in-process input generation (forked workers under the profiler's signal handlers can hang) and, for the counter passes,
+# only the window kernels (the selector's thousands of small launches serialize under --pmc)
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fsel-problems 4 --gen-procs 1 --distinct 512"
+PMCCMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fsel --gen-procs 1 --distinct 512"
+KF='--kernel-include-regex (window_solve|marginalize|prior_eig|preint)' 
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+timeout 300 rocprofv3 --kernel-trace $KF --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- $PMCCMD > /dev/null 2> $OUT/pmc_fetch.log
+timeout 300 rocprofv3 --kernel-trace $KF --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- $PMCCMD > /dev/null 2> $OUT/pmc_write.log
+timeout 300 rocprofv3 --kernel-trace $KF --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY -d $OUT/pmc_sq -o run -- $PMCCMD > /dev/null 2> $OUT/pmc_sq.log
 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.log
 python scripts/dev_prof.py 256 dense > $OUT/phase_breakdown_dense.txt 2>&1
 python scripts/dev_prof.py 256 sparse > $OUT/phase_breakdown_sparse.txt 2>&1

@@ -349,6 +349,38 @@ def test_speculative_evaluation_is_exact_including_rejected_steps(estimator, ora
         assert rel(s1["radius_trace"][i][:n], so["radius_trace"][i][:n]) < 1e-4, i   # radius = 3 |step| follows the (wild) states
 
 
+def test_observation_table_with_holes_solves_like_the_compact_one(estimator, monkeypatch):
+    """avm_slide_window drops a feature's first observation in place, so the observation table of a rolled window has
+    holes.  The slot-indexed loops of the solve (the residual-only evaluation, the Cauchy point's |J u|^2) must not see
+    them - not even through what an earlier solve left in the context's slot map."""
+    o = abi.default_options()
+    o.marginalization_flag = abi.MARGIN_NONE
+    o.initial_trust_region_radius = 1e-1          # radius-limited steps: every iteration computes the Cauchy point
+    E = importlib_est().Estimator(ctx=estimator.ctx, options=o)
+    w = synth.make_windows(4, tracks="sparse", n_feat=50, max_feat=150)
+    holes = w.copy()
+    a, b = w.a, holes.a
+    for k in range(4):
+        n = a["n_feat"][k]
+        assert a["feat_obs_begin"][k, n - 1] + a["feat_nobs"][k, n - 1] + 2 * n <= a["obs_xy"].shape[1]
+        b["obs_xy"][k] = 1e3                      # what a hole holds must never be read as an observation
+        for e in range(n):
+            s0, no = a["feat_obs_begin"][k, e], a["feat_nobs"][k, e]
+            b["feat_obs_begin"][k, e] = s0 + 2 * e + 1
+            b["obs_xy"][k, s0 + 2 * e + 1:s0 + 2 * e + 1 + no] = a["obs_xy"][k, s0:s0 + no]
+    for spec in ("0", "1"):                        # "1": every candidate goes through the residual-only evaluation
+        monkeypatch.setenv("AVM_NO_SPECULATE", spec)
+        E.optimization(synth.make_windows(4, tracks="dense"))    # leaves a different slot map behind
+        g1, g2 = w.copy(), holes.copy()
+        s1 = buffers.summary_to_numpy(E.optimization(g1))
+        s2 = buffers.summary_to_numpy(E.optimization(g2))
+        assert (s1["num_iterations"] >= 3).all()
+        for k in ("pose", "speedbias", "inv_depth"):
+            assert np.array_equal(g1.a[k], g2.a[k]), (spec, k)
+        # (a factor's slot decides which thread adds its cost: the sums agree to rounding, the decisions exactly)
+        assert rel(s1["cost_trace"], s2["cost_trace"]) < 1e-13 and np.array_equal(s1["accept_mask"], s2["accept_mask"])
+
+
 def test_solve_is_bit_reproducible_and_shard_invariant(estimator):
     w = synth.make_windows(6, tracks="sparse", n_feat=50, max_feat=150)
     a, b = w.copy(), w.copy()
