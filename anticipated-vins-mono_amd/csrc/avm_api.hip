@@ -385,7 +385,7 @@ int avm_create(const avm_config* cfg, avm_ctx** out) {
   c->n_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   for (auto& e : c->ev) (void)hipEventCreate(&e);
   if (const char* pe = getenv("AVM_PROFILE"))
-    if (pe[0] == '1') (void)hipMalloc(&c->prof, sizeof(long long) * 32 * c->n_slots);
+    if (pe[0] == '1') (void)hipMalloc(&c->prof, sizeof(long long) * PROF_SLOTS * c->n_slots);
   *out = c;
   return AVM_OK;
 }
@@ -519,7 +519,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     const char* ns = getenv("AVM_NO_SPECULATE");
     sa.speculate = (ns && ns[0] == '1') ? 0 : 1;
   }
-  if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * 32 * c->n_slots, c->stream));
+  if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * PROF_SLOTS * c->n_slots, c->stream));
   // ex_pose / td as variables, relocalization factors: the build of the solve kernel with the wider dense block
   const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || d.relo_n != nullptr;
   HIPCHK(c, extended ? launch_window_solve_x(sa, c->stream) : launch_window_solve(sa, c->stream));
@@ -635,14 +635,14 @@ int avm_imu_preintegrate_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, 
   return AVM_OK;
 }
 
-// debug hook (not in avm.h): per-phase shader clocks of the last solve, summed over slots, [32]
+// debug hook (not in avm.h): per-phase shader clocks of the last solve, summed over slots, [PROF_SLOTS = 64]
 int avm_debug_copy_profile(avm_ctx* c, long long* host_out) {
   if (!c || !c->prof) return AVM_ERR_INVALID;
-  std::vector<long long> h((size_t)32 * c->n_slots);
+  std::vector<long long> h((size_t)PROF_SLOTS * c->n_slots);
   HIPCHK(c, hipMemcpy(h.data(), c->prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-  for (int k = 0; k < 32; k++) host_out[k] = 0;
+  for (int k = 0; k < PROF_SLOTS; k++) host_out[k] = 0;
   for (int s = 0; s < c->n_slots; s++)
-    for (int k = 0; k < 32; k++) host_out[k] += h[(size_t)s * 32 + k];
+    for (int k = 0; k < PROF_SLOTS; k++) host_out[k] += h[(size_t)s * PROF_SLOTS + k];
   return AVM_OK;
 }
 

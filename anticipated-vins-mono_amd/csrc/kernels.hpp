@@ -52,6 +52,7 @@ struct Scratch {
 };
 constexpr int ISCRATCH = MAXOBS + (NFR + 1) * MAXE;  // ints per slot: observation slot -> feature, then cov[12][150] (row 11: the relocalization frame)
 
+constexpr int PROF_SLOTS = 64;
 struct SolveArgs {
   avm_window_batch b;  // device pointers
   avm_options opt;
@@ -60,7 +61,7 @@ struct SolveArgs {
   int32_t* iscratch;                                          // [n_slots][ISCRATCH]
   avm_solve_summary* summary;                                 // [B] or null
   int n_slots;
-  long long* prof;  // optional [n_slots][32] per-phase shader-clock accumulators (debug)
+  long long* prof;  // optional [n_slots][PROF_SLOTS] per-phase shader-clock accumulators (debug)
   int speculate;    // 1: evaluate the Jacobian at the candidate directly while steps keep being accepted (window_solve.hip)
 };
 

@@ -49,8 +49,7 @@ AVM_DEV void lds_base_check() {
 #define AVM_NOINL __device__ __noinline__
 #define PROF_T0() long long pt__ = clock64()
 #define PROF(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pt__; pt__ = n__; } } while (0)
-// second, independent stopwatch for the trust-region loop's own segments (slots 16.. are shared with the marginalization
-// kernel: read them from a run without marginalization)
+// second, independent stopwatch for the trust-region loop's own segments (slots 32..)
 #define PROFQ_T0() pq__ = clock64()
 #define PROFQ(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pq__; pq__ = n__; } } while (0)
 
@@ -444,6 +443,17 @@ AVM_NOINL void prior_residual_dev(const WinCtx&, int xs_off) {
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   (void)ids;
   const int t = threadIdx.x;
+  // r_p[i] = r0[i] + sum_k J0[i][k] dx[k] : 4 lanes per row (k = part, part + 4, ...).  The row's entries do not depend on
+  // dx: their loads are issued first, so the trip to the slot's memory overlaps the dx computation and the barrier
+  const int row = t >> 2, part = t & 3;
+  static_assert(NT >= 4 * MAXPRIOR, "one pass over the rows");
+  double v[MAXPRIOR / 4], r0 = 0.0;
+  {
+    gcdouble* Jr = c.pJ + (size_t)min(row, max(c.pn - 1, 0)) * c.ldp;
+#pragma unroll
+    for (int j = 0; j < MAXPRIOR / 4; j++) v[j] = Jr[min(part + 4 * j, max(c.pn - 1, 0))];  // clamped, masked below
+    r0 = c.pr[min(row, max(c.pn - 1, 0))];
+  }
   if (t < c.pnblk) {
     const int kind = ids[I_PBLK + t * 3], fr = ids[I_PBLK + t * 3 + 1], off = ids[I_PBLK + t * 3 + 2];
 #ifdef AVM_X
@@ -458,25 +468,101 @@ AVM_NOINL void prior_residual_dev(const WinCtx&, int xs_off) {
     for (int k = 0; k < n; k++) lds[L_DXP + off + k] = dx[k];
   }
   __syncthreads();
-  // r_p[i] = r0[i] + sum_k J0[i][k] dx[k] : 4 lanes per row (k = part, part + 4, ...), all loads of a lane in flight
-  // at once; the four partial sums are combined in a fixed order
   {
-    const int row = t >> 2, part = t & 3;
-    static_assert(NT >= 4 * MAXPRIOR, "one pass over the rows");
     double s = 0;
-    if (row < c.pn) {
-      gcdouble* Jr = c.pJ + (size_t)row * c.ldp;
-      double v[MAXPRIOR / 4];
 #pragma unroll
-      for (int j = 0; j < MAXPRIOR / 4; j++) v[j] = (part + 4 * j < c.pn) ? Jr[part + 4 * j] : 0.0;
-#pragma unroll
-      for (int j = 0; j < MAXPRIOR / 4; j++) s += v[j] * lds[L_DXP + part + 4 * j];
-    }
+    for (int j = 0; j < MAXPRIOR / 4; j++) s += (part + 4 * j < c.pn ? v[j] : 0.0) * lds[L_DXP + part + 4 * j];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if (row < c.pn && part == 0) lds[L_RP + row] = c.pr[row] + s;
+    if (row < c.pn && part == 0) lds[L_RP + row] = r0 + s;
   }
   __syncthreads();
+}
+
+// The prior's share of an evaluation on ONE wavefront, with wave-level synchronisation only, so that it runs beside the
+// projection factors (whose wavefronts do not touch these LDS ranges) instead of in a phase of its own:
+//   dx -> lds[L_DXP],  r_p = r0 + J0 dx -> lds[L_RP],  and (WANT_G) g_p = J0^T r_p -> lds[L_DXP], over dx;
+// returns 1/2 |r_p|^2 on every lane.  J0 is read along its rows both times (16 lanes per row for r_p, a lane per column
+// for g_p), several rows in flight; every sum has a fixed order.
+template <bool WANT_G>
+AVM_DEV double prior_wave(int xs_off) {
+  const WinCtx& c = lds_ctx();
+  double* lds = LDS();
+  const double* xs = lds + xs_off;
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  (void)ids;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  const int pn = c.pn, pn1 = max(pn - 1, 0);
+  if (lane < c.pnblk) {
+    const int kind = ids[I_PBLK + lane * 3], fr = ids[I_PBLK + lane * 3 + 1], off = ids[I_PBLK + lane * 3 + 2];
+#ifdef AVM_X
+    const double* xb = kind == AVM_BLK_POSE ? xs + fr * 7 : (kind == AVM_BLK_SPEEDBIAS ? xs + XSB + fr * 9 : (kind == AVM_BLK_TD ? xs + XTD : xs + XEX));
+#else
+    // ex_pose is constant in the solve; its current value sits behind ric/tic
+    const double* xb = kind == AVM_BLK_POSE ? xs + fr * 7 : (kind == AVM_BLK_SPEEDBIAS ? xs + XSB + fr * 9 : lds + L_RIC + (kind == AVM_BLK_TD ? 19 : 12));
+#endif
+    double dx[9];
+    prior_block_dx(kind, xb, c.px0 + lane * 9, dx);
+    const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
+    for (int k = 0; k < n; k++) lds[L_DXP + off + k] = dx[k];
+  }
+  wave_lds_sync();
+  constexpr int NK = MAXPRIOR / 16, RU = 4;  // 6 column groups of 16; 4 x 4 rows in flight
+  double dxv[NK];
+#pragma unroll
+  for (int j = 0; j < NK; j++) dxv[j] = lr + 16 * j < pn ? lds[L_DXP + lr + 16 * j] : 0.0;
+  double cost = 0;
+  for (int r0 = 0; r0 < pn; r0 += 4 * RU) {
+    double v[RU][NK], rr[RU];
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+      const int rc = min(r0 + 4 * u + lg, pn1);
+      gcdouble* Jr = c.pJ + (size_t)rc * c.ldp;
+#pragma unroll
+      for (int j = 0; j < NK; j++) v[u][j] = Jr[min(lr + 16 * j, pn1)];  // clamped; the padding columns meet dx = 0
+      rr[u] = c.pr[rc];
+    }
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+      double sacc = 0;
+#pragma unroll
+      for (int j = 0; j < NK; j++) sacc += v[u][j] * dxv[j];
+      sacc += __shfl_xor(sacc, 8, 64);
+      sacc += __shfl_xor(sacc, 4, 64);
+      sacc += __shfl_xor(sacc, 2, 64);
+      sacc += __shfl_xor(sacc, 1, 64);
+      const int row = r0 + 4 * u + lg;
+      const double rp = rr[u] + sacc;
+      if (lr == 0 && row < pn) {
+        lds[L_RP + row] = rp;
+        cost += 0.5 * rp * rp;
+      }
+    }
+  }
+  cost = wave_sum(cost);
+  if (WANT_G) {
+    wave_lds_sync();
+    // g_p[k] = sum_i J0[i][k] r_p[i]: lane = column (k = lane, lane + 64), rows in ascending order, 8 rows in flight
+    constexpr int GU = 8;
+    const int k0 = min(lane, pn1), k1 = min(lane + 64, pn1);
+    double g0 = 0, g1 = 0;
+    for (int i0 = 0; i0 < pn; i0 += GU) {
+      double a0[GU], a1[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        gcdouble* Jr = c.pJ + (size_t)min(i0 + u, pn1) * c.ldp;
+        a0[u] = Jr[k0], a1[u] = Jr[k1];
+      }
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const double r = i0 + u < pn ? lds[L_RP + min(i0 + u, MAXPRIOR - 1)] : 0.0;
+        g0 += a0[u] * r, g1 += a1[u] * r;
+      }
+    }
+    lds[L_DXP + lane] = lane < pn ? g0 : 0.0;  // (dx lives in dxv by now)
+    if (lane + 64 < MAXPRIOR) lds[L_DXP + lane + 64] = lane + 64 < pn ? g1 : 0.0;
+  }
+  return cost;
 }
 
 // residual-only cost at state xs (frames slot `which` must be built). Uses lds[L_S..] as IMU staging.
@@ -545,6 +631,11 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
                             ids[I_FSTART + e], NFRP - 1, sqi, o.cauchy_a, true, r, nullptr, nullptr, nullptr);
   }
 #endif
+  // the prior on the last wavefront (the same code, hence the same rounding, as in eval_jac)
+  if (t >= NT - 64 && c.pn > 0) {
+    const double pc = prior_wave<false>(xs_off);
+    if (t == NT - 64) acc += pc;
+  }
   __syncthreads();
   if (t < 150) {
     const int i = t / 15, r = t % 15;
@@ -554,10 +645,7 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
       acc += 0.5 * s * s;
     }
   }
-  if (c.pn > 0) {
-    prior_residual_dev(c, xs_off);
-    if (t < c.pn) acc += 0.5 * lds[L_RP + t] * lds[L_RP + t];
-  }
+
   return block_sum<NT>(acc, lds + L_RED);
 }
 
@@ -1063,6 +1151,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   Frames fr{lds + L_FR, lds + L_FR + 9 * NFRP};
   double acc = 0;
   // ---- phase A: projection factors (waves 0..ASM_WAVES-1, one frame at a time) || IMU raw Jacobians (the next wave)
+  const long long pa__ = c.prof ? clock64() : 0;
   if (wv < ASM_WAVES) {
     for (int b = 1; b < NFRP; b++)
       if (ids[I_FRW + b] == wv) acc += frame_task(c, o, b, L_S + SPP + wv * XSTG);
@@ -1071,6 +1160,12 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     if (c.psum[i] <= o.max_sum_dt)
       imu_raw<true>(xs, fr.R, o, c.pdelta + i * 10, c.pjac + i * 225, c.psum[i], c.lba + i * 3, c.lbg + i * 3, i, IJR + i * 465);
   }
+  // ... || the prior (dx, residual, cost, J0^T r_p) on the last wavefront, which has the lightest load of phase A
+  if (wv == NT / 64 - 1 && c.pn > 0) {
+    const double pc = prior_wave<true>(xs_off);
+    if (lane == 0) acc += pc;
+  }
+  if (c.prof && lane == 0) c.prof[48 + wv] += clock64() - pa__;  // this wavefront's busy time in phase A
   __syncthreads();
   PROF(c, 0);
   // ---- phase B: per-feature sums over the start pose, diagonal blocks, pose gradient
@@ -1079,24 +1174,50 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     const double* PF = c.sc + Scratch::PF;
     // sums over the feature's own factors: one thread per (quantity, feature), features along the lanes
     // (the W blocks of frames that do not observe a feature were zeroed once, at window load)
-    for (int idx = t; idx < c.nf * NQ; idx += NT) {
-      const int q = idx / c.nf, e = idx - q * c.nf;
+    // (every round's loads are requested before the first sum: one trip to the slot's memory instead of one per round)
+    constexpr int NRND = (MAXE * NQ + NT - 1) / NT;
+    double pv[NRND][NFR - 1];
+#ifdef AVM_X
+    double prl[NRND];
+#endif
+#pragma unroll
+    for (int u = 0; u < NRND; u++) {
+      const int idx = min(t + u * NT, max(c.nf * NQ - 1, 0));
+      const int q = idx / max(c.nf, 1), e = idx - q * c.nf;
       const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
       const double* P = PF + (q * NFRP + a) * WLE + e;  // + k * WLE : the factor observed in frame a + k
       // all (<= 10) loads in flight, clamped to the feature's last observation and masked; same pairing of the
       // partial sums as a sequential two-accumulator loop
-      double pv[NFR - 1];
 #pragma unroll
-      for (int k = 1; k < NFR; k++) pv[k - 1] = P[min(k, max(no - 1, 0)) * WLE];
+      for (int k = 1; k < NFR; k++) pv[u][k - 1] = P[min(k, max(no - 1, 0)) * WLE];
+#ifdef AVM_X
+      prl[u] = PF[(q * NFRP + (NFRP - 1)) * WLE + e];
+#endif
+    }
+#ifndef AVM_X
+    // the partial (a,a) blocks of the frame tasks, summed further down, are requested now as well
+    double pp[NFR - 1];
+    if (t < NFR * 27) {
+      const int f = t / 27, q = t % 27;
+#pragma unroll
+      for (int b = 1; b < NFR; b++) pp[b - 1] = (c.sc + Scratch::PART)[((size_t)b * NFR + f) * 27 + q];  // unconditional, masked below
+    }
+#endif
+#pragma unroll
+    for (int u = 0; u < NRND; u++) {
+      const int idx = t + u * NT;
+      if (idx >= c.nf * NQ) break;
+      const int q = idx / c.nf, e = idx - q * c.nf;
+      const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
       double s0a = 0, s1a = 0;
 #pragma unroll
       for (int k = 1; k < NFR; k++) {
-        const double v = k < no ? pv[k - 1] : 0.0;
+        const double v = k < no ? pv[u][k - 1] : 0.0;
         if (k & 1) s0a += v; else s1a += v;
       }
 #ifdef AVM_X
       // + the feature's relocalization factor (frame 11; its slots were zeroed at window load for unmatched features)
-      const double sacc = (s0a + s1a) + (c.relo_n > 0 ? PF[(q * NFRP + (NFRP - 1)) * WLE + e] : 0.0);
+      const double sacc = (s0a + s1a) + (c.relo_n > 0 ? prl[u] : 0.0);
       if (q < 6)
         W[(6 * a + q) * WLE + e] = sacc;
       else if (q == 6)
@@ -1162,9 +1283,6 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     if (t < NFR * 27) {
       const int f = t / 27, q = t % 27;
       double sacc = 0;
-      double pp[NFR - 1];
-#pragma unroll
-      for (int b = 1; b < NFR; b++) pp[b - 1] = PART[((size_t)b * NFR + f) * 27 + q];  // unconditional, masked below
 #pragma unroll
       for (int b = 1; b < NFR; b++)
         if (b > f && (ids[I_PMASK + b] & (1 << f))) sacc += pp[b - 1];
@@ -1180,22 +1298,29 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
 #endif
   }
   PROF(c, 1);
-  // prior residual (uses L_DXP/L_RP; includes syncs)
+  // phase D's operands (sqrt_info, the raw Jacobians wave ASM_WAVES left in the slot during phase A) and phase E's packed
+  // prior are fetched now: their trip to the slot's memory overlaps the zeroing and the barriers in between
+  ImuOperands io[2];
+  if (wv < 5) imu_factor_load(2 * wv, io[0]), imu_factor_load(2 * wv + 1, io[1]);
+  constexpr int NIT = (HPK_MAX + NT - 1) / NT;  // 10 rounds cover the largest prior
+  const int npk = c.pn * (c.pn + 1) / 2;
+  int dd[NIT];
+  double hv[NIT];
   if (c.pn > 0) {
-    prior_residual_dev(c, xs_off);
-    if (t < c.pn) acc += 0.5 * lds[L_RP + t] * lds[L_RP + t];
-  } else {
-    __syncthreads();
+    gcdouble* HPk = c.sc + Scratch::HP;
+    const gint* dst = reinterpret_cast<const gint*>(c.sc + Scratch::HP + HPK_MAX);
+#pragma unroll
+    for (int u = 0; u < NIT; u++) {
+      const int idx = min(t + u * NT, npk - 1);
+      dd[u] = dst[idx], hv[u] = HPk[idx];
+    }
   }
-  PROF(c, 2);
   // rows 66.. of S (the staging area is dead now)
   for (int i = SPP + t; i < SROWS; i += NT) lds[L_S + i] = 0.0;
   __syncthreads();
   PROF(c, 3);
   // ---- phase D: IMU factors on MFMA, one wavefront per factor; even factors then odd ones (neighbours share a frame)
   {
-    ImuOperands io[2];
-    if (wv < 5) imu_factor_load(2 * wv, io[0]), imu_factor_load(2 * wv + 1, io[1]);
 #pragma unroll
     for (int par = 0; par < 2; par++) {
       if (wv < 5) {
@@ -1208,38 +1333,15 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   PROF(c, 7);
   // ---- phase E: prior  H += Hp (packed values + destinations prepared once per solve), g += J0^T r_p
   if (c.pn > 0) {
-    gcdouble* HPk = c.sc + Scratch::HP;
-    const gint* dst = reinterpret_cast<const gint*>(c.sc + Scratch::HP + HPK_MAX);
-    const int npk = c.pn * (c.pn + 1) / 2;
+    // H += Hp (packed values + destinations, fetched above), g += J0^T r_p (phase A left it in lds[L_DXP])
     {
-      constexpr int NIT = (HPK_MAX + NT - 1) / NT;  // 10 rounds cover the largest prior
-      int dd[NIT];
-      double hv[NIT];
-#pragma unroll
-      for (int u = 0; u < NIT; u++) {
-        const int idx = min(t + u * NT, npk - 1);
-        dd[u] = dst[idx], hv[u] = HPk[idx];
-      }
 #pragma unroll
       for (int u = 0; u < NIT; u++)
         if (t + u * NT < npk && dd[u] >= 0) lds[L_S + dd[u]] += hv[u];
     }
-    // g += J0^T r_p : 4 lanes per column, each a quarter of the rows (rows part, part + 4, ...)
     {
       const int* pidx = ids + I_PIDX;
-      const int col = t >> 2, part = t & 3;
-      double sacc = 0;
-      const bool on = col < c.pn && pidx[col] >= 0;
-      if (on) {
-        double v[MAXPRIOR / 4];
-#pragma unroll
-        for (int j = 0; j < MAXPRIOR / 4; j++) v[j] = (part + 4 * j < c.pn) ? c.pJ[(size_t)(part + 4 * j) * c.ldp + col] : 0.0;
-#pragma unroll
-        for (int j = 0; j < MAXPRIOR / 4; j++) sacc += v[j] * lds[L_RP + part + 4 * j];
-      }
-      sacc += __shfl_xor(sacc, 1, 64);
-      sacc += __shfl_xor(sacc, 2, 64);
-      if (on && part == 0) lds[L_G + pidx[col]] += sacc;
+      if (t < c.pn && pidx[t] >= 0) lds[L_G + pidx[t]] += lds[L_DXP + t];
     }
   }
   const double cost = block_sum<NT>(acc, lds + L_RED);
@@ -1520,7 +1622,11 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
       const double isq = fast_rsqrt(dc);  // applied to the product's columns below: its latency hides under the loads and MFMAs
 #pragma unroll
       for (int m = 0; m < NB / 4; m++) bop[m] = (lk + 4 * m < nb && lr < nb) ? bop[m] : 0.0;
-      for (int ti = (c1 >> 4) + wv; ti <= TLAST; ti += NT / 64) {
+      // (wavefront 4 shares its SIMD - and with it the FP64 pipe the MFMAs run on - with wavefront 0, whose pivot chain is
+      //  the critical path: it gets no tiles, here or in Q_j)
+      constexpr int NHELP = NT / 64 - 1;
+      const int slot = wv < 4 ? wv : wv - 1;  // 0 1 2 3 - 4 5 6
+      for (int ti = (c1 >> 4) + slot; ti <= TLAST && wv != 4; ti += NHELP) {
         const int row = 16 * ti + lr;
         const double* pa = S + roff(min(row, NR - 1)) + c0 + lk;
         const bool va = row < NR && row >= c1;
@@ -1560,7 +1666,7 @@ AVM_NOINL bool cholesky_lds(long long* prof) {
         // items: tiles (tm + 1 .. 10, tm), then the early part of the NEXT diagonal tile (tm + 1, tm + 1): all panels solved
         // so far, so that wavefront 0 only has to add one panel to it before it factors the block
         const int nitem = (TLAST - tm) + (tm + 1 <= TLAST ? 1 : 0);
-        for (int k = wv - 1; k < nitem; k += NT / 64 - 1) {
+        for (int k = (wv < 4 ? wv - 1 : wv - 2); k < nitem && wv != 4; k += NT / 64 - 2) {
           if (k < TLAST - tm)
             chol_left_tile(tm + 1 + k, tm, 0, tm);
           else
@@ -1764,7 +1870,7 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
     case 1: schur_macro_tile<0, 1, 0, 1>(c); break;  // 3 tiles
     case 2: schur_macro_tile<2, 3, 2, 3>(c); break;  // 3 tiles
     case 3: schur_macro_tile<4, -1, 0, 1>(c); break;
-    case 4: schur_macro_tile<4, -1, 2, 3>(c); break;
+    case 7: schur_macro_tile<4, -1, 2, 3>(c); break;  // (wavefronts w and w + 4 share a SIMD: 4 | 3 + 1 | 3 | 2 + 2 tiles per SIMD)
     case 5: schur_macro_tile<4, -1, 4, -1>(c); break;
     default: break;
   }
@@ -1818,29 +1924,40 @@ AVM_NOINL void scale_system(const WinCtx&) {
   const int t = threadIdx.x;
   const double* scl = lds + L_SC;
   // 16x16 tiles of the packed lower triangle dealt to the wavefronts, 4 entries per lane and tile (the same lane <-> entry
-  // map as the accumulators of the factorization): every lane has the same amount of work, a round's loads are all in
-  // flight before its stores, and entries outside the matrix go to the lane's dump slot instead of a predicated store
+  // map as the accumulators of the factorization): every lane has the same amount of work; three tiles per round with
+  // all their loads in flight before the first store, the tile index arithmetic on the scalar unit, and entries outside
+  // the matrix go to the lane's dump slot instead of a predicated store
   {
-    const int lane = t & 63, wv = t >> 6, lr = lane & 15, lk = lane >> 4;
-    constexpr int NTR = (NF + 15) / 16, NTILE = NTR * (NTR + 1) / 2;
-    for (int tile = wv; tile < NTILE; tile += NT / 64) {
-      int ti = 0;
-      while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
-      const int tj = tile - ti * (ti + 1) / 2;
-      const int gj = 16 * tj + lr;
-      const double sj = scl[min(gj, NF - 1)];
-      int off[4];
-      double v[4], si[4];
+    const int lane = t & 63, lr = lane & 15, lk = lane >> 4;
+    const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int NTR = (NF + 15) / 16, NTILE = NTR * (NTR + 1) / 2, NW = NT / 64, UN = 3;
+#pragma unroll 1
+    for (int base = wvu; base < NTILE; base += UN * NW) {
+      int off[UN][4];
+      double v[UN][4], f[UN][4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int gi = 16 * ti + lk + 4 * r;
-        const bool ok = gi < NF && gj <= gi;
-        off[r] = ok ? L_S + roff(gi) + gj : L_WCH + 512 + lane;
-        si[r] = scl[min(gi, NF - 1)];
-        v[r] = lds[off[r]];
+      for (int u = 0; u < UN; u++) {
+        const int tile = base + u * NW;
+        const bool tv = tile < NTILE;
+        const int tl = min(tile, NTILE - 1);
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tl) ti++;
+        const int tj = tl - ti * (ti + 1) / 2;
+        const int gj = 16 * tj + lr;
+        const double sj = scl[min(gj, NF - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = 16 * ti + lk + 4 * r;
+          const bool ok = tv && gi < NF && gj <= gi;
+          off[u][r] = ok ? L_S + roff(gi) + gj : L_WCH + 512 + lane;
+          f[u][r] = scl[min(gi, NF - 1)] * sj;
+          v[u][r] = lds[off[u][r]];
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) lds[off[r]] = v[r] * (si[r] * sj);
+      for (int u = 0; u < UN; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds[off[u][r]] = v[u][r] * f[u][r];
     }
   }
   if (t < c.nf) lds[L_HEE + t] *= scl[NF + t] * scl[NF + t];
@@ -1911,7 +2028,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     cl.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
     cl.cov = cl.osf + MAXOBS;
     cl.w = w;
-    cl.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
+    cl.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * PROF_SLOTS) : nullptr;
     cl.nf = B.n_feat[w];
     cl.obs = as_global(B.obs_xy + (size_t)w * B.max_obs * 2);
     cl.pdelta = as_global(A.pre_delta + (size_t)w * 100), cl.pjac = as_global(A.pre_jac + (size_t)w * 2250), cl.psqrt = as_global(A.pre_sqrt + (size_t)w * 2250);
@@ -1943,6 +2060,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     long long pq__ = 0;
     (void)pq__;
     PROFQ_T0();
+    const long long pw__ = clock64();
     // ---------------- load ----------------
     for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
     for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
@@ -1979,7 +2097,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     }
 #endif
     __syncthreads();
-    PROFQ(c, 22);
+    PROFQ(c, 38);
 #ifndef AVM_X
     if (t < 7) lds[L_RIC + 12 + t] = B.ex_pose[(size_t)w * 7 + t];  // current ex_pose for the prior's dx
     if (t == 7) lds[L_RIC + 19] = B.td ? B.td[w] : 0.0;             // ... and para_Td (a constant here)
@@ -1988,10 +2106,15 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       const int s0 = ids[I_FOBS + t], no = ids[I_FNOBS + t];
       for (int k = 0; k < no; k++) c.osf[s0 + k] = t;
     }
-    if (t <= NFR) {  // fs[a] = first feature with start >= a
-      int cnt = 0;
-      for (int e = 0; e < c.nf; e++) cnt += (ids[I_FSTART + e] < t) ? 1 : 0;
-      ids[I_FS + t] = cnt;
+    {
+      // fs[a] = first feature with start >= a, and per frame the features observed in it (as imu_j) in feature order:
+      // one wavefront per list, features along the lanes, positions from a ballot's prefix population count
+      const int ln = t & 63;
+      for (int q = t >> 6; q <= NFR; q += NT / 64) {
+        int cnt = 0;
+        for (int e0 = 0; e0 < c.nf; e0 += 64) cnt += __popcll(__ballot(e0 + ln < c.nf && ids[I_FSTART + min(e0 + ln, MAXE - 1)] < q));
+        if (ln == 0) ids[I_FS + q] = cnt;
+      }
     }
     if (t == 0) {
       int off = 0;
@@ -2010,13 +2133,17 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         off += n;
       }
     }
-    if (t >= 1 && t < NFR) {  // features observed in frame t (as imu_j), in feature order
+    for (int f = 1 + (t >> 6); f < NFR; f += NT / 64) {  // features observed in frame f (as imu_j), in feature order
+      const int ln = t & 63;
       int n = 0;
-      for (int e = 0; e < c.nf; e++) {
-        const int a = ids[I_FSTART + e];
-        if (a < t && t < a + ids[I_FNOBS + e]) c.cov[t * MAXE + n++] = e;
+      for (int e0 = 0; e0 < c.nf; e0 += 64) {
+        const int e = min(e0 + ln, MAXE - 1), a = ids[I_FSTART + e];
+        const bool in = e0 + ln < c.nf && a < f && f < a + ids[I_FNOBS + e];
+        const unsigned long long m = __ballot(in);
+        if (in) c.cov[f * MAXE + n + __popcll(m & ((1ull << ln) - 1ull))] = e;
+        n += __popcll(m);
       }
-      ids[I_NCOV + t] = n;
+      if (ln == 0) ids[I_NCOV + f] = n;
     }
     if (t == 0) ids[I_NCOV] = 0;
 #ifdef AVM_X
@@ -2025,7 +2152,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     if (t == 64) ids[I_NCOV + NFRP - 1] = c.relo_n;
 #endif
     __syncthreads();
-    PROFQ(c, 23);
+    PROFQ(c, 39);
     if (t == 0) {  // longest-processing-time assignment of the frames to the assembling wavefronts
       int load[ASM_WAVES];
       for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
@@ -2066,11 +2193,11 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       for (int idx = t; idx < MAXE * NQ; idx += NT) PF[((idx / MAXE) * NFRP + (NFRP - 1)) * WLE + idx % MAXE] = 0.0;
 #endif
     }
-    PROFQ(c, 24);
+    PROFQ(c, 40);
     // Hp = J0^T J0 (constant during the solve: hoisted out of the per-iteration J^T J)
     if (c.pn > 0) prior_jtj_packed(c.pJ, c.ldp, c.pn, c.sc + Scratch::HP, reinterpret_cast<gint*>(c.sc + Scratch::HP + HPK_MAX));
     __syncthreads();
-    PROFQ(c, 25);
+    PROFQ(c, 41);
 
     PROF(c, 9);
     // ---------------- TrustRegionMinimizer ----------------
@@ -2153,6 +2280,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       }
       gradient_max_norm = block_max<NT>(gm, lds + L_RED);
       __syncthreads();
+      if (c.prof && t == 0) c.prof[43] += clock64() - pt__;
       scale_system(c);
       PROF(c, 10);
     };
@@ -2240,7 +2368,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         // Gauss-Newton step with mu retry (DoglegStrategy::ComputeGaussNewtonStep)
         solver_ok = false;
         bool rebuilt = true;
-        PROFQ(c, 16);
+        PROFQ(c, 32);
         while (mu < max_mu) {
           if (!rebuilt) {  // S was destroyed by a failed factorisation: rebuild the normal equations
             evaluate_x();
@@ -2291,12 +2419,12 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           if (!have_alpha) {  // Cauchy point, needed only when the GN step leaves the trust region
             for (int i = t; i < VEC; i += NT) lds[L_ST + i] = i < NF + c.nf ? DG(i) / lds[L_DD + i] : 0.0;
             __syncthreads();
-            PROFQ(c, 17);
+            PROFQ(c, 33);
             jusq = jac_times_vec_sq(c, o);
             alpha = gnorm * gnorm / jusq;
             have_alpha = true;
             __syncthreads();
-            PROFQ(c, 18);
+            PROFQ(c, 34);
           }
           if (gnorm * alpha >= radius) {
             k1 = radius / gnorm, k2 = 0;
@@ -2344,7 +2472,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         continue;
       }
       // candidate
-      PROFQ(c, 17);
+      PROFQ(c, 33);
       PROF_T0();
       state_plus();
       __syncthreads();
@@ -2364,7 +2492,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       const bool last_iteration = iteration >= o.max_num_iterations;
       const bool spec = speculate && !last_iteration;
       double cand_cost;
-      PROFQ(c, 19);
+      PROFQ(c, 35);
       if (spec) {
         spec_enter();  // x <- candidate; the current point and the GN step are parked in the slot
         cand_cost = eval_jac(c, o);
@@ -2422,7 +2550,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         radius *= 0.5;
         reuse = true;
       }
-      PROFQ(c, 20);
+      PROFQ(c, 36);
     }
     __syncthreads();
     PROFQ_T0();
@@ -2513,8 +2641,8 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         B.inv_depth[(size_t)w * B.max_feat + e] = 1.0 / (1.0 / lds[L_X + XLAM + e]);
       }
     }
-    PROFQ(c, 21);
-    if (c.prof && t == 0) c.prof[31] += 1;
+    PROFQ(c, 37);
+    if (c.prof && t == 0) c.prof[31] += 1, c.prof[42] += clock64() - pw__;
     if (t == 0 && A.summary) {
       avm_solve_summary* so = A.summary + w;
       so->termination = termination;
@@ -2962,7 +3090,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
   const int flag = A.opt.marginalization_flag;
   for (int w = blockIdx.x; w < B.n_windows; w += gridDim.x) {
     WinCtx cl;
-    cl.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * 32) : nullptr;
+    cl.prof = A.prof ? as_global(A.prof + (size_t)blockIdx.x * PROF_SLOTS) : nullptr;
     cl.sc = as_global(A.scratch + (size_t)blockIdx.x * Scratch::TOTAL);
     cl.osf = as_global(A.iscratch + (size_t)blockIdx.x * ISCRATCH);
     cl.cov = cl.osf + MAXOBS;
@@ -3029,11 +3157,16 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     }
     const bool imu0 = flag == AVM_MARGIN_OLD && c.psum[0] < o.max_sum_dt;  // estimator.cpp:841
     if (flag == AVM_MARGIN_OLD) {
-      if (t >= 1 && t < NFR) {  // start-frame-0 features observed in frame t
+      for (int f = 1 + wv; f < NFR; f += NT / 64) {  // start-frame-0 features observed in frame f (ballot compaction, see the solve)
         int n = 0;
-        for (int e = 0; e < c.nf; e++)
-          if (ids[I_FSTART + e] == 0 && t < ids[I_FNOBS + e]) c.cov[t * MAXE + n++] = e;
-        ids[I_NCOV + t] = n;
+        for (int e0 = 0; e0 < c.nf; e0 += 64) {
+          const int e = min(e0 + lane, MAXE - 1);
+          const bool in = e0 + lane < c.nf && ids[I_FSTART + e] == 0 && f < ids[I_FNOBS + e];
+          const unsigned long long m = __ballot(in);
+          if (in) c.cov[f * MAXE + n + __popcll(m & ((1ull << lane) - 1ull))] = e;
+          n += __popcll(m);
+        }
+        if (lane == 0) ids[I_NCOV + f] = n;
       }
     } else if (t < NFR) {
       ids[I_NCOV + t] = 0;
@@ -3044,7 +3177,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     for (int i = t; i < 465; i += NT) IJR[i] = 0.0;
     __syncthreads();
     int nf0 = 0;  // features starting at frame 0 (they come first)
-    for (int e = 0; e < c.nf; e++) nf0 += ids[I_FSTART + e] == 0 ? 1 : 0;
+    for (int e0 = 0; e0 < c.nf; e0 += 64) nf0 += __popcll(__ballot(e0 + lane < c.nf && ids[I_FSTART + min(e0 + lane, MAXE - 1)] == 0));
     PROF(c, 16);
     // ---- phase A: projection factors of the start-0 features || IMU factor 0
     if (wv < MASM) {
@@ -3193,7 +3326,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0); break;
         case 2: marg_schur_macro_tile<2, 3, 2, 3>(nf0); break;
         case 3: marg_schur_macro_tile<4, -1, 0, 1>(nf0); break;
-        case 4: marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
+        case 7: marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
         case 5: marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
         default: break;
       }

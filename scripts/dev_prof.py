@@ -18,7 +18,7 @@ w = synth.tile_windows(base, nw)
 E.optimization(w.copy())
 E.optimization(w.copy())
 ms = E.ctx.kernel_ms("window_solve")
-prof = (C.c_longlong * 32)()
+prof = (C.c_longlong * 64)()
 E.ctx._L.avm_debug_copy_profile.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 E.ctx.check(E.ctx._L.avm_debug_copy_profile(E.ctx.h, prof), "prof")
 tot = sum(prof[:4]) + sum(prof[7:16]); n = prof[31]
@@ -26,11 +26,12 @@ print(f"windows {nw} tracks {tracks}: kernel {ms:.3f} ms, {nw/ms*1e3:.0f} solves
 for k, nm in enumerate(NAMES):
     print(f"  {nm:22s} {prof[k]/n:12.0f} cyc/window  {100*prof[k]/tot:5.1f}%")
 print(f'  chol lookahead: wave0 (tile+diag) {prof[28]/n:.0f} cyc/window ; wave1 (tiles) {prof[27]/n:.0f} cyc/window')
-if not prof[30]:
+if True:
     QN = ["iteration head: D, |g/D|", "dogleg vectors + model", "Cauchy: |J u|^2", "state_plus + step norm", "accept / reject", "gauge fix + outputs",
-          "load: states, tables", "load: cov lists, fs", "load: LPT + zero slot", "load: Hp = J0^T J0"]
+          "load: states, tables", "load: cov lists, fs", "load: LPT + zero slot", "load: Hp = J0^T J0", "WINDOW TOTAL (wall)", "  of scale/gmax: gmax part"]
     for k, nm in enumerate(QN):
-        print(f"  {nm:26s} {prof[16+k]/n:12.0f} cyc/window  {100*prof[16+k]/tot:5.1f}%")
+        print(f"  {nm:26s} {prof[32+k]/n:12.0f} cyc/window  {100*prof[32+k]/tot:5.1f}%")
+print("  phase A busy time per wavefront (cyc/window):", " ".join(f"{prof[48+k]/n:.0f}" for k in range(8)))
 MN = ["load", "A: frames+imu0", "B: feat sums/PART", "D: imu0 JtJ", "E: prior", "F: feature schur", "G+extract", "eig16", "pinv+schur15", "eig n", "write out"]
 if prof[30]:
     mt = sum(prof[16:27]); print(f"preint {E.ctx.kernel_ms('preint'):.3f} ms; marginalize: kernel {E.ctx.kernel_ms('marginalize'):.3f} ms + prior_eig {E.ctx.kernel_ms('prior_eig'):.3f} ms; per-window cycles {mt/prof[30]:.0f}")
