@@ -772,6 +772,7 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
   double* W = c.sc + Scratch::W;
   double* PF = c.sc + Scratch::PF;
   double* PART = c.sc + Scratch::PART + (size_t)b * NFR * 27;
+  const double* scl = lds + L_SC;
   d4 Dtot = {0, 0, 0, 0}, Drun = {0, 0, 0, 0}, Drun1 = {0, 0, 0, 0}, Drun2 = {0, 0, 0, 0}, Drun3 = {0, 0, 0, 0};
   int a_run = -1, pmask = 0;
   double cost = 0;
@@ -784,7 +785,9 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
     for (int r = 0; r < 4; r++) {
       const int row = drow + 4 * r;
       const double v = Drun[r];
-      if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + 6 * a_run + (dcol - 6)] = v;  // Jj^T Ji
+      // (entries of S are written Jacobi-scaled: s_i s_j H_ij, with s = 1 until the first evaluation has fixed it)
+      if (row < 6 && dcol >= 6 && dcol < 12)
+        lds[L_S + roff(6 * b + row) + 6 * a_run + (dcol - 6)] = v * (scl[6 * b + row] * scl[6 * a_run + (dcol - 6)]);  // Jj^T Ji
       if (row >= 6 && row < 12) {
         const int i = row - 6;
         if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[a_run * 27 + i * (i + 1) / 2 + (dcol - 6)] = v;  // Ji^T Ji (lower)
@@ -880,7 +883,7 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = drow + 4 * r;
-    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r];
+    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r] * (scl[6 * b + row] * scl[6 * b + dcol]);
     if (row < 6 && dcol == 12) lds[L_G + 6 * b + row] = Dtot[r];
   }
   if (lane == 0) ids[I_PMASK + b] = pmask;
@@ -1099,6 +1102,12 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
   // its (up to) 12 entries - or its private dump slot in the scratch tile - then all reads, all adds, all writes
   // (a predicated LDS read-modify-write is a branch with its own s_waitcnt; 16 of them in a row cost ~2K cycles).
   double half_rr = 0;
+  // entries of S are written Jacobi-scaled (see frame_task); the gradient is scaled afterwards, as a vector
+#ifdef AVM_X
+#define SCL(i) 1.0
+#else
+#define SCL(i) lds[L_SC + max(i, 0)]
+#endif
   const int ccol0 = li > 0 ? imu_col(i, li - 1) : -1;          // state column of combined column li
   const int ccol1 = li < 15 ? imu_col(i, 15 + li) : -1;        // ... of combined column 16 + li
   const int dump = L_WCH + 512 + lane;
@@ -1113,16 +1122,17 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
     if (R0 == 0 && li == 0) half_rr = 0.5 * G00[r];
     const bool v00 = R0 > 0 && li <= R0;
     off[3 * r] = !v00 ? dump : (li == 0 ? L_G + sr0 : L_S + roff(max(sr0, ccol0)) + min(sr0, ccol0));
-    val[3 * r] = G00[r];
+    val[3 * r] = G00[r] * (li == 0 ? 1.0 : SCL(sr0) * SCL(ccol0));
     // G10: rows 16..30, columns 0..15
     const bool v10 = R1 < 31;
     off[3 * r + 1] = !v10 ? dump : (li == 0 ? L_G + sr1 : L_S + roff(max(sr1, ccol0)) + min(sr1, ccol0));
-    val[3 * r + 1] = G10[r];
+    val[3 * r + 1] = G10[r] * (li == 0 ? 1.0 : SCL(sr1) * SCL(ccol0));
     // G11: rows / columns 16..30, lower part
     const bool v11 = R1 < 31 && li < 15 && 16 + li <= R1;
     off[3 * r + 2] = !v11 ? dump : L_S + roff(max(sr1, ccol1)) + min(sr1, ccol1);
-    val[3 * r + 2] = G11[r];
+    val[3 * r + 2] = G11[r] * (SCL(sr1) * SCL(ccol1));
   }
+#undef SCL
   double cur[12];
 #pragma unroll
   for (int q = 0; q < 12; q++) cur[q] = lds[off[q]];
@@ -1290,7 +1300,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
         int i = 0;
         while ((i + 1) * (i + 2) / 2 <= q) i++;
         const int j = q - i * (i + 1) / 2;
-        lds[L_S + roff(6 * f + i) + 6 * f + j] += sacc;
+        lds[L_S + roff(6 * f + i) + 6 * f + j] += sacc * (lds[L_SC + 6 * f + i] * lds[L_SC + 6 * f + j]);
       } else {
         lds[L_G + 6 * f + (q - 21)] += sacc;
       }
@@ -1458,9 +1468,9 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
-// Scratch of the factorization inside the [32][80] tile at L_WCH (dead while S is being factored): L^-T of the current
-// diagonal block, a 16x16 identity, and a per-lane dump slot for the masked-out stores.
-constexpr int L_CLT = L_WCH, L_CID = L_WCH + 256, L_CDUMP = L_WCH + 512;
+// Scratch of the factorization inside the tile at L_WCH (dead while S is being factored): L^-T of the current and of the
+// next diagonal block, and a per-lane dump slot for the masked-out stores.
+constexpr int L_CLT = L_WCH /* two buffers of 256: block j's L^-T in buffer j & 1 */, L_CDUMP = L_WCH + 512;
 
 // ---- tiles of the factorization, 16x16 on v_mfma_f64_16x16x4 --------------------------------------------------------
 // Everything is unconditional (a predicated LDS access compiles to a branch with its own s_waitcnt): operand rows are
@@ -1491,7 +1501,7 @@ AVM_DEV double fast_rsqrt(double x) {
 //  * The wavefront is instruction-issue bound (~4.5 cycles per FP64 / v_readlane instruction, 3 instructions per
 //    (pivot, column) pair), so everything else is kept out of it: no pivot bookkeeping, stores by address select, and the
 //    rank-1 update of pivot j-1 is software-pipelined by hand into the latency shadows of pivot j's reciprocal chain.
-AVM_NOINL void chol_diag_block(int c0, int nb) {
+AVM_NOINL void chol_diag_block(int c0, int nb, int buf) {
   constexpr int NB = CNB;
   double* S = LDS() + L_S;
   const int r = threadIdx.x & 63;
@@ -1501,10 +1511,10 @@ AVM_NOINL void chol_diag_block(int c0, int nb) {
   const int rc = min(r, nb - 1);
   double* row = S + roff(c0 + rc) + c0;
   {
-    const double* src = idl ? LDS() + L_CID + (r & 15) * NB : row;
-    const int kc = idl ? NB - 1 : rc;
 #pragma unroll
-    for (int k = 0; k < NB; k++) a[k] = src[min(k, kc)];  // 16 reads in flight, always a valid address
+    for (int k = 0; k < NB; k++) a[k] = row[min(k, rc)];  // 16 reads in flight, always a valid address
+#pragma unroll
+    for (int k = 0; k < NB; k++) a[k] = idl ? ((r & 15) == k ? 1.0 : 0.0) : a[k];  // lanes 16..31: the identity's rows
   }
   double uprev = 0.0;
 #pragma unroll
@@ -1535,7 +1545,7 @@ AVM_NOINL void chol_diag_block(int c0, int nb) {
     uprev = a[j] * y;
   }
   {
-    double* dst = idl ? LDS() + L_CLT + (r & 15) * NB : row;
+    double* dst = idl ? LDS() + L_CLT + buf * (NB * NB) + (r & 15) * NB : row;
     double* dump = LDS() + L_CDUMP + r;
     const int kmax = idl ? NB - 1 : (r < nb ? r : -1);
 #pragma unroll
@@ -1583,100 +1593,127 @@ AVM_DEV void chol_left_tile(int ti, int tj, int p_begin, int p_end) {
   for (int r = 0; r < 4; r++) LDS()[T.o[r]] = T.d[r] - D[r];
 }
 
+// X_ij = (A_ij - X_{i,j-1} X_{j,j-1}^T) L_jj^-T: the tile of row block ti in block column j (c0 = 16 j, nb columns), for the
+// rows >= c0 + nb.  `upd`: the tile still lacks the update of the last solved panel (j - 1); that product is computed
+// TRANSPOSED - X_{j,j-1} X_{i,j-1}^T - because the accumulator layout of the transposed tile is exactly the A operand
+// layout of the solve: the update costs no round trip through LDS.  bop = L_jj^-T (B operand), isq = rsqrt(d_c) of the
+// lane's column (see chol_diag_block).
+AVM_DEV void chol_panel_tile(int ti, int c0, int nb, const double (&bop)[CNB / 4], double isq, bool upd) {
+  constexpr int NB = CNB, NR = NF + 1;
+  double* lds = LDS();
+  double* S = lds + L_S;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int c1 = c0 + nb;
+  const int row = 16 * ti + lr;
+  const double* pa = S + roff(min(row, NR - 1)) + c0 + lk;
+  const bool va = row < NR && row >= c1;
+  double aop[NB / 4];
+#pragma unroll
+  for (int m = 0; m < NB / 4; m++) aop[m] = pa[4 * m];  // past-the-row reads stay inside the LDS carve and are masked below
+  if (upd) {
+    const dv2* pj = reinterpret_cast<const dv2*>(S + roff(min(c0 + lr, NF - 1)) + (c0 - NB) + 4 * lk);
+    const dv2* pi = reinterpret_cast<const dv2*>(S + roff(min(row, NR - 1)) + (c0 - NB) + 4 * lk);
+    const dv2 a0 = pj[0], a1 = pj[1], b0 = pi[0], b1 = pi[1];
+    d4 C0 = {0, 0, 0, 0}, C1 = {0, 0, 0, 0}, C2 = {0, 0, 0, 0}, C3 = {0, 0, 0, 0};
+    C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], C0, 0, 0, 0);
+    C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], C1, 0, 0, 0);
+    C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], C2, 0, 0, 0);
+    C3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], C3, 0, 0, 0);
+    const d4 C = (C0 + C1) + (C2 + C3);  // C[m] = (X_{i,j-1} X_{j,j-1}^T)[row lr][column lk + 4 m]
+#pragma unroll
+    for (int m = 0; m < NB / 4; m++) aop[m] -= C[m];
+  }
+#pragma unroll
+  for (int m = 0; m < NB / 4; m++) aop[m] = (va && lk + 4 * m < nb) ? aop[m] : 0.0;
+  d4 Da = {0, 0, 0, 0}, Db = {0, 0, 0, 0};
+  Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], bop[0], Da, 0, 0, 0);
+  Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], bop[1], Db, 0, 0, 0);
+  Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], bop[2], Da, 0, 0, 0);
+  Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], bop[3], Db, 0, 0, 0);
+  const d4 D = (Da + Db) * isq;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi = 16 * ti + lk + 4 * r;
+    lds[(gi < NR && gi >= c1 && lr < nb) ? L_S + roff(gi) + c0 + lr : L_CDUMP + lane] = D[r];
+  }
+}
+
 // In-place lower Cholesky of the packed NFxNF matrix in lds[L_S]; returns false on a non-positive pivot.
 // The right-hand side rides along as row NF of the packed storage, so the forward substitution L z = b happens as part of
-// the factorization (z ends up in that row).  LEFT-looking by 16-column blocks, with look-ahead:
-//   P_j: panel solve of block column j, X_ij = U_ij L_jj^-T on the MFMA (L_jj^-T comes out of chol_diag_block); wavefront 0
-//        takes row block j + 1 first;
-//   Q_j: every tile (i, j + 1) receives its whole update sum_{p <= j} X_ip X_{j+1,p}^T at once (chol_left_tile); wavefront 0
-//        does the diagonal tile (j + 1, j + 1) and immediately factors it in its registers (chol_diag_block) while the
-//        others finish the rest of the column.
-// The critical path per block column is wavefront 0's: one row-block solve, one tile update, the 16-pivot chain.
+// the factorization (z ends up in that row).  LEFT-looking by 16-column blocks, ONE workgroup barrier per block column,
+// everything lagging one panel behind the diagonal.  At the barrier that opens phase j: the panels p < j are solved, the
+// diagonal block j is factored (L_jj^-T in buffer j & 1), the tiles of block column j carry the updates of the panels
+// p <= j - 2 and the diagonal tile (j + 1, j + 1) those of the panels p <= j - 1.  Phase j:
+//   wavefront 0  (the critical path): tile (j + 1, j) = [last panel's update, solve]; diagonal tile (j + 1, j + 1) -= panel
+//                j; then its 16-pivot chain (chol_diag_block).  It reads nothing the others write in this phase.
+//   the helpers  (wavefronts 1-3, 5-7; wavefront 4 shares wavefront 0's SIMD and FP64 pipe and stays idle): the other
+//                tiles (i, j) = [last panel's update, solve]; block column j + 1 receives the panels p < j (solved before
+//                the phase began); the diagonal tile (j + 2, j + 2) receives the panels p <= j from the helper that
+//                solves tile (j + 2, j).
+// Every tile is read-modify-written once for all its early panels and once more, fused with its solve, for the last one.
 AVM_NOINL bool cholesky_lds(long long* prof) {
   struct { long long* prof; } c{prof};
   double* lds = LDS();
   double* S = lds + L_S;
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, lr = lane & 15, lk = lane >> 4;
   constexpr int NB = CNB;
-  constexpr int NR = NF + 1;  // rows incl. the augmented RHS row
+  constexpr int NHELP = NT / 64 - 2;
+  const int hslot = wv < 4 ? wv - 1 : wv - 5 + 3;  // helpers 1 2 3 5 6 7 -> 0..5 (wavefronts 0 and 4: not helpers)
+  const bool helper = wv != 0 && wv != 4;
   int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
   if (t == 0) *s_fail = 0;
-  if (t < NB * NB) lds[L_CID + t] = (t >> 4) == (t & 15) ? 1.0 : 0.0;
-  __syncthreads();
   PROF_T0();
-  if (wv == 0) chol_diag_block(0, NB);
+  if (wv == 0) chol_diag_block(0, NB, 0);
   __syncthreads();
   PROF(c, 4);
-  for (int c0 = 0; c0 < NF; c0 += NB) {
+  for (int j = 0, c0 = 0; c0 < NF; j++, c0 += NB) {
     const int nb = min(NB, NF - c0), c1 = c0 + nb;
-    // ---- P_j: X = U L^-T for the rows below the block (and the RHS row); B operand = L^-T (lds[L_CLT], left there by
-    //      chol_diag_block, stored times sqrt(d_c) per column: the pivots sit on the diagonal of the block)
+    const int t0 = c1 >> 4;  // first tile row with rows below the block (the block's own tile row when nb < 16)
+    // B operand of the solves = L_jj^-T (left in buffer j & 1 by chol_diag_block, stored times sqrt(d_c) per column: the
+    // pivots sit on the diagonal of the block)
+    double bop[NB / 4];
     {
-      const double* LT = lds + L_CLT;
-      double bop[NB / 4];
+      const double* LT = lds + L_CLT + (j & 1) * (NB * NB);
 #pragma unroll
       for (int m = 0; m < NB / 4; m++) bop[m] = LT[(lk + 4 * m) * NB + lr];
-      const int cc = c0 + min(lr, nb - 1);
-      const double dc = S[roff(cc) + cc];
-      if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront sees the same values
-      const double isq = fast_rsqrt(dc);  // applied to the product's columns below: its latency hides under the loads and MFMAs
+    }
+    const int cc = c0 + min(lr, nb - 1);
+    const double dc = S[roff(cc) + cc];
+    if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront sees the same values
+    const double isq = fast_rsqrt(dc);  // applied to the product's columns: its latency hides under the loads and MFMAs
 #pragma unroll
-      for (int m = 0; m < NB / 4; m++) bop[m] = (lk + 4 * m < nb && lr < nb) ? bop[m] : 0.0;
-      // (wavefront 4 shares its SIMD - and with it the FP64 pipe the MFMAs run on - with wavefront 0, whose pivot chain is
-      //  the critical path: it gets no tiles, here or in Q_j)
-      constexpr int NHELP = NT / 64 - 1;
-      const int slot = wv < 4 ? wv : wv - 1;  // 0 1 2 3 - 4 5 6
-      for (int ti = (c1 >> 4) + slot; ti <= TLAST && wv != 4; ti += NHELP) {
-        const int row = 16 * ti + lr;
-        const double* pa = S + roff(min(row, NR - 1)) + c0 + lk;
-        const bool va = row < NR && row >= c1;
-        double aop[NB / 4];
-#pragma unroll
-        for (int m = 0; m < NB / 4; m++) aop[m] = pa[4 * m];  // past-the-row reads stay inside the LDS carve and are masked below
-#pragma unroll
-        for (int m = 0; m < NB / 4; m++) aop[m] = (va && lk + 4 * m < nb) ? aop[m] : 0.0;
-        d4 Da = {0, 0, 0, 0}, Db = {0, 0, 0, 0};
-        Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], bop[0], Da, 0, 0, 0);
-        Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], bop[1], Db, 0, 0, 0);
-        Da = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], bop[2], Da, 0, 0, 0);
-        Db = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], bop[3], Db, 0, 0, 0);
-        const d4 D = (Da + Db) * isq;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int gi = 16 * ti + lk + 4 * r;
-          lds[(gi < NR && gi >= c1 && lr < nb) ? L_S + roff(gi) + c0 + lr : L_CDUMP + lane] = D[r];
-        }
+    for (int m = 0; m < NB / 4; m++) bop[m] = (lk + 4 * m < nb && lr < nb) ? bop[m] : 0.0;
+    const bool last = c1 >= NF;
+    if (wv == 0) {
+      const long long q0 = clock64();
+      chol_panel_tile(t0, c0, nb, bop, isq, j > 0 && t0 > j);
+      if (!last) {
+        wave_lds_sync();
+        chol_left_tile(j + 1, j + 1, j, j + 1);  // (the panels before were applied a phase ago by the first helper)
+        wave_lds_sync();
+        chol_diag_block(c1, min(NB, NF - c1), (j + 1) & 1);
       }
+      if (c.prof && t == 0) c.prof[28] += clock64() - q0;
+    } else if (helper) {
+      const long long q0 = clock64();
+      for (int ti = t0 + 1 + hslot; ti <= TLAST; ti += NHELP) chol_panel_tile(ti, c0, nb, bop, isq, j > 0 && ti > j);
+      // the diagonal tile (j + 2, j + 2) only needs its own row block's panels: the helper that has just solved tile
+      // (j + 2, j) applies all of them, panel j included, so that wavefront 0 adds a single panel next phase
+      if (!last && hslot == 0 && j + 2 <= TLAST) {
+        wave_lds_sync();
+        chol_left_tile(j + 2, j + 2, 0, j + 1);
+      }
+      if (!last && j > 0) {
+        // tiles (j + 2 .. TLAST, j + 1) receive the panels p < j; dealt in the opposite order of the panel tiles above
+        const int ntile = TLAST - (j + 1);
+        for (int k = NHELP - 1 - hslot; k < ntile; k += NHELP) chol_left_tile(j + 2 + k, j + 1, 0, j);
+      }
+      if (c.prof && t == 64) c.prof[27] += clock64() - q0;
     }
     __syncthreads();
     PROF(c, 5);
     if (*s_fail) return false;
-    if (c1 >= NF) break;
-    // ---- Q_j: block column j + 1 gets all its updates; look-ahead factorization of its diagonal block
-    {
-      const int tm = c1 >> 4;  // = j + 1
-      if (wv == 0) {
-        const long long q0 = clock64();
-        chol_left_tile(tm, tm, tm - 1, tm);  // the panels before the last one were applied a phase ago (below)
-        wave_lds_sync();
-        chol_diag_block(c1, min(NB, NF - c1));
-        if (c.prof && t == 0) c.prof[28] += clock64() - q0;
-      } else {
-        const long long q0 = clock64();
-        // items: tiles (tm + 1 .. 10, tm), then the early part of the NEXT diagonal tile (tm + 1, tm + 1): all panels solved
-        // so far, so that wavefront 0 only has to add one panel to it before it factors the block
-        const int nitem = (TLAST - tm) + (tm + 1 <= TLAST ? 1 : 0);
-        for (int k = (wv < 4 ? wv - 1 : wv - 2); k < nitem && wv != 4; k += NT / 64 - 2) {
-          if (k < TLAST - tm)
-            chol_left_tile(tm + 1 + k, tm, 0, tm);
-          else
-            chol_left_tile(tm + 1, tm + 1, 0, tm);
-        }
-        if (c.prof && t == 64) c.prof[27] += clock64() - q0;
-      }
-    }
-    __syncthreads();
-    PROF(c, 6);
+    if (last) break;
   }
   return true;
 }
@@ -1918,11 +1955,30 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
 }
 
 // Jacobi column scaling of the assembled system: H' = S H S, hee', g'  (W stays unscaled: see schur_reduce)
-AVM_NOINL void scale_system(const WinCtx&) {
+// `matrix`: also the entries of S.  In the base build that is needed once per solve, after the evaluation that fixes the
+// scaling: from then on the evaluations write S scaled (frame_task, the (a,a) sums, imu_factor_mfma) and the packed prior
+// in the slot is scaled in place here, once.
+AVM_NOINL void scale_system(const WinCtx&, bool matrix) {
   const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const int t = threadIdx.x;
   const double* scl = lds + L_SC;
+#ifndef AVM_X
+  if (matrix && c.pn > 0) {
+    const int* pidx = reinterpret_cast<const int*>(lds + L_INT) + I_PIDX;
+    gdouble* HPk = c.sc + Scratch::HP;
+    const int npk = c.pn * (c.pn + 1) / 2;
+    for (int idx = t; idx < npk; idx += NT) {
+      int gi = (int)((__builtin_sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (gi * (gi + 1) / 2 > idx) gi--;
+      while ((gi + 1) * (gi + 2) / 2 <= idx) gi++;
+      const int gj = idx - gi * (gi + 1) / 2;
+      const int ip = pidx[gi], iq = pidx[gj];
+      if (ip >= 0 && iq >= 0) HPk[idx] *= scl[ip] * scl[iq];
+    }
+  }
+#endif
+  if (matrix)
   // 16x16 tiles of the packed lower triangle dealt to the wavefronts, 4 entries per lane and tile (the same lane <-> entry
   // map as the accumulators of the factorization): every lane has the same amount of work; three tiles per round with
   // all their loads in flight before the first store, the tile index arithmetic on the scalar unit, and entries outside
@@ -2247,6 +2303,8 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     auto post_evaluate = [&]() {
       PROF_T0();
       // Jacobi scaling from the column norms of the first Jacobian (diag of unscaled H)
+      const bool was_first = first;
+      (void)was_first;
       if (first) {
         if (o.jacobi_scaling) {
           if (t < NF) lds[L_SC + t] = 1.0 / (1.0 + sqrt(lds[L_S + roff(t) + t]));
@@ -2281,7 +2339,11 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       gradient_max_norm = block_max<NT>(gm, lds + L_RED);
       __syncthreads();
       if (c.prof && t == 0) c.prof[43] += clock64() - pt__;
-      scale_system(c);
+#ifdef AVM_X
+      scale_system(c, true);
+#else
+      scale_system(c, was_first);
+#endif
       PROF(c, 10);
     };
     auto evaluate_x = [&]() {
