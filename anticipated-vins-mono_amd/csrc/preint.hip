@@ -4,17 +4,26 @@
 //   (midPointIntegration: F, V, jacobian = F*jacobian, covariance = F P F^T + V Q V^T),
 //   :130-158 (propagate), and imu_factor.h:64 (sqrt_info = LLT(cov^-1).matrixL()^T, which the
 //   reference recomputes on every Evaluate; it is constant during a solve, so hoisted here).
-// Mapping: one 64-lane wavefront per (window, interval); the 15x15 state lives in LDS, the
-// 225 outputs of each 15x15 product are spread 4 per lane.  4 intervals per 256-thread block.
+// Mapping: one 64-lane wavefront per FOUR (window, interval) pairs, two kernels.
+//  preint_kernel   the sample loop.  Its scalar part (the running delta_p / delta_q / delta_v, the rotation blocks of F and
+//                  V) is lane-agnostic code: each 16-lane group runs it for its own interval, so one instruction stream
+//                  serves four intervals.  The matrix products need all 64 lanes per interval: they are done for the four
+//                  intervals one after the other, each with its own 15x15 state in registers and its own images of the
+//                  sample-dependent rows of F and V in LDS (the other rows are synthesized in registers).
+//  sqrt_info_kernel  lane = (interval, row): the 15 x 30 tableau [P | I] lives in registers, a row per lane; the pivot row
+//                  of a step travels through a 30-double LDS buffer.  Partial pivoting without moving rows (every lane
+//                  tracks the position its row would have after the swaps, which also settles ties the way the swapped
+//                  storage would), same operations per entry as the row-swapping form.
 #include "devmath.hpp"
 #include "kernels.hpp"
 
 namespace avm {
 
 namespace {
-constexpr int PW = 4;  // waves per block
+constexpr int PW = 2;  // wavefronts per block
+constexpr int PG = 4;  // intervals per wavefront
 
-// every wavefront integrates its own interval: only wave-level ordering of its LDS traffic is needed
+// every wavefront works on its own intervals: only wave-level ordering of its LDS traffic is needed
 AVM_DEV void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -23,12 +32,18 @@ AVM_DEV void wsync() {
 }
 
 struct PreLds {
-  double Fi[256];  // F, 16 x 16 image (row/column 15 = 0); the sqrt_info phase reuses it as its 15 x 15 work matrix
-  double Vi[320];  // V, 16 x 20 image (row 15, columns 18-19 = 0); reused for the inverse in the sqrt_info phase
-  double m[72];    // Rd, Rr, Ra0, Ra1, IRw (I - Rw*dt), T1=Rd*Ra0, T2=Rr*Ra1, T3=T2*IRw
-  double piv[16];
+  double Fi[9 * 16];  // rows 0..8 of F, 16 columns (column 15 = 0); rows 9..14 are rows of the identity
+  double Vi[9 * 20];  // rows 0..8 of V, 20 columns (18-19 = 0); rows 9..14 hold I dt in the columns row + 3
+  double m[72];       // Rd, Rr, Ra0, Ra1, IRw (I - Rw*dt), T1=Rd*Ra0, T2=Rr*Ra1, T3=T2*IRw
 };
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+AVM_DEV double readlane_f64(double v, int srclane) {  // srclane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
 }  // namespace
 
 // The 15 x 15 state matrices never leave registers: with v_mfma_f64_16x16x4 the accumulator layout
@@ -37,16 +52,24 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //   covariance <- F * (P * F^T) + V * (Q V^T)       4 + 4 + 5 MFMAs; P is symmetric, so its accumulator registers
 //                                                   double as the A operand P[l & 15][(l >> 4) + 4 m], and the
 //                                                   A-layout registers of F (of V) double as the B operand F^T (V^T)
-// F and V are rebuilt per sample as small LDS images (only their sample-dependent 3x3 blocks are rewritten) and
-// each lane fetches its 4 + 5 operand entries from there.
-__global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8))) void preint_kernel(PreintArgs a) {
+__global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   PreLds* all = reinterpret_cast<PreLds*>(smem_raw);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  PreLds& L = all[wv];
-  const long iv = (long)blockIdx.x * PW + wv;  // interval index = w*10 + j
-  if (iv >= (long)a.n_windows * 10) return;    // no block-level barriers below
-  const int ns = a.imu_n[iv];
+  const int li = lane & 15, lk = lane >> 4;
+  const long n_iv = (long)a.n_windows * 10;
+  const long iv0 = ((long)blockIdx.x * PW + wv) * PG;  // first interval of this wavefront (interval index = w*10 + j)
+  if (iv0 >= n_iv) return;                             // no block-level barriers below
+  PreLds* Lw = all + wv * PG;                          // the wavefront's four images
+  // ---- scalar side: this lane works for interval iv0 + lk (clamped: a group past the end repeats the last interval and
+  //      stores nothing)
+  const bool gv = iv0 + lk < n_iv;
+  const long iv = gv ? iv0 + lk : n_iv - 1;
+  PreLds& L = Lw[lk];
+  const int ns = gv ? a.imu_n[iv] : 0;
+  int nsg[PG], ns_max = 0;
+#pragma unroll
+  for (int g = 0; g < PG; g++) nsg[g] = __builtin_amdgcn_readlane(ns, 16 * g), ns_max = max(ns_max, nsg[g]);
 
   const double* acc = a.imu_acc + iv * (a.max_samp + 1) * 3;
   const double* gyr = a.imu_gyr + iv * (a.max_samp + 1) * 3;
@@ -54,13 +77,16 @@ __global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8)))
   const v3 lba = mk3(a.imu_lin_ba[iv * 3], a.imu_lin_ba[iv * 3 + 1], a.imu_lin_ba[iv * 3 + 2]);
   const v3 lbg = mk3(a.imu_lin_bg[iv * 3], a.imu_lin_bg[iv * 3 + 1], a.imu_lin_bg[iv * 3 + 2]);
 
-  const int li = lane & 15, lk = lane >> 4;
-  // static part of the images: zeros, the identity blocks of F
-  for (int i = lane; i < 256; i += 64) L.Fi[i] = (i / 16 == i % 16 && i / 16 < 15) ? 1.0 : 0.0;
-  for (int i = lane; i < 320; i += 64) L.Vi[i] = 0.0;
-  d4 Jb = {0, 0, 0, 0}, Pb = {0, 0, 0, 0};
+  // static part of the images: zeros, the identity blocks of F's rows 0..8 (16 lanes per image)
+  for (int i = li; i < 9 * 16; i += 16) L.Fi[i] = (i / 16 == i % 16) ? 1.0 : 0.0;
+  for (int i = li; i < 9 * 20; i += 16) L.Vi[i] = 0.0;
+  d4 Jb[PG], Pb[PG];
 #pragma unroll
-  for (int r = 0; r < 4; r++) Jb[r] = (lk + 4 * r == li && li < 15) ? 1.0 : 0.0;
+  for (int g = 0; g < PG; g++) {
+    Pb[g] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) Jb[g][r] = (lk + 4 * r == li && li < 15) ? 1.0 : 0.0;
+  }
   // noise variance of V's column k = lk + 4 m (integration_base.h:21-27)
   double qn[5];
 #pragma unroll
@@ -68,17 +94,19 @@ __global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8)))
     const int k = lk + 4 * m;
     qn[m] = k >= 18 ? 0.0 : (k < 3 || (k >= 6 && k < 9)) ? a.acc_n * a.acc_n : (k < 12 ? a.gyr_n * a.gyr_n : (k < 15 ? a.acc_w * a.acc_w : a.gyr_w * a.gyr_w));
   }
-  // wave-uniform running state (every lane holds a copy)
+  // running state of the lane's interval (the 16 lanes of a group hold copies)
   v3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
   quat dq{1, 0, 0, 0};
   v3 acc0 = mk3(acc[0], acc[1], acc[2]), gyr0 = mk3(gyr[0], gyr[1], gyr[2]);
   double sum_dt = 0;
   wsync();
 
-  for (int s = 0; s < ns; s++) {
-    const double dt = dts[s];
-    const v3 acc1 = mk3(acc[3 * (s + 1)], acc[3 * (s + 1) + 1], acc[3 * (s + 1) + 2]);
-    const v3 gyr1 = mk3(gyr[3 * (s + 1)], gyr[3 * (s + 1) + 1], gyr[3 * (s + 1) + 2]);
+  for (int s = 0; s < ns_max; s++) {
+    const bool on = s < ns;              // (uniform within a 16-lane group)
+    const int sc = on ? s : 0;           // clamped sample index: the loads stay inside the interval's arrays
+    const double dt = dts[sc];
+    const v3 acc1 = mk3(acc[3 * (sc + 1)], acc[3 * (sc + 1) + 1], acc[3 * (sc + 1) + 2]);
+    const v3 gyr1 = mk3(gyr[3 * (sc + 1)], gyr[3 * (sc + 1) + 1], gyr[3 * (sc + 1) + 2]);
     // integration_base.h:63-69
     v3 un_acc_0 = qrot(dq, acc0 - lba);
     v3 un_gyr = 0.5 * (gyr0 + gyr1) - lbg;
@@ -87,7 +115,7 @@ __global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8)))
     v3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
     v3 rp = dp + dt * dv + (0.5 * dt * dt) * un_acc;
     v3 rv = dv + dt * un_acc;
-    if (lane == 0) {
+    if (li == 0 && on) {
       double Ra0[9], Ra1[9], Rw[9];
       q2R(dq, &L.m[0]);
       q2R(rq, &L.m[9]);
@@ -101,25 +129,29 @@ __global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8)))
       }
     }
     wsync();
-    if (lane < 18) {  // T1 = Rd * R_a_0_x (lanes 0-8), T2 = Rr * R_a_1_x (lanes 9-17)
-      const int e = lane % 9, r = e / 3, c = e % 3, o = lane < 9 ? 0 : 9;
-      L.m[45 + lane] = L.m[o + 3 * r] * L.m[18 + o + c] + L.m[o + 3 * r + 1] * L.m[18 + o + 3 + c] + L.m[o + 3 * r + 2] * L.m[18 + o + 6 + c];
+    if (li < 9 && on) {  // T1 = Rd * R_a_0_x, T2 = Rr * R_a_1_x
+      const int r = li / 3, c = li % 3;
+#pragma unroll
+      for (int o = 0; o < 18; o += 9)
+        L.m[45 + o + li] = L.m[o + 3 * r] * L.m[18 + o + c] + L.m[o + 3 * r + 1] * L.m[18 + o + 3 + c] + L.m[o + 3 * r + 2] * L.m[18 + o + 6 + c];
     }
     wsync();
-    if (lane < 9) {  // T3 = T2 * (I - R_w_x dt)
-      const int r = lane / 3, c = lane % 3;
-      L.m[63 + lane] = L.m[54 + 3 * r] * L.m[36 + c] + L.m[54 + 3 * r + 1] * L.m[36 + 3 + c] + L.m[54 + 3 * r + 2] * L.m[36 + 6 + c];
+    if (li < 9 && on) {  // T3 = T2 * (I - R_w_x dt)
+      const int r = li / 3, c = li % 3;
+      L.m[63 + li] = L.m[54 + 3 * r] * L.m[36 + c] + L.m[54 + 3 * r + 1] * L.m[36 + 3 + c] + L.m[54 + 3 * r + 2] * L.m[36 + 6 + c];
     }
-    dp = rp;
-    dv = rv;
-    dq = qnormalized(rq);  // integration_base.h:153
-    sum_dt += dt;
-    acc0 = acc1;
-    gyr0 = gyr1;
+    if (on) {
+      dp = rp;
+      dv = rv;
+      dq = qnormalized(rq);  // integration_base.h:153
+      sum_dt += dt;
+      acc0 = acc1;
+      gyr0 = gyr1;
+    }
     wsync();
-    if (lane < 9) {
-      const int r = lane / 3, c = lane % 3;
-      const double Rd = L.m[lane], Rr = L.m[9 + lane], T1 = L.m[45 + lane], T2 = L.m[54 + lane], T3 = L.m[63 + lane];
+    if (li < 9 && on) {
+      const int r = li / 3, c = li % 3;
+      const double Rd = L.m[li], Rr = L.m[9 + li], T1 = L.m[45 + li], T2 = L.m[54 + li], T3 = L.m[63 + li];
       const double I = (r == c) ? 1.0 : 0.0;
       const double dt2 = dt * dt;
       // F (integration_base.h:90-105)
@@ -127,7 +159,7 @@ __global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8)))
       L.Fi[(0 + r) * 16 + 6 + c] = I * dt;
       L.Fi[(0 + r) * 16 + 9 + c] = -0.25 * (Rd + Rr) * dt2;
       L.Fi[(0 + r) * 16 + 12 + c] = -0.25 * T2 * dt2 * -dt;
-      L.Fi[(3 + r) * 16 + 3 + c] = L.m[36 + lane];
+      L.Fi[(3 + r) * 16 + 3 + c] = L.m[36 + li];
       L.Fi[(3 + r) * 16 + 12 + c] = -1.0 * I * dt;
       L.Fi[(6 + r) * 16 + 3 + c] = -0.5 * T1 * dt + -0.5 * T3 * dt;
       L.Fi[(6 + r) * 16 + 9 + c] = -0.5 * (Rd + Rr) * dt;
@@ -145,139 +177,159 @@ __global__ __launch_bounds__(64 * PW) __attribute__((amdgpu_waves_per_eu(4, 8)))
       L.Vi[(6 + r) * 20 + 3 + c] = v63;
       L.Vi[(6 + r) * 20 + 6 + c] = 0.5 * Rr * dt;
       L.Vi[(6 + r) * 20 + 9 + c] = v63;
-      L.Vi[(9 + r) * 20 + 12 + c] = I * dt;
-      L.Vi[(12 + r) * 20 + 15 + c] = I * dt;
     }
     wsync();
-    double fa[4], va[5];
+    // ---- matrix side: the four intervals in turn, all 64 lanes each.  Rows 9..14 of the operands do not depend on the
+    //      rotations: F's are rows of the identity, V's hold I dt in column row + 3 (integration_base.h:102-104, 119-120)
+    const int lic = min(li, 8);
 #pragma unroll
-    for (int m = 0; m < 4; m++) fa[m] = L.Fi[li * 16 + lk + 4 * m];
+    for (int g = 0; g < PG; g++) {
+      if (s >= nsg[g]) continue;  // (wave-uniform)
+      const PreLds& G = Lw[g];
+      const double dtg = readlane_f64(dt, 16 * g);
+      double fa[4], va[5];
 #pragma unroll
-    for (int m = 0; m < 5; m++) va[m] = L.Vi[li * 20 + lk + 4 * m];
-    // jacobian = F * jacobian
-    d4 Jn = {0, 0, 0, 0}, Z = {0, 0, 0, 0}, Pn = {0, 0, 0, 0};
+      for (int m = 0; m < 4; m++) fa[m] = G.Fi[lic * 16 + lk + 4 * m];
 #pragma unroll
-    for (int m = 0; m < 4; m++) Jn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Jb[m], Jn, 0, 0, 0);
-    // Z = P * F^T ; covariance = F * Z + V * (Q V^T)
+      for (int m = 0; m < 5; m++) va[m] = G.Vi[lic * 20 + lk + 4 * m];
 #pragma unroll
-    for (int m = 0; m < 4; m++) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(Pb[m], fa[m], Z, 0, 0, 0);
+      for (int m = 0; m < 4; m++) fa[m] = li < 9 ? fa[m] : ((li < 15 && lk + 4 * m == li) ? 1.0 : 0.0);
 #pragma unroll
-    for (int m = 0; m < 4; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Z[m], Pn, 0, 0, 0);
+      for (int m = 0; m < 5; m++) va[m] = li < 9 ? va[m] : ((li < 15 && lk + 4 * m == li + 3) ? dtg : 0.0);
+      // jacobian = F * jacobian
+      d4 Jn = {0, 0, 0, 0}, Z = {0, 0, 0, 0}, Pn = {0, 0, 0, 0};
 #pragma unroll
-    for (int m = 0; m < 5; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(va[m], va[m] * qn[m], Pn, 0, 0, 0);
-    Jb = Jn;
-    Pb = Pn;
+      for (int m = 0; m < 4; m++) Jn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Jb[g][m], Jn, 0, 0, 0);
+      // Z = P * F^T ; covariance = F * Z + V * (Q V^T)
+#pragma unroll
+      for (int m = 0; m < 4; m++) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(Pb[g][m], fa[m], Z, 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Z[m], Pn, 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 5; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(va[m], va[m] * qn[m], Pn, 0, 0, 0);
+      Jb[g] = Jn;
+      Pb[g] = Pn;
+    }
     wsync();  // the images are rewritten by the next sample
   }
 
-  // covariance to LDS for the sqrt_info phase (15 x 15, row-major)
-  double* LA = L.Fi;
-  double* LI = L.Vi;
-  wsync();
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = lk + 4 * r;
-    if (row < 15 && li < 15) LA[row * 15 + li] = Pb[r];
-  }
-  for (int i = lane; i < 225; i += 64) LI[i] = (i / 15 == i % 15) ? 1.0 : 0.0;
-  wsync();
-  // ---- sqrt_info = LLT(P^-1).matrixL()^T : partial-pivot Gauss-Jordan then Cholesky -------
-  for (int k = 0; k < 15; k++) {
-    if (lane == 0) {
-      int p = k;
-      double best = fabs(LA[k * 15 + k]);
-      for (int i = k + 1; i < 15; i++)
-        if (fabs(LA[i * 15 + k]) > best) best = fabs(LA[i * 15 + k]), p = i;
-      L.piv[0] = (double)p;
-    }
-    wsync();
-    const int p = (int)L.piv[0];
-    if (p != k && lane < 15) {
-      double t = LA[k * 15 + lane];
-      LA[k * 15 + lane] = LA[p * 15 + lane];
-      LA[p * 15 + lane] = t;
-      t = LI[k * 15 + lane];
-      LI[k * 15 + lane] = LI[p * 15 + lane];
-      LI[p * 15 + lane] = t;
-    }
-    wsync();
-    const double piv = LA[k * 15 + k];
-    double fa[4], fi[4];
-    for (int q = 0; q < 4; q++) {
-      const int i = lane + 64 * q;
-      if (i < 225) {
-        const int r = i / 15, c = i % 15;
-        const double f = LA[r * 15 + k] / piv;
-        fa[q] = (r > k && c >= k) ? LA[i] - f * LA[k * 15 + c] : LA[i];
-        fi[q] = (r > k) ? LI[i] - f * LI[k * 15 + c] : LI[i];
-      }
-    }
-    wsync();
-    for (int q = 0; q < 4; q++) {
-      const int i = lane + 64 * q;
-      if (i < 225) LA[i] = fa[q], LI[i] = fi[q];
-    }
-    wsync();
-  }
-  for (int k = 14; k >= 0; k--) {
-    const double piv = LA[k * 15 + k];
-    if (lane < 15) LI[k * 15 + lane] = LI[k * 15 + lane] / piv;
-    wsync();
-    double fi[4];
-    for (int q = 0; q < 4; q++) {
-      const int i = lane + 64 * q;
-      if (i < 225) {
-        const int r = i / 15, c = i % 15;
-        fi[q] = (r < k) ? LI[i] - LA[r * 15 + k] * LI[k * 15 + c] : LI[i];
-      }
-    }
-    wsync();
-    for (int q = 0; q < 4; q++) {
-      const int i = lane + 64 * q;
-      if (i < 225) LI[i] = fi[q];
-    }
-    wsync();
-  }
-  // lower Cholesky of Inv (column algorithm, same operation order as the oracle's llt_lower), one lane per row
-  for (int k = 0; k < 15; k++) {
-    if (lane == 0) {
-      double x = LI[k * 15 + k];
-      for (int j = 0; j < k; j++) x -= LI[k * 15 + j] * LI[k * 15 + j];
-      LI[k * 15 + k] = sqrt(x);
-    }
-    wsync();
-    if (lane > k && lane < 15) {
-      double sacc = LI[lane * 15 + k];
-      for (int j = 0; j < k; j++) sacc -= LI[lane * 15 + j] * LI[k * 15 + j];
-      LI[lane * 15 + k] = sacc / LI[k * 15 + k];
-    }
-    wsync();
-  }
-  double* od = a.out_delta + iv * 10;
-  if (lane == 0) {
+  if (gv && li == 0) {
+    double* od = a.out_delta + iv * 10;
     od[0] = dp.x, od[1] = dp.y, od[2] = dp.z;
     od[3] = dq.x, od[4] = dq.y, od[5] = dq.z, od[6] = dq.w;
     od[7] = dv.x, od[8] = dv.y, od[9] = dv.z;
     a.out_sum_dt[iv] = sum_dt;
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = lk + 4 * r;
-    if (row < 15 && li < 15) {
-      a.out_jacobian[iv * 225 + row * 15 + li] = Jb[r];
-      a.out_covariance[iv * 225 + row * 15 + li] = Pb[r];
+  for (int g = 0; g < PG; g++) {
+    if (iv0 + g >= n_iv) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = lk + 4 * r;
+      if (row < 15 && li < 15) {
+        a.out_jacobian[(iv0 + g) * 225 + row * 15 + li] = Jb[g][r];
+        a.out_covariance[(iv0 + g) * 225 + row * 15 + li] = Pb[g][r];
+      }
     }
   }
-  for (int i = lane; i < 225; i += 64) {
-    const int r = i / 15, c = i % 15;
-    a.out_sqrt_info[iv * 225 + i] = (c >= r) ? LI[c * 15 + r] : 0.0;  // U = L^T
+}
+
+// ---- sqrt_info = LLT(P^-1).matrixL()^T (imu_factor.h:64): Gaussian elimination with partial pivoting on [P | I], back
+// substitution, then the lower Cholesky factor of the inverse (column algorithm, the oracle's llt_lower) --------------------
+__global__ __launch_bounds__(64 * PW) void sqrt_info_kernel(PreintArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const long n_iv = (long)a.n_windows * 10;
+  const long iv0 = ((long)blockIdx.x * PW + wv) * PG;
+  if (iv0 >= n_iv) return;
+  double* buf = reinterpret_cast<double*>(smem_raw) + (wv * PG + lk) * 32;  // the group's pivot-row buffer
+  const bool gv = iv0 + lk < n_iv;
+  const long iv = gv ? iv0 + lk : n_iv - 1;
+  const bool rowv = li < 15;
+  double A[15], Iv[15];
+  {
+    const double* P = a.out_covariance + iv * 225 + min(li, 14) * 15;
+#pragma unroll
+    for (int c = 0; c < 15; c++) A[c] = P[c], Iv[c] = c == li ? 1.0 : 0.0;
+  }
+  int pos = li;  // where this lane's row would sit after the row swaps done so far
+  // forward elimination
+#pragma unroll
+  for (int k = 0; k < 15; k++) {
+    // pivot: among the rows at positions k..14 the largest |a_k|, the lowest position on a tie
+    double best = (rowv && pos >= k) ? fabs(A[k]) : -1.0;
+    int bp = pos, bl = li;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o, 64);
+      const int op = __shfl_xor(bp, o, 64), ol = __shfl_xor(bl, o, 64);
+      const bool take = ob > best || (ob == best && op < bp);
+      best = take ? ob : best, bp = take ? op : bp, bl = take ? ol : bl;
+    }
+    // the swap of positions k and bp
+    if (rowv) pos = li == bl ? k : (pos == k ? bp : pos);
+    if (li == bl) {
+#pragma unroll
+      for (int c = k; c < 15; c++) buf[c] = A[c];
+#pragma unroll
+      for (int c = 0; c < 15; c++) buf[15 + c] = Iv[c];
+    }
+    wsync();
+    if (rowv && pos > k) {
+      const double f = A[k] / buf[k];
+#pragma unroll
+      for (int c = k; c < 15; c++) A[c] = A[c] - f * buf[c];
+#pragma unroll
+      for (int c = 0; c < 15; c++) Iv[c] = Iv[c] - f * buf[15 + c];
+    }
+    wsync();
+  }
+  // back substitution
+#pragma unroll
+  for (int k = 14; k >= 0; k--) {
+    if (rowv && pos == k) {
+      const double piv = A[k];
+#pragma unroll
+      for (int c = 0; c < 15; c++) Iv[c] = Iv[c] / piv, buf[c] = Iv[c];
+    }
+    wsync();
+    if (rowv && pos < k) {
+#pragma unroll
+      for (int c = 0; c < 15; c++) Iv[c] = Iv[c] - A[k] * buf[c];
+    }
+    wsync();
+  }
+  // lower Cholesky of the inverse; the lane at position r holds row r, overwritten in place by row r of L
+#pragma unroll
+  for (int k = 0; k < 15; k++) {
+    if (rowv && pos == k) {
+#pragma unroll
+      for (int j = 0; j < k; j++) buf[j] = Iv[j];
+    }
+    wsync();
+    double sacc = Iv[k];
+#pragma unroll
+    for (int j = 0; j < k; j++) sacc -= Iv[j] * buf[j];
+    if (rowv && pos == k) buf[16] = sacc;
+    wsync();
+    const double lkk = sqrt(buf[16]);
+    if (rowv && pos >= k) Iv[k] = pos == k ? lkk : sacc / lkk;
+    wsync();
+  }
+  // U = L^T: the lane at position c writes column c
+  if (gv && rowv) {
+    double* out = a.out_sqrt_info + iv * 225;
+#pragma unroll
+    for (int r = 0; r < 15; r++) out[r * 15 + pos] = r <= pos ? Iv[r] : 0.0;
   }
 }
 
 void launch_preint(const PreintArgs& a, hipStream_t stream) {
   const long n_iv = (long)a.n_windows * 10;
-  const int blocks = (int)((n_iv + PW - 1) / PW);
-  hipLaunchKernelGGL(preint_kernel, dim3(blocks), dim3(64 * PW), sizeof(PreLds) * PW, stream, a);
+  const int blocks = (int)((n_iv + PW * PG - 1) / (PW * PG));
+  hipLaunchKernelGGL(preint_kernel, dim3(blocks), dim3(64 * PW), sizeof(PreLds) * PW * PG, stream, a);
+  hipLaunchKernelGGL(sqrt_info_kernel, dim3(blocks), dim3(64 * PW), sizeof(double) * 32 * PW * PG, stream, a);
 }
 
 }  // namespace avm

@@ -1194,7 +1194,8 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     for (int u = 0; u < NRND; u++) {
       const int idx = min(t + u * NT, max(c.nf * NQ - 1, 0));
       const int q = idx / max(c.nf, 1), e = idx - q * c.nf;
-      const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
+      // (a window without features has no table entry to read: the clamped loads then stay at the start of the region)
+      const int a = c.nf > 0 ? ids[I_FSTART + e] : 0, no = c.nf > 0 ? ids[I_FNOBS + e] : 0;
       const double* P = PF + (q * NFRP + a) * WLE + e;  // + k * WLE : the factor observed in frame a + k
       // all (<= 10) loads in flight, clamped to the feature's last observation and masked; same pairing of the
       // partial sums as a sequential two-accumulator loop
