@@ -2738,8 +2738,9 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
 // speed-bias by frame, ex_pose.
 namespace mg {
 constexpr int MEX0 = 165, MTD = 171, MROWS = croff(172);  // 172 variables: poses | speed-biases | ex_pose | td
-constexpr int MXSTG = 20 * XRS;                       // column-major staging tile: Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18 | Jtd 19, XRS rows each
-constexpr int MASM = 4;                               // assembling wavefronts (staging must stay below row 165)
+constexpr int MXRS = 68;                              // rows per staged column: HALF a chunk (32 factors x 2 residual rows) + 4 (bank spread)
+constexpr int MXSTG = 20 * MXRS;                      // column-major staging tile: Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18 | Jtd 19
+constexpr int MASM = 7;                               // assembling wavefronts (staging must stay below row 165: half tiles let seven fit)
 constexpr int M_G = MROWS;                            // b over the 171 variables (176)
 constexpr int M_GE = M_G + 176;                       // g_e (152)
 constexpr int M_WCH = M_GE + 152;                     // [24][80] Schur staging / IMU factor rows
@@ -2875,46 +2876,52 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
       PF2[6 * MAXOBS + s] = Jt[0] * Je[0] + Jt[1] * Je[1];
     }
     // staged column-major like the solve kernel's frame tasks (Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18): one 16-byte store
-    // per column, contiguous across the lanes; inactive lanes stage zeros, so no row needs masking
-    {
-      dv2* st = reinterpret_cast<dv2*>(stage) + lane;
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        st[k * (XRS / 2)] = dv2{Jj[k], Jj[6 + k]};
-        st[(6 + k) * (XRS / 2)] = dv2{Ji[k], Ji[6 + k]};
-        st[(13 + k) * (XRS / 2)] = dv2{Jx[k], Jx[6 + k]};
-      }
-      st[12 * (XRS / 2)] = dv2{r[0], r[1]};
-      st[19 * (XRS / 2)] = dv2{Jt[0], Jt[1]};
-    }
-    wave_lds_sync();
+    // per column, contiguous across the lanes; inactive lanes stage zeros, so no row needs masking.  The tile holds half
+    // a chunk: lanes 0-31 stage and the wavefront multiplies, then lanes 32-63.
     const int nact = min(64, ncov - chunk0);
-    // lane group drow takes the two rows of factor 4 j + drow (one 16-byte read per tile), four j at a time: 24 MFMAs on
-    // six independent chains
-    const int j_end = (nact + 3) >> 2;
 #pragma unroll 1
-    for (int j0 = 0; j0 < j_end; j0 += 4) {
-      dv2 u0[4], u1[4];
+    for (int half = 0; half < 2; half++) {
+      const int nh = min(max(nact - 32 * half, 0), 32);
+      if (nh == 0) break;  // (uniform)
+      if ((lane >> 5) == half) {
+        dv2* st = reinterpret_cast<dv2*>(stage) + (lane & 31);
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int ro = 8 * min(j0 + u, 15) + 2 * drow;
-        u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS + ro);
-        u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * XRS + ro);
+        for (int k = 0; k < 6; k++) {
+          st[k * (MXRS / 2)] = dv2{Jj[k], Jj[6 + k]};
+          st[(6 + k) * (MXRS / 2)] = dv2{Ji[k], Ji[6 + k]};
+          st[(13 + k) * (MXRS / 2)] = dv2{Jx[k], Jx[6 + k]};
+        }
+        st[12 * (MXRS / 2)] = dv2{r[0], r[1]};
+        st[19 * (MXRS / 2)] = dv2{Jt[0], Jt[1]};
       }
+      wave_lds_sync();
+      // lane group drow takes the two rows of factor 4 j + drow (one 16-byte read per tile), four j at a time: 24 MFMAs on
+      // six independent chains
+      const int j_end = (nh + 3) >> 2;
+#pragma unroll 1
+      for (int j0 = 0; j0 < j_end; j0 += 4) {
+        dv2 u0[4], u1[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const bool on = j0 + u < j_end;
-        const double a0 = (on && dcol < 13) ? u0[u][0] : 0.0, a1 = (on && dcol < 13) ? u0[u][1] : 0.0;
-        const double x0 = (on && dcol < 7) ? u1[u][0] : 0.0, x1 = (on && dcol < 7) ? u1[u][1] : 0.0;
-        D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
-        D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
-        D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
-        E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
-        E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
-        E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+        for (int u = 0; u < 4; u++) {
+          const int ro = 8 * min(j0 + u, 7) + 2 * drow;
+          u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * MXRS + ro);
+          u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * MXRS + ro);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool on = j0 + u < j_end;
+          const double a0 = (on && dcol < 13) ? u0[u][0] : 0.0, a1 = (on && dcol < 13) ? u0[u][1] : 0.0;
+          const double x0 = (on && dcol < 7) ? u1[u][0] : 0.0, x1 = (on && dcol < 7) ? u1[u][1] : 0.0;
+          D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
+          D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
+          D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
+          E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
+          E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
+          E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+        }
       }
+      wave_lds_sync();
     }
-    wave_lds_sync();
   }
   D00 += E00, D10 += E10, D11 += E11;
 #pragma unroll
@@ -3245,8 +3252,10 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     // ---- phase A: projection factors of the start-0 features || IMU factor 0
     if (wv < MASM) {
       for (int b = 1 + wv; b < NFR; b += MASM) marg_frame_task(c, o, b, L_S + SPP + wv * MXSTG);
-    } else if (wv == 7 && lane == 0 && imu0) {
-      imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
+    } else if (wv == 7) {
+      if (lane == 0 && imu0) imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
+      // ... and the old prior's residual and gradient (MarginalizationFactor at the current state): dx, r_p, J0^T r_p
+      if (use_prior) prior_wave<true>(L_X);
     }
     __syncthreads();
     PROF(c, 17);
@@ -3359,24 +3368,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     PROF(c, 19);
     // ---- phase E: old prior (MarginalizationFactor at the current state)
     if (use_prior) {
-      prior_residual_dev(c, L_X);
       const int* pidx = ids + I_PIDX;
       prior_jtj_add_lds(c.pJ, c.ldp, c.pn, L_S);
-      // g += J0^T r_p : 4 lanes per column, each a quarter of the rows, all loads in flight at once
-      {
-        const int col = t >> 2, part = t & 3;
-        double sacc = 0;
-        if (col < c.pn) {
-          double v[MAXPRIOR / 4];
-#pragma unroll
-          for (int j = 0; j < MAXPRIOR / 4; j++) v[j] = c.pJ[(size_t)min(part + 4 * j, c.pn - 1) * c.ldp + col];
-#pragma unroll
-          for (int j = 0; j < MAXPRIOR / 4; j++) sacc += (part + 4 * j < c.pn ? v[j] : 0.0) * lds[L_RP + min(part + 4 * j, MAXPRIOR - 1)];
-        }
-        sacc += __shfl_xor(sacc, 1, 64);
-        sacc += __shfl_xor(sacc, 2, 64);
-        if (col < c.pn && part == 0) lds[M_G + pidx[col]] += sacc;
-      }
+      if (t < c.pn) lds[M_G + pidx[t]] += lds[L_DXP + t];  // g += J0^T r_p (left in lds[L_DXP] by phase A)
     }
     __syncthreads();
     PROF(c, 20);
