@@ -81,7 +81,7 @@ constexpr int WCH = 32;
 constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r (+1 pad)
 constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows (>= 13 * XRS)
 static_assert(13 * XRS <= XSTG, "column-major staging tile fits");
-constexpr int ASM_WAVES = 7;       // wavefronts assembling projection factors (the 8th does the IMU factors)
+constexpr int ASM_WAVES = 6;       // wavefronts assembling projection factors (wavefront 6: the raw IMU Jacobians, 7: the prior)
 #endif
 constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diagonal block); trailing tiles stay 16x16
 constexpr int TLAST = NF / 16;     // last 16-row tile of the packed matrix incl. the augmented row NF: 10 (11)
@@ -507,7 +507,7 @@ AVM_DEV double prior_wave(int xs_off) {
     for (int k = 0; k < n; k++) lds[L_DXP + off + k] = dx[k];
   }
   wave_lds_sync();
-  constexpr int NK = MAXPRIOR / 16, RU = 4;  // 6 column groups of 16; 4 x 4 rows in flight
+  constexpr int NK = MAXPRIOR / 16, RU = 7;  // 6 column groups of 16; 7 x 4 rows in flight (three trips to the slot's memory for 75 rows)
   double dxv[NK];
 #pragma unroll
   for (int j = 0; j < NK; j++) dxv[j] = lr + 16 * j < pn ? lds[L_DXP + lr + 16 * j] : 0.0;
@@ -542,8 +542,8 @@ AVM_DEV double prior_wave(int xs_off) {
   cost = wave_sum(cost);
   if (WANT_G) {
     wave_lds_sync();
-    // g_p[k] = sum_i J0[i][k] r_p[i]: lane = column (k = lane, lane + 64), rows in ascending order, 8 rows in flight
-    constexpr int GU = 8;
+    // g_p[k] = sum_i J0[i][k] r_p[i]: lane = column (k = lane, lane + 64), rows in ascending order, 19 rows in flight
+    constexpr int GU = 19;  // (four trips for 75 rows)
     const int k0 = min(lane, pn1), k1 = min(lane + 64, pn1);
     double g0 = 0, g1 = 0;
     for (int i0 = 0; i0 < pn; i0 += GU) {
@@ -756,7 +756,10 @@ AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gin
 // Blocks (b,b), (b,a) and g_b belong to this frame only and are written straight into LDS; the (a,a)
 // contributions go to PART[b][a] in the scratch slot and are summed in a fixed order afterwards.
 #ifndef AVM_X
-AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
+// One wavefront takes ALL the frames assigned to it as one list of factors (frames in ascending order, each frame's factors
+// in feature order), 64 at a time: a chunk may straddle two frames, so a wavefront with two frames of 150 factors runs 5
+// chunks instead of 3 + 3.  The runs of the MFMA accumulation are keyed by (frame b, start frame a).
+AVM_DEV double frame_task(const WinCtx&, const avm_options&, int wvi, int stage_off) {
   const WinCtx& c = lds_ctx();
   const avm_options& o = lds_opt();
   double* lds = LDS();
@@ -764,30 +767,55 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   (void)ids;
   const int lane = threadIdx.x & 63;
-  const int ncov = ids[I_NCOV + b];
-  const int32_t* cov = c.cov + b * MAXE;
   Frames fr{lds + L_FR, lds + L_FR + 99};
   const double* xs = lds + L_X;
   const double sqi = o.focal_length / 1.5;
   double* W = c.sc + Scratch::W;
   double* PF = c.sc + Scratch::PF;
-  double* PART = c.sc + Scratch::PART + (size_t)b * NFR * 27;
+  double* PART0 = c.sc + Scratch::PART;
   const double* scl = lds + L_SC;
   d4 Dtot = {0, 0, 0, 0}, Drun = {0, 0, 0, 0}, Drun1 = {0, 0, 0, 0}, Drun2 = {0, 0, 0, 0}, Drun3 = {0, 0, 0, 0};
-  int a_run = -1, pmask = 0;
+  int a_run = -1, b_run = -1, pmask = 0;
   double cost = 0;
   const int drow = lane >> 4, dcol = lane & 15;
-  auto flush = [&]() {
+  // end offsets of the frames in this wavefront's list (a frame of another wavefront has zero width); wave-uniform values
+  // kept in scalar registers, so that locating a factor costs a few compares and no LDS traffic
+  int endo[NFR];
+  endo[0] = 0;
+  {
+    int off = 0;
+#pragma unroll
+    for (int bb = 1; bb < NFR; bb++) {
+      off += ids[I_FRW + bb] == wvi ? ids[I_NCOV + bb] : 0;
+      endo[bb] = __builtin_amdgcn_readfirstlane(off);
+    }
+  }
+  const int ntot = endo[NFR - 1];  // factors of this wavefront's frames
+  // position in the wavefront's list -> (frame, index in the frame's list); past the end: the last factor (masked by `act`)
+  auto locate = [&](int idx, int& bl, int& pos) {
+    const int ic = min(idx, ntot - 1);
+    int start = 0;
+    bl = 1;
+#pragma unroll
+    for (int bb = 1; bb < NFR - 1; bb++) {
+      const bool past = ic >= endo[bb];
+      bl += past ? 1 : 0;
+      start = past ? endo[bb] : start;
+    }
+    pos = ic - start;
+  };
+  auto flush = [&]() {  // ends the run (b_run, a_run)
     if (a_run < 0) return;
     Drun = (Drun + Drun1) + (Drun2 + Drun3);
     Drun1 = Drun2 = Drun3 = d4{0, 0, 0, 0};
+    double* PART = PART0 + (size_t)b_run * NFR * 27;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = drow + 4 * r;
       const double v = Drun[r];
       // (entries of S are written Jacobi-scaled: s_i s_j H_ij, with s = 1 until the first evaluation has fixed it)
       if (row < 6 && dcol >= 6 && dcol < 12)
-        lds[L_S + roff(6 * b + row) + 6 * a_run + (dcol - 6)] = v * (scl[6 * b + row] * scl[6 * a_run + (dcol - 6)]);  // Jj^T Ji
+        lds[L_S + roff(6 * b_run + row) + 6 * a_run + (dcol - 6)] = v * (scl[6 * b_run + row] * scl[6 * a_run + (dcol - 6)]);  // Jj^T Ji
       if (row >= 6 && row < 12) {
         const int i = row - 6;
         if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[a_run * 27 + i * (i + 1) / 2 + (dcol - 6)] = v;  // Ji^T Ji (lower)
@@ -797,26 +825,40 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
     pmask |= 1 << a_run;
     Dtot += Drun;
     Drun = d4{0, 0, 0, 0};
+    a_run = -1;
+  };
+  auto end_frame = [&]() {  // block (b,b) lower triangle and g_b of the frame that just ended
+    flush();
+    if (b_run < 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = drow + 4 * r;
+      if (row < 6 && dcol <= row) lds[L_S + roff(6 * b_run + row) + 6 * b_run + dcol] = Dtot[r] * (scl[6 * b_run + row] * scl[6 * b_run + dcol]);
+      if (row < 6 && dcol == 12) lds[L_G + 6 * b_run + row] = Dtot[r];
+    }
+    if (lane == 0) ids[I_PMASK + b_run] = pmask;
+    Dtot = d4{0, 0, 0, 0};
+    pmask = 0;
   };
   // inputs of a chunk (feature id, its two observations) are fetched one chunk ahead: their HBM / L2 latency hides
   // behind the stores, the staging and the MFMA chain of the chunk before
-  int e_nx = 0, fa_nx = 0;
+  int e_nx = 0, fa_nx = 0, b_nx = 1;
   double ob_nx[4] = {0, 0, 0, 0};
   auto fetch = [&](int chunk0) {
-    const int idx = chunk0 + lane;
-    e_nx = cov[min(idx, max(ncov - 1, 0))];
+    int pos;
+    locate(chunk0 + lane, b_nx, pos);
+    e_nx = c.cov[b_nx * MAXE + pos];
     fa_nx = ids[I_FSTART + e_nx];
-    const int s0 = ids[I_FOBS + e_nx], s = s0 + (b - fa_nx);
+    const int s0 = ids[I_FOBS + e_nx], s = s0 + (b_nx - fa_nx);
     ob_nx[0] = c.obs[2 * s0], ob_nx[1] = c.obs[2 * s0 + 1], ob_nx[2] = c.obs[2 * s], ob_nx[3] = c.obs[2 * s + 1];
   };
-  if (ncov > 0) fetch(0);
-  for (int chunk0 = 0; chunk0 < ncov; chunk0 += 64) {
+  if (ntot > 0) fetch(0);
+  for (int chunk0 = 0; chunk0 < ntot; chunk0 += 64) {
     const int idx = chunk0 + lane;
-    const bool act = idx < ncov;
-    const int e = act ? e_nx : 0;
-    const int fa = act ? fa_nx : ids[I_FSTART];
+    const bool act = idx < ntot;
+    const int e = e_nx, fa = fa_nx, b = b_nx;  // (inactive lanes repeat the wavefront's last factor: valid, never stored)
     const double ob0 = ob_nx[0], ob1 = ob_nx[1], ob2 = ob_nx[2], ob3 = ob_nx[3];
-    if (chunk0 + 64 < ncov) fetch(chunk0 + 64);
+    if (chunk0 + 64 < ntot) fetch(chunk0 + 64);
     double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < 12; k++) Ji[k] = 0, Jj[k] = 0;
@@ -840,15 +882,20 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
       st[12 * (XRS / 2)] = dv2{r[0], r[1]};
     }
     wave_lds_sync();
-    const int nact = min(64, ncov - chunk0);
+    const int nact = min(64, ntot - chunk0);
+    const int key = (b << 4) | fa;  // frames ascending, start frames ascending inside a frame: equal keys are consecutive
     int l = 0;
     while (l < nact) {
-      const int a_cur = __shfl(fa, l, 64);
-      const int cnt = __popcll(__ballot(act && fa == a_cur));
+      const int k_cur = __shfl(key, l, 64);
+      const int cnt = __popcll(__ballot(act && key == k_cur));
       const int l_end = l + cnt;
-      if (a_cur != a_run) {
+      if ((k_cur >> 4) != b_run) {
+        end_frame();
+        b_run = k_cur >> 4;
+      }
+      if ((k_cur & 15) != a_run) {
         flush();
-        a_run = a_cur;
+        a_run = k_cur & 15;
       }
       // The k index of X^T X is a summation index: lane group drow takes the two rows of factor 4 j + drow for the
       // k-step pair j (one 16-byte read, conflict-free with the 132-row column stride), four pairs = eight MFMAs at a
@@ -878,15 +925,7 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
     }
     wave_lds_sync();
   }
-  flush();
-  // block (b,b) lower triangle and g_b
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = drow + 4 * r;
-    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r] * (scl[6 * b + row] * scl[6 * b + dcol]);
-    if (row < 6 && dcol == 12) lds[L_G + 6 * b + row] = Dtot[r];
-  }
-  if (lane == 0) ids[I_PMASK + b] = pmask;
+  end_frame();
   return cost;
 }
 #else
@@ -1163,8 +1202,12 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   // ---- phase A: projection factors (waves 0..ASM_WAVES-1, one frame at a time) || IMU raw Jacobians (the next wave)
   const long long pa__ = c.prof ? clock64() : 0;
   if (wv < ASM_WAVES) {
+#ifdef AVM_X
     for (int b = 1; b < NFRP; b++)
       if (ids[I_FRW + b] == wv) acc += frame_task(c, o, b, L_S + SPP + wv * XSTG);
+#else
+    acc += frame_task(c, o, wv, L_S + SPP + wv * XSTG);  // all the frames of this wavefront as one list
+#endif
   } else if (wv == ASM_WAVES && lane < 10) {
     const int i = lane;
     if (c.psum[i] <= o.max_sum_dt)
@@ -2211,10 +2254,11 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     __syncthreads();
     PROFQ(c, 39);
     if (t == 0) {  // longest-processing-time assignment of the frames to the assembling wavefronts
-      int load[ASM_WAVES];
-      for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
       int done = 0;
       ids[I_FRW] = -1;
+#ifdef AVM_X
+      int load[ASM_WAVES];
+      for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
       for (int k = 1; k < NFRP; k++) {
         int bb = -1, bn = -1;
         for (int f = 1; f < NFRP; f++)
@@ -2226,6 +2270,30 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         load[bw] += ((bn + 63) / 64) * 64 + 8;
         done |= 1 << bb;
       }
+#else
+      // A wavefront's cost is its number of 64-factor chunks over ALL its frames; wavefronts w and w + 4 share a SIMD, so
+      // the quantity to keep level is the chunk count per SIMD (the raw-IMU wavefront 6 weighs about two chunks on SIMD 2,
+      // the prior's wavefront 7 about one on SIMD 3).  Largest frame first, to the wavefront that leaves its SIMD lowest.
+      int fcnt[ASM_WAVES];
+      for (int k = 0; k < ASM_WAVES; k++) fcnt[k] = 0;
+      auto chunks = [](int n) { return (n + 63) >> 6; };
+      for (int k = 1; k < NFRP; k++) {
+        int bb = -1, bn = -1;
+        for (int f = 1; f < NFRP; f++)
+          if (!(done & (1 << f)) && ids[I_NCOV + f] > bn) bn = ids[I_NCOV + f], bb = f;
+        int bw = 0, bcost = 1 << 30, bown = 1 << 30;
+        for (int q = 0; q < ASM_WAVES; q++) {
+          int simd = (q & 3) == 2 ? 2 : ((q & 3) == 3 ? 1 : 0);
+          for (int q2 = 0; q2 < ASM_WAVES; q2++)
+            if ((q2 & 3) == (q & 3)) simd += chunks(fcnt[q2] + (q2 == q ? bn : 0));
+          const int own = chunks(fcnt[q]);
+          if (simd < bcost || (simd == bcost && own < bown)) bw = q, bcost = simd, bown = own;
+        }
+        ids[I_FRW + bb] = bw;
+        fcnt[bw] += bn;
+        done |= 1 << bb;
+      }
+#endif
     }
     __syncthreads();
     // once per window: the structural zeros of the scratch slot (raw IMU Jacobians outside their blocks, E^T F of
