@@ -3332,10 +3332,12 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       double* W = c.sc + Scratch::W;
       const double* PF = c.sc + Scratch::PF;
       const double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;
-      for (int idx = t; idx < nf0 * 12; idx += NT) {
-        const int e = idx / 12, f = idx % 12;  // f == 11 : ex_pose column block
+      // the two heavy items of a feature (f == 0: its own pose block, hee, g_e;  f == 11: the ex_pose / td columns) are dealt
+      // densely to the threads; the structural zeros of the frames that do not observe it follow in a loop of their own
+      for (int idx = t; idx < nf0 * 2; idx += NT) {
+        const int e = idx >> 1, f = (idx & 1) ? 11 : 0;
         const int no = ids[I_FNOBS + e], s0 = ids[I_FOBS + e];
-        if (f == 0 || f == 11) {
+        {
           const double* P = f == 0 ? PF : PF2;
           // all loads of the feature's (<= 10) factors in flight at once, clamped to its last observation and masked
           // (f == 11: the six ex_pose columns and the td column, W columns 66..72)
@@ -3365,7 +3367,11 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
             lds[L_HEE + e] = he;
             lds[M_GE + e] = ge;
           }
-        } else if (f >= no) {
+        }
+      }
+      for (int idx = t; idx < nf0 * (NFR - 1); idx += NT) {
+        const int e = idx / (NFR - 1), f = 1 + idx % (NFR - 1);
+        if (f >= ids[I_FNOBS + e]) {
 #pragma unroll
           for (int q = 0; q < 6; q++) W[(size_t)e * MWS + 6 * f + q] = 0.0;
         }
