@@ -111,7 +111,8 @@ constexpr int L_HEE = L_RIC + 20;      // E^T E (150) padded
 constexpr int L_DXP = L_HEE + 152;
 constexpr int L_RP = L_DXP + MAXPRIOR;
 constexpr int L_RED = L_RP + MAXPRIOR;
-constexpr int L_INT = L_RED + 32;  // int region (as doubles): 360 doubles = 720 ints
+constexpr int L_RED_B = L_RED + 16, L_RED_CNT = L_RED + 32;  // second value of a paired reduction; the wavefronts' reduction counters (8 ints)
+constexpr int L_INT = L_RED + 36;  // int region (as doubles): 360 doubles = 720 ints
 constexpr int L_SUM = L_INT + 360;  // cost_trace[16], radius_trace[16]
 constexpr int L_CTX = L_SUM + 32;   // WinCtx of the window being solved (32 doubles)
 constexpr int L_OPT = L_CTX + 32;   // avm_options (copied from the kernel arguments)
@@ -129,6 +130,49 @@ AVM_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup reductions of the solve kernel with ONE barrier each.  The partial sums of consecutive reductions go to alternating
+// halves of lds[L_RED]: a wavefront can only overwrite a half two reductions later, i.e. after a barrier that every wavefront
+// reaches with its reads of that half done.  Which half is next is a counter every wavefront keeps for itself in LDS (all
+// wavefronts run the same sequence of reductions, so the counters agree); red_init() zeroes it at kernel entry.
+AVM_DEV int* red_counter() { return reinterpret_cast<int*>(LDS() + L_RED_CNT) + (threadIdx.x >> 6); }
+AVM_DEV void red_init() {
+  if ((threadIdx.x & 63) == 0) *red_counter() = 0;
+}
+template <class Op>
+AVM_DEV double block_reduce1(double v, Op op) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* cnt = red_counter();
+  const int k = *cnt;
+  double* red = LDS() + L_RED + 8 * (k & 1);
+  if (lane == 0) red[wv] = v, *cnt = k + 1;
+  __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; i++) s = op(s, red[i]);
+  return s;
+}
+AVM_DEV double block_sum1(double v) {
+  return block_reduce1(wave_sum(v), [](double a, double b) { return a + b; });
+}
+AVM_DEV double block_max1(double v) {
+  return block_reduce1(wave_max(v), [](double a, double b) { return fmax(a, b); });
+}
+// two sums at once (one barrier, both halves of the pair in the same half of lds[L_RED])
+AVM_DEV void block_sum1x2(double& a, double& b) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double wa = wave_sum(a), wb = wave_sum(b);
+  int* cnt = red_counter();
+  const int k = *cnt;
+  double* red = LDS() + L_RED + 8 * (k & 1);
+  double* redb = LDS() + L_RED_B + 8 * (k & 1);
+  if (lane == 0) red[wv] = wa, redb[wv] = wb, *cnt = k + 1;
+  __syncthreads();
+  double sa = red[0], sb = redb[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; i++) sa += red[i], sb += redb[i];
+  a = sa, b = sb;
 }
 
 AVM_DEV int roff(int i) {  // even i = 2q: 2q(q+1); odd i = 2q+1: 2(q+1)^2 -> every row starts 16-byte aligned
@@ -646,7 +690,7 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
     }
   }
 
-  return block_sum<NT>(acc, lds + L_RED);
+  return block_sum1(acc);
 }
 
 // Prior J0^T J0 on the matrix cores (16x16 tiles, K = prior rows), marginalization-kernel variant: the tiles are
@@ -1398,7 +1442,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       if (t < c.pn && pidx[t] >= 0) lds[L_G + pidx[t]] += lds[L_DXP + t];
     }
   }
-  const double cost = block_sum<NT>(acc, lds + L_RED);
+  const double cost = block_sum1(acc);
   __syncthreads();
   PROF(c, 8);
   return cost;
@@ -1502,7 +1546,7 @@ AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
       if (pidx[k] >= 0) y += c.pJ[(size_t)i * c.ldp + k] * (u[pidx[k]] * scl[pidx[k]]);
     acc += y * y;
   }
-  return block_sum<NT>(acc, lds + L_RED);
+  return block_sum1(acc);
 }
 
 AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-uniform
@@ -1995,7 +2039,7 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
   double bad = 0;
   for (int i = t; i < NF + c.nf; i += NT)
     if (!isfinite(lds[L_Y + i])) bad = 1;
-  return block_max<NT>(bad, lds + L_RED);
+  return block_max1(bad);
 }
 
 // Jacobi column scaling of the assembled system: H' = S H S, hee', g'  (W stays unscaled: see schur_reduce)
@@ -2116,6 +2160,7 @@ AVM_DEV void state_plus() {
 #endif
 __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
   lds_base_check();
+  red_init();
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
@@ -2357,14 +2402,14 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       for (int i = t; i < 99 + c.nf; i += NT) term(XSB + i);                          // speed-biases, inverse depths
       if (c.est_ex && t >= 192 && t < 199) term(XEX + t - 192);
       if (c.est_td && t == 200) term(XTD);
-      return block_sum<NT>(s, lds + L_RED);
+      return block_sum1(s);
     };
     auto amb_norm = [&](const double* xs) { return sqrt(amb_sq(xs, nullptr)); };
 #else
     auto amb_norm = [&](const double* xs) {
       double s = 0;
       for (int i = t; i < 176 + c.nf; i += NT) s += xs[i] * xs[i];
-      return sqrt(block_sum<NT>(s, lds + L_RED));
+      return sqrt(block_sum1(s));
     };
 #endif
     // evaluate + scaling + gradient max norm at lds[L_X]
@@ -2405,7 +2450,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         if (t == 402 && c.est_td) gm = fmax(gm, fabs(g[XC_TD]));
 #endif
       }
-      gradient_max_norm = block_max<NT>(gm, lds + L_RED);
+      gradient_max_norm = block_max1(gm);
       __syncthreads();
       if (c.prof && t == 0) c.prof[43] += clock64() - pt__;
 #ifdef AVM_X
@@ -2495,7 +2540,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
 #endif
           g2 += v * v;
         }
-        gnorm = sqrt(block_sum<NT>(g2, lds + L_RED));
+        gnorm = sqrt(block_sum1(g2));
         // Gauss-Newton step with mu retry (DoglegStrategy::ComputeGaussNewtonStep)
         solver_ok = false;
         bool rebuilt = true;
@@ -2535,8 +2580,9 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
             a1 += dv * dv;
             a2 += yv * lds[L_G + i];
           }
-          gn_norm = sqrt(block_sum<NT>(a1, lds + L_RED));
-          ytg = block_sum<NT>(a2, lds + L_RED);
+          block_sum1x2(a1, a2);
+          gn_norm = sqrt(a1);
+          ytg = a2;
         }
       }
       bool step_is_valid = false;
@@ -2574,7 +2620,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
               const double v = -k1 * DG(i) - k2 * lds[L_DD + i] * lds[L_Y + i];
               s2 += v * v;
             }
-            dogleg_step_norm = sqrt(block_sum<NT>(s2, lds + L_RED));
+            dogleg_step_norm = sqrt(block_sum1(s2));
           }
         }
         for (int i = t; i < VEC; i += NT)
@@ -2615,7 +2661,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         const double d = lds[L_X + i] - lds[L_XC + i];
         d2 += d * d;
       }
-      const double step_norm = sqrt(block_sum<NT>(d2, lds + L_RED));
+      const double step_norm = sqrt(block_sum1(d2));
 #endif
       // the last iteration the options allow: the minimizer stops right after it (the iteration limit is checked before
       // the gradient tolerance, trust_region_minimizer.cc FinalizeIterationAndCheckIfMinimizerCanContinue), so the
