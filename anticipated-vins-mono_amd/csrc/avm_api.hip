@@ -904,21 +904,21 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
 #define GET(field, type, count)                                                             \
   w->field = static_cast<type*>(pool_get(c, "fw_" #field, sizeof(type) * (count)));          \
   if (!w->field) return fail(c, AVM_ERR_HIP, "hipMalloc failed (selector work buffer)");
-  GET(C, double, P * T * T)
-  GET(dpp, double, P * T)
+  GET(C, double, 2 * P * T * T)  // (two buffers: csrc/fsel.hip, FselPar)
+  GET(dpp, double, 2 * P * T)  // (two buffers: csrc/fsel.hip, FselPar)
   GET(consts, double, P * 4)
   GET(delta, double, P * mc * T * T)
   GET(delta_u, double, P * mu * T * T)
-  GET(fval, double, P * mc)
-  GET(ub, double, P * mc)
+  GET(fval, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)
+  GET(ub, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)
   GET(valid, int32_t, P * mc)
   GET(valid_u, int32_t, P * mu)
   GET(black, int32_t, P * mc)
   GET(nsel, int32_t, P)
   GET(done, int32_t, P)
-  GET(live, int32_t, P * mc)
-  GET(pos, int32_t, P * mc)
-  GET(nlive, int32_t, P)
+  GET(live, int32_t, 2 * P * mc)
+  GET(pos, int32_t, 2 * P * mc)
+  GET(nlive, int32_t, 2 * P)
 #undef GET
   return AVM_OK;
 }

@@ -452,25 +452,201 @@ AVM_DEV double fs_rowbcast(double v, int k) {  // k is a compile-time constant a
 
 constexpr int FS_CPWG = (FS_NT / 64) * 4;  // candidates per workgroup of the round kernel
 
+// State that changes from round to round exists twice (C, dpp, the live list and its inverse, nlive, fval, ub: buffer `par` at
+// offset par * size): launch k reads the buffers k & 1 and writes the others, so that no workgroup of a launch reads what another
+// one writes.  That lets ONE launch per round do both halves of a greedy step:
+//   1. every workgroup picks the winner of the previous round for itself from the values the previous launch left (a few KB,
+//      the same deterministic argmax everywhere; workgroup 0 of the problem also records it and writes the next buffers:
+//      C + p Delta_winner, the live list with the winner swap-removed);
+//   2. it evaluates its candidates against that next state, which it patches in on the fly (the same expressions workgroup 0
+//      stores, so the values are bit-identical to the stored ones).
+// Round 1 and the first half of round 2 launched a pick kernel between two evaluations: 300 dependent launches per select, and the
+// gaps between them were 40 % of the time.  Now 151.
+struct FselPar {
+  const double *C, *dpp, *fval, *ub;
+  const int32_t *live, *pos;
+  double *Cn, *dppn, *fvaln, *ubn;
+  int32_t *liven, *posn, *nliven;
+  int nl;
+};
+AVM_DEV FselPar fsel_par(const FselDev& A, int p, int k) {
+  const avm_fsel_batch& b = A.b;
+  const int T = 3 * b.horizon, cur = k & 1, nxt = cur ^ 1;
+  const size_t P = b.n_problems, mc = b.max_cand, TT = (size_t)T * T;
+  FselPar r;
+  r.C = A.C + (cur * P + p) * TT, r.Cn = A.C + (nxt * P + p) * TT;
+  r.dpp = A.dpp + (cur * P + p) * T, r.dppn = A.dpp + (nxt * P + p) * T;
+  r.fval = A.fval + (cur * P + p) * mc, r.fvaln = A.fval + (nxt * P + p) * mc;
+  r.ub = A.ub + (cur * P + p) * mc, r.ubn = A.ub + (nxt * P + p) * mc;
+  r.live = A.live + (cur * P + p) * mc, r.liven = A.live + (nxt * P + p) * mc;
+  r.pos = A.pos + (cur * P + p) * mc, r.posn = A.pos + (nxt * P + p) * mc;
+  r.nl = A.nlive[cur * P + p], r.nliven = A.nlive + nxt * P + p;
+  return r;
+}
+
+// ---- the round's winner (feature_selector.cpp:669-683), computed by every workgroup of the problem for itself ---------------
+// returns the winner's candidate index (-1: none) to all threads; *fwin its value
+AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
+  __shared__ double s_f[FS_NT / 64], s_u[FS_NT / 64];
+  __shared__ int s_i[FS_NT / 64];
+  __shared__ int s_win;
+  const int t = threadIdx.x;
+  const int32_t* live = S.live;
+  const int nl = S.nl;
+  auto better = [](double f, double u, int i, double f2, double u2, int i2) {
+    if (i2 < 0) return false;
+    if (i < 0) return true;
+    return f2 > f || (f2 == f && (u2 > u || (u2 == u && i2 > i)));
+  };
+  // sortedlogDetUB keeps the upper bounds in a std::map<double, int> (feature_selector.cpp:724): of two live candidates
+  // with BIT-IDENTICAL upper bounds only the later (higher) id survives the round, the other one is never scored.  The
+  // argmax below therefore runs until its winner is not shadowed by a higher id with the same key; `shadowed` holds the
+  // (at most a handful of) candidates that were ruled out this way.  One extra pass over the bounds in the usual case.
+  constexpr int MAXSH = 8;
+  __shared__ int s_shadow[MAXSH];
+  __shared__ int s_nsh, s_hit;
+  __syncthreads();  // (the shared variables may still be read by a slower wavefront of this workgroup's previous use)
+  if (t == 0) s_nsh = 0;
+  __syncthreads();
+  // this thread's candidates (at most FS_PC of them) stay in registers for every pass of the loop below
+  constexpr int FS_PC = 4;  // (candidates beyond FS_PC * FS_NT = 1024 are re-read in every pass)
+  int cl[FS_PC];
+  double cf[FS_PC], cu[FS_PC];
+  // (values are stored by SLOT of the live list they were computed for - the list of these buffers - so the three loads are
+  //  independent: one trip to memory)
+#pragma unroll
+  for (int q = 0; q < FS_PC; q++) {
+    const int sq = min(t + q * FS_NT, max(nl - 1, 0));
+    cl[q] = live[sq], cf[q] = S.fval[sq], cu[q] = S.ub[sq];
+  }
+#pragma unroll
+  for (int q = 0; q < FS_PC; q++)
+    if (t + q * FS_NT >= nl) cl[q] = -1;
+  double bf;
+  int bi;
+  for (;;) {
+    // lexicographic max of (fValue, ub, id) over live candidates with fValue > fMax0 = -1.0 (NaN never wins)
+    bf = -1.0;
+    double bu = -DBL_MAX;
+    bi = -1;
+    const int nsh = s_nsh;
+#pragma unroll
+    for (int q = 0; q < FS_PC; q++) {
+      const int l = cl[q];
+      bool sh = l < 0;
+      for (int qq = 0; qq < nsh; qq++) sh |= s_shadow[qq] == l;
+      const double f = cf[q], u = cu[q];
+      if (sh || !(f > -1.0)) continue;
+      if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
+    }
+    for (int s = t + FS_PC * FS_NT; s < nl; s += FS_NT) {
+      const int l = live[s];
+      bool sh = false;
+      for (int qq = 0; qq < nsh; qq++) sh |= s_shadow[qq] == l;
+      const double f = S.fval[s], u = S.ub[s];
+      if (sh || !(f > -1.0)) continue;
+      if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double f2 = __shfl_xor(bf, o, 64), u2 = __shfl_xor(bu, o, 64);
+      const int i2 = __shfl_xor(bi, o, 64);
+      if (better(bf, bu, bi, f2, u2, i2)) bf = f2, bu = u2, bi = i2;
+    }
+    if ((t & 63) == 0) s_f[t >> 6] = bf, s_u[t >> 6] = bu, s_i[t >> 6] = bi;
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < FS_NT / 64; w++)
+        if (better(bf, bu, bi, s_f[w], s_u[w], s_i[w])) bf = s_f[w], bu = s_u[w], bi = s_i[w];
+      s_win = bi, s_f[0] = bf, s_u[0] = bu, s_hit = 0;
+    }
+    __syncthreads();
+    const int cand = s_win;
+    if (cand < 0) break;
+    const double cuw = s_u[0];
+    int hit = 0;
+#pragma unroll
+    for (int q = 0; q < FS_PC; q++)  // a live candidate with a higher id and the same key?
+      if (cl[q] > cand && cu[q] == cuw) hit = 1;
+    for (int s = t + FS_PC * FS_NT; s < nl; s += FS_NT)
+      if (live[s] > cand && S.ub[s] == cuw) hit = 1;
+    if (hit) s_hit = 1;
+    __syncthreads();
+    if (!s_hit || s_nsh >= MAXSH || A.no_key_rule) break;  // (more than MAXSH chained collisions in one round: keep the last winner)
+    __syncthreads();
+    if (t == 0) s_shadow[s_nsh++] = cand;
+    __syncthreads();
+  }
+  *fwin = s_f[0];
+  return s_win;
+}
+
 template <int T, int BS, int NB>
-__global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int round) {
+__global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
   static_assert(BS * NB == T && BS <= 16, "block rows of at most 16 lanes");
   const avm_fsel_batch& b = A.b;
-  const int p = blockIdx.y;
+  const int p = blockIdx.y, t = threadIdx.x;
   const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
-  if (round >= kappa || A.done[p]) return;
+  if (A.done[p]) return;  // (set by an earlier launch: the state is frozen)
+  const bool has_pick = k >= 1 && k <= kappa, has_eval = k < kappa;
+  if (!has_pick && !has_eval) return;
+  const FselPar S = fsel_par(A, p, k);
+  // ---- 1. the previous round's winner
+  int win = -1;
+  double fwin = 0.0;
+  if (has_pick) {
+    win = fsel_pick_local(A, S, &fwin);
+    if (win < 0) {
+      if (blockIdx.x == 0 && t == 0) A.done[p] = 1;  // lMax == -1: nothing is added; later rounds would repeat the same state
+      return;
+    }
+  }
+  const bool won = win >= 0;
+  const int wc = max(win, 0);
+  const int nl = S.nl, nln = won ? nl - 1 : nl;
+  const int at = won ? S.pos[wc] : -1, lastc = S.live[max(nl - 1, 0)];  // swap-remove: the last candidate takes the winner's slot
+  const double prw = b.cand_prob[(size_t)p * b.max_cand + wc];
+  const double* Dw = A.delta + ((size_t)p * b.max_cand + wc) * T * T;
+  if (blockIdx.x == 0) {  // this problem's recorder: outputs and the next buffers
+    if (won && t == 0) {
+      const int ks = A.nsel[p];
+      A.out.selected_ids[(size_t)p * b.max_features + ks] = b.cand_id[(size_t)p * b.max_cand + win];
+      if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + ks] = fwin;
+      A.nsel[p] = ks + 1;
+      A.out.n_selected[p] = ks + 1;
+      A.black[(size_t)p * b.max_cand + win] = 1;
+    }
+    for (int idx = t; idx < T * T; idx += FS_NT) {
+      const double c = won ? S.C[idx] + prw * Dw[idx] : S.C[idx];
+      S.Cn[idx] = c;
+      if (idx / T == idx % T) S.dppn[idx / T] = won ? S.dpp[idx / T] + prw * Dw[idx] : S.dpp[idx / T];
+    }
+    for (int s = t; s < nln; s += FS_NT) {
+      const int l = s == at ? lastc : S.live[s];
+      S.liven[s] = l, S.posn[l] = s;
+    }
+    if (t == 0) *S.nliven = nln;
+  }
+  if (!has_eval) return;
+  // ---- 2. this round's candidates against the state with the winner folded in: every workgroup builds it in LDS (the same
+  //         expressions workgroup 0 stores), and the candidates' matrices take their C part from there
+  __shared__ double sC[T * T], sdpp[T];
+  for (int idx = t; idx < T * T; idx += FS_NT) {
+    const double c = won ? S.C[idx] + prw * Dw[idx] : S.C[idx];
+    sC[idx] = c;
+    if (idx / T == idx % T) sdpp[idx / T] = won ? S.dpp[idx / T] + prw * Dw[idx] : S.dpp[idx / T];
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = lane >> 4, r = min(lane & 15, BS - 1);  // candidate slot of this lane, its row inside every block row
-  // the candidates still in the race are kept compact (fsel_pick_kernel swap-removes the winner), so late rounds do not pay for
+  // the candidates still in the race are kept compact (the winner is swap-removed), so late rounds do not pay for
   // the slots of the features already selected
-  const int nl = A.nlive[p];
   const int slot = (blockIdx.x * (FS_NT / 64) + wv) * 4 + g;
-  const bool live = slot < nl;
+  const bool live = slot < nln;
   if (!__any(live)) return;  // (wave-uniform)
-  const int l = A.live[(size_t)p * b.max_cand + min(slot, max(nl - 1, 0))];
+  const int sc = min(slot, max(nln - 1, 0));
+  const int l = sc == at ? lastc : S.live[sc];
   const int lc = l;  // a slot past the end factors the last live candidate's matrix again and throws the result away
   const double pr = b.cand_prob[(size_t)p * b.max_cand + lc];
-  const double* C = A.C + (size_t)p * T * T;
   const double* D = A.delta + ((size_t)p * b.max_cand + lc) * T * T;
   // m[bi][c] = (C + p Delta)[bi BS + r][c], c < (bi + 1) BS.  Both matrices are symmetric, so the entry is fetched as
   // [c][bi BS + r]: the 15 lanes of a candidate then read 15 consecutive doubles instead of 15 different cache lines
@@ -478,11 +654,17 @@ __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int round)
 #pragma unroll
   for (int bi = 0; bi < NB; bi++)
 #pragma unroll
-    for (int c = 0; c < (bi + 1) * BS; c++) m[bi][c] = C[c * T + bi * BS + r] + pr * D[c * T + bi * BS + r];
+    for (int c = 0; c < (bi + 1) * BS; c++) {
+      const int idx = c * T + bi * BS + r;
+      m[bi][c] = sC[idx] + pr * D[idx];
+    }
   // Hadamard upper bound: sum over the rows, block row by block row, then across the 16 lanes in lane order
   double ubl = 0.0;
 #pragma unroll
-  for (int bi = 0; bi < NB; bi++) ubl += log(A.dpp[(size_t)p * T + bi * BS + r] + pr * D[(bi * BS + r) * T + bi * BS + r]);
+  for (int bi = 0; bi < NB; bi++) {
+    const int dgi = bi * BS + r, idx = dgi * T + dgi;
+    ubl += log(sdpp[dgi] + pr * D[idx]);
+  }
   double ubt = 0.0;
 #pragma unroll
   for (int k = 0; k < BS; k++) ubt += fs_rowbcast(ubl, k);
@@ -525,105 +707,8 @@ __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int round)
   }
   if (live && (lane & 15) == 0) {
     const double f = bad ? __builtin_nan("") : (A.consts[(size_t)p * 4] + 2.0 * ld);
-    A.fval[(size_t)p * b.max_cand + l] = f;
-    A.ub[(size_t)p * b.max_cand + l] = A.consts[(size_t)p * 4 + 1] + ubt;
-  }
-}
-
-// ---- pick the round's winner and fold it into OmegaS ------------------------------------------
-__global__ __launch_bounds__(FS_NT) void fsel_pick_kernel(FselDev A, int round) {
-  __shared__ double s_f[FS_NT / 64], s_u[FS_NT / 64];
-  __shared__ int s_i[FS_NT / 64];
-  __shared__ int s_win;
-  const avm_fsel_batch& b = A.b;
-  const int p = blockIdx.x, t = threadIdx.x;
-  const int T = 3 * b.horizon;
-  const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
-  if (round >= kappa || A.done[p]) return;
-  int32_t* live = A.live + (size_t)p * b.max_cand;
-  const int nl = A.nlive[p];
-  auto better = [](double f, double u, int i, double f2, double u2, int i2) {
-    if (i2 < 0) return false;
-    if (i < 0) return true;
-    return f2 > f || (f2 == f && (u2 > u || (u2 == u && i2 > i)));
-  };
-  // sortedlogDetUB keeps the upper bounds in a std::map<double, int> (feature_selector.cpp:724): of two live candidates
-  // with BIT-IDENTICAL upper bounds only the later (higher) id survives the round, the other one is never scored.  The
-  // argmax below therefore runs until its winner is not shadowed by a higher id with the same key; `shadowed` holds the
-  // (at most a handful of) candidates that were ruled out this way.  One extra pass over the bounds in the usual case.
-  constexpr int MAXSH = 8;
-  __shared__ int s_shadow[MAXSH];
-  __shared__ int s_nsh, s_hit;
-  if (t == 0) s_nsh = 0;
-  __syncthreads();
-  double bf;
-  int bi;
-  for (;;) {
-    // lexicographic max of (fValue, ub, id) over live candidates with fValue > fMax0 = -1.0 (NaN never wins)
-    bf = -1.0;
-    double bu = -DBL_MAX;
-    bi = -1;
-    const int nsh = s_nsh;
-    for (int s = t; s < nl; s += FS_NT) {
-      const int l = live[s];
-      bool sh = false;
-      for (int q = 0; q < nsh; q++) sh |= s_shadow[q] == l;
-      if (sh) continue;
-      const double f = A.fval[(size_t)p * b.max_cand + l], u = A.ub[(size_t)p * b.max_cand + l];
-      if (!(f > -1.0)) continue;
-      if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double f2 = __shfl_xor(bf, o, 64), u2 = __shfl_xor(bu, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (better(bf, bu, bi, f2, u2, i2)) bf = f2, bu = u2, bi = i2;
-    }
-    if ((t & 63) == 0) s_f[t >> 6] = bf, s_u[t >> 6] = bu, s_i[t >> 6] = bi;
-    __syncthreads();
-    if (t == 0) {
-      for (int w = 1; w < FS_NT / 64; w++)
-        if (better(bf, bu, bi, s_f[w], s_u[w], s_i[w])) bf = s_f[w], bu = s_u[w], bi = s_i[w];
-      s_win = bi, s_f[0] = bf, s_u[0] = bu, s_hit = 0;
-    }
-    __syncthreads();
-    const int cand = s_win;
-    if (cand < 0) break;
-    const double cu = s_u[0];
-    int hit = 0;
-    for (int s = t; s < nl; s += FS_NT)  // a live candidate with a higher id and the same key?
-      if (live[s] > cand && A.ub[(size_t)p * b.max_cand + live[s]] == cu) hit = 1;
-    if (hit) s_hit = 1;
-    __syncthreads();
-    if (!s_hit || s_nsh >= MAXSH || A.no_key_rule) break;  // (more than MAXSH chained collisions in one round: keep the last winner)
-    __syncthreads();
-    if (t == 0) s_shadow[s_nsh++] = cand;
-    __syncthreads();
-  }
-  if (t == 0) {
-    bi = s_win, bf = s_f[0];
-    if (bi >= 0) {
-      const int k = A.nsel[p];
-      A.out.selected_ids[(size_t)p * b.max_features + k] = b.cand_id[(size_t)p * b.max_cand + bi];
-      if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + k] = bf;
-      A.nsel[p] = k + 1;
-      A.out.n_selected[p] = k + 1;
-      A.black[(size_t)p * b.max_cand + bi] = 1;
-      const int at = A.pos[(size_t)p * b.max_cand + bi], last = live[nl - 1];  // swap-remove the winner from the live list
-      live[at] = last, A.pos[(size_t)p * b.max_cand + last] = at;
-      A.nlive[p] = nl - 1;
-    } else {
-      A.done[p] = 1;  // lMax == -1: nothing is added; later rounds would repeat the same state
-    }
-  }
-  __syncthreads();
-  const int win = s_win;
-  if (win < 0) return;
-  const double pr = b.cand_prob[(size_t)p * b.max_cand + win];
-  const double* D = A.delta + ((size_t)p * b.max_cand + win) * T * T;
-  double* C = A.C + (size_t)p * T * T;
-  for (int idx = t; idx < T * T; idx += FS_NT) {
-    C[idx] += pr * D[idx];
-    if (idx / T == idx % T) A.dpp[(size_t)p * T + idx / T] += pr * D[idx];
+    S.fvaln[sc] = f;  // (by slot of the next live list: see fsel_pick_local)
+    S.ubn[sc] = A.consts[(size_t)p * 4 + 1] + ubt;
   }
 }
 
@@ -680,7 +765,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   hipLaunchKernelGGL(fsel_live_init_kernel, dim3(b.n_problems), dim3(64), 0, stream, d);
   const int per_block = FS_CPWG;  // four candidates per wavefront
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
-  for (int r = 0; r < b.max_features; r++) {
+  for (int r = 0; r <= b.max_features; r++) {  // launch r: the winner of round r - 1, then the values of round r
     switch (T) {
       case 6: hipLaunchKernelGGL((fsel_round_kernel<6, 6, 1>), grid, dim3(FS_NT), 0, stream, d, r); break;
       case 9: hipLaunchKernelGGL((fsel_round_kernel<9, 9, 1>), grid, dim3(FS_NT), 0, stream, d, r); break;
@@ -689,7 +774,6 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
       case 39: hipLaunchKernelGGL((fsel_round_kernel<39, 13, 3>), grid, dim3(FS_NT), 0, stream, d, r); break;
       default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(fsel_pick_kernel, dim3(b.n_problems), dim3(FS_NT), 0, stream, d, r);
   }
   return hipGetLastError();
 }
