@@ -110,7 +110,13 @@ constexpr int L_HEE = L_RIC + 20;      // E^T E (150) padded
 #endif
 constexpr int L_DXP = L_HEE + 152;
 constexpr int L_RP = L_DXP + MAXPRIOR;
+#ifdef AVM_X
+constexpr int L_DX2 = L_DXP;       // (the extended build keeps the prior on one wavefront)
 constexpr int L_RED = L_RP + MAXPRIOR;
+#else
+constexpr int L_DX2 = L_RP + MAXPRIOR;  // dx / J0^T r_p of the second wavefront that shares the prior
+constexpr int L_RED = L_DX2 + MAXPRIOR;
+#endif
 constexpr int L_RED_B = L_RED + 16, L_RED_CNT = L_RED + 32;  // second value of a paired reduction; the wavefronts' reduction counters (8 ints)
 constexpr int L_INT = L_RED + 36;  // int region (as doubles): 360 doubles = 720 ints
 constexpr int L_SUM = L_INT + 360;  // cost_trace[16], radius_trace[16]
@@ -180,6 +186,21 @@ AVM_DEV int roff(int i) {  // even i = 2q: 2q(q+1); odd i = 2q+1: 2(q+1)^2 -> ev
   return 2 * __mul24(q + 1, q + (i & 1));  // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
 }
 
+// reciprocal / reciprocal square root from the hardware estimate + two Newton steps (about one ulp; the library forms spend
+// two to three times as long on range handling that the operands here - depths, squared norms >= 1 - never need)
+AVM_DEV double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x), e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+AVM_DEV double fast_rsqrt_pe(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  return y;
+}
+
 struct Frames {
   const double* R;  // [11][9]
   const double* A;  // [11][9]  ric^T * R_f^T
@@ -197,23 +218,23 @@ AVM_DEV double proj_eval(const double* x, Frames fr, const double* ric, const do
   const v3 Pa = mk3(x[fa * 7], x[fa * 7 + 1], x[fa * 7 + 2]);
   const v3 Pb = mk3(x[fb * 7], x[fb * 7 + 1], x[fb * 7 + 2]);
   const v3 t = mk3(tic[0], tic[1], tic[2]);
-  const double il = 1.0 / lam;
+  const double il = fast_rcp(lam);
   const v3 pci = mk3(pix * il, piy * il, il);
   const v3 pimu_i = Rmul(ric, pci) + t;
   const v3 pw = Rmul(Ra, pimu_i) + Pa;
   const v3 pimu_j = RTmul(Rb, pw - Pb);
   const v3 pcj = RTmul(ric, pimu_j - t);
   const double dep = pcj.z;
-  const double id = 1.0 / dep;  // one division per quantity: the quotients below are products with the reciprocal
+  const double id = fast_rcp(dep);  // one reciprocal per quantity: the quotients below are products with it
   double r0 = sqi * (pcj.x * id - pjx);
   double r1 = sqi * (pcj.y * id - pjy);
   const double sn = r0 * r0 + r1 * r1;
   // ceres::CauchyLoss + Corrector: rho'' < 0 => residual and Jacobian scale by sqrt(rho')
-  const double b = cauchy_a * cauchy_a, c = 1.0 / b;
+  const double b = cauchy_a * cauchy_a, c = fast_rcp(b);
   const double sum = 1.0 + sn * c;
-  const double inv = 1.0 / sum;
   const double rho0 = b * log(sum);
-  const double srho = apply_loss ? sqrt(fmax(DBL_MIN, inv)) : 1.0;
+  // sqrt(max(DBL_MIN, 1 / sum)), Corrector's sqrt(rho'): 1.4916681462400413e-154 = sqrt(DBL_MIN)
+  const double srho = apply_loss ? fmax(fast_rsqrt_pe(sum), 1.4916681462400413e-154) : 1.0;
   r[0] = srho * r0;
   r[1] = srho * r1;
   if (WANT_J) {
@@ -528,8 +549,10 @@ AVM_NOINL void prior_residual_dev(const WinCtx&, int xs_off) {
 //   dx -> lds[L_DXP],  r_p = r0 + J0 dx -> lds[L_RP],  and (WANT_G) g_p = J0^T r_p -> lds[L_DXP], over dx;
 // returns 1/2 |r_p|^2 on every lane.  J0 is read along its rows both times (16 lanes per row for r_p, a lane per column
 // for g_p), several rows in flight; every sum has a fixed order.
+// Rows [rb, re) of the prior only, dx / g_p in the buffer at buf_off: two wavefronts can share the prior, each with its own buffer;
+// their costs and their g_p add up (r_p rows are disjoint).
 template <bool WANT_G>
-AVM_DEV double prior_wave(int xs_off) {
+AVM_DEV double prior_wave(int xs_off, int rb, int re, int buf_off) {
   const WinCtx& c = lds_ctx();
   double* lds = LDS();
   const double* xs = lds + xs_off;
@@ -548,15 +571,15 @@ AVM_DEV double prior_wave(int xs_off) {
     double dx[9];
     prior_block_dx(kind, xb, c.px0 + lane * 9, dx);
     const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
-    for (int k = 0; k < n; k++) lds[L_DXP + off + k] = dx[k];
+    for (int k = 0; k < n; k++) lds[buf_off + off + k] = dx[k];
   }
   wave_lds_sync();
   constexpr int NK = MAXPRIOR / 16, RU = 7;  // 6 column groups of 16; 7 x 4 rows in flight (three trips to the slot's memory for 75 rows)
   double dxv[NK];
 #pragma unroll
-  for (int j = 0; j < NK; j++) dxv[j] = lr + 16 * j < pn ? lds[L_DXP + lr + 16 * j] : 0.0;
+  for (int j = 0; j < NK; j++) dxv[j] = lr + 16 * j < pn ? lds[buf_off + lr + 16 * j] : 0.0;
   double cost = 0;
-  for (int r0 = 0; r0 < pn; r0 += 4 * RU) {
+  for (int r0 = rb; r0 < re; r0 += 4 * RU) {
     double v[RU][NK], rr[RU];
 #pragma unroll
     for (int u = 0; u < RU; u++) {
@@ -577,7 +600,7 @@ AVM_DEV double prior_wave(int xs_off) {
       sacc += __shfl_xor(sacc, 1, 64);
       const int row = r0 + 4 * u + lg;
       const double rp = rr[u] + sacc;
-      if (lr == 0 && row < pn) {
+      if (lr == 0 && row < re) {
         lds[L_RP + row] = rp;
         cost += 0.5 * rp * rp;
       }
@@ -590,7 +613,7 @@ AVM_DEV double prior_wave(int xs_off) {
     constexpr int GU = 19;  // (four trips for 75 rows)
     const int k0 = min(lane, pn1), k1 = min(lane + 64, pn1);
     double g0 = 0, g1 = 0;
-    for (int i0 = 0; i0 < pn; i0 += GU) {
+    for (int i0 = rb; i0 < re; i0 += GU) {
       double a0[GU], a1[GU];
 #pragma unroll
       for (int u = 0; u < GU; u++) {
@@ -599,12 +622,12 @@ AVM_DEV double prior_wave(int xs_off) {
       }
 #pragma unroll
       for (int u = 0; u < GU; u++) {
-        const double r = i0 + u < pn ? lds[L_RP + min(i0 + u, MAXPRIOR - 1)] : 0.0;
+        const double r = i0 + u < re ? lds[L_RP + min(i0 + u, MAXPRIOR - 1)] : 0.0;
         g0 += a0[u] * r, g1 += a1[u] * r;
       }
     }
-    lds[L_DXP + lane] = lane < pn ? g0 : 0.0;  // (dx lives in dxv by now)
-    if (lane + 64 < MAXPRIOR) lds[L_DXP + lane + 64] = lane + 64 < pn ? g1 : 0.0;
+    lds[buf_off + lane] = lane < pn ? g0 : 0.0;  // (dx lives in dxv by now)
+    if (lane + 64 < MAXPRIOR) lds[buf_off + lane + 64] = lane + 64 < pn ? g1 : 0.0;
   }
   return cost;
 }
@@ -677,7 +700,7 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
 #endif
   // the prior on the last wavefront (the same code, hence the same rounding, as in eval_jac)
   if (t >= NT - 64 && c.pn > 0) {
-    const double pc = prior_wave<false>(xs_off);
+    const double pc = prior_wave<false>(xs_off, 0, c.pn, L_DXP);
     if (t == NT - 64) acc += pc;
   }
   __syncthreads();
@@ -1258,10 +1281,20 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       imu_raw<true>(xs, fr.R, o, c.pdelta + i * 10, c.pjac + i * 225, c.psum[i], c.lba + i * 3, c.lbg + i * 3, i, IJR + i * 465);
   }
   // ... || the prior (dx, residual, cost, J0^T r_p) on the last wavefront, which has the lightest load of phase A
+#ifdef AVM_X
   if (wv == NT / 64 - 1 && c.pn > 0) {
-    const double pc = prior_wave<true>(xs_off);
+    const double pc = prior_wave<true>(xs_off, 0, c.pn, L_DXP);
     if (lane == 0) acc += pc;
   }
+#else
+  // (the raw-IMU wavefront takes the last two fifths of the prior's rows once it is done: each of the two reads J0 along its
+  //  own rows only)
+  if (wv >= ASM_WAVES && c.pn > 0) {
+    const int h = (3 * c.pn + 2) / 5;
+    const double pc = wv == ASM_WAVES ? prior_wave<true>(xs_off, h, c.pn, L_DX2) : prior_wave<true>(xs_off, 0, h, L_DXP);
+    if (lane == 0) acc += pc;
+  }
+#endif
   if (c.prof && lane == 0) c.prof[48 + wv] += clock64() - pa__;  // this wavefront's busy time in phase A
   __syncthreads();
   PROF(c, 0);
@@ -1439,7 +1472,11 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     }
     {
       const int* pidx = ids + I_PIDX;
+#ifdef AVM_X
       if (t < c.pn && pidx[t] >= 0) lds[L_G + pidx[t]] += lds[L_DXP + t];
+#else
+      if (t < c.pn && pidx[t] >= 0) lds[L_G + pidx[t]] += lds[L_DXP + t] + lds[L_DX2 + t];
+#endif
     }
   }
   const double cost = block_sum1(acc);
@@ -3369,7 +3406,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     } else if (wv == 7) {
       if (lane == 0 && imu0) imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
       // ... and the old prior's residual and gradient (MarginalizationFactor at the current state): dx, r_p, J0^T r_p
-      if (use_prior) prior_wave<true>(L_X);
+      if (use_prior) prior_wave<true>(L_X, 0, c.pn, L_DXP);
     }
     __syncthreads();
     PROF(c, 17);
