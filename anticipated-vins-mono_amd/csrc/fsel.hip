@@ -11,8 +11,8 @@
 // select() call.  So the Cholesky pivots of those rows are hoisted: setup eliminates them once
 // per frame (partial Cholesky in LDS) leaving C0 = Omega_pp - Omega_pn Omega_nn^-1 Omega_np and
 // logdet(Omega_nn); every candidate evaluation logdet(Omega + OmegaS + p*Delta) is then
-// logdet(Omega_nn) + logdet(C + p*Delta_pp) with a 3H x 3H factorisation held entirely in the
-// registers of one wavefront (lane = matrix row; two candidates per wave when 3H <= 32).
+// logdet(Omega_nn) + logdet(C + p*Delta_pp) with a 3H x 3H factorisation held entirely in
+// registers (four candidates per wavefront, one per 16-lane DPP row; one launch per greedy round).
 // This is the same Cholesky with the constant leading pivots factored once — the same kind of
 // hoist as IMUFactor's sqrt_info.  All FP64; selection order is deterministic.
 #include <cfloat>
@@ -422,7 +422,7 @@ AVM_DEV double fs_readlane_d(double v, int srclane) {  // srclane must be wave-u
 // blocks is computed and never read), only the lanes are used four times as densely and there are no SGPR round trips:
 // 2 DPP moves + 1-3 FMAs per (pivot, column) pair for four candidates instead of 2 v_readlane + 1 FMA for one.
 // logdet = sum_j log(d_j) in pivot order; the Hadamard bound (sortedlogDetUB) is summed the same way for every candidate, so
-// mirror-image candidates still get bit-identical bounds (the std::map rule of the pick kernel depends on that).
+// mirror-image candidates still get bit-identical bounds (the std::map rule of the pick depends on that).
 template <int K>
 AVM_DEV double fs_rowbcast_k(double v) {  // lane K of every 16-lane row -> the whole row (row_newbcast:K = dpp_ctrl 0x150 + K)
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, true);

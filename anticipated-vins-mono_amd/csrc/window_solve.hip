@@ -1266,7 +1266,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   __syncthreads();
   Frames fr{lds + L_FR, lds + L_FR + 9 * NFRP};
   double acc = 0;
-  // ---- phase A: projection factors (waves 0..ASM_WAVES-1, one frame at a time) || IMU raw Jacobians (the next wave)
+  // ---- phase A: projection factors (wavefronts 0..ASM_WAVES-1) || raw IMU Jacobians (the next wavefront) || the prior
   const long long pa__ = c.prof ? clock64() : 0;
   if (wv < ASM_WAVES) {
 #ifdef AVM_X

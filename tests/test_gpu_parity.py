@@ -922,7 +922,7 @@ def _mirror_frame(H=5, npairs=20, n_used=3, seed=0):
 def test_selector_equal_upper_bounds_follow_the_std_map_rule(selector, oracle, monkeypatch):
     """sortedlogDetUB stores the bounds in a std::map<double, int> (feature_selector.cpp:724): of two live candidates with
     bit-identical bounds only the higher id is scored in that round.  The oracle keeps the map; the device reproduces the
-    rule in its pick kernel.  With the rule switched off the same frame selects in a different order - i.e. the frame really
+    rule in its pick.  With the rule switched off the same frame selects in a different order - i.e. the frame really
     exercises it."""
     for seed in (0, 1):
         pr = _mirror_frame(seed=seed)
