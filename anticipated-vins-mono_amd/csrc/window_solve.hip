@@ -2335,10 +2335,10 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
 #endif
     __syncthreads();
     PROFQ(c, 39);
+#ifdef AVM_X
     if (t == 0) {  // longest-processing-time assignment of the frames to the assembling wavefronts
       int done = 0;
       ids[I_FRW] = -1;
-#ifdef AVM_X
       int load[ASM_WAVES];
       for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
       for (int k = 1; k < NFRP; k++) {
@@ -2352,31 +2352,35 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         load[bw] += ((bn + 63) / 64) * 64 + 8;
         done |= 1 << bb;
       }
+    }
 #else
-      // A wavefront's cost is its number of 64-factor chunks over ALL its frames; wavefronts w and w + 4 share a SIMD, so
-      // the quantity to keep level is the chunk count per SIMD (the raw-IMU wavefront 6 weighs about two chunks on SIMD 2,
-      // the prior's wavefront 7 about one on SIMD 3).  Largest frame first, to the wavefront that leaves its SIMD lowest.
-      int fcnt[ASM_WAVES];
-      for (int k = 0; k < ASM_WAVES; k++) fcnt[k] = 0;
-      auto chunks = [](int n) { return (n + 63) >> 6; };
+    if (t < 64) {
+      // Longest-processing-time assignment of the frames to the assembling wavefronts, by the lanes of wavefront 0 (lane q
+      // keeps the factor count of wavefront q).  A wavefront's cost is its number of 64-factor chunks over ALL its frames;
+      // wavefronts w and w + 4 share a SIMD, so the quantity to keep level is the chunk count per SIMD (the raw-IMU
+      // wavefront 6 weighs about two chunks on SIMD 2, the prior's wavefront 7 about one on SIMD 3).  Largest frame first,
+      // to the wavefront that leaves its SIMD lowest (ties: the one with fewer chunks of its own, then the lower index).
+      int fc = 0, done = 0;
+      if (t == 0) ids[I_FRW] = -1;
       for (int k = 1; k < NFRP; k++) {
         int bb = -1, bn = -1;
-        for (int f = 1; f < NFRP; f++)
-          if (!(done & (1 << f)) && ids[I_NCOV + f] > bn) bn = ids[I_NCOV + f], bb = f;
-        int bw = 0, bcost = 1 << 30, bown = 1 << 30;
-        for (int q = 0; q < ASM_WAVES; q++) {
-          int simd = (q & 3) == 2 ? 2 : ((q & 3) == 3 ? 1 : 0);
-          for (int q2 = 0; q2 < ASM_WAVES; q2++)
-            if ((q2 & 3) == (q & 3)) simd += chunks(fcnt[q2] + (q2 == q ? bn : 0));
-          const int own = chunks(fcnt[q]);
-          if (simd < bcost || (simd == bcost && own < bown)) bw = q, bcost = simd, bown = own;
+        for (int f = 1; f < NFRP; f++) {
+          const int n = ids[I_NCOV + f];
+          if (!(done & (1 << f)) && n > bn) bn = n, bb = f;
         }
-        ids[I_FRW + bb] = bw;
-        fcnt[bw] += bn;
+        const int own = (fc + 63) >> 6, with = (fc + bn + 63) >> 6;
+        const int partner = __shfl(own, t ^ 4, 64);
+        int key = ((with + partner + ((t & 3) == 2 ? 2 : ((t & 3) == 3 ? 1 : 0))) << 16) | (own << 8) | t;
+        if (t >= ASM_WAVES) key = 0x7fffffff;
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, 64));
+        const int bw = __builtin_amdgcn_readfirstlane(key) & 255;
+        if (t == bw) fc += bn;
+        if (t == 0) ids[I_FRW + bb] = bw;
         done |= 1 << bb;
       }
-#endif
     }
+#endif
     __syncthreads();
     // once per window: the structural zeros of the scratch slot (raw IMU Jacobians outside their blocks, E^T F of
     // the frames that do not observe a feature) - the evaluations only ever rewrite the same nonzero entries
