@@ -2980,7 +2980,9 @@ AVM_DEV void marg_schur_macro_tile(int nf0) {
     }
 }
 
-AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int stage_off) {
+AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1, int stage_off) {
+  // The wavefront's (at most two) frames b0 < b1 as ONE list of factors, 64 at a time: a chunk may straddle the two frames (5
+  // chunks for two frames of 150 factors instead of 3 + 3), the MFMA accumulation is cut at the frame boundary.
   const WinCtx& c = lds_ctx();
   const avm_options& o = lds_opt();
   using namespace mg;
@@ -2989,8 +2991,7 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   (void)ids;
   const int lane = threadIdx.x & 63;
-  const int ncov = ids[I_NCOV + b];
-  const int32_t* cov = c.cov + b * MAXE;
+  const int n0 = ids[I_NCOV + b0], n1 = b1 < NFR ? ids[I_NCOV + b1] : 0, ntot = n0 + n1;
   Frames fr{lds + L_FR, lds + L_FR + 99};
   const double* xs = lds + L_X;
   const double sqi = o.focal_length / 1.5;
@@ -2998,13 +2999,39 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
   double* PF = c.sc + Scratch::PF;     // [8][MAXOBS] Ji^T Je (6), Je^T Je, Je^T r per observation slot
   double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;  // [7][MAXOBS] Jex^T Je (6), Jtd^T Je
   const double td = lds[L_RIC + 19];   // para_Td (0 unless estimate_td)
-  double* PART = c.sc + Scratch::PART + (size_t)b * PARTW;
   d4 D00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, D11 = {0, 0, 0, 0}, E00 = {0, 0, 0, 0}, E10 = {0, 0, 0, 0}, E11 = {0, 0, 0, 0};
   const int drow = lane >> 4, dcol = lane & 15;
-  for (int chunk0 = 0; chunk0 < ncov; chunk0 += 64) {
+  auto end_frame = [&](int b) {  // the blocks frame b owns, from the accumulators
+    double* PART = c.sc + Scratch::PART + (size_t)b * PARTW;
+    D00 += E00, D10 += E10, D11 += E11;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = drow + 4 * r;
+      // D00: rows/cols over [Jj | Ji | r]
+      if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = D00[r];                   // (b,b)
+      if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + (dcol - 6)] = D00[r];          // (b,0)
+      if (row < 6 && dcol == 12) lds[M_G + 6 * b + row] = D00[r];                                         // g_b
+      if (row >= 6 && row < 12) {
+        const int i = row - 6;
+        if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[i * (i + 1) / 2 + (dcol - 6)] = D00[r];         // (0,0)
+        if (dcol == 12) PART[21 + i] = D00[r];                                                            // g_0
+      }
+      // D10: rows = [Jex | Jtd] (7), cols = [Jj | Ji | r]
+      if (row < 7) {
+        if (dcol < 6) PART[104 + row * 6 + dcol] = D10[r];                      // ([ex td], pose b)
+        if (dcol >= 6 && dcol < 12) PART[27 + row * 6 + (dcol - 6)] = D10[r];   // ([ex td], pose 0)
+        if (dcol == 12) PART[97 + row] = D10[r];                                // g_[ex td]
+        if (dcol <= row) PART[69 + row * (row + 1) / 2 + dcol] = D11[r];        // ([ex td], [ex td])
+      }
+    }
+    D00 = D10 = D11 = E00 = E10 = E11 = d4{0, 0, 0, 0};
+  };
+  for (int chunk0 = 0; chunk0 < ntot; chunk0 += 64) {
     const int idx = chunk0 + lane;
-    const bool act = idx < ncov;
-    const int e = act ? cov[idx] : 0;
+    const bool act = idx < ntot;
+    const int ic = min(idx, max(ntot - 1, 0));
+    const int b = ic < n0 ? b0 : b1;
+    const int e = c.cov[b * MAXE + (ic < n0 ? ic : ic - n0)];  // (inactive lanes repeat the last factor: valid, never stored)
     const int s0 = ids[I_FOBS + e];
     const int s = s0 + b;
     double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0}, Jx[12], Jt[2] = {0, 0};
@@ -3033,7 +3060,7 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
     // staged column-major like the solve kernel's frame tasks (Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18): one 16-byte store
     // per column, contiguous across the lanes; inactive lanes stage zeros, so no row needs masking.  The tile holds half
     // a chunk: lanes 0-31 stage and the wavefront multiplies, then lanes 32-63.
-    const int nact = min(64, ncov - chunk0);
+    const int nact = min(64, ntot - chunk0);
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
       const int nh = min(max(nact - 32 * half, 0), 32);
@@ -3050,54 +3077,51 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b, int sta
         st[19 * (MXRS / 2)] = dv2{Jt[0], Jt[1]};
       }
       wave_lds_sync();
-      // lane group drow takes the two rows of factor 4 j + drow (one 16-byte read per tile), four j at a time: 24 MFMAs on
-      // six independent chains
-      const int j_end = (nh + 3) >> 2;
+      // the factors of frame b0 in this half, then those of b1 (either may be empty)
+      const int g0 = chunk0 + 32 * half;                      // list position of the half's first factor
+      const int nb0 = min(max(n0 - g0, 0), nh);               // factors of b0 in the half
 #pragma unroll 1
-      for (int j0 = 0; j0 < j_end; j0 += 4) {
-        dv2 u0[4], u1[4];
+      for (int run = 0; run < 2; run++) {
+        const int l = run == 0 ? 0 : nb0, l_end = run == 0 ? nb0 : nh;
+        if (l_end <= l) continue;  // (uniform)
+        if (run == 1 && g0 + l == n0 && n0 > 0) end_frame(b0);  // frame b1 begins exactly here: frame b0 is complete
+        // lane group drow takes the two rows of factor 4 j + drow (one 16-byte read per tile), four j at a time: 24 MFMAs on
+        // six independent chains; factors outside the run are masked out by their index
+        const int j_end = (l_end + 3) >> 2;
+#pragma unroll 1
+        for (int j0 = l >> 2; j0 < j_end; j0 += 4) {
+          dv2 u0[4], u1[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int ro = 8 * min(j0 + u, 7) + 2 * drow;
-          u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * MXRS + ro);
-          u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * MXRS + ro);
-        }
+          for (int u = 0; u < 4; u++) {
+            const int ro = 8 * min(j0 + u, 7) + 2 * drow;
+            u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * MXRS + ro);
+            u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * MXRS + ro);
+          }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const bool on = j0 + u < j_end;
-          const double a0 = (on && dcol < 13) ? u0[u][0] : 0.0, a1 = (on && dcol < 13) ? u0[u][1] : 0.0;
-          const double x0 = (on && dcol < 7) ? u1[u][0] : 0.0, x1 = (on && dcol < 7) ? u1[u][1] : 0.0;
-          D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
-          D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
-          D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
-          E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
-          E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
-          E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+          for (int u = 0; u < 4; u++) {
+            const int f = 4 * (j0 + u) + drow;
+            const bool on = f >= l && f < l_end;
+            const double a0 = (on && dcol < 13) ? u0[u][0] : 0.0, a1 = (on && dcol < 13) ? u0[u][1] : 0.0;
+            const double x0 = (on && dcol < 7) ? u1[u][0] : 0.0, x1 = (on && dcol < 7) ? u1[u][1] : 0.0;
+            D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
+            D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
+            D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
+            E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
+            E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
+            E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+          }
         }
       }
       wave_lds_sync();
     }
   }
-  D00 += E00, D10 += E10, D11 += E11;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = drow + 4 * r;
-    // D00: rows/cols over [Jj | Ji | r]
-    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = D00[r];                   // (b,b)
-    if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + (dcol - 6)] = D00[r];          // (b,0)
-    if (row < 6 && dcol == 12) lds[M_G + 6 * b + row] = D00[r];                                         // g_b
-    if (row >= 6 && row < 12) {
-      const int i = row - 6;
-      if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[i * (i + 1) / 2 + (dcol - 6)] = D00[r];         // (0,0)
-      if (dcol == 12) PART[21 + i] = D00[r];                                                            // g_0
-    }
-    // D10: rows = [Jex | Jtd] (7), cols = [Jj | Ji | r]
-    if (row < 7) {
-      if (dcol < 6) PART[104 + row * 6 + dcol] = D10[r];                      // ([ex td], pose b)
-      if (dcol >= 6 && dcol < 12) PART[27 + row * 6 + (dcol - 6)] = D10[r];   // ([ex td], pose 0)
-      if (dcol == 12) PART[97 + row] = D10[r];                                // g_[ex td]
-      if (dcol <= row) PART[69 + row * (row + 1) / 2 + dcol] = D11[r];        // ([ex td], [ex td])
-    }
+  // what is still in the accumulators belongs to the last frame with factors; a frame without factors owns zeros
+  if (n1 > 0) {
+    end_frame(b1);
+    if (n0 == 0) end_frame(b0);
+  } else {
+    end_frame(b0);
+    if (b1 < NFR) end_frame(b1);
   }
 }
 
@@ -3406,7 +3430,8 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     PROF(c, 16);
     // ---- phase A: projection factors of the start-0 features || IMU factor 0
     if (wv < MASM) {
-      for (int b = 1 + wv; b < NFR; b += MASM) marg_frame_task(c, o, b, L_S + SPP + wv * MXSTG);
+      marg_frame_task(c, o, 1 + wv, 1 + wv + MASM, L_S + SPP + wv * MXSTG);  // this wavefront's (at most two) frames
+      static_assert(1 + 2 * MASM >= NFR, "two frames per wavefront cover all frames");
     } else if (wv == 7) {
       if (lane == 0 && imu0) imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
       // ... and the old prior's residual and gradient (MarginalizationFactor at the current state): dx, r_p, J0^T r_p
