@@ -1908,6 +1908,8 @@ AVM_NOINL void chol_solve_lds(int vec) {
       if (lane + 64 * q < NF) b[lane + 64 * q] = S[roff(NF) + lane + 64 * q];
     wave_lds_sync();
     if (NF % NB) chol_solve_block<(NF % NB) ? (NF % NB) : NB>(S, b, (NF / NB) * NB, lane);
+    // (unrolled: every block's row offsets become immediates of its LDS reads)
+#pragma unroll
     for (int blk = NF / NB - 1; blk >= 0; blk--) chol_solve_block<NB>(S, b, blk << 4, lane);
   }
   __syncthreads();
