@@ -66,6 +66,9 @@ struct avm_ctx {
   bool packed_in = false;  // the last stage_window_batch took the packed path (states are contiguous on the device)
   hipEvent_t ev[8];
   std::map<std::string, float> last_ms;
+  // single-frame selects run all greedy rounds in one launch (csrc/fsel.hip, fsel_frame_kernel) until that kernel has
+  // once reported that its barrier did not complete on this device; AVM_FSEL_PERSISTENT=0 switches it off
+  bool fsel_persistent = true;
   ncclComm_t comm = nullptr;  // avm_comm_init
   int comm_ranks = 0, comm_rank = 0;
 };
@@ -919,6 +922,7 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   GET(live, int32_t, 2 * P * mc)
   GET(pos, int32_t, 2 * P * mc)
   GET(nlive, int32_t, 2 * P)
+  GET(sync, int32_t, FS_SYNC_INTS)
 #undef GET
   return AVM_OK;
 }
@@ -948,11 +952,28 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   }
   FselBuffers w;
   if ((rc = fsel_buffers(c, &d, &w)) != AVM_OK) return rc;
-  HIPCHK(c, hipMemsetAsync(dout.n_selected, 0, sizeof(int32_t) * P, c->stream));
-  HIPCHK(c, hipMemsetAsync(dout.selected_ids, 0xff, sizeof(int32_t) * P * mf, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-  HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  bool persistent = P == 1 && d.max_cand <= 512 && c->fsel_persistent;  // (FS_FRAME_MAXC, csrc/fsel.hip)
+  if (const char* e = getenv("AVM_FSEL_PERSISTENT"))
+    if (e[0] == '0') persistent = false;
+  int32_t* hsync = persistent ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 32)) : nullptr;
+  if (persistent && !hsync) persistent = false;
+  for (;;) {
+    HIPCHK(c, hipMemsetAsync(dout.n_selected, 0, sizeof(int32_t) * P, c->stream));
+    HIPCHK(c, hipMemsetAsync(dout.selected_ids, 0xff, sizeof(int32_t) * P * mf, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, persistent, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    if (!persistent) break;
+    HIPCHK(c, hipMemcpyAsync(hsync, w.sync, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("AVM_FSEL_TRACE")) {
+      const long long* q = reinterpret_cast<const long long*>(hsync + 4);
+      fprintf(stderr, "fsel frame kernel (cycles): wg0 pick %lld update %lld eval %lld arrive %lld wait %lld | last wg pick %lld update %lld eval %lld arrive %lld wait %lld\n", q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9]);
+    }
+    if (hsync[2] == 0) break;
+    // the in-kernel barrier did not complete (see fsel_frame_kernel): run this and every later frame launch by launch
+    c->fsel_persistent = persistent = false;
+  }
   if (mem == AVM_MEM_HOST) {
     HIPCHK(c, hipMemcpyAsync(out->n_selected, dout.n_selected, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out->selected_ids, dout.selected_ids, sizeof(int32_t) * P * mf, hipMemcpyDeviceToHost, c->stream));
@@ -1069,7 +1090,7 @@ int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, d
     if (!d_om) return fail(c, AVM_ERR_HIP, "hipMalloc failed (omega)");
   }
   avm_fsel_out none{nullptr, nullptr, nullptr};
-  HIPCHK(c, launch_fsel(d, w, none, d_om, false, c->stream));
+  HIPCHK(c, launch_fsel(d, w, none, d_om, false, false, c->stream));
   const hipMemcpyKind kind = mem == AVM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (omega && mem == AVM_MEM_HOST) HIPCHK(c, hipMemcpyAsync(omega, d_om, sizeof(double) * P * N * N, kind, c->stream));
   if (delta_cand) HIPCHK(c, hipMemcpyAsync(delta_cand, w.delta, sizeof(double) * P * mc * T * T, kind, c->stream));

@@ -486,7 +486,11 @@ AVM_DEV FselPar fsel_par(const FselDev& A, int p, int k) {
 
 // ---- the round's winner (feature_selector.cpp:669-683), computed by every workgroup of the problem for itself ---------------
 // returns the winner's candidate index (-1: none) to all threads; *fwin its value
-AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
+// BYID (the single-frame kernel): there is no live list - slot s IS candidate s - and the caller hands in this thread's
+// candidates t + q FS_NT (q < 2; index -1 = not in the race) with their values, which it has read and validated itself.
+template <bool BYID = false>
+AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin, const int* rl = nullptr, const double* rf = nullptr,
+                            const double* ru = nullptr) {
   __shared__ double s_f[FS_NT / 64], s_u[FS_NT / 64];
   __shared__ int s_i[FS_NT / 64];
   __shared__ int s_win;
@@ -516,12 +520,14 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
   //  independent: one trip to memory)
 #pragma unroll
   for (int q = 0; q < FS_PC; q++) {
-    const int sq = min(t + q * FS_NT, max(nl - 1, 0));
-    cl[q] = live[sq], cf[q] = S.fval[sq], cu[q] = S.ub[sq];
+    if (BYID) {
+      cl[q] = q < 2 ? rl[q] : -1, cf[q] = q < 2 ? rf[q] : 0.0, cu[q] = q < 2 ? ru[q] : 0.0;
+    } else {
+      const int sq = min(t + q * FS_NT, max(nl - 1, 0));
+      cl[q] = live[sq], cf[q] = S.fval[sq], cu[q] = S.ub[sq];
+      if (t + q * FS_NT >= nl) cl[q] = -1;
+    }
   }
-#pragma unroll
-  for (int q = 0; q < FS_PC; q++)
-    if (t + q * FS_NT >= nl) cl[q] = -1;
   double bf;
   int bi;
   for (;;) {
@@ -539,7 +545,7 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
       if (sh || !(f > -1.0)) continue;
       if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
     }
-    for (int s = t + FS_PC * FS_NT; s < nl; s += FS_NT) {
+    for (int s = t + FS_PC * FS_NT; !BYID && s < nl; s += FS_NT) {
       const int l = live[s];
       bool sh = false;
       for (int qq = 0; qq < nsh; qq++) sh |= s_shadow[qq] == l;
@@ -567,7 +573,7 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
 #pragma unroll
     for (int q = 0; q < FS_PC; q++)  // a live candidate with a higher id and the same key?
       if (cl[q] > cand && cu[q] == cuw) hit = 1;
-    for (int s = t + FS_PC * FS_NT; s < nl; s += FS_NT)
+    for (int s = t + FS_PC * FS_NT; !BYID && s < nl; s += FS_NT)
       if (live[s] > cand && S.ub[s] == cuw) hit = 1;
     if (hit) s_hit = 1;
     __syncthreads();
@@ -580,74 +586,13 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
   return s_win;
 }
 
+// logdet(C + pr D) and the Hadamard bound for the candidate of this lane's 16-lane row (see the comment above fs_rowbcast_k):
+// *ld_out = sum_j log(sqrt(d_j)) in pivot order, *ub_out = sum_i log((dpp + pr D)_ii); returns false on a non-positive pivot.
+// sC / sdpp: the frame's current reduced information and position diagonal (LDS), D: the candidate's Delta (global).
 template <int T, int BS, int NB>
-__global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
-  static_assert(BS * NB == T && BS <= 16, "block rows of at most 16 lanes");
-  const avm_fsel_batch& b = A.b;
-  const int p = blockIdx.y, t = threadIdx.x;
-  const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
-  if (A.done[p]) return;  // (set by an earlier launch: the state is frozen)
-  const bool has_pick = k >= 1 && k <= kappa, has_eval = k < kappa;
-  if (!has_pick && !has_eval) return;
-  const FselPar S = fsel_par(A, p, k);
-  // ---- 1. the previous round's winner
-  int win = -1;
-  double fwin = 0.0;
-  if (has_pick) {
-    win = fsel_pick_local(A, S, &fwin);
-    if (win < 0) {
-      if (blockIdx.x == 0 && t == 0) A.done[p] = 1;  // lMax == -1: nothing is added; later rounds would repeat the same state
-      return;
-    }
-  }
-  const bool won = win >= 0;
-  const int wc = max(win, 0);
-  const int nl = S.nl, nln = won ? nl - 1 : nl;
-  const int at = won ? S.pos[wc] : -1, lastc = S.live[max(nl - 1, 0)];  // swap-remove: the last candidate takes the winner's slot
-  const double prw = b.cand_prob[(size_t)p * b.max_cand + wc];
-  const double* Dw = A.delta + ((size_t)p * b.max_cand + wc) * T * T;
-  if (blockIdx.x == 0) {  // this problem's recorder: outputs and the next buffers
-    if (won && t == 0) {
-      const int ks = A.nsel[p];
-      A.out.selected_ids[(size_t)p * b.max_features + ks] = b.cand_id[(size_t)p * b.max_cand + win];
-      if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + ks] = fwin;
-      A.nsel[p] = ks + 1;
-      A.out.n_selected[p] = ks + 1;
-      A.black[(size_t)p * b.max_cand + win] = 1;
-    }
-    for (int idx = t; idx < T * T; idx += FS_NT) {
-      const double c = won ? S.C[idx] + prw * Dw[idx] : S.C[idx];
-      S.Cn[idx] = c;
-      if (idx / T == idx % T) S.dppn[idx / T] = won ? S.dpp[idx / T] + prw * Dw[idx] : S.dpp[idx / T];
-    }
-    for (int s = t; s < nln; s += FS_NT) {
-      const int l = s == at ? lastc : S.live[s];
-      S.liven[s] = l, S.posn[l] = s;
-    }
-    if (t == 0) *S.nliven = nln;
-  }
-  if (!has_eval) return;
-  // ---- 2. this round's candidates against the state with the winner folded in: every workgroup builds it in LDS (the same
-  //         expressions workgroup 0 stores), and the candidates' matrices take their C part from there
-  __shared__ double sC[T * T], sdpp[T];
-  for (int idx = t; idx < T * T; idx += FS_NT) {
-    const double c = won ? S.C[idx] + prw * Dw[idx] : S.C[idx];
-    sC[idx] = c;
-    if (idx / T == idx % T) sdpp[idx / T] = won ? S.dpp[idx / T] + prw * Dw[idx] : S.dpp[idx / T];
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int g = lane >> 4, r = min(lane & 15, BS - 1);  // candidate slot of this lane, its row inside every block row
-  // the candidates still in the race are kept compact (the winner is swap-removed), so late rounds do not pay for
-  // the slots of the features already selected
-  const int slot = (blockIdx.x * (FS_NT / 64) + wv) * 4 + g;
-  const bool live = slot < nln;
-  if (!__any(live)) return;  // (wave-uniform)
-  const int sc = min(slot, max(nln - 1, 0));
-  const int l = sc == at ? lastc : S.live[sc];
-  const int lc = l;  // a slot past the end factors the last live candidate's matrix again and throws the result away
-  const double pr = b.cand_prob[(size_t)p * b.max_cand + lc];
-  const double* D = A.delta + ((size_t)p * b.max_cand + lc) * T * T;
+AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D, double pr, double* ld_out, double* ub_out) {
+  const int lane = threadIdx.x & 63;
+  const int r = min(lane & 15, BS - 1);  // this lane's row inside every block row
   // m[bi][c] = (C + p Delta)[bi BS + r][c], c < (bi + 1) BS.  Both matrices are symmetric, so the entry is fetched as
   // [c][bi BS + r]: the 15 lanes of a candidate then read 15 consecutive doubles instead of 15 different cache lines
   double m[NB][T];
@@ -705,10 +650,239 @@ __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
 #pragma unroll
     for (int j = 0; j < BS; j++) ld += fs_rowbcast(mylog, j);
   }
+  *ld_out = ld, *ub_out = ubt;
+  return !bad;
+}
+
+// One greedy step of workgroup `bx` of problem p: settle round k - 1, evaluate round k.  Returns true when the problem is
+// finished (the same answer in every workgroup of the problem: it depends on the shared state only).
+template <int T, int BS, int NB>
+AVM_DEV bool fsel_round_body(const FselDev& A, int p, int k, int bx) {
+  static_assert(BS * NB == T && BS <= 16, "block rows of at most 16 lanes");
+  const avm_fsel_batch& b = A.b;
+  const int t = threadIdx.x;
+  const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
+  if (A.done[p]) return true;  // (set by an earlier round: the state is frozen)
+  const bool has_pick = k >= 1 && k <= kappa, has_eval = k < kappa;
+  if (!has_pick && !has_eval) return true;
+  const FselPar S = fsel_par(A, p, k);
+  // ---- 1. the previous round's winner
+  int win = -1;
+  double fwin = 0.0;
+  if (has_pick) {
+    win = fsel_pick_local(A, S, &fwin);
+    if (win < 0) {
+      if (bx == 0 && t == 0) A.done[p] = 1;  // lMax == -1: nothing is added; later rounds would repeat the same state
+      return true;
+    }
+  }
+  const bool won = win >= 0;
+  const int wc = max(win, 0);
+  const int nl = S.nl, nln = won ? nl - 1 : nl;
+  const int at = won ? S.pos[wc] : -1, lastc = S.live[max(nl - 1, 0)];  // swap-remove: the last candidate takes the winner's slot
+  const double prw = b.cand_prob[(size_t)p * b.max_cand + wc];
+  const double* Dw = A.delta + ((size_t)p * b.max_cand + wc) * T * T;
+  if (bx == 0) {  // this problem's recorder: outputs and the next buffers
+    if (won && t == 0) {
+      const int ks = A.nsel[p];
+      A.out.selected_ids[(size_t)p * b.max_features + ks] = b.cand_id[(size_t)p * b.max_cand + win];
+      if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + ks] = fwin;
+      A.nsel[p] = ks + 1;
+      A.out.n_selected[p] = ks + 1;
+      A.black[(size_t)p * b.max_cand + win] = 1;
+    }
+    for (int idx = t; idx < T * T; idx += FS_NT) {
+      const double c = won ? S.C[idx] + prw * Dw[idx] : S.C[idx];
+      S.Cn[idx] = c;
+      if (idx / T == idx % T) S.dppn[idx / T] = won ? S.dpp[idx / T] + prw * Dw[idx] : S.dpp[idx / T];
+    }
+    for (int s = t; s < nln; s += FS_NT) {
+      const int l = s == at ? lastc : S.live[s];
+      S.liven[s] = l, S.posn[l] = s;
+    }
+    if (t == 0) *S.nliven = nln;
+  }
+  if (!has_eval) return true;
+  // ---- 2. this round's candidates against the state with the winner folded in: every workgroup builds it in LDS (the same
+  //         expressions workgroup 0 stores), and the candidates' matrices take their C part from there
+  __shared__ double sC[T * T], sdpp[T];
+  for (int idx = t; idx < T * T; idx += FS_NT) {
+    const double c = won ? S.C[idx] + prw * Dw[idx] : S.C[idx];
+    sC[idx] = c;
+    if (idx / T == idx % T) sdpp[idx / T] = won ? S.dpp[idx / T] + prw * Dw[idx] : S.dpp[idx / T];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = lane >> 4;  // candidate slot of this lane
+  // the candidates still in the race are kept compact (the winner is swap-removed), so late rounds do not pay for
+  // the slots of the features already selected
+  const int slot = (bx * (FS_NT / 64) + wv) * 4 + g;
+  const bool live = slot < nln;
+  if (!__any(live)) return false;  // (wave-uniform; no workgroup barrier follows in this function)
+  const int sc = min(slot, max(nln - 1, 0));
+  const int l = sc == at ? lastc : S.live[sc];
+  const int lc = l;  // a slot past the end factors the last live candidate's matrix again and throws the result away
+  const double pr = b.cand_prob[(size_t)p * b.max_cand + lc];
+  const double* D = A.delta + ((size_t)p * b.max_cand + lc) * T * T;
+  double ld, ubt;
+  const bool bad = !fsel_logdet4<T, BS, NB>(sC, sdpp, D, pr, &ld, &ubt);
   if (live && (lane & 15) == 0) {
     const double f = bad ? __builtin_nan("") : (A.consts[(size_t)p * 4] + 2.0 * ld);
     S.fvaln[sc] = f;  // (by slot of the next live list: see fsel_pick_local)
     S.ubn[sc] = A.consts[(size_t)p * 4 + 1] + ubt;
+  }
+  return false;
+}
+
+template <int T, int BS, int NB>
+__global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
+  (void)fsel_round_body<T, BS, NB>(A, blockIdx.y, k, blockIdx.x);
+}
+
+// ---- all rounds of ONE frame in one launch (the latency path: a select() of a single frame is 151 dependent steps) -----------
+// Measured on the launch-per-round path: a step is bound by its chain of dependent trips to memory (state, live list, values,
+// the winner's Delta, the candidates' Delta: each a miss, because a kernel boundary invalidates the caches), not by the launch.
+// Here the frame's state never leaves the compute unit: every workgroup keeps its own copy of C, of the position diagonal and
+// of the candidates' alive flags in LDS and applies the same deterministic update (winner out, C += p Delta_winner) to it.  The
+// only thing exchanged per round is (fValue, ub) of each workgroup's 16 candidates - a fixed assignment by candidate index, no
+// live list.
+// There is no barrier and no fence.  A value travels as a 16-byte record {value, round tag} written with ONE store and read with
+// ONE device-scope load (a single request each, never served by the vector L1; two parity buffers): a reader spins until the
+// records of all candidates still in the race carry the round's tag, and then it has the values - one trip after the last
+// writer, nothing to order, no cache maintenance.  Everything else the kernel reads from global memory was written before the
+// launch.
+// ONEXCD: the launch is 8 x `nslots` workgroups, the ones that find themselves on XCD 0 (HW_REG_XCC_ID) take a slot, the rest
+// exit at once; the records then never leave that XCD's L2 (a trip is ~0.5 us instead of a trip across the fabric).
+// A spin longer than FS_SPIN_TICKS of the 100 MHz clock (fewer participants than slots, e.g. a workgroup-to-XCD distribution
+// other than round-robin) raises sync[2], every participant leaves, and the host runs the launch-per-round path instead (and
+// stays on it).
+constexpr long long FS_SPIN_TICKS = 20 * 100000;  // 20 ms
+constexpr int FS_FRAME_MAXC = 512;                // candidates of a frame on the single-launch path (32 slots of 16)
+struct alignas(16) FselRec {
+  double v;
+  int32_t tag, pad;
+};
+template <bool SC1>
+AVM_DEV void fsel_rec_load2(const FselRec* pa, const FselRec* pb, FselRec* a, FselRec* b) {  // device-scope loads
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i va, vb;
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(va), "=&v"(vb)
+               : "v"(pa), "v"(pb)
+               : "memory");
+  a->v = __hiloint2double(va[1], va[0]), a->tag = va[2];
+  b->v = __hiloint2double(vb[1], vb[0]), b->tag = vb[2];
+}
+template <bool SC1>
+AVM_DEV void fsel_rec_store(FselRec* p, double v, int tag) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i x = {__double2loint(v), __double2hiint(v), tag, 0};
+  if (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(x) : "memory");
+}
+
+template <int T, int BS, int NB, bool ONEXCD>
+__global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots) {
+  __shared__ int s_slot, s_fail;
+  __shared__ double sC[T * T], sdpp[T];
+  __shared__ int32_t s_alive[FS_FRAME_MAXC];
+  const int t = threadIdx.x;
+  int bx = blockIdx.x;
+  if (ONEXCD) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));  // HW_REG_XCC_ID[3:0]
+    if (xcc != 0) return;
+    if (t == 0) s_slot = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    bx = s_slot;
+    if (bx >= nslots) return;
+  }
+  if (t == 0) s_fail = 0;
+  FselRec* recF = reinterpret_cast<FselRec*>(sync + 32);  // [2][FS_FRAME_MAXC] fValue records
+  FselRec* recU = recF + 2 * FS_FRAME_MAXC;               // [2][FS_FRAME_MAXC] upper bound records
+  const avm_fsel_batch& b = A.b;
+  const int p = 0, mc = b.max_cand, nc = b.n_cand[p];
+  const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
+  for (int idx = t; idx < T * T; idx += FS_NT) sC[idx] = A.C[idx];
+  for (int idx = t; idx < T; idx += FS_NT) sdpp[idx] = A.dpp[idx];
+  for (int l = t; l < FS_FRAME_MAXC; l += FS_NT) s_alive[l] = (l < nc && A.valid[l] != 0) ? 1 : 0;
+  __syncthreads();
+  const int lane = t & 63, wv = t >> 6, g = lane >> 4;
+  const int l = (bx * (FS_NT / 64) + wv) * 4 + g;  // this 16-lane row's candidate, for the whole select
+  const int lc = min(l, mc - 1);
+  const double pr = b.cand_prob[lc];
+  const double* D = A.delta + (size_t)lc * T * T;
+  int nsel = 0;
+  long long tk_body = 0, tk_wait = 0, tk_pick = 0, tk_upd = 0, tk0 = clock64();
+  for (int k = 0; k <= kappa; k++) {
+    // ---- 1. the previous round's winner (its values are in parity buffer (k - 1) & 1, tagged k)
+    if (k >= 1) {
+      const int par = (k - 1) & 1;
+      int cl[2];
+      double cf[2], cu[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {  // this thread's candidates: t and t + FS_NT
+        const int sq = t + q * FS_NT;
+        cl[q] = (sq < nc && s_alive[sq]) ? sq : -1;
+        const FselRec *pf = recF + par * FS_FRAME_MAXC + sq, *pu = recU + par * FS_FRAME_MAXC + sq;
+        FselRec rf, ru;
+        const long long t0 = wall_clock64();
+        for (;;) {
+          fsel_rec_load2<true>(pf, pu, &rf, &ru);
+          if (__all(cl[q] < 0 || (rf.tag == k && ru.tag == k))) break;
+          if (__hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > FS_SPIN_TICKS) {
+            __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_fail = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        cf[q] = rf.v, cu[q] = ru.v;
+      }
+      { const long long n = clock64(); tk_wait += n - tk0; tk0 = n; }
+      FselPar S;
+      S.live = nullptr, S.nl = nc;
+      double fwin;
+      const int win = fsel_pick_local<true>(A, S, &fwin, cl, cf, cu);  // (workgroup barriers inside: s_fail is settled after it)
+      { const long long n = clock64(); tk_pick += n - tk0; tk0 = n; }
+      if (s_fail) return;
+      if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
+      if (bx == 0 && t == 0) {  // this frame's recorder
+        A.out.selected_ids[nsel] = b.cand_id[win];
+        if (A.out.fvalues) A.out.fvalues[nsel] = fwin;
+        A.out.n_selected[0] = nsel + 1;
+        A.black[win] = 1;
+      }
+      nsel++;
+      const double prw = b.cand_prob[win];
+      const double* Dw = A.delta + (size_t)win * T * T;
+      for (int idx = t; idx < T * T; idx += FS_NT) {
+        const double dw = Dw[idx];
+        sC[idx] = sC[idx] + prw * dw;
+        if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dw;
+      }
+      if (t == 0) s_alive[win] = 0;
+      __syncthreads();
+      { const long long n = clock64(); tk_upd += n - tk0; tk0 = n; }
+    }
+    if (k >= kappa) break;
+    // ---- 2. this round's values of this workgroup's candidates, published with tag k + 1
+    const bool live = l < nc && s_alive[min(l, FS_FRAME_MAXC - 1)] != 0;
+    if (__any(live)) {
+      double ld, ubt;
+      const bool ok = fsel_logdet4<T, BS, NB>(sC, sdpp, D, pr, &ld, &ubt);
+      if (live && (lane & 15) == 0) {
+        fsel_rec_store<!ONEXCD>(recF + (k & 1) * FS_FRAME_MAXC + l, ok ? (A.consts[0] + 2.0 * ld) : __builtin_nan(""), k + 1);
+        fsel_rec_store<!ONEXCD>(recU + (k & 1) * FS_FRAME_MAXC + l, A.consts[1] + ubt, k + 1);
+      }
+    }
+    __syncthreads();  // (sC / s_alive are read by the evaluation above and written by the next round's update)
+    { const long long n = clock64(); tk_body += n - tk0; tk0 = n; }
+  }
+  if (bx == 0 && t == 0) A.nsel[0] = nsel;
+  if (t == 0 && (bx == 0 || bx == nslots - 1)) {
+    long long* o = reinterpret_cast<long long*>(sync + 4) + (bx == 0 ? 0 : 5);
+    o[0] = tk_pick, o[1] = tk_upd, o[2] = tk_body, o[3] = 0, o[4] = tk_wait;
   }
 }
 
@@ -744,7 +918,7 @@ size_t fsel_setup_lds_bytes(int H) {
 
 // Launches setup (+ optional rounds).  All pointers in `d` are device pointers.
 hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
-                       hipStream_t stream) {
+                       bool persistent, hipStream_t stream) {
   FselDev d;
   d.b = b;
   {
@@ -765,6 +939,24 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   hipLaunchKernelGGL(fsel_live_init_kernel, dim3(b.n_problems), dim3(64), 0, stream, d);
   const int per_block = FS_CPWG;  // four candidates per wavefront
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
+  if (persistent) {  // (one frame: all rounds in one launch, see fsel_frame_kernel)
+    if ((e = hipMemsetAsync(w.sync, 0, sizeof(int32_t) * FS_SYNC_INTS, stream)) != hipSuccess) return e;
+    const int ns = (int)grid.x;
+    static const bool all_xcds = [] { const char* e = getenv("AVM_FSEL_ALL_XCDS"); return e && e[0] == '1'; }();
+#define AVM_FRAME(T_, BS_, NB_)                                                                                              \
+  if (all_xcds) hipLaunchKernelGGL((fsel_frame_kernel<T_, BS_, NB_, false>), dim3(ns), dim3(FS_NT), 0, stream, d, w.sync, ns); \
+  else hipLaunchKernelGGL((fsel_frame_kernel<T_, BS_, NB_, true>), dim3(ns * 8), dim3(FS_NT), 0, stream, d, w.sync, ns);
+    switch (T) {
+      case 6: AVM_FRAME(6, 6, 1) break;
+      case 9: AVM_FRAME(9, 9, 1) break;
+      case 15: AVM_FRAME(15, 15, 1) break;
+      case 30: AVM_FRAME(30, 15, 2) break;
+      case 39: AVM_FRAME(39, 13, 3) break;
+      default: return hipErrorInvalidValue;
+    }
+#undef AVM_FRAME
+    return hipGetLastError();
+  }
   for (int r = 0; r <= b.max_features; r++) {  // launch r: the winner of round r - 1, then the values of round r
     switch (T) {
       case 6: hipLaunchKernelGGL((fsel_round_kernel<6, 6, 1>), grid, dim3(FS_NT), 0, stream, d, r); break;

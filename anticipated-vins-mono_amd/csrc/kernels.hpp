@@ -74,9 +74,11 @@ struct EvalArgs {
 };
 
 // device work buffers of the feature selector (owned by the ctx)
+constexpr int FS_SYNC_INTS = 32 + 2 * 2 * 512 * 4;  // header + (fValue, ub) x two parities x 512 16-byte records
 struct FselBuffers {
   double *C, *dpp, *consts, *delta, *delta_u, *fval, *ub;
   int32_t *valid, *valid_u, *black, *nsel, *done, *live, *pos, *nlive;
+  int32_t* sync;  // [FS_SYNC_INTS] slot counter / failure flag / cycle trace / per-slot records of the single-frame kernel (csrc/fsel.hip)
 };
 
 // ---- table validation (every entry point that takes tables runs it before any kernel indexes with them) -----------
@@ -142,7 +144,7 @@ hipError_t launch_validate_fsel(const avm_fsel_batch& b, int* first_bad, hipStre
 
 void launch_preint(const PreintArgs& a, hipStream_t stream);
 hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
-                       hipStream_t stream);
+                       bool persistent, hipStream_t stream);
 bool fsel_horizon_supported(int H);
 hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,
                                    double* cloud_xy, double* cloud_depth, hipStream_t stream);

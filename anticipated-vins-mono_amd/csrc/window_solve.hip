@@ -1637,7 +1637,8 @@ AVM_NOINL void chol_diag_block(int c0, int nb, int buf) {
   double* row = S + roff(c0 + rc) + c0;
   {
 #pragma unroll
-    for (int k = 0; k < NB; k++) a[k] = row[min(k, rc)];  // 16 reads in flight, always a valid address
+    for (int k = 0; k < NB; k++) a[k] = row[k];  // 16 reads in flight at immediate offsets; past the diagonal they run into the
+                                                 // next packed rows (still inside the factor's LDS region + slack): junk, never stored
 #pragma unroll
     for (int k = 0; k < NB; k++) a[k] = idl ? ((r & 15) == k ? 1.0 : 0.0) : a[k];  // lanes 16..31: the identity's rows
   }
