@@ -66,9 +66,7 @@ struct avm_ctx {
   bool packed_in = false;  // the last stage_window_batch took the packed path (states are contiguous on the device)
   hipEvent_t ev[8];
   std::map<std::string, float> last_ms;
-  // single-frame selects run all greedy rounds in one launch (csrc/fsel.hip, fsel_frame_kernel) until that kernel has
-  // once reported that its barrier did not complete on this device; AVM_FSEL_PERSISTENT=0 switches it off
-  bool fsel_persistent = true;
+  int fsel_frame_mode = 2;  // how a single-frame select runs (avm_fsel_select_batch); AVM_FSEL_FRAME=0/1/2 caps it
   ncclComm_t comm = nullptr;  // avm_comm_init
   int comm_ranks = 0, comm_rank = 0;
 };
@@ -952,27 +950,29 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   }
   FselBuffers w;
   if ((rc = fsel_buffers(c, &d, &w)) != AVM_OK) return rc;
-  bool persistent = P == 1 && d.max_cand <= 512 && c->fsel_persistent;  // (FS_FRAME_MAXC, csrc/fsel.hip)
-  if (const char* e = getenv("AVM_FSEL_PERSISTENT"))
-    if (e[0] == '0') persistent = false;
-  int32_t* hsync = persistent ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 32)) : nullptr;
-  if (persistent && !hsync) persistent = false;
+  // a single frame runs all its greedy rounds in one launch (csrc/fsel.hip, fsel_frame_kernel): 2 = on one XCD, 1 = on all XCDs,
+  // 0 = one launch per round.  A kernel that reports that its wait timed out is re-run one mode down, and the ctx stays there.
+  int mode = (P == 1 && d.max_cand <= 512) ? c->fsel_frame_mode : 0;  // (512: FS_FRAME_MAXC)
+  if (const char* e = getenv("AVM_FSEL_FRAME"))
+    if (e[0] >= '0' && e[0] <= '2') mode = std::min(mode, e[0] - '0');
+  int32_t* hsync = mode ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 32)) : nullptr;
+  if (mode && !hsync) mode = 0;
   for (;;) {
     HIPCHK(c, hipMemsetAsync(dout.n_selected, 0, sizeof(int32_t) * P, c->stream));
     HIPCHK(c, hipMemsetAsync(dout.selected_ids, 0xff, sizeof(int32_t) * P * mf, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, persistent, c->stream));
+    HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, mode, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    if (!persistent) break;
+    if (!mode) break;
     HIPCHK(c, hipMemcpyAsync(hsync, w.sync, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (getenv("AVM_FSEL_TRACE")) {
+    if (getenv("AVM_FSEL_TRACE")) {  // (cycle counters of a -DFS_TRACE_EVAL build of fsel.hip; zeros otherwise)
       const long long* q = reinterpret_cast<const long long*>(hsync + 4);
-      fprintf(stderr, "fsel frame kernel (cycles): wg0 pick %lld update %lld eval %lld arrive %lld wait %lld | last wg pick %lld update %lld eval %lld arrive %lld wait %lld\n", q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9]);
+      fprintf(stderr, "fsel frame kernel, mode %d (cycles): pick %lld update %lld eval %lld wait %lld | eval: loads %lld bound %lld elimination %lld logdet %lld\n",
+              mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8]);
     }
     if (hsync[2] == 0) break;
-    // the in-kernel barrier did not complete (see fsel_frame_kernel): run this and every later frame launch by launch
-    c->fsel_persistent = persistent = false;
+    c->fsel_frame_mode = --mode;
   }
   if (mem == AVM_MEM_HOST) {
     HIPCHK(c, hipMemcpyAsync(out->n_selected, dout.n_selected, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
@@ -1090,7 +1090,7 @@ int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, d
     if (!d_om) return fail(c, AVM_ERR_HIP, "hipMalloc failed (omega)");
   }
   avm_fsel_out none{nullptr, nullptr, nullptr};
-  HIPCHK(c, launch_fsel(d, w, none, d_om, false, false, c->stream));
+  HIPCHK(c, launch_fsel(d, w, none, d_om, false, 0, c->stream));
   const hipMemcpyKind kind = mem == AVM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (omega && mem == AVM_MEM_HOST) HIPCHK(c, hipMemcpyAsync(omega, d_om, sizeof(double) * P * N * N, kind, c->stream));
   if (delta_cand) HIPCHK(c, hipMemcpyAsync(delta_cand, w.delta, sizeof(double) * P * mc * T * T, kind, c->stream));

@@ -486,11 +486,7 @@ AVM_DEV FselPar fsel_par(const FselDev& A, int p, int k) {
 
 // ---- the round's winner (feature_selector.cpp:669-683), computed by every workgroup of the problem for itself ---------------
 // returns the winner's candidate index (-1: none) to all threads; *fwin its value
-// BYID (the single-frame kernel): there is no live list - slot s IS candidate s - and the caller hands in this thread's
-// candidates t + q FS_NT (q < 2; index -1 = not in the race) with their values, which it has read and validated itself.
-template <bool BYID = false>
-AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin, const int* rl = nullptr, const double* rf = nullptr,
-                            const double* ru = nullptr) {
+AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
   __shared__ double s_f[FS_NT / 64], s_u[FS_NT / 64];
   __shared__ int s_i[FS_NT / 64];
   __shared__ int s_win;
@@ -520,13 +516,9 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin, co
   //  independent: one trip to memory)
 #pragma unroll
   for (int q = 0; q < FS_PC; q++) {
-    if (BYID) {
-      cl[q] = q < 2 ? rl[q] : -1, cf[q] = q < 2 ? rf[q] : 0.0, cu[q] = q < 2 ? ru[q] : 0.0;
-    } else {
-      const int sq = min(t + q * FS_NT, max(nl - 1, 0));
-      cl[q] = live[sq], cf[q] = S.fval[sq], cu[q] = S.ub[sq];
-      if (t + q * FS_NT >= nl) cl[q] = -1;
-    }
+    const int sq = min(t + q * FS_NT, max(nl - 1, 0));
+    cl[q] = live[sq], cf[q] = S.fval[sq], cu[q] = S.ub[sq];
+    if (t + q * FS_NT >= nl) cl[q] = -1;
   }
   double bf;
   int bi;
@@ -545,7 +537,7 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin, co
       if (sh || !(f > -1.0)) continue;
       if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
     }
-    for (int s = t + FS_PC * FS_NT; !BYID && s < nl; s += FS_NT) {
+    for (int s = t + FS_PC * FS_NT; s < nl; s += FS_NT) {
       const int l = live[s];
       bool sh = false;
       for (int qq = 0; qq < nsh; qq++) sh |= s_shadow[qq] == l;
@@ -573,7 +565,7 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin, co
 #pragma unroll
     for (int q = 0; q < FS_PC; q++)  // a live candidate with a higher id and the same key?
       if (cl[q] > cand && cu[q] == cuw) hit = 1;
-    for (int s = t + FS_PC * FS_NT; !BYID && s < nl; s += FS_NT)
+    for (int s = t + FS_PC * FS_NT; s < nl; s += FS_NT)
       if (live[s] > cand && S.ub[s] == cuw) hit = 1;
     if (hit) s_hit = 1;
     __syncthreads();
@@ -586,11 +578,109 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin, co
   return s_win;
 }
 
+// Maximum over the wavefront, in every lane: four DPP exchange steps inside the 16-lane rows (lane ^ 1, lane ^ 2, mirror of 8,
+// mirror of 16 - any pairing of already-reduced groups will do for a maximum), then the four row results through SGPRs.
+// (__shfl_xor is a ds_bpermute per 32 bits and step: the lexicographic argmax below took 30 of them, 2 K cycles.)
+template <int CTRL>
+AVM_DEV double fs_dpp_d(double v) {
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+AVM_DEV double fs_wave_max(double v) {
+  v = fmax(v, fs_dpp_d<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = fmax(v, fs_dpp_d<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = fmax(v, fs_dpp_d<0x141>(v));  // row_half_mirror
+  v = fmax(v, fs_dpp_d<0x140>(v));  // row_mirror
+  const double r0 = fs_readlane_d(v, 0), r1 = fs_readlane_d(v, 16), r2 = fs_readlane_d(v, 32), r3 = fs_readlane_d(v, 48);
+  return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+AVM_DEV int fs_wave_max(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// The same pick for the single-frame kernel (slot s IS candidate s; the caller hands in this thread's two candidates - index -1 =
+// not in the race - with the values it has read): two workgroup barriers per pass, the shadow list in registers, and the
+// lexicographic maximum of (fValue, ub, id) as three maxima in a row, each over the lanes that tie in the previous ones.
+AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, const double* cu, double* fwin) {
+  __shared__ double s_f[2][FS_NT / 64], s_u[2][FS_NT / 64];
+  __shared__ int s_i[2][FS_NT / 64], s_h[2][FS_NT / 64];
+  const int t = threadIdx.x, wv = t >> 6;
+  constexpr int MAXSH = 8;
+  int sh[MAXSH], nsh = 0;
+#pragma unroll
+  for (int qq = 0; qq < MAXSH; qq++) sh[qq] = -1;
+  for (int pass = 0;; pass++) {
+    const int sl = pass & 1;
+    double bf = -1.0, bu = -DBL_MAX;
+    int bi = -1;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int l = cl[q];
+      bool out = l < 0;
+#pragma unroll
+      for (int qq = 0; qq < MAXSH; qq++) out |= sh[qq] == l;
+      const double f = cf[q], u = cu[q];
+      if (out || !(f > -1.0)) continue;
+      if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
+    }
+    {  // the wavefront's best (a lane without a candidate carries f = -1, which no candidate in the race has)
+      const double wf = fs_wave_max(bi >= 0 ? bf : -1.0);
+      const bool tf = bi >= 0 && bf == wf;
+      const double wu = fs_wave_max(tf ? bu : -DBL_MAX);
+      const bool tu = tf && bu == wu;
+      const int wi = fs_wave_max(tu ? bi : -1);
+      if ((t & 63) == 0) s_f[sl][wv] = wf, s_u[sl][wv] = wu, s_i[sl][wv] = wi;
+    }
+    __syncthreads();
+    bf = s_f[sl][0], bu = s_u[sl][0], bi = s_i[sl][0];
+#pragma unroll
+    for (int w = 1; w < FS_NT / 64; w++) {
+      const double f2 = s_f[sl][w], u2 = s_u[sl][w];
+      const int i2 = s_i[sl][w];
+      if (i2 >= 0 && (bi < 0 || f2 > bf || (f2 == bf && (u2 > bu || (u2 == bu && i2 > bi))))) bf = f2, bu = u2, bi = i2;
+    }
+    *fwin = bf;
+    if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;  // (more than MAXSH chained collisions in one round: keep the last winner)
+    // std::map rule (see fsel_pick_local): a live candidate with a higher id and the same key shadows the winner
+    const bool hit = (cl[0] > bi && cu[0] == bu) || (cl[1] > bi && cu[1] == bu);
+    const bool wh = __any(hit);
+    if ((t & 63) == 0) s_h[sl][wv] = wh ? 1 : 0;
+    __syncthreads();
+    int any = 0;
+#pragma unroll
+    for (int w = 0; w < FS_NT / 64; w++) any |= s_h[sl][w];
+    if (!any) return bi;
+#pragma unroll
+    for (int qq = 0; qq < MAXSH; qq++)
+      if (qq == nsh) sh[qq] = bi;
+    nsh++;
+  }
+}
+
 // logdet(C + pr D) and the Hadamard bound for the candidate of this lane's 16-lane row (see the comment above fs_rowbcast_k):
 // *ld_out = sum_j log(sqrt(d_j)) in pivot order, *ub_out = sum_i log((dpp + pr D)_ii); returns false on a non-positive pivot.
 // sC / sdpp: the frame's current reduced information and position diagonal (LDS), D: the candidate's Delta (global).
-template <int T, int BS, int NB>
-AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D, double pr, double* ld_out, double* ub_out) {
+// PHASED (the single-frame kernel, one wavefront per SIMD): the phases are kept apart in the schedule; the compiler's own
+// interleaving of the loads, the logarithms and the elimination was measured 10 % slower there - and 6 % faster on the batched
+// path, where a second wavefront fills the gaps.
+#ifdef FS_TRACE_EVAL
+#define FS_TK(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const long long n__ = clock64(); tk[i] += n__ - tkp; tkp = n__; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define FS_TK(i) if (PHASED) __builtin_amdgcn_sched_barrier(0);
+#endif
+// (Measured and dropped: the multipliers as LDS broadcasts - a column written once, one ds_read per gk instead of two DPP moves
+//  per pair, the round trip hidden by look-ahead - made the evaluation 10-17 % slower.)
+template <int T, int BS, int NB, bool PHASED = false>
+AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D, double pr, double* ld_out, double* ub_out, long long* tk = nullptr) {
+#ifdef FS_TRACE_EVAL
+  long long tkp = clock64();
+#endif
   const int lane = threadIdx.x & 63;
   const int r = min(lane & 15, BS - 1);  // this lane's row inside every block row
   // m[bi][c] = (C + p Delta)[bi BS + r][c], c < (bi + 1) BS.  Both matrices are symmetric, so the entry is fetched as
@@ -603,6 +693,7 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
       const int idx = c * T + bi * BS + r;
       m[bi][c] = sC[idx] + pr * D[idx];
     }
+  FS_TK(0)
   // Hadamard upper bound: sum over the rows, block row by block row, then across the 16 lanes in lane order
   double ubl = 0.0;
 #pragma unroll
@@ -613,6 +704,7 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
   double ubt = 0.0;
 #pragma unroll
   for (int k = 0; k < BS; k++) ubt += fs_rowbcast(ubl, k);
+  FS_TK(1)
   double dkeep[NB];  // lane j keeps the pivot of row bj BS + j
   bool bad = false;
 #pragma unroll
@@ -642,6 +734,7 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
         }
     }
   }
+  FS_TK(2)
   // log(sqrt(d)) per lane and block row, summed in pivot order
   double ld = 0;
 #pragma unroll
@@ -650,6 +743,7 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
 #pragma unroll
     for (int j = 0; j < BS; j++) ld += fs_rowbcast(mylog, j);
   }
+  FS_TK(3)
   *ld_out = ld, *ub_out = ubt;
   return !bad;
 }
@@ -782,7 +876,8 @@ AVM_DEV void fsel_rec_store(FselRec* p, double v, int tag) {
 }
 
 template <int T, int BS, int NB, bool ONEXCD>
-__global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots) {
+__global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots, int test_drop) {
+  constexpr bool DLDS = T <= 30;
   __shared__ int s_slot, s_fail;
   __shared__ double sC[T * T], sdpp[T];
   __shared__ int32_t s_alive[FS_FRAME_MAXC];
@@ -812,8 +907,26 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
   const int lc = min(l, mc - 1);
   const double pr = b.cand_prob[lc];
   const double* D = A.delta + (size_t)lc * T * T;
+  const double ld_nn = A.consts[0], ub_nn = A.consts[1];  // logdet of the hoisted pivots / their share of the Hadamard bound
+  if (DLDS) {  // the workgroup's 16 Delta matrices stay in LDS for the whole select (T <= 30: 16 x 7.2 KB)
+    extern __shared__ double s_delta[];
+    for (int q = 0; q < FS_CPWG; q++) {
+      const double* src = A.delta + (size_t)min(bx * FS_CPWG + q, mc - 1) * T * T;
+      for (int idx = t; idx < T * T; idx += FS_NT) s_delta[q * T * T + idx] = src[idx];
+    }
+    D = s_delta + (wv * 4 + g) * T * T;
+    __syncthreads();
+  }
   int nsel = 0;
+#ifdef FS_TRACE_EVAL
   long long tk_body = 0, tk_wait = 0, tk_pick = 0, tk_upd = 0, tk0 = clock64();
+#define FS_SEG(acc) { const long long n__ = clock64(); acc += n__ - tk0; tk0 = n__; }
+#else
+#define FS_SEG(acc)
+#endif
+#ifdef FS_TRACE_EVAL
+  long long tke[4] = {0, 0, 0, 0};
+#endif
   for (int k = 0; k <= kappa; k++) {
     // ---- 1. the previous round's winner (its values are in parity buffer (k - 1) & 1, tagged k)
     if (k >= 1) {
@@ -839,12 +952,10 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
         }
         cf[q] = rf.v, cu[q] = ru.v;
       }
-      { const long long n = clock64(); tk_wait += n - tk0; tk0 = n; }
-      FselPar S;
-      S.live = nullptr, S.nl = nc;
+      FS_SEG(tk_wait)
       double fwin;
-      const int win = fsel_pick_local<true>(A, S, &fwin, cl, cf, cu);  // (workgroup barriers inside: s_fail is settled after it)
-      { const long long n = clock64(); tk_pick += n - tk0; tk0 = n; }
+      const int win = fsel_pick_frame(A, cl, cf, cu, &fwin);  // (a workgroup barrier inside: s_fail is settled after it)
+      FS_SEG(tk_pick)
       if (s_fail) return;
       if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
       if (bx == 0 && t == 0) {  // this frame's recorder
@@ -863,27 +974,35 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
       }
       if (t == 0) s_alive[win] = 0;
       __syncthreads();
-      { const long long n = clock64(); tk_upd += n - tk0; tk0 = n; }
+      FS_SEG(tk_upd)
     }
     if (k >= kappa) break;
     // ---- 2. this round's values of this workgroup's candidates, published with tag k + 1
     const bool live = l < nc && s_alive[min(l, FS_FRAME_MAXC - 1)] != 0;
     if (__any(live)) {
       double ld, ubt;
-      const bool ok = fsel_logdet4<T, BS, NB>(sC, sdpp, D, pr, &ld, &ubt);
-      if (live && (lane & 15) == 0) {
-        fsel_rec_store<!ONEXCD>(recF + (k & 1) * FS_FRAME_MAXC + l, ok ? (A.consts[0] + 2.0 * ld) : __builtin_nan(""), k + 1);
-        fsel_rec_store<!ONEXCD>(recU + (k & 1) * FS_FRAME_MAXC + l, A.consts[1] + ubt, k + 1);
+#ifdef FS_TRACE_EVAL
+      const bool ok = fsel_logdet4<T, BS, NB, true>(sC, sdpp, D, pr, &ld, &ubt, tke);
+#else
+      const bool ok = fsel_logdet4<T, BS, NB, true>(sC, sdpp, D, pr, &ld, &ubt);
+#endif
+      if (live && (lane & 15) == 0 && l != test_drop) {  // (test_drop: a record that never arrives, tests only; -1 otherwise)
+        fsel_rec_store<!ONEXCD>(recF + (k & 1) * FS_FRAME_MAXC + l, ok ? (ld_nn + 2.0 * ld) : __builtin_nan(""), k + 1);
+        fsel_rec_store<!ONEXCD>(recU + (k & 1) * FS_FRAME_MAXC + l, ub_nn + ubt, k + 1);
       }
     }
     __syncthreads();  // (sC / s_alive are read by the evaluation above and written by the next round's update)
-    { const long long n = clock64(); tk_body += n - tk0; tk0 = n; }
+    FS_SEG(tk_body)
   }
   if (bx == 0 && t == 0) A.nsel[0] = nsel;
-  if (t == 0 && (bx == 0 || bx == nslots - 1)) {
-    long long* o = reinterpret_cast<long long*>(sync + 4) + (bx == 0 ? 0 : 5);
+#ifdef FS_TRACE_EVAL  // (development: cycles per phase of workgroup 0, printed by the host with AVM_FSEL_TRACE=1)
+  if (t == 0 && bx == 0) {
+    long long* o = reinterpret_cast<long long*>(sync + 4);
     o[0] = tk_pick, o[1] = tk_upd, o[2] = tk_body, o[3] = 0, o[4] = tk_wait;
+    o[5] = tke[0], o[6] = tke[1], o[7] = tke[2], o[8] = tke[3];
   }
+#endif
+#undef FS_SEG
 }
 
 // the compact list of the candidates that take part in the greedy rounds: the valid ones, in ascending index (= id) order
@@ -917,8 +1036,9 @@ size_t fsel_setup_lds_bytes(int H) {
 }
 
 // Launches setup (+ optional rounds).  All pointers in `d` are device pointers.
+// frame_mode (single frames only): 0 = one launch per greedy round, 1 = fsel_frame_kernel on all XCDs, 2 = on one XCD
 hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
-                       bool persistent, hipStream_t stream) {
+                       int frame_mode, hipStream_t stream) {
   FselDev d;
   d.b = b;
   {
@@ -936,16 +1056,24 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems, 1 + (b.max_cand + cand_per_wg - 1) / cand_per_wg), dim3(FS_NT), lds, stream, d);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (!run_rounds) return hipSuccess;
-  hipLaunchKernelGGL(fsel_live_init_kernel, dim3(b.n_problems), dim3(64), 0, stream, d);
   const int per_block = FS_CPWG;  // four candidates per wavefront
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
-  if (persistent) {  // (one frame: all rounds in one launch, see fsel_frame_kernel)
+  if (frame_mode != 0) {  // (one frame: all rounds in one launch, see fsel_frame_kernel)
+    if (b.n_problems != 1 || b.max_cand > FS_FRAME_MAXC) return hipErrorInvalidValue;
+    const bool all_xcds = frame_mode == 1;
+    const char* td = getenv("AVM_FSEL_TEST_DROP");  // (tests: the candidate whose values never arrive -> timeout -> fallback)
+    const int test_drop = td ? atoi(td) : -1;
     if ((e = hipMemsetAsync(w.sync, 0, sizeof(int32_t) * FS_SYNC_INTS, stream)) != hipSuccess) return e;
     const int ns = (int)grid.x;
-    static const bool all_xcds = [] { const char* e = getenv("AVM_FSEL_ALL_XCDS"); return e && e[0] == '1'; }();
 #define AVM_FRAME(T_, BS_, NB_)                                                                                              \
-  if (all_xcds) hipLaunchKernelGGL((fsel_frame_kernel<T_, BS_, NB_, false>), dim3(ns), dim3(FS_NT), 0, stream, d, w.sync, ns); \
-  else hipLaunchKernelGGL((fsel_frame_kernel<T_, BS_, NB_, true>), dim3(ns * 8), dim3(FS_NT), 0, stream, d, w.sync, ns);
+  {                                                                                                                          \
+    const size_t dl = T_ <= 30 ? sizeof(double) * FS_CPWG * T_ * T_ : 0;                                                     \
+    auto kf = all_xcds ? fsel_frame_kernel<T_, BS_, NB_, false> : fsel_frame_kernel<T_, BS_, NB_, true>;                     \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl)) != \
+        hipSuccess)                                                                                                          \
+      return e;                                                                                                              \
+    hipLaunchKernelGGL(kf, dim3(all_xcds ? ns : ns * 8), dim3(FS_NT), dl, stream, d, w.sync, ns, test_drop);                            \
+  }
     switch (T) {
       case 6: AVM_FRAME(6, 6, 1) break;
       case 9: AVM_FRAME(9, 9, 1) break;
@@ -957,6 +1085,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
 #undef AVM_FRAME
     return hipGetLastError();
   }
+  hipLaunchKernelGGL(fsel_live_init_kernel, dim3(b.n_problems), dim3(64), 0, stream, d);
   for (int r = 0; r <= b.max_features; r++) {  // launch r: the winner of round r - 1, then the values of round r
     switch (T) {
       case 6: hipLaunchKernelGGL((fsel_round_kernel<6, 6, 1>), grid, dim3(FS_NT), 0, stream, d, r); break;

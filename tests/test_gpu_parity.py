@@ -948,6 +948,51 @@ def test_selector_equal_upper_bounds_follow_the_std_map_rule(selector, oracle, m
     assert differs >= 1
 
 
+def test_selector_single_frame_kernel_equals_the_launch_per_round_path(selector, oracle, monkeypatch):
+    """A single frame runs all greedy rounds in one launch (csrc/fsel.hip, fsel_frame_kernel: on one XCD by default, on all
+    XCDs as the first fallback); AVM_FSEL_FRAME=0 forces one launch per round, the path a batch takes.  The three must agree
+    to the bit - ids in selection order AND the fValues - and with the oracle's ids: the usual frames, the reference's
+    HORIZON 13 (Delta not kept in LDS), the mirror-pair frames of the std::map rule, tiny / exhausted candidate sets."""
+    frames = [synth.make_fsel(1, horizon=10, n_cand=500, n_used=0, max_features=150),
+              synth.make_fsel(1, horizon=13, n_cand=300, n_used=5, max_features=60, first_id=3),
+              synth.make_fsel(1, horizon=3, n_cand=10, n_used=4, max_features=4, n_cloud=0),
+              synth.make_fsel(1, horizon=5, n_cand=12, n_used=0, max_features=20, n_cloud=5),
+              _mirror_frame(seed=0), _mirror_frame(seed=1)]
+    for pr in frames:
+        oo = buffers.FselOutArrays.alloc(1, pr.dims["max_features"])
+        oracle.fsel_select(pr, oo)
+        outs = []
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("AVM_FSEL_FRAME", mode)
+            outs.append(selector.select_batch(pr))
+        for o in outs:
+            assert np.array_equal(o.a["n_selected"], oo.a["n_selected"]) and np.array_equal(o.a["selected_ids"], oo.a["selected_ids"])
+            n = int(o.a["n_selected"][0])
+            assert np.array_equal(o.a["fvalues"][0, :n], outs[0].a["fvalues"][0, :n])
+    # a value that never arrives: the kernel's wait times out (20 ms), the select is re-run one mode down - twice - and the
+    # context stays on the launch-per-round path
+    monkeypatch.delenv("AVM_FSEL_FRAME")
+    lib_m = __import__("importlib").import_module("anticipated-vins-mono_amd.lib")
+    fs_m = __import__("importlib").import_module("anticipated-vins-mono_amd.feature_selector")
+    FS2 = fs_m.FeatureSelector(ctx=lib_m.Context(0))
+    pr = frames[1]
+    oo = buffers.FselOutArrays.alloc(1, pr.dims["max_features"])
+    oracle.fsel_select(pr, oo)
+    monkeypatch.setenv("AVM_FSEL_TEST_DROP", "7")
+    assert np.array_equal(FS2.select_batch(pr).a["selected_ids"], oo.a["selected_ids"])
+    monkeypatch.delenv("AVM_FSEL_TEST_DROP")
+    import time
+    t0 = time.perf_counter()
+    assert np.array_equal(FS2.select_batch(pr).a["selected_ids"], oo.a["selected_ids"])
+    assert time.perf_counter() - t0 < 0.02   # (no 20 ms timeout any more: the context does not try the frame kernel again)
+    # a device-resident frame takes the same path
+    pr = frames[0]
+    od = selector.select_batch(pr.to_device("cuda:0")).to_host()
+    oo = buffers.FselOutArrays.alloc(1, pr.dims["max_features"])
+    oracle.fsel_select(pr, oo)
+    assert np.array_equal(od.a["selected_ids"], oo.a["selected_ids"])
+
+
 def test_selector_edge_cases(selector, oracle):
     for kw in (dict(n_cand=10, n_used=4, max_features=4, n_cloud=0), dict(n_cand=12, n_used=0, max_features=20, n_cloud=5)):
         pr = synth.make_fsel(1, horizon=3, **kw)
