@@ -963,23 +963,22 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, mode, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    if (mode) HIPCHK(c, hipMemcpyAsync(hsync, w.sync, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
+    if (mem == AVM_MEM_HOST) {
+      HIPCHK(c, hipMemcpyAsync(out->n_selected, dout.n_selected, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(out->selected_ids, dout.selected_ids, sizeof(int32_t) * P * mf, hipMemcpyDeviceToHost, c->stream));
+      if (out->fvalues) HIPCHK(c, hipMemcpyAsync(out->fvalues, dout.fvalues, sizeof(double) * P * mf, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the one synchronization of the call)
     if (!mode) break;
-    HIPCHK(c, hipMemcpyAsync(hsync, w.sync, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (getenv("AVM_FSEL_TRACE")) {  // (cycle counters of a -DFS_TRACE_EVAL build of fsel.hip; zeros otherwise)
       const long long* q = reinterpret_cast<const long long*>(hsync + 4);
-      fprintf(stderr, "fsel frame kernel, mode %d (cycles): pick %lld update %lld eval %lld wait %lld | eval: loads %lld bound %lld elimination %lld logdet %lld\n",
-              mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8]);
+      fprintf(stderr, "fsel frame kernel, mode %d (cycles): pick %lld update %lld eval %lld wait %lld | eval: loads %lld bound %lld elimination %lld logdet %lld | setup: before the elimination %lld, elimination %lld\n",
+              mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8], q[9], q[3]);
     }
     if (hsync[2] == 0) break;
-    c->fsel_frame_mode = --mode;
+    c->fsel_frame_mode = --mode;  // (the outputs of the failed attempt are overwritten by the next one)
   }
-  if (mem == AVM_MEM_HOST) {
-    HIPCHK(c, hipMemcpyAsync(out->n_selected, dout.n_selected, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out->selected_ids, dout.selected_ids, sizeof(int32_t) * P * mf, hipMemcpyDeviceToHost, c->stream));
-    if (out->fvalues) HIPCHK(c, hipMemcpyAsync(out->fvalues, dout.fvalues, sizeof(double) * P * mf, hipMemcpyDeviceToHost, c->stream));
-  }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->last_ms["fsel_select"] = ms;
   return AVM_OK;

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
   const avm_fsel_batch& b = A.b;
   const int p = blockIdx.x, t = threadIdx.x;
   const int slice = blockIdx.y;  // 0: Omega, its partial factorization, the used features; >= 1: candidates [256 (slice-1), 256 slice)
+#ifdef FS_TRACE_EVAL
+  const long long ts0 = clock64();
+#endif
   const int H = b.horizon, N = 9 * (H + 1), T = 3 * H;
   double* Om = lds;                 // N*N
   double* Wh = Om + N * N;          // [H+1][81] Omega_h (h>=1)
@@ -222,8 +225,22 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
   const quat qic{b.q_ic[3], b.q_ic[0], b.q_ic[1], b.q_ic[2]};
   for (int i = t; i < N * N; i += FS_NT) Om[i] = 0.0;
   for (int i = t; i < N; i += FS_NT) isp[i] = (i >= 9 && (i % 9) < 3) ? 1 : 0;
-  // per consecutive pair: createLinearImuMatrices
-  if (t >= 1 && t <= H) {
+  // per consecutive pair: createLinearImuMatrices (only slice 0 needs them).  The nr interpolated rotations of a pair are
+  // independent: one thread each first (parked in Omega's storage, re-zeroed below), then thread h sums them in the
+  // reference's order.  More rotations than fit there: thread h computes them in its loop as before.
+  const int nri = b.nr_imu[p];
+  const bool rpar = slice == 0 && nri > 0 && (long long)H * nri * 9 <= (long long)N * N;
+  if (rpar) {
+    __syncthreads();
+    for (int idx = t; idx < H * nri; idx += FS_NT) {
+      const int h = 1 + idx / nri, i = idx % nri;
+      const quat Qi{hq[(h - 1) * 4 + 3], hq[(h - 1) * 4], hq[(h - 1) * 4 + 1], hq[(h - 1) * 4 + 2]};
+      const quat Qj{hq[h * 4 + 3], hq[h * 4], hq[h * 4 + 1], hq[h * 4 + 2]};
+      q2R(slerp_eigen(Qi, i / (double)nri, Qj), Om + (size_t)idx * 9);
+    }
+    __syncthreads();
+  }
+  if (slice == 0 && t >= 1 && t <= H) {
     const int h = t;
     const quat Qi{hq[(h - 1) * 4 + 3], hq[(h - 1) * 4], hq[(h - 1) * 4 + 1], hq[(h - 1) * 4 + 2]};
     const quat Qj{hq[h * 4 + 3], hq[h * 4], hq[h * 4 + 1], hq[h * 4 + 2]};
@@ -232,9 +249,12 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
     for (int k = 0; k < 9; k++) Nij[k] = 0, Mij[k] = 0;
     double c11 = 0, c12 = 0;
     for (int i = 0; i < nr; ++i) {
-      const quat q = slerp_eigen(Qi, i / nr, Qj);
       double R[9];
-      q2R(q, R);
+      if (rpar) {
+        for (int k = 0; k < 9; k++) R[k] = Om[((size_t)(h - 1) * nri + i) * 9 + k];
+      } else {
+        q2R(slerp_eigen(Qi, i / nr, Qj), R);
+      }
       const double jkh = (nr - i - 0.5);
       for (int k = 0; k < 9; k++) Nij[k] += jkh * R[k], Mij[k] += R[k];
       c11 += jkh * jkh;
@@ -303,6 +323,8 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
     }
     return;
   }
+  if (rpar)
+    for (int idx = t; idx < H * nri * 9; idx += FS_NT) Om[idx] = 0.0;  // (the parked rotations)
   for (int idx = t; idx < H * 81; idx += FS_NT) {  // Th = A^T W
     const int h = 1 + idx / 81, i = (idx % 81) / 9, j = idx % 9;
     double s = 0;
@@ -339,39 +361,62 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
   kn = block_sum<FS_NT>(kn, red);
   if (t < T) A.dpp[(size_t)p * T + t] = Om[(9 * (1 + t / 3) + t % 3) * (N + 1)];
   __syncthreads();
-  // partial right-looking Cholesky over the non-position rows (ascending order)
-  double ld = 0;
-  for (int k = 0; k < N; k++) {
-    if (isp[k]) continue;
-    const double d = sqrt(Om[k * N + k]);
-    ld += log(d);
-    for (int i = t; i < N; i += FS_NT) col[i] = (i > k || isp[i]) && i != k ? Om[i * N + k] / d : 0.0;
-    __syncthreads();
-    {
-      // two threads per row (no integer division by the runtime N); rows whose multiplier is zero are skipped as a whole
-      const int i = t >> 1;
-      const double li = i < N ? col[i] : 0.0;
+  // Partial right-looking elimination of the non-position rows (ascending order), square-root free: row i loses
+  // (A_ik / d_k) A_kj.  Omega is block tridiagonal, so a pivot of state s only reaches the rows of states s and s + 1 and -
+  // through fill - the position rows of the states before s: at most 3 (s - 1) + 18 <= 54 rows, listed once per state.  Four
+  // threads per listed row, every fourth listed column each (<= 14): all loads of a pivot are in flight at once, one trip
+  // through LDS and ONE workgroup barrier per pivot - nobody writes row k while it is being read, and the multiplier is the
+  // row's own column-k entry.  Column k is zeroed as it is consumed, so eliminated columns need no mask later; the pivots
+  // are parked for the logarithms.  (The previous form - two threads per row over all columns, a column buffer and two
+  // barriers per pivot - took 150 us of a single frame's select.)
+  double* piv = col;  // (col[] has no other use any more)
+#ifdef FS_TRACE_EVAL
+  const long long ts1 = clock64();
+#endif
+  for (int st = 0; st <= H; st++) {
+    const int npre = st >= 1 ? 3 * (st - 1) : 0;
+    const int na = npre + 9 + (st < H ? 9 : 0);
+    auto rowof = [&](int a) { return a < npre ? 9 * (1 + a / 3) + a % 3 : 9 * st + (a - npre); };
+    const int a = t >> 2, q = t & 3;
+    const int i = rowof(min(a, na - 1));
+    const bool ipos = i >= 9 && (i % 9) < 3;
+    constexpr int MC = 14;  // ceil(54 / 4)
+    int cj[MC];
+#pragma unroll
+    for (int m = 0; m < MC; m++) cj[m] = q + 4 * m < na ? rowof(q + 4 * m) : -1;
+    double* row = Om + i * N;
+    for (int kk = st == 0 ? 0 : 3; kk < 9; kk++) {
+      const int k = 9 * st + kk;
+      const double dkk = Om[k * N + k];
+      double inv = __builtin_amdgcn_rcp(dkk), e = fma(-dkk, inv, 1.0);
+      inv = fma(inv, e, inv);
+      e = fma(-dkk, inv, 1.0);
+      inv = fma(inv, e, inv);
+      const bool act = a < na && i != k && (i > k || ipos);
+      // (every load of the pivot is requested before the first use: one trip through LDS)
+      const double* rk = Om + k * N;
+      const double xik = row[k];
+      double rv[MC], xk[MC];
+#pragma unroll
+      for (int m = 0; m < MC; m++) rv[m] = row[max(cj[m], 0)], xk[m] = rk[max(cj[m], 0)];
+      const double li = act ? xik * inv : 0.0;
       if (li != 0.0) {
-        // unconditional (a zero multiplier subtracts an exact zero), eight columns in flight: a predicated LDS
-        // read-modify-write is a branch with its own s_waitcnt
-        double* row = Om + i * N;
-        for (int j0 = t & 1; j0 < N; j0 += 16) {
-          double rv[8], lj[8];
 #pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int j = min(j0 + 2 * u, N - 1);
-            rv[u] = row[j], lj[u] = col[j];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int j = j0 + 2 * u;
-            *(j < N ? row + j : red + (t & 63)) = rv[u] - li * lj[u];  // the tail goes to a dump slot
-          }
-        }
+        for (int m = 0; m < MC; m++)  // (an unlisted slot goes to a dump slot: no predicated LDS store)
+          *(cj[m] >= 0 ? row + cj[m] : red + (t & 63)) = cj[m] == k ? 0.0 : rv[m] - li * xk[m];
       }
+      __syncthreads();
+      if (t == 0) piv[k] = dkk;
     }
-    __syncthreads();
   }
+  __syncthreads();
+  double ld = 0;
+  for (int i = t; i < N; i += FS_NT)
+    if (!isp[i]) ld += log(piv[i]);
+  ld = 0.5 * block_sum<FS_NT>(ld, red);
+#ifdef FS_TRACE_EVAL
+  if (t == 0) A.consts[(size_t)p * 4 + 2] = (double)(clock64() - ts1), A.consts[(size_t)p * 4 + 3] = (double)(ts1 - ts0);
+#endif
   double* C = A.C + (size_t)p * T * T;
   for (int idx = t; idx < T * T; idx += FS_NT) {
     const int i = idx / T, j = idx % T;
@@ -670,7 +715,7 @@ AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, c
 // interleaving of the loads, the logarithms and the elimination was measured 10 % slower there - and 6 % faster on the batched
 // path, where a second wavefront fills the gaps.
 #ifdef FS_TRACE_EVAL
-#define FS_TK(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const long long n__ = clock64(); tk[i] += n__ - tkp; tkp = n__; __builtin_amdgcn_sched_barrier(0); }
+#define FS_TK(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const long long n__ = clock64(); if (tk) tk[i] += n__ - tkp; tkp = n__; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define FS_TK(i) if (PHASED) __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -998,7 +1043,8 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
 #ifdef FS_TRACE_EVAL  // (development: cycles per phase of workgroup 0, printed by the host with AVM_FSEL_TRACE=1)
   if (t == 0 && bx == 0) {
     long long* o = reinterpret_cast<long long*>(sync + 4);
-    o[0] = tk_pick, o[1] = tk_upd, o[2] = tk_body, o[3] = 0, o[4] = tk_wait;
+    o[0] = tk_pick, o[1] = tk_upd, o[2] = tk_body, o[3] = (long long)A.consts[2], o[4] = tk_wait;
+    o[9] = (long long)A.consts[3];
     o[5] = tke[0], o[6] = tke[1], o[7] = tke[2], o[8] = tke[3];
   }
 #endif
