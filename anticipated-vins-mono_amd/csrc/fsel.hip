@@ -529,6 +529,32 @@ AVM_DEV FselPar fsel_par(const FselDev& A, int p, int k) {
   return r;
 }
 
+// Maximum over the wavefront, in every lane: four DPP exchange steps inside the 16-lane rows (lane ^ 1, lane ^ 2, mirror of 8,
+// mirror of 16 - any pairing of already-reduced groups will do for a maximum), then the four row results through SGPRs.
+// (__shfl_xor is a ds_bpermute per 32 bits and step: the lexicographic argmax below took 30 of them, 2 K cycles.)
+template <int CTRL>
+AVM_DEV double fs_dpp_d(double v) {
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+AVM_DEV double fs_wave_max(double v) {
+  v = fmax(v, fs_dpp_d<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = fmax(v, fs_dpp_d<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = fmax(v, fs_dpp_d<0x141>(v));  // row_half_mirror
+  v = fmax(v, fs_dpp_d<0x140>(v));  // row_mirror
+  const double r0 = fs_readlane_d(v, 0), r1 = fs_readlane_d(v, 16), r2 = fs_readlane_d(v, 32), r3 = fs_readlane_d(v, 48);
+  return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+AVM_DEV int fs_wave_max(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // ---- the round's winner (feature_selector.cpp:669-683), computed by every workgroup of the problem for itself ---------------
 // returns the winner's candidate index (-1: none) to all threads; *fwin its value
 AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
@@ -590,10 +616,12 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
       if (sh || !(f > -1.0)) continue;
       if (bi < 0 || f > bf || (f == bf && (u > bu || (u == bu && l > bi)))) bf = f, bu = u, bi = l;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double f2 = __shfl_xor(bf, o, 64), u2 = __shfl_xor(bu, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (better(bf, bu, bi, f2, u2, i2)) bf = f2, bu = u2, bi = i2;
+    {  // the wavefront's best: three maxima in a row, each over the lanes that tie in the previous ones
+      const double wf = fs_wave_max(bi >= 0 ? bf : -1.0);
+      const bool tf = bi >= 0 && bf == wf;
+      const double wu = fs_wave_max(tf ? bu : -DBL_MAX);
+      const bool tu = tf && bu == wu;
+      bi = fs_wave_max(tu ? bi : -1), bf = wf, bu = wu;
     }
     if ((t & 63) == 0) s_f[t >> 6] = bf, s_u[t >> 6] = bu, s_i[t >> 6] = bi;
     __syncthreads();
@@ -621,32 +649,6 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
   }
   *fwin = s_f[0];
   return s_win;
-}
-
-// Maximum over the wavefront, in every lane: four DPP exchange steps inside the 16-lane rows (lane ^ 1, lane ^ 2, mirror of 8,
-// mirror of 16 - any pairing of already-reduced groups will do for a maximum), then the four row results through SGPRs.
-// (__shfl_xor is a ds_bpermute per 32 bits and step: the lexicographic argmax below took 30 of them, 2 K cycles.)
-template <int CTRL>
-AVM_DEV double fs_dpp_d(double v) {
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-AVM_DEV double fs_wave_max(double v) {
-  v = fmax(v, fs_dpp_d<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = fmax(v, fs_dpp_d<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = fmax(v, fs_dpp_d<0x141>(v));  // row_half_mirror
-  v = fmax(v, fs_dpp_d<0x140>(v));  // row_mirror
-  const double r0 = fs_readlane_d(v, 0), r1 = fs_readlane_d(v, 16), r2 = fs_readlane_d(v, 32), r3 = fs_readlane_d(v, 48);
-  return fmax(fmax(r0, r1), fmax(r2, r3));
-}
-AVM_DEV int fs_wave_max(int v) {
-  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
-  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
-  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
-  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
-  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // The same pick for the single-frame kernel (slot s IS candidate s; the caller hands in this thread's two candidates - index -1 =
@@ -863,12 +865,13 @@ AVM_DEV bool fsel_round_body(const FselDev& A, int p, int k, int bx) {
   const int lc = l;  // a slot past the end factors the last live candidate's matrix again and throws the result away
   const double pr = b.cand_prob[(size_t)p * b.max_cand + lc];
   const double* D = A.delta + ((size_t)p * b.max_cand + lc) * T * T;
+  const double ld_nn = A.consts[(size_t)p * 4], ub_nn = A.consts[(size_t)p * 4 + 1];  // (requested before the evaluation, not after it)
   double ld, ubt;
   const bool bad = !fsel_logdet4<T, BS, NB>(sC, sdpp, D, pr, &ld, &ubt);
   if (live && (lane & 15) == 0) {
-    const double f = bad ? __builtin_nan("") : (A.consts[(size_t)p * 4] + 2.0 * ld);
+    const double f = bad ? __builtin_nan("") : (ld_nn + 2.0 * ld);
     S.fvaln[sc] = f;  // (by slot of the next live list: see fsel_pick_local)
-    S.ubn[sc] = A.consts[(size_t)p * 4 + 1] + ubt;
+    S.ubn[sc] = ub_nn + ubt;
   }
   return false;
 }
