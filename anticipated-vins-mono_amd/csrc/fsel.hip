@@ -723,7 +723,9 @@ AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, c
 #endif
 // (Measured and dropped: the multipliers as LDS broadcasts - a column written once, one ds_read per gk instead of two DPP moves
 //  per pair, the round trip hidden by look-ahead - made the evaluation 10-17 % slower.)
-template <int T, int BS, int NB, bool PHASED = false>
+// PACKED: D is the packed lower triangle (row R at R (R + 1) / 2, the single-frame kernel's LDS copy) instead of the full
+// T x T block; an entry past the diagonal of a diagonal block - never used, see above - then reads into the next row.
+template <int T, int BS, int NB, bool PHASED = false, bool PACKED = false>
 AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D, double pr, double* ld_out, double* ub_out, long long* tk = nullptr) {
 #ifdef FS_TRACE_EVAL
   long long tkp = clock64();
@@ -737,8 +739,8 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
   for (int bi = 0; bi < NB; bi++)
 #pragma unroll
     for (int c = 0; c < (bi + 1) * BS; c++) {
-      const int idx = c * T + bi * BS + r;
-      m[bi][c] = sC[idx] + pr * D[idx];
+      const int idx = c * T + bi * BS + r, R = bi * BS + r;
+      m[bi][c] = sC[idx] + pr * D[PACKED ? R * (R + 1) / 2 + c : idx];
     }
   FS_TK(0)
   // Hadamard upper bound: sum over the rows, block row by block row, then across the 16 lanes in lane order
@@ -746,7 +748,7 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
 #pragma unroll
   for (int bi = 0; bi < NB; bi++) {
     const int dgi = bi * BS + r, idx = dgi * T + dgi;
-    ubl += log(sdpp[dgi] + pr * D[idx]);
+    ubl += log(sdpp[dgi] + pr * D[PACKED ? dgi * (dgi + 1) / 2 + dgi : idx]);
   }
   double ubt = 0.0;
 #pragma unroll
@@ -925,7 +927,10 @@ AVM_DEV void fsel_rec_store(FselRec* p, double v, int tag) {
 
 template <int T, int BS, int NB, bool ONEXCD>
 __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots, int test_drop) {
-  constexpr bool DLDS = T <= 30;
+  // the workgroup's 16 Delta matrices stay in LDS for the whole select: full blocks while they fit (3H <= 30: 16 x 7.2 KB), packed
+  // lower triangles beyond (3H = 39: 16 x 6.2 KB; the packed indexing costs 3 % at 3H = 30)
+  constexpr bool PACKD = T > 30;
+  constexpr int PK = PACKD ? T * (T + 1) / 2 : T * T;
   __shared__ int s_slot, s_fail;
   __shared__ double sC[T * T], sdpp[T];
   __shared__ int32_t s_alive[FS_FRAME_MAXC];
@@ -956,13 +961,17 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
   const double pr = b.cand_prob[lc];
   const double* D = A.delta + (size_t)lc * T * T;
   const double ld_nn = A.consts[0], ub_nn = A.consts[1];  // logdet of the hoisted pivots / their share of the Hadamard bound
-  if (DLDS) {  // the workgroup's 16 Delta matrices stay in LDS for the whole select (T <= 30: 16 x 7.2 KB)
+  {
     extern __shared__ double s_delta[];
     for (int q = 0; q < FS_CPWG; q++) {
       const double* src = A.delta + (size_t)min(bx * FS_CPWG + q, mc - 1) * T * T;
-      for (int idx = t; idx < T * T; idx += FS_NT) s_delta[q * T * T + idx] = src[idx];
+      for (int idx = t; idx < T * T; idx += FS_NT) {
+        const int R = idx / T, c = idx % T;
+        if (!PACKD) s_delta[q * PK + idx] = src[idx];
+        else if (c >= R) s_delta[q * PK + c * (c + 1) / 2 + R] = src[idx];  // (slot (c, R) <- entry [R][c]: the entry the full form reads for it)
+      }
     }
-    D = s_delta + (wv * 4 + g) * T * T;
+    D = s_delta + (wv * 4 + g) * PK;
     __syncthreads();
   }
   int nsel = 0;
@@ -1030,9 +1039,9 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
     if (__any(live)) {
       double ld, ubt;
 #ifdef FS_TRACE_EVAL
-      const bool ok = fsel_logdet4<T, BS, NB, true>(sC, sdpp, D, pr, &ld, &ubt, tke);
+      const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt, tke);
 #else
-      const bool ok = fsel_logdet4<T, BS, NB, true>(sC, sdpp, D, pr, &ld, &ubt);
+      const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt);
 #endif
       if (live && (lane & 15) == 0 && l != test_drop) {  // (test_drop: a record that never arrives, tests only; -1 otherwise)
         fsel_rec_store<!ONEXCD>(recF + (k & 1) * FS_FRAME_MAXC + l, ok ? (ld_nn + 2.0 * ld) : __builtin_nan(""), k + 1);
@@ -1116,7 +1125,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
     const int ns = (int)grid.x;
 #define AVM_FRAME(T_, BS_, NB_)                                                                                              \
   {                                                                                                                          \
-    const size_t dl = T_ <= 30 ? sizeof(double) * FS_CPWG * T_ * T_ : 0;                                                     \
+    const size_t dl = sizeof(double) * FS_CPWG * (T_ > 30 ? T_ * (T_ + 1) / 2 : T_ * T_);                                                     \
     auto kf = all_xcds ? fsel_frame_kernel<T_, BS_, NB_, false> : fsel_frame_kernel<T_, BS_, NB_, true>;                     \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl)) != \
         hipSuccess)                                                                                                          \
