@@ -934,7 +934,21 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   if (rc != AVM_OK) return rc;
   if (!out || !out->n_selected || !out->selected_ids) return fail(c, AVM_ERR_INVALID, "null output");
   if (batch->n_problems == 0) return AVM_OK;
-  if ((rc = validate_fsel(c, mem, batch)) != AVM_OK) return rc;
+  // Host tables are checked on the host.  Device-resident ones by a kernel that runs AHEAD of the select on the same stream:
+  // every kernel of the select looks at its flag before it indexes with a table, and the host reads the flag with the results
+  // (no extra synchronization for the check).
+  int* vflag = nullptr;
+  int32_t* hflag = nullptr;
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = validate_fsel(c, mem, batch)) != AVM_OK) return rc;
+  } else {
+    if (!batch->n_cand || !batch->nr_imu) return fail(c, AVM_ERR_INVALID, "null n_cand / nr_imu");
+    vflag = static_cast<int*>(pool_get(c, "v_flag", sizeof(int)));
+    hflag = static_cast<int32_t*>(pinned_get(c, "v_flag_h", sizeof(int32_t)));
+    if (!vflag || !hflag) return fail(c, AVM_ERR_HIP, "allocation failed (validation flag)");
+    HIPCHK(c, hipMemsetAsync(vflag, 0x7f, sizeof(int), c->stream));
+    HIPCHK(c, launch_validate_fsel(*batch, vflag, c->stream));
+  }
   avm_fsel_batch d;
   avm_fsel_out dout;
   const size_t P = batch->n_problems, mf = batch->max_features;
@@ -961,7 +975,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     HIPCHK(c, hipMemsetAsync(dout.n_selected, 0, sizeof(int32_t) * P, c->stream));
     HIPCHK(c, hipMemsetAsync(dout.selected_ids, 0xff, sizeof(int32_t) * P * mf, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, mode, c->stream));
+    HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, mode, vflag, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     if (mode) HIPCHK(c, hipMemcpyAsync(hsync, w.sync, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
     if (mem == AVM_MEM_HOST) {
@@ -969,7 +983,9 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
       HIPCHK(c, hipMemcpyAsync(out->selected_ids, dout.selected_ids, sizeof(int32_t) * P * mf, hipMemcpyDeviceToHost, c->stream));
       if (out->fvalues) HIPCHK(c, hipMemcpyAsync(out->fvalues, dout.fvalues, sizeof(double) * P * mf, hipMemcpyDeviceToHost, c->stream));
     }
+    if (vflag) HIPCHK(c, hipMemcpyAsync(hflag, vflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (the one synchronization of the call)
+    if (vflag && *hflag != 0x7f7f7f7f) return report_bad(c, *hflag, "frame");  // (no kernel of the select has touched a table)
     if (!mode) break;
     if (getenv("AVM_FSEL_TRACE")) {  // (cycle counters of a -DFS_TRACE_EVAL build of fsel.hip; zeros otherwise)
       const long long* q = reinterpret_cast<const long long*>(hsync + 4);
@@ -1089,7 +1105,7 @@ int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, d
     if (!d_om) return fail(c, AVM_ERR_HIP, "hipMalloc failed (omega)");
   }
   avm_fsel_out none{nullptr, nullptr, nullptr};
-  HIPCHK(c, launch_fsel(d, w, none, d_om, false, 0, c->stream));
+  HIPCHK(c, launch_fsel(d, w, none, d_om, false, 0, nullptr, c->stream));
   const hipMemcpyKind kind = mem == AVM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (omega && mem == AVM_MEM_HOST) HIPCHK(c, hipMemcpyAsync(omega, d_om, sizeof(double) * P * N * N, kind, c->stream));
   if (delta_cand) HIPCHK(c, hipMemcpyAsync(delta_cand, w.delta, sizeof(double) * P * mc * T * T, kind, c->stream));

@@ -27,10 +27,14 @@ namespace {
 
 constexpr int FS_NT = 256;
 constexpr int FS_CPW = 4;  // candidates per wavefront in the Delta slices of the setup kernel
+constexpr int FS_TABLES_OK = 0x7f7f7f7f;  // (what launch_validate_fsel leaves in the flag when every frame passes)
+#define FS_TABLES_GUARD(A) if ((A).vflag && *(A).vflag != FS_TABLES_OK) return
 
 struct FselDev {
   avm_fsel_batch b;  // device pointers
   int no_key_rule;   // test switch (AVM_FSEL_NO_KEY_RULE=1): skip the std::map equal-key rule of sortedlogDetUB
+  const int* vflag;  // result of the table validation that runs ahead on the same stream (null: already checked by the host): any
+                     // value but FS_TABLES_OK means a malformed table - no kernel of the select may index with the tables then
   // work buffers
   double* C;        // [P][T*T] current reduced position information (C0 + used + OmegaS)
   double* dpp;      // [P][T]   un-reduced diagonal of the position rows (for the Hadamard bound)
@@ -203,6 +207,7 @@ AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, do
 
 // ---- setup: Omega, partial Cholesky of the non-position rows, Delta of every feature ------
 __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
+  FS_TABLES_GUARD(A);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* lds = reinterpret_cast<double*>(smem_raw);
   const avm_fsel_batch& b = A.b;
@@ -880,6 +885,7 @@ AVM_DEV bool fsel_round_body(const FselDev& A, int p, int k, int bx) {
 
 template <int T, int BS, int NB>
 __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
+  FS_TABLES_GUARD(A);
   (void)fsel_round_body<T, BS, NB>(A, blockIdx.y, k, blockIdx.x);
 }
 
@@ -891,7 +897,8 @@ __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
 // only thing exchanged per round is (fValue, ub) of each workgroup's 16 candidates - a fixed assignment by candidate index, no
 // live list.
 // There is no barrier and no fence.  A value travels as a 16-byte record {value, round tag} written with ONE store and read with
-// ONE device-scope load (a single request each, never served by the vector L1; two parity buffers): a reader spins until the
+// ONE device-scope load (a single request each, never served by the vector L1; two parity buffers; a check word guards against a
+// half-written record): a reader spins until the
 // records of all candidates still in the race carry the round's tag, and then it has the values - one trip after the last
 // writer, nothing to order, no cache maintenance.  Everything else the kernel reads from global memory was written before the
 // launch.
@@ -902,10 +909,14 @@ __global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
 // stays on it).
 constexpr long long FS_SPIN_TICKS = 20 * 100000;  // 20 ms
 constexpr int FS_FRAME_MAXC = 512;                // candidates of a frame on the single-launch path (32 slots of 16)
+// {value, round tag, check}: `check` = the value's two halves xor-ed with the tag.  The 16 bytes travel as one request, but
+// nothing in the ISA promises that a concurrent reader cannot see them half-written: a record counts as arrived only when its
+// tag is the round's AND its check matches its value.
 struct alignas(16) FselRec {
   double v;
-  int32_t tag, pad;
+  int32_t tag, chk;
 };
+AVM_DEV int fsel_rec_check(int lo, int hi, int tag) { return lo ^ hi ^ (tag * 0x9E3779B1); }
 template <bool SC1>
 AVM_DEV void fsel_rec_load2(const FselRec* pa, const FselRec* pb, FselRec* a, FselRec* b) {  // device-scope loads
   typedef int v4i __attribute__((ext_vector_type(4)));
@@ -914,19 +925,20 @@ AVM_DEV void fsel_rec_load2(const FselRec* pa, const FselRec* pb, FselRec* a, Fs
                : "=&v"(va), "=&v"(vb)
                : "v"(pa), "v"(pb)
                : "memory");
-  a->v = __hiloint2double(va[1], va[0]), a->tag = va[2];
-  b->v = __hiloint2double(vb[1], vb[0]), b->tag = vb[2];
+  a->v = __hiloint2double(va[1], va[0]), a->tag = va[3] == fsel_rec_check(va[0], va[1], va[2]) ? va[2] : -1;
+  b->v = __hiloint2double(vb[1], vb[0]), b->tag = vb[3] == fsel_rec_check(vb[0], vb[1], vb[2]) ? vb[2] : -1;
 }
 template <bool SC1>
 AVM_DEV void fsel_rec_store(FselRec* p, double v, int tag) {
   typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i x = {__double2loint(v), __double2hiint(v), tag, 0};
+  const v4i x = {__double2loint(v), __double2hiint(v), tag, fsel_rec_check(__double2loint(v), __double2hiint(v), tag)};
   if (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(x) : "memory");
 }
 
 template <int T, int BS, int NB, bool ONEXCD>
 __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots, int test_drop) {
+  FS_TABLES_GUARD(A);
   // the workgroup's 16 Delta matrices stay in LDS for the whole select: full blocks while they fit (3H <= 30: 16 x 7.2 KB), packed
   // lower triangles beyond (3H = 39: 16 x 6.2 KB; the packed indexing costs 3 % at 3H = 30)
   constexpr bool PACKD = T > 30;
@@ -1065,6 +1077,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
 
 // the compact list of the candidates that take part in the greedy rounds: the valid ones, in ascending index (= id) order
 __global__ __launch_bounds__(64) void fsel_live_init_kernel(FselDev A) {
+  FS_TABLES_GUARD(A);
   const avm_fsel_batch& b = A.b;
   const int p = blockIdx.x, lane = threadIdx.x;
   const int nc = b.n_cand[p];
@@ -1096,9 +1109,10 @@ size_t fsel_setup_lds_bytes(int H) {
 // Launches setup (+ optional rounds).  All pointers in `d` are device pointers.
 // frame_mode (single frames only): 0 = one launch per greedy round, 1 = fsel_frame_kernel on all XCDs, 2 = on one XCD
 hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
-                       int frame_mode, hipStream_t stream) {
+                       int frame_mode, const int* vflag, hipStream_t stream) {
   FselDev d;
   d.b = b;
+  d.vflag = vflag;
   {
     const char* nk = getenv("AVM_FSEL_NO_KEY_RULE");
     d.no_key_rule = (nk && nk[0] == '1') ? 1 : 0;

@@ -144,7 +144,7 @@ hipError_t launch_validate_fsel(const avm_fsel_batch& b, int* first_bad, hipStre
 
 void launch_preint(const PreintArgs& a, hipStream_t stream);
 hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_fsel_out& out, double* omega_out, bool run_rounds,
-                       int frame_mode, hipStream_t stream);
+                       int frame_mode, const int* vflag, hipStream_t stream);
 bool fsel_horizon_supported(int H);
 hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,
                                    double* cloud_xy, double* cloud_depth, hipStream_t stream);

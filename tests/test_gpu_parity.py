@@ -524,6 +524,14 @@ def test_malformed_tables_are_rejected_before_any_kernel_indexes_with_them(ctx, 
     x = pr.to_device("cuda:0") if where == "device" else pr
     with pytest.raises(lib_m.AvmError, match="frame 1: n_cand"):
         selector.select_batch(x)
+    # a single frame (all greedy rounds in one launch; the check of a device-resident frame runs ahead on the stream)
+    pr1 = synth.make_fsel(1, horizon=5, n_cand=20, n_used=2, n_cloud=10, max_features=8)
+    good1 = pr1.to_device("cuda:0") if where == "device" else pr1.copy()
+    pr1.a["n_cand"][0] = 21
+    x = pr1.to_device("cuda:0") if where == "device" else pr1
+    with pytest.raises(lib_m.AvmError, match="frame 0: n_cand"):
+        selector.select_batch(x)
+    assert int(selector.select_batch(good1).to_host().a["n_selected"][0]) == 6
     # and a well-formed batch still runs afterwards on the same ctx
     ok = good.to_device("cuda:0") if where == "device" else good.copy()
     E.optimization(ok)
