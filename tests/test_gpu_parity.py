@@ -1001,6 +1001,36 @@ def test_selector_single_frame_kernel_equals_the_launch_per_round_path(selector,
     assert np.array_equal(od.a["selected_ids"], oo.a["selected_ids"])
 
 
+def test_selector_single_frames_from_two_host_threads_at_once(oracle):
+    """One avm_ctx per host thread is the documented model.  Two threads that select a single frame at the same moment compete
+    for the compute units the frame kernel's workgroups must hold together; whatever happens (both fit, or a wait times out and
+    the call repeats itself one mode down) every call returns the oracle's ids."""
+    import threading
+    lib_m = __import__("importlib").import_module("anticipated-vins-mono_amd.lib")
+    fs_m = __import__("importlib").import_module("anticipated-vins-mono_amd.feature_selector")
+    frames = [synth.make_fsel(1, horizon=10, n_cand=300, n_used=0, max_features=60, first_id=k) for k in range(2)]
+    want = []
+    for pr in frames:
+        oo = buffers.FselOutArrays.alloc(1, 60)
+        oracle.fsel_select(pr, oo)
+        want.append(oo.a["selected_ids"].copy())
+    sels = [fs_m.FeatureSelector(ctx=lib_m.Context(0)) for _ in range(2)]
+    bad = []
+
+    def work(k):
+        for _ in range(12):
+            got = sels[k].select_batch(frames[k]).a["selected_ids"]
+            if not np.array_equal(got, want[k]):
+                bad.append(k)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    assert not any(x.is_alive() for x in th) and not bad
+
+
 def test_selector_edge_cases(selector, oracle):
     for kw in (dict(n_cand=10, n_used=4, max_features=4, n_cloud=0), dict(n_cand=12, n_used=0, max_features=20, n_cloud=5)):
         pr = synth.make_fsel(1, horizon=3, **kw)
