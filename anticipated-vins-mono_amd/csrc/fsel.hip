@@ -471,7 +471,7 @@ AVM_DEV double fs_readlane_d(double v, int srclane) {  // srclane must be wave-u
 // LDL^T as before (column j divided by its pivot with v_rcp_f64 + two Newton steps; junk above the diagonal of the diagonal
 // blocks is computed and never read), only the lanes are used four times as densely and there are no SGPR round trips:
 // 2 DPP moves + 1-3 FMAs per (pivot, column) pair for four candidates instead of 2 v_readlane + 1 FMA for one.
-// logdet = sum_j log(d_j) in pivot order; the Hadamard bound (sortedlogDetUB) is summed the same way for every candidate, so
+// logdet = sum_j log(d_j) and the Hadamard bound (sortedlogDetUB) are summed in one fixed association for every candidate, so
 // mirror-image candidates still get bit-identical bounds (the std::map rule of the pick depends on that).
 template <int K>
 AVM_DEV double fs_rowbcast_k(double v) {  // lane K of every 16-lane row -> the whole row (row_newbcast:K = dpp_ctrl 0x150 + K)
@@ -542,6 +542,15 @@ AVM_DEV double fs_dpp_d(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
+}
+// Sum over the 16 lanes of a DPP row, in every lane of the row: the same four exchange steps as fs_wave_max (a fixed
+// association, the same for every candidate - mirror-image candidates keep bit-identical Hadamard bounds).
+AVM_DEV double fs_row_sum(double v) {
+  v += fs_dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += fs_dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += fs_dpp_d<0x141>(v);  // row_half_mirror
+  v += fs_dpp_d<0x140>(v);  // row_mirror
+  return v;
 }
 AVM_DEV double fs_wave_max(double v) {
   v = fmax(v, fs_dpp_d<0xB1>(v));   // quad_perm [1,0,3,2]
@@ -715,6 +724,31 @@ AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, c
   }
 }
 
+// Natural logarithm of a positive, normal, finite double (every argument here is a pivot or a diagonal entry that has already
+// passed `> 0`; anything else gives finite junk or NaN, which the callers discard): the fdlibm reduction - x = 2^k (1 + f),
+// sqrt(1/2) <= 1 + f < sqrt(2), s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-14 minimax R - with
+// the quotient from v_rcp_f64 + two Newton steps + a residual correction.  < 1 ulp like the library's, in 45 instead of ~80
+// instructions: the evaluation takes five logarithms per candidate and round.
+AVM_DEV double fs_log(double x) {
+  int k = __builtin_amdgcn_frexp_exp(x);           // x = m 2^k, 1/2 <= m < 1
+  double m = __builtin_amdgcn_frexp_mant(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  k = lo ? k - 1 : k;
+  const double f = m - 1.0, d = 2.0 + f;
+  double r = __builtin_amdgcn_rcp(d), e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  double sq = f * r;
+  sq = fma(fma(-d, sq, f), r, sq);                  // s = f / (2 + f)
+  const double z = sq * sq, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
 // logdet(C + pr D) and the Hadamard bound for the candidate of this lane's 16-lane row (see the comment above fs_rowbcast_k):
 // *ld_out = sum_j log(sqrt(d_j)) in pivot order, *ub_out = sum_i log((dpp + pr D)_ii); returns false on a non-positive pivot.
 // sC / sdpp: the frame's current reduced information and position diagonal (LDS), D: the candidate's Delta (global).
@@ -753,11 +787,9 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
 #pragma unroll
   for (int bi = 0; bi < NB; bi++) {
     const int dgi = bi * BS + r, idx = dgi * T + dgi;
-    ubl += log(sdpp[dgi] + pr * D[PACKED ? dgi * (dgi + 1) / 2 + dgi : idx]);
+    ubl += fs_log(sdpp[dgi] + pr * D[PACKED ? dgi * (dgi + 1) / 2 + dgi : idx]);
   }
-  double ubt = 0.0;
-#pragma unroll
-  for (int k = 0; k < BS; k++) ubt += fs_rowbcast(ubl, k);
+  const double ubt = fs_row_sum((lane & 15) < BS ? ubl : 0.0);
   FS_TK(1)
   double dkeep[NB];  // lane j keeps the pivot of row bj BS + j
   bool bad = false;
@@ -789,14 +821,11 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
     }
   }
   FS_TK(2)
-  // log(sqrt(d)) per lane and block row, summed in pivot order
-  double ld = 0;
+  // log(sqrt(d)): per lane over its block rows, then across the candidate's lanes
+  double ldl = 0;
 #pragma unroll
-  for (int bj = 0; bj < NB; bj++) {
-    const double mylog = dkeep[bj] > 0.0 ? 0.5 * log(dkeep[bj]) : 0.0;
-#pragma unroll
-    for (int j = 0; j < BS; j++) ld += fs_rowbcast(mylog, j);
-  }
+  for (int bj = 0; bj < NB; bj++) ldl += dkeep[bj] > 0.0 ? 0.5 * fs_log(dkeep[bj]) : 0.0;
+  const double ld = fs_row_sum((lane & 15) < BS ? ldl : 0.0);
   FS_TK(3)
   *ld_out = ld, *ub_out = ubt;
   return !bad;
@@ -883,8 +912,10 @@ AVM_DEV bool fsel_round_body(const FselDev& A, int p, int k, int bx) {
   return false;
 }
 
+// (amdgpu_waves_per_eu(2, 2): a batch puts two of these wavefronts on a SIMD; left to itself the scheduler trades the
+//  evaluation's instruction-level parallelism for an occupancy the launch never reaches - measured 0.22 -> 0.30 ms per frame)
 template <int T, int BS, int NB>
-__global__ __launch_bounds__(FS_NT) void fsel_round_kernel(FselDev A, int k) {
+__global__ __launch_bounds__(FS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fsel_round_kernel(FselDev A, int k) {
   FS_TABLES_GUARD(A);
   (void)fsel_round_body<T, BS, NB>(A, blockIdx.y, k, blockIdx.x);
 }
