@@ -113,7 +113,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // `literal` != 0 forces the eigen-decomposition even where the Cholesky factor would do (AVM_PRIOR_LITERAL=1, for A/B tests)
-__global__ __launch_bounds__(NT) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof, int literal) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof, int literal) {
   extern __shared__ char pe_smem[];
   double* lds = reinterpret_cast<double*>(pe_smem);
   double* A = lds + P_A;
