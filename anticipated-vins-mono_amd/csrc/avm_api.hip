@@ -964,9 +964,11 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   }
   FselBuffers w;
   if ((rc = fsel_buffers(c, &d, &w)) != AVM_OK) return rc;
-  // a single frame runs all its greedy rounds in one launch (csrc/fsel.hip, fsel_frame_kernel): 2 = on one XCD, 1 = on all XCDs,
-  // 0 = one launch per round.  A kernel that reports that its wait timed out is re-run one mode down, and the ctx stays there.
-  int mode = (P == 1 && d.max_cand <= 512) ? c->fsel_frame_mode : 0;  // (512: FS_FRAME_MAXC)
+  // Every frame's greedy rounds in ONE launch (csrc/fsel.hip, fsel_frame_kernel): 2 = a team of workgroups per XCD, the teams
+  // take frames from a queue; 1 = one team over all XCDs (a single frame only); 0 = one launch per round.  A kernel that reports
+  // a timed-out wait, or that did not finish every frame, is re-run one mode down, and the ctx stays there.
+  int mode = (d.max_cand <= 512 && mf < 4096) ? c->fsel_frame_mode : 0;  // (512: FS_FRAME_MAXC)
+  if (mode == 1 && P != 1) mode = 0;  // (the one-team-over-all-XCDs form takes one frame)
   if (const char* e = getenv("AVM_FSEL_FRAME"))
     if (e[0] >= '0' && e[0] <= '2') mode = std::min(mode, e[0] - '0');
   int32_t* hsync = mode ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 32)) : nullptr;
@@ -988,12 +990,13 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     if (vflag && *hflag != 0x7f7f7f7f) return report_bad(c, *hflag, "frame");  // (no kernel of the select has touched a table)
     if (!mode) break;
     if (getenv("AVM_FSEL_TRACE")) {  // (cycle counters of a -DFS_TRACE_EVAL build of fsel.hip; zeros otherwise)
-      const long long* q = reinterpret_cast<const long long*>(hsync + 4);
+      const long long* q = reinterpret_cast<const long long*>(hsync + 6);
       fprintf(stderr, "fsel frame kernel, mode %d (cycles): pick %lld update %lld eval %lld wait %lld | eval: loads %lld bound %lld elimination %lld logdet %lld | setup: before the elimination %lld, elimination %lld\n",
               mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8], q[9], q[3]);
     }
-    if (hsync[2] == 0) break;
+    if (hsync[2] == 0 && hsync[4] == (int32_t)P) break;
     c->fsel_frame_mode = --mode;  // (the outputs of the failed attempt are overwritten by the next one)
+    if (mode == 1 && P != 1) c->fsel_frame_mode = mode = 0;
   }
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->last_ms["fsel_select"] = ms;

@@ -967,142 +967,204 @@ AVM_DEV void fsel_rec_store(FselRec* p, double v, int tag) {
   else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(x) : "memory");
 }
 
-template <int T, int BS, int NB, bool ONEXCD>
+// TEAMS: the workgroups of every XCD form a team of `nslots` (first come, first slot; the rest exit), and a team takes frames from
+// a queue until it is empty - a batch of P frames runs as up to eight independent selects side by side, each inside one L2.
+// A team's leader (slot 0) hands out the frame: it waits for the team to be complete (first frame) or for everybody's `done`
+// (later frames: nobody may still be reading the last frame's records), takes the next frame number and publishes it as a tagged
+// record; a team that does not fill up within FS_TEAM_TICKS (its XCD is busy with something else) dissolves and leaves the frames
+// to the others.  The host checks that every frame was finished (sync[4]) and runs the launch-per-round path otherwise.
+// !TEAMS: one team over the whole device (blockIdx.x = slot, records written through to memory), one frame: the first fallback.
+constexpr long long FS_TEAM_TICKS = 2 * 100000;  // 2 ms
+constexpr int FS_TEAM_HDR = 32;                   // ints per team header: [0] members [1] done [4..7] the frame assignment record
+template <int T, int BS, int NB, bool TEAMS>
 __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots, int test_drop) {
   FS_TABLES_GUARD(A);
   // the workgroup's 16 Delta matrices stay in LDS for the whole select: full blocks while they fit (3H <= 30: 16 x 7.2 KB), packed
   // lower triangles beyond (3H = 39: 16 x 6.2 KB; the packed indexing costs 3 % at 3H = 30)
   constexpr bool PACKD = T > 30;
   constexpr int PK = PACKD ? T * (T + 1) / 2 : T * T;
-  __shared__ int s_slot, s_fail;
+  __shared__ int s_slot, s_fail, s_frame;
   __shared__ double sC[T * T], sdpp[T];
   __shared__ int32_t s_alive[FS_FRAME_MAXC];
-  const int t = threadIdx.x;
-  int bx = blockIdx.x;
-  if (ONEXCD) {
+  extern __shared__ double s_delta[];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4;
+  int bx = blockIdx.x, team = 0;
+  if (TEAMS) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));  // HW_REG_XCC_ID[3:0]
-    if (xcc != 0) return;
-    if (t == 0) s_slot = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    team = xcc & 7;
+  }
+  int32_t* th = sync + 32 + team * FS_TEAM_HDR;
+  if (TEAMS) {
+    if (t == 0) s_slot = __hip_atomic_fetch_add(&th[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     bx = s_slot;
     if (bx >= nslots) return;
   }
   if (t == 0) s_fail = 0;
-  FselRec* recF = reinterpret_cast<FselRec*>(sync + 32);  // [2][FS_FRAME_MAXC] fValue records
-  FselRec* recU = recF + 2 * FS_FRAME_MAXC;               // [2][FS_FRAME_MAXC] upper bound records
+  FselRec* recF = reinterpret_cast<FselRec*>(sync + 32 + 8 * FS_TEAM_HDR) + (size_t)team * 4 * FS_FRAME_MAXC;  // [2][MAXC] fValues
+  FselRec* recU = recF + 2 * FS_FRAME_MAXC;                                                                      // [2][MAXC] bounds
+  FselRec* assign = reinterpret_cast<FselRec*>(th + 4);
   const avm_fsel_batch& b = A.b;
-  const int p = 0, mc = b.max_cand, nc = b.n_cand[p];
-  const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
-  for (int idx = t; idx < T * T; idx += FS_NT) sC[idx] = A.C[idx];
-  for (int idx = t; idx < T; idx += FS_NT) sdpp[idx] = A.dpp[idx];
-  for (int l = t; l < FS_FRAME_MAXC; l += FS_NT) s_alive[l] = (l < nc && A.valid[l] != 0) ? 1 : 0;
-  __syncthreads();
-  const int lane = t & 63, wv = t >> 6, g = lane >> 4;
-  const int l = (bx * (FS_NT / 64) + wv) * 4 + g;  // this 16-lane row's candidate, for the whole select
+  const int mc = b.max_cand, P = b.n_problems;
+  const int l = (bx * (FS_NT / 64) + wv) * 4 + g;  // this 16-lane row's candidate index, in every frame
   const int lc = min(l, mc - 1);
-  const double pr = b.cand_prob[lc];
-  const double* D = A.delta + (size_t)lc * T * T;
-  const double ld_nn = A.consts[0], ub_nn = A.consts[1];  // logdet of the hoisted pivots / their share of the Hadamard bound
-  {
-    extern __shared__ double s_delta[];
+  auto give_up = [&]() { __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+#ifdef FS_TRACE_EVAL
+  long long tk_body = 0, tk_wait = 0, tk_pick = 0, tk_upd = 0, tk0 = clock64();
+  long long tke[4] = {0, 0, 0, 0};
+#define FS_SEG(acc) { const long long n__ = clock64(); acc += n__ - tk0; tk0 = n__; }
+#else
+#define FS_SEG(acc)
+#endif
+  for (int seq = 1;; seq++) {
+    // ---- which frame
+    int p = 0;
+    if (TEAMS) {
+      __syncthreads();  // (s_frame / s_fail of the previous frame have been read)
+      if (t == 0) {
+        const long long t0 = wall_clock64();
+        if (bx == 0) {  // the leader
+          int f = -2;   // (-2: the team never filled up)
+          for (;;) {
+            const int have = seq == 1 ? __hip_atomic_load(&th[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : __hip_atomic_load(&th[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (seq - 1);
+            if (have >= nslots) {
+              f = __hip_atomic_fetch_add(&sync[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (f >= P) f = -1;
+              break;
+            }
+            if (wall_clock64() - t0 > (seq == 1 ? FS_TEAM_TICKS : FS_SPIN_TICKS)) {
+              if (seq > 1) give_up();  // (a member got lost in the middle of the batch)
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          fsel_rec_store<false>(assign, (double)f, seq);
+        }
+        FselRec ra, rb;
+        for (;;) {
+          fsel_rec_load2<true>(assign, assign, &ra, &rb);
+          if (ra.tag == seq) break;
+          if (__hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > 2 * FS_SPIN_TICKS) {
+            give_up();
+            ra.v = -3.0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        s_frame = (int)ra.v;
+      }
+      __syncthreads();
+      p = s_frame;
+      if (p < 0) return;
+    } else if (seq > 1) {
+      return;
+    }
+    // ---- the frame's state, this workgroup's copy
+    const int nc = b.n_cand[p];
+    const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
+    const size_t pc = (size_t)p * mc;
+    for (int idx = t; idx < T * T; idx += FS_NT) sC[idx] = A.C[(size_t)p * T * T + idx];
+    for (int idx = t; idx < T; idx += FS_NT) sdpp[idx] = A.dpp[(size_t)p * T + idx];
+    for (int c = t; c < FS_FRAME_MAXC; c += FS_NT) s_alive[c] = (c < nc && A.valid[pc + min(c, mc - 1)] != 0) ? 1 : 0;
     for (int q = 0; q < FS_CPWG; q++) {
-      const double* src = A.delta + (size_t)min(bx * FS_CPWG + q, mc - 1) * T * T;
+      const double* src = A.delta + (pc + min(bx * FS_CPWG + q, mc - 1)) * T * T;
       for (int idx = t; idx < T * T; idx += FS_NT) {
         const int R = idx / T, c = idx % T;
         if (!PACKD) s_delta[q * PK + idx] = src[idx];
         else if (c >= R) s_delta[q * PK + c * (c + 1) / 2 + R] = src[idx];  // (slot (c, R) <- entry [R][c]: the entry the full form reads for it)
       }
     }
-    D = s_delta + (wv * 4 + g) * PK;
+    const double pr = b.cand_prob[pc + lc];
+    const double* D = s_delta + (wv * 4 + g) * PK;
+    const double ld_nn = A.consts[(size_t)p * 4], ub_nn = A.consts[(size_t)p * 4 + 1];  // logdet of the hoisted pivots / their share of the bound
+    const int tag0 = seq << 12;  // (round tags of different frames never meet: max_features < 4096 on this path)
     __syncthreads();
-  }
-  int nsel = 0;
-#ifdef FS_TRACE_EVAL
-  long long tk_body = 0, tk_wait = 0, tk_pick = 0, tk_upd = 0, tk0 = clock64();
-#define FS_SEG(acc) { const long long n__ = clock64(); acc += n__ - tk0; tk0 = n__; }
-#else
-#define FS_SEG(acc)
-#endif
-#ifdef FS_TRACE_EVAL
-  long long tke[4] = {0, 0, 0, 0};
-#endif
-  for (int k = 0; k <= kappa; k++) {
-    // ---- 1. the previous round's winner (its values are in parity buffer (k - 1) & 1, tagged k)
-    if (k >= 1) {
-      const int par = (k - 1) & 1;
-      int cl[2];
-      double cf[2], cu[2];
+    int nsel = 0;
+    for (int k = 0; k <= kappa; k++) {
+      // ---- 1. the previous round's winner (its values are in parity buffer (k - 1) & 1, tagged k)
+      if (k >= 1) {
+        const int par = (k - 1) & 1;
+        int cl[2];
+        double cf[2], cu[2];
 #pragma unroll
-      for (int q = 0; q < 2; q++) {  // this thread's candidates: t and t + FS_NT
-        const int sq = t + q * FS_NT;
-        cl[q] = (sq < nc && s_alive[sq]) ? sq : -1;
-        const FselRec *pf = recF + par * FS_FRAME_MAXC + sq, *pu = recU + par * FS_FRAME_MAXC + sq;
-        FselRec rf, ru;
-        const long long t0 = wall_clock64();
-        for (;;) {
-          fsel_rec_load2<true>(pf, pu, &rf, &ru);
-          if (__all(cl[q] < 0 || (rf.tag == k && ru.tag == k))) break;
-          if (__hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > FS_SPIN_TICKS) {
-            __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_fail = 1;
-            break;
+        for (int q = 0; q < 2; q++) {  // this thread's candidates: t and t + FS_NT
+          const int sq = t + q * FS_NT;
+          cl[q] = (sq < nc && s_alive[sq]) ? sq : -1;
+          const FselRec *pf = recF + par * FS_FRAME_MAXC + sq, *pu = recU + par * FS_FRAME_MAXC + sq;
+          FselRec rf, ru;
+          const long long t0 = wall_clock64();
+          for (;;) {
+            fsel_rec_load2<true>(pf, pu, &rf, &ru);
+            if (__all(cl[q] < 0 || (rf.tag == tag0 + k && ru.tag == tag0 + k))) break;
+            if (__hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > FS_SPIN_TICKS) {
+              give_up();
+              s_fail = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
           }
-          __builtin_amdgcn_s_sleep(1);
+          cf[q] = rf.v, cu[q] = ru.v;
         }
-        cf[q] = rf.v, cu[q] = ru.v;
+        FS_SEG(tk_wait)
+        double fwin;
+        const int win = fsel_pick_frame(A, cl, cf, cu, &fwin);  // (a workgroup barrier inside: s_fail is settled after it)
+        FS_SEG(tk_pick)
+        if (s_fail) return;
+        if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
+        if (bx == 0 && t == 0) {  // this frame's recorder
+          A.out.selected_ids[(size_t)p * b.max_features + nsel] = b.cand_id[pc + win];
+          if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + nsel] = fwin;
+          A.out.n_selected[p] = nsel + 1;
+          A.black[pc + win] = 1;
+        }
+        nsel++;
+        const double prw = b.cand_prob[pc + win];
+        const double* Dw = A.delta + (pc + win) * T * T;
+        for (int idx = t; idx < T * T; idx += FS_NT) {
+          const double dw = Dw[idx];
+          sC[idx] = sC[idx] + prw * dw;
+          if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dw;
+        }
+        if (t == 0) s_alive[win] = 0;
+        __syncthreads();
+        FS_SEG(tk_upd)
       }
-      FS_SEG(tk_wait)
-      double fwin;
-      const int win = fsel_pick_frame(A, cl, cf, cu, &fwin);  // (a workgroup barrier inside: s_fail is settled after it)
-      FS_SEG(tk_pick)
-      if (s_fail) return;
-      if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
-      if (bx == 0 && t == 0) {  // this frame's recorder
-        A.out.selected_ids[nsel] = b.cand_id[win];
-        if (A.out.fvalues) A.out.fvalues[nsel] = fwin;
-        A.out.n_selected[0] = nsel + 1;
-        A.black[win] = 1;
-      }
-      nsel++;
-      const double prw = b.cand_prob[win];
-      const double* Dw = A.delta + (size_t)win * T * T;
-      for (int idx = t; idx < T * T; idx += FS_NT) {
-        const double dw = Dw[idx];
-        sC[idx] = sC[idx] + prw * dw;
-        if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dw;
-      }
-      if (t == 0) s_alive[win] = 0;
-      __syncthreads();
-      FS_SEG(tk_upd)
-    }
-    if (k >= kappa) break;
-    // ---- 2. this round's values of this workgroup's candidates, published with tag k + 1
-    const bool live = l < nc && s_alive[min(l, FS_FRAME_MAXC - 1)] != 0;
-    if (__any(live)) {
-      double ld, ubt;
+      if (k >= kappa) break;
+      // ---- 2. this round's values of this workgroup's candidates, published with tag k + 1
+      const bool live = l < nc && s_alive[min(l, FS_FRAME_MAXC - 1)] != 0;
+      if (__any(live)) {
+        double ld, ubt;
 #ifdef FS_TRACE_EVAL
-      const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt, tke);
+        const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt, tke);
 #else
-      const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt);
+        const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt);
 #endif
-      if (live && (lane & 15) == 0 && l != test_drop) {  // (test_drop: a record that never arrives, tests only; -1 otherwise)
-        fsel_rec_store<!ONEXCD>(recF + (k & 1) * FS_FRAME_MAXC + l, ok ? (ld_nn + 2.0 * ld) : __builtin_nan(""), k + 1);
-        fsel_rec_store<!ONEXCD>(recU + (k & 1) * FS_FRAME_MAXC + l, ub_nn + ubt, k + 1);
+        if (live && (lane & 15) == 0 && l != test_drop) {  // (test_drop: a record that never arrives, tests only; -1 otherwise)
+          fsel_rec_store<!TEAMS>(recF + (k & 1) * FS_FRAME_MAXC + l, ok ? (ld_nn + 2.0 * ld) : __builtin_nan(""), tag0 + k + 1);
+          fsel_rec_store<!TEAMS>(recU + (k & 1) * FS_FRAME_MAXC + l, ub_nn + ubt, tag0 + k + 1);
+        }
       }
+      __syncthreads();  // (sC / s_alive are read by the evaluation above and written by the next round's update)
+      FS_SEG(tk_body)
     }
-    __syncthreads();  // (sC / s_alive are read by the evaluation above and written by the next round's update)
-    FS_SEG(tk_body)
-  }
-  if (bx == 0 && t == 0) A.nsel[0] = nsel;
-#ifdef FS_TRACE_EVAL  // (development: cycles per phase of workgroup 0, printed by the host with AVM_FSEL_TRACE=1)
-  if (t == 0 && bx == 0) {
-    long long* o = reinterpret_cast<long long*>(sync + 4);
-    o[0] = tk_pick, o[1] = tk_upd, o[2] = tk_body, o[3] = (long long)A.consts[2], o[4] = tk_wait;
-    o[9] = (long long)A.consts[3];
-    o[5] = tke[0], o[6] = tke[1], o[7] = tke[2], o[8] = tke[3];
-  }
+#ifdef FS_TRACE_EVAL  // (development: cycles per phase of workgroup 0 of the team that took frame 0, printed with AVM_FSEL_TRACE=1)
+    if (t == 0 && bx == 0 && p == 0) {
+      long long* o = reinterpret_cast<long long*>(sync + 6);
+      o[0] = tk_pick, o[1] = tk_upd, o[2] = tk_body, o[3] = (long long)A.consts[2], o[4] = tk_wait;
+      o[9] = (long long)A.consts[3];
+      o[5] = tke[0], o[6] = tke[1], o[7] = tke[2], o[8] = tke[3];
+    }
 #endif
+    if (t == 0) {
+      if (bx == 0) {
+        A.nsel[p] = nsel;
+        __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // frames finished
+      }
+      if (TEAMS) __hip_atomic_fetch_add(&th[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // done with this frame's records
+    }
+  }
 #undef FS_SEG
 }
 
@@ -1161,21 +1223,21 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   if (!run_rounds) return hipSuccess;
   const int per_block = FS_CPWG;  // four candidates per wavefront
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
-  if (frame_mode != 0) {  // (one frame: all rounds in one launch, see fsel_frame_kernel)
-    if (b.n_problems != 1 || b.max_cand > FS_FRAME_MAXC) return hipErrorInvalidValue;
-    const bool all_xcds = frame_mode == 1;
+  if (frame_mode != 0) {  // (every frame's rounds in one launch, see fsel_frame_kernel)
+    if (b.max_cand > FS_FRAME_MAXC || b.max_features >= 4096 || (frame_mode == 1 && b.n_problems != 1)) return hipErrorInvalidValue;
+    const bool teams = frame_mode == 2;
     const char* td = getenv("AVM_FSEL_TEST_DROP");  // (tests: the candidate whose values never arrive -> timeout -> fallback)
     const int test_drop = td ? atoi(td) : -1;
     if ((e = hipMemsetAsync(w.sync, 0, sizeof(int32_t) * FS_SYNC_INTS, stream)) != hipSuccess) return e;
     const int ns = (int)grid.x;
 #define AVM_FRAME(T_, BS_, NB_)                                                                                              \
   {                                                                                                                          \
-    const size_t dl = sizeof(double) * FS_CPWG * (T_ > 30 ? T_ * (T_ + 1) / 2 : T_ * T_);                                                     \
-    auto kf = all_xcds ? fsel_frame_kernel<T_, BS_, NB_, false> : fsel_frame_kernel<T_, BS_, NB_, true>;                     \
+    const size_t dl = sizeof(double) * FS_CPWG * (T_ > 30 ? T_ * (T_ + 1) / 2 : T_ * T_);                                    \
+    auto kf = teams ? fsel_frame_kernel<T_, BS_, NB_, true> : fsel_frame_kernel<T_, BS_, NB_, false>;                        \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl)) != \
         hipSuccess)                                                                                                          \
       return e;                                                                                                              \
-    hipLaunchKernelGGL(kf, dim3(all_xcds ? ns : ns * 8), dim3(FS_NT), dl, stream, d, w.sync, ns, test_drop);                            \
+    hipLaunchKernelGGL(kf, dim3(teams ? ns * 8 : ns), dim3(FS_NT), dl, stream, d, w.sync, ns, test_drop);                    \
   }
     switch (T) {
       case 6: AVM_FRAME(6, 6, 1) break;

@@ -327,7 +327,7 @@ def main():
                 "ms_per_frame_single": tl * 1e3,
                 "roofline": {
                     "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "achieved": fl / (k_ms_f * 1e-3) / 1e12,
-                    "frac": fl / (k_ms_f * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "kernel": "fsel_setup + 151 x fsel_round (batched path), HIP events around the whole select",
+                    "frac": fl / (k_ms_f * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "kernel": "fsel_setup + fsel_frame_kernel (eight teams, one per XCD, take the frames from a queue), HIP events around the whole select",
                     "kernel_ms": k_ms_f, "flops_per_launch": fl, "candidate_evaluations": evals,
                     "reference_flops_unhoisted": evals * ((9.0 * (fsel_host.dims["horizon"] + 1)) ** 3 / 3.0),
                 },

@@ -957,8 +957,8 @@ def test_selector_equal_upper_bounds_follow_the_std_map_rule(selector, oracle, m
 
 
 def test_selector_single_frame_kernel_equals_the_launch_per_round_path(selector, oracle, monkeypatch):
-    """A single frame runs all greedy rounds in one launch (csrc/fsel.hip, fsel_frame_kernel: on one XCD by default, on all
-    XCDs as the first fallback); AVM_FSEL_FRAME=0 forces one launch per round, the path a batch takes.  The three must agree
+    """A frame runs all its greedy rounds in one launch (csrc/fsel.hip, fsel_frame_kernel: a team of workgroups on one XCD by
+    default, one team over all XCDs as the first fallback); AVM_FSEL_FRAME=0 forces one launch per round.  The three must agree
     to the bit - ids in selection order AND the fValues - and with the oracle's ids: the usual frames, the reference's
     HORIZON 13 (Delta not kept in LDS), the mirror-pair frames of the std::map rule, tiny / exhausted candidate sets."""
     frames = [synth.make_fsel(1, horizon=10, n_cand=500, n_used=0, max_features=150),
