@@ -971,7 +971,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   if (mode == 1 && P != 1) mode = 0;  // (the one-team-over-all-XCDs form takes one frame)
   if (const char* e = getenv("AVM_FSEL_FRAME"))
     if (e[0] >= '0' && e[0] <= '2') mode = std::min(mode, e[0] - '0');
-  int32_t* hsync = mode ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 32)) : nullptr;
+  int32_t* hsync = mode ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 64)) : nullptr;
   if (mode && !hsync) mode = 0;
   for (;;) {
     HIPCHK(c, hipMemsetAsync(dout.n_selected, 0, sizeof(int32_t) * P, c->stream));
@@ -979,7 +979,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, launch_fsel(d, w, dout, nullptr, true, mode, vflag, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    if (mode) HIPCHK(c, hipMemcpyAsync(hsync, w.sync, sizeof(int32_t) * 32, hipMemcpyDeviceToHost, c->stream));
+    if (mode) HIPCHK(c, hipMemcpyAsync(hsync, w.sync, sizeof(int32_t) * 64, hipMemcpyDeviceToHost, c->stream));
     if (mem == AVM_MEM_HOST) {
       HIPCHK(c, hipMemcpyAsync(out->n_selected, dout.n_selected, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync(out->selected_ids, dout.selected_ids, sizeof(int32_t) * P * mf, hipMemcpyDeviceToHost, c->stream));
@@ -990,7 +990,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     if (vflag && *hflag != 0x7f7f7f7f) return report_bad(c, *hflag, "frame");  // (no kernel of the select has touched a table)
     if (!mode) break;
     if (getenv("AVM_FSEL_TRACE")) {  // (cycle counters of a -DFS_TRACE_EVAL build of fsel.hip; zeros otherwise)
-      const long long* q = reinterpret_cast<const long long*>(hsync + 6);
+      const long long* q = reinterpret_cast<const long long*>(hsync + 32);
       fprintf(stderr, "fsel frame kernel, mode %d (cycles): pick %lld update %lld eval %lld wait %lld | eval: loads %lld bound %lld elimination %lld logdet %lld | setup: before the elimination %lld, elimination %lld\n",
               mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8], q[9], q[3]);
     }

@@ -976,12 +976,18 @@ AVM_DEV void fsel_rec_store(FselRec* p, double v, int tag) {
 // !TEAMS: one team over the whole device (blockIdx.x = slot, records written through to memory), one frame: the first fallback.
 constexpr long long FS_TEAM_TICKS = 2 * 100000;  // 2 ms
 constexpr int FS_TEAM_HDR = 32;                   // ints per team header: [0] members [1] done [4..7] the frame assignment record
-template <int T, int BS, int NB, bool TEAMS>
+constexpr int FS_SYNC_HDR = 64;                   // ints: [2] failure [3] frame queue [4] frames finished [8..15] arrivals per XCD [32..] trace
+constexpr int FS_MAX_TEAMS = 16;
+// TPX = 2 (batches of more than eight frames, 3H <= 30): TWO teams per XCD, i.e. two wavefronts per SIMD - the second one fills the
+// latency gaps of the first (a team alone is bound by dependent latencies, not by issue).  Two workgroups then share a compute
+// unit's LDS, so the Delta copies are packed lower triangles (16 x 3.7 KB).
+template <int T, int BS, int NB, int TPX>
 __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots, int test_drop) {
   FS_TABLES_GUARD(A);
+  constexpr bool TEAMS = TPX > 0;
   // the workgroup's 16 Delta matrices stay in LDS for the whole select: full blocks while they fit (3H <= 30: 16 x 7.2 KB), packed
-  // lower triangles beyond (3H = 39: 16 x 6.2 KB; the packed indexing costs 3 % at 3H = 30)
-  constexpr bool PACKD = T > 30;
+  // lower triangles beyond (3H = 39: 16 x 6.2 KB; the packed indexing costs 3 % at 3H = 30) or when two workgroups share the LDS
+  constexpr bool PACKD = T > 30 || TPX > 1;
   constexpr int PK = PACKD ? T * (T + 1) / 2 : T * T;
   __shared__ int s_slot, s_fail, s_frame;
   __shared__ double sC[T * T], sdpp[T];
@@ -992,17 +998,18 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
   if (TEAMS) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));  // HW_REG_XCC_ID[3:0]
-    team = xcc & 7;
-  }
-  int32_t* th = sync + 32 + team * FS_TEAM_HDR;
-  if (TEAMS) {
-    if (t == 0) s_slot = __hip_atomic_fetch_add(&th[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xcc &= 7;
+    if (t == 0) s_slot = __hip_atomic_fetch_add(&sync[8 + xcc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    bx = s_slot;
-    if (bx >= nslots) return;
+    const int arrival = s_slot;  // order of arrival on this XCD: the first nslots are its first team, ...
+    if (arrival >= TPX * nslots) return;
+    team = xcc * TPX + arrival / nslots, bx = arrival % nslots;
+    __syncthreads();
   }
+  int32_t* th = sync + FS_SYNC_HDR + team * FS_TEAM_HDR;
+  if (TEAMS && t == 0) __hip_atomic_fetch_add(&th[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (t == 0) s_fail = 0;
-  FselRec* recF = reinterpret_cast<FselRec*>(sync + 32 + 8 * FS_TEAM_HDR) + (size_t)team * 4 * FS_FRAME_MAXC;  // [2][MAXC] fValues
+  FselRec* recF = reinterpret_cast<FselRec*>(sync + FS_SYNC_HDR + FS_MAX_TEAMS * FS_TEAM_HDR) + (size_t)team * 4 * FS_FRAME_MAXC;  // [2][MAXC] fValues
   FselRec* recU = recF + 2 * FS_FRAME_MAXC;                                                                      // [2][MAXC] bounds
   FselRec* assign = reinterpret_cast<FselRec*>(th + 4);
   const avm_fsel_batch& b = A.b;
@@ -1151,7 +1158,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
     }
 #ifdef FS_TRACE_EVAL  // (development: cycles per phase of workgroup 0 of the team that took frame 0, printed with AVM_FSEL_TRACE=1)
     if (t == 0 && bx == 0 && p == 0) {
-      long long* o = reinterpret_cast<long long*>(sync + 6);
+      long long* o = reinterpret_cast<long long*>(sync + 32);
       o[0] = tk_pick, o[1] = tk_upd, o[2] = tk_body, o[3] = (long long)A.consts[2], o[4] = tk_wait;
       o[9] = (long long)A.consts[3];
       o[5] = tke[0], o[6] = tke[1], o[7] = tke[2], o[8] = tke[3];
@@ -1225,19 +1232,22 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
   if (frame_mode != 0) {  // (every frame's rounds in one launch, see fsel_frame_kernel)
     if (b.max_cand > FS_FRAME_MAXC || b.max_features >= 4096 || (frame_mode == 1 && b.n_problems != 1)) return hipErrorInvalidValue;
-    const bool teams = frame_mode == 2;
+    // teams per XCD: 0 = one team over the whole device (a single frame), 1, or 2 when there are frames for more than eight teams
+    // and two workgroups fit a compute unit's LDS (3H <= 30)
+    const int tpx = frame_mode == 2 ? ((b.n_problems > 8 && T <= 30) ? 2 : 1) : 0;
     const char* td = getenv("AVM_FSEL_TEST_DROP");  // (tests: the candidate whose values never arrive -> timeout -> fallback)
     const int test_drop = td ? atoi(td) : -1;
     if ((e = hipMemsetAsync(w.sync, 0, sizeof(int32_t) * FS_SYNC_INTS, stream)) != hipSuccess) return e;
     const int ns = (int)grid.x;
 #define AVM_FRAME(T_, BS_, NB_)                                                                                              \
   {                                                                                                                          \
-    const size_t dl = sizeof(double) * FS_CPWG * (T_ > 30 ? T_ * (T_ + 1) / 2 : T_ * T_);                                    \
-    auto kf = teams ? fsel_frame_kernel<T_, BS_, NB_, true> : fsel_frame_kernel<T_, BS_, NB_, false>;                        \
+    const size_t dl = sizeof(double) * FS_CPWG * ((T_ > 30 || tpx == 2) ? T_ * (T_ + 1) / 2 : T_ * T_);                      \
+    auto kf = tpx == 2 ? fsel_frame_kernel<T_, BS_, NB_, (T_ <= 30 ? 2 : 1)> : tpx == 1 ? fsel_frame_kernel<T_, BS_, NB_, 1> \
+                                                                                         : fsel_frame_kernel<T_, BS_, NB_, 0>; \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl)) != \
         hipSuccess)                                                                                                          \
       return e;                                                                                                              \
-    hipLaunchKernelGGL(kf, dim3(teams ? ns * 8 : ns), dim3(FS_NT), dl, stream, d, w.sync, ns, test_drop);                    \
+    hipLaunchKernelGGL(kf, dim3(tpx ? ns * 8 * tpx : ns), dim3(FS_NT), dl, stream, d, w.sync, ns, test_drop);                \
   }
     switch (T) {
       case 6: AVM_FRAME(6, 6, 1) break;

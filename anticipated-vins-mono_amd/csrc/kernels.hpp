@@ -74,7 +74,7 @@ struct EvalArgs {
 };
 
 // device work buffers of the feature selector (owned by the ctx)
-constexpr int FS_SYNC_INTS = 32 + 8 * 32 + 8 * 2 * 2 * 512 * 4;  // header, 8 team headers, per team (fValue, ub) x two parities x 512 16-byte records
+constexpr int FS_SYNC_INTS = 64 + 16 * 32 + 16 * 2 * 2 * 512 * 4;  // header, 16 team headers, per team (fValue, ub) x two parities x 512 16-byte records
 struct FselBuffers {
   double *C, *dpp, *consts, *delta, *delta_u, *fval, *ub;
   int32_t *valid, *valid_u, *black, *nsel, *done, *live, *pos, *nlive;
