@@ -1001,6 +1001,27 @@ def test_selector_single_frame_kernel_equals_the_launch_per_round_path(selector,
     assert np.array_equal(od.a["selected_ids"], oo.a["selected_ids"])
 
 
+def test_selector_batches_on_the_frame_kernel(selector, oracle, monkeypatch):
+    """Batches run on the frame kernel too: the workgroups of every XCD form a team (two per XCD above eight frames), the teams
+    take frames from a queue.  12 and 19 frames (more frames than teams; ragged candidate counts; the reference's HORIZON 13 keeps
+    one team per XCD): ids identical to the oracle's, ids and fValues identical to the launch-per-round path to the bit."""
+    for H, P, nc, mf in ((10, 12, 220, 50), (5, 19, 90, 30), (13, 11, 130, 25)):
+        pr = synth.make_fsel(P, horizon=H, n_cand=nc, n_used=3, max_features=mf)
+        pr.a["n_cand"][::3] = nc - 17          # ragged
+        oo = buffers.FselOutArrays.alloc(P, mf)
+        oracle.fsel_select(pr, oo, n_threads=8)
+        monkeypatch.setenv("AVM_FSEL_FRAME", "2")
+        a = selector.select_batch(pr)
+        monkeypatch.setenv("AVM_FSEL_FRAME", "0")
+        b = selector.select_batch(pr)
+        monkeypatch.delenv("AVM_FSEL_FRAME")
+        for o in (a, b):
+            assert np.array_equal(o.a["n_selected"], oo.a["n_selected"]) and np.array_equal(o.a["selected_ids"], oo.a["selected_ids"])
+        for q in range(P):
+            n = int(a.a["n_selected"][q])
+            assert n > 0 and np.array_equal(a.a["fvalues"][q, :n], b.a["fvalues"][q, :n])
+
+
 def test_selector_single_frames_from_two_host_threads_at_once(oracle):
     """One avm_ctx per host thread is the documented model.  Two threads that select a single frame at the same moment compete
     for the compute units the frame kernel's workgroups must hold together; whatever happens (both fit, or a wait times out and
