@@ -920,24 +920,21 @@ __global__ __launch_bounds__(FS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
   (void)fsel_round_body<T, BS, NB>(A, blockIdx.y, k, blockIdx.x);
 }
 
-// ---- all rounds of ONE frame in one launch (the latency path: a select() of a single frame is 151 dependent steps) -----------
+// ---- all rounds of a frame in ONE launch (a select() is 151 dependent steps) ----------------------------------------------------
 // Measured on the launch-per-round path: a step is bound by its chain of dependent trips to memory (state, live list, values,
 // the winner's Delta, the candidates' Delta: each a miss, because a kernel boundary invalidates the caches), not by the launch.
 // Here the frame's state never leaves the compute unit: every workgroup keeps its own copy of C, of the position diagonal and
 // of the candidates' alive flags in LDS and applies the same deterministic update (winner out, C += p Delta_winner) to it.  The
 // only thing exchanged per round is (fValue, ub) of each workgroup's 16 candidates - a fixed assignment by candidate index, no
 // live list.
-// There is no barrier and no fence.  A value travels as a 16-byte record {value, round tag} written with ONE store and read with
-// ONE device-scope load (a single request each, never served by the vector L1; two parity buffers; a check word guards against a
-// half-written record): a reader spins until the
-// records of all candidates still in the race carry the round's tag, and then it has the values - one trip after the last
-// writer, nothing to order, no cache maintenance.  Everything else the kernel reads from global memory was written before the
-// launch.
-// ONEXCD: the launch is 8 x `nslots` workgroups, the ones that find themselves on XCD 0 (HW_REG_XCC_ID) take a slot, the rest
-// exit at once; the records then never leave that XCD's L2 (a trip is ~0.5 us instead of a trip across the fabric).
-// A spin longer than FS_SPIN_TICKS of the 100 MHz clock (fewer participants than slots, e.g. a workgroup-to-XCD distribution
-// other than round-robin) raises sync[2], every participant leaves, and the host runs the launch-per-round path instead (and
-// stays on it).
+// There is no barrier and no fence.  A value travels as a 16-byte record {value, round tag, check word} written with ONE store
+// and read with ONE device-scope load (a single request each, never served by the vector L1; two parity buffers): a reader spins
+// until the records of all candidates still in the race carry the round's tag, and then it has the values - one trip after the
+// last writer, nothing to order, no cache maintenance.  Everything else the kernel reads from global memory was written before
+// the launch.  The workgroups that exchange records sit on ONE XCD (a team, see fsel_frame_kernel): the records never leave
+// that XCD's L2 - a trip is ~0.5 us instead of a trip across the fabric.
+// A spin longer than FS_SPIN_TICKS of the 100 MHz clock raises sync[2], every participant leaves, and the host runs the call
+// again one mode down (and stays there).
 constexpr long long FS_SPIN_TICKS = 20 * 100000;  // 20 ms
 constexpr int FS_FRAME_MAXC = 512;                // candidates of a frame on the single-launch path (32 slots of 16)
 // {value, round tag, check}: `check` = the value's two halves xor-ed with the tag.  The 16 bytes travel as one request, but
