@@ -1022,6 +1022,17 @@ def test_selector_batches_on_the_frame_kernel(selector, oracle, monkeypatch):
             assert n > 0 and np.array_equal(a.a["fvalues"][q, :n], b.a["fvalues"][q, :n])
 
 
+def test_selector_bench_batch_matches_the_oracle(selector, oracle):
+    """The batch `bench.py` times (16 frames, 500 candidates -> 150, horizon 10: two teams per XCD on the frame kernel),
+    device-resident as in the bench: every frame's ids are the oracle's, in selection order."""
+    pr = synth.make_fsel(16, first_id=0)
+    oo = buffers.FselOutArrays.alloc(16, pr.dims["max_features"])
+    oracle.fsel_select(pr, oo, n_threads=8)
+    out = selector.select_batch(pr.to_device("cuda:0")).to_host()
+    assert (oo.a["n_selected"] == 150).all()
+    assert np.array_equal(out.a["n_selected"], oo.a["n_selected"]) and np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+
+
 def test_selector_single_frames_from_two_host_threads_at_once(oracle):
     """One avm_ctx per host thread is the documented model.  Two threads that select a single frame at the same moment compete
     for the compute units the frame kernel's workgroups must hold together; whatever happens (both fit, or a wait times out and
