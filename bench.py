@@ -102,6 +102,98 @@ def median_rate(fn, units, passes=5, budget_s=12.0):
     return units / statistics.median(times), len(times)
 
 
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves - one process per GPU with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would set them -, relay rank 0's
+    stdout (the JSON line), send every other rank's output to stderr, and exit non-zero if ANY rank fails (the others are
+    then terminated by process group, never by pattern)."""
+    import signal
+
+    port = int(os.environ.get("MASTER_PORT", 0)) or free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), AVM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this host driver only supports dmabuf IPC (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
+                                      stdout=(subprocess.PIPE if r == 0 else sys.stderr)))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    try:
+        pending = set(range(n))
+        t_rank0_done = None
+        while pending and failed is None:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is not None:
+                    pending.discard(r)
+                    if rc != 0:
+                        failed = (r, f"exit code {rc}")
+                    elif r == 0:
+                        t_rank0_done = time.time()
+            if failed is None and t_rank0_done is not None and pending and time.time() - t_rank0_done > 120.0:
+                failed = (min(pending), "still running 120 s after rank 0 finished")
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)  # exactly the process groups we started
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if failed is not None:
+        print(f"[bench] rank {failed[0]} failed ({failed[1]}); the other ranks were stopped", file=sys.stderr)
+        raise SystemExit(1)
+    raise SystemExit(0)
+
+
+def launch_check(rank, world):
+    """--launch-check: the rendezvous of the N ranks and the max-over-ranks reduction of the timing, on gloo, BEFORE anything
+    touches HIP - what the CPU tier can test of `bench.py --gpus N` (tests/test_bench_launch.py)."""
+    import torch
+    import torch.distributed as dist
+
+    if os.environ.get("AVM_BENCH_FAIL_RANK") == str(rank):  # the failure leg of the launcher test
+        raise SystemExit(7)
+    ranks = [rank]
+    tmax = float(rank + 1)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        ranks = [int(g.item()) for g in got]
+        t = torch.tensor([tmax], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": ranks, "max_over_ranks": tmax,
+                          "self_launched": bool(os.environ.get("AVM_BENCH_SELF_LAUNCHED"))}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,14 +207,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fsel", action="store_true")
     ap.add_argument("--gather", default="library", choices=["library", "torch"], help="who issues the all-gather of the final poses (N > 1)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous of the N ranks on gloo and exit, before HIP is initialised")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])  # never returns
 
     import numpy as np
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it spawns "
+                         f"its own ranks) or under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if args.launch_check:
+        return launch_check(rank, world)
     ncpu, cpu_info = host_cpus()
 
     abi = importlib.import_module(PKG + ".abi")
@@ -222,6 +322,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = world * W * args.steps / elapsed
+    per_rank_solve_ms = [float(np.mean(kernel_ms))]
+    per_rank_gather_ms = None
+    if world > 1:  # every rank's own solve-kernel time (HIP events on its ctx stream) and its last gather, for the scaling record
+        pr = torch.tensor([float(np.mean(kernel_ms)), ctx.kernel_ms("gather_states") if use_lib_gather else -1.0], dtype=torch.float64, device=dev)
+        allr = torch.empty((world, 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, pr)
+        per_rank_solve_ms = [float(x) for x in allr[:, 0].cpu()]
+        per_rank_gather_ms = [float(x) for x in allr[:, 1].cpu()] if use_lib_gather else None
 
     result = None
     if rank == 0:
@@ -266,6 +374,10 @@ def main():
                 "mean_successful_steps": float(s["num_successful"].mean()),
                 "iterations_histogram": {int(k): int(v) for k, v in zip(*np.unique(s["num_iterations"], return_counts=True))},
                 "pose_gather": (("avm_gather_states (library, raw rccl.h)" if use_lib_gather else "torch.distributed all_gather") if world > 1 else "none (1 GPU)"),
+                "per_rank_window_solve_kernel_ms": per_rank_solve_ms,
+                "per_rank_gather_ms": per_rank_gather_ms,
+                "launch": ("self-launched (bench.py spawned its ranks)" if os.environ.get("AVM_BENCH_SELF_LAUNCHED") else
+                           ("external launcher (torch.distributed.run)" if world > 1 else "single process")),
                 "input_generation_s": t_gen,
             },
             "roofline": {
