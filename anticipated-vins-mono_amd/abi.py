@@ -51,6 +51,7 @@ class Options(C.Structure):
         ("marg_eps", C.c_double),
         ("tr", C.c_double),
         ("row", C.c_double),
+        ("max_solver_time_s", C.c_double),
     ]
 
 
@@ -268,6 +269,7 @@ def default_options() -> Options:
     o.jacobi_scaling = 1
     o.marg_eps = 1e-8
     o.tr, o.row = 0.0, 480.0  # global shutter (euroc_config.yaml:66), image_height 480
+    o.max_solver_time_s = 0.0  # no wall-clock cap (estimator.cpp:803-806 sets SOLVER_TIME; off for parity and the bench)
     return o
 
 

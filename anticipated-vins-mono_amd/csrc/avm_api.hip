@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,19 +26,27 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;  // every symbol resolved; decided once for the process
+  std::once_flag once;
   bool load() {
-    if (lib) return true;
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);  // (a process that already maps an RCCL under this soname, e.g. PyTorch's, gets that one)
-      if (lib) break;
-    }
-    if (!lib) return false;
-    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
-    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
-    AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
-    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
-    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-    return GetUniqueId && CommInitRank && AllGather && CommDestroy && GetErrorString;
+    std::call_once(once, [this] {
+      for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);  // (a process that already maps an RCCL under this soname, e.g. PyTorch's, gets that one)
+        if (lib) break;
+      }
+      if (!lib) return;
+      GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+      CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+      AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+      CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+      GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+      ok = GetUniqueId && CommInitRank && AllGather && CommDestroy && GetErrorString;
+      if (!ok) {  // a library without the five entry points is no RCCL for us: never call through a null pointer later
+        dlclose(lib);
+        lib = nullptr;
+      }
+    });
+    return ok;
   }
 };
 Rccl& rccl() {
@@ -69,6 +78,10 @@ struct avm_ctx {
   int fsel_frame_mode = 2;  // how a single-frame select runs (avm_fsel_select_batch); AVM_FSEL_FRAME=0/1/2 caps it
   ncclComm_t comm = nullptr;  // avm_comm_init
   int comm_ranks = 0, comm_rank = 0;
+  double wall_clock_hz = 1.0e8;  // rate of wall_clock64() (hipDeviceAttributeWallClockRate; 100 MHz on gfx950)
+  // fallbacks of the selector's all-rounds-in-one-launch kernel (avm_fsel_fallback_stats)
+  int64_t fsel_calls = 0, fsel_reruns = 0, fsel_failed_launches = 0;
+  int fsel_cooldown = 0;  // calls left before a degraded ctx probes the fast mode again
 };
 
 namespace {
@@ -356,6 +369,7 @@ int avm_default_options(avm_options* o) {
   o->jacobi_scaling = 1;
   o->marg_eps = 1e-8;
   o->tr = 0.0, o->row = 480.0;  // global shutter (config/euroc/euroc_config.yaml:66), image_height
+  o->max_solver_time_s = 0.0;   // no wall-clock cap (the host sets SOLVER_TIME, estimator.cpp:803-806; avm_host.hpp does)
   return AVM_OK;
 }
 
@@ -384,6 +398,10 @@ int avm_create(const avm_config* cfg, avm_ctx** out) {
   }
   // one resident 512-thread workgroup per CU (the solve kernel takes ~158 KiB of the 160 KiB LDS)
   c->n_slots = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) c->wall_clock_hz = 1.0e3 * khz;
+  }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
   if (const char* pe = getenv("AVM_PROFILE"))
     if (pe[0] == '1') (void)hipMalloc(&c->prof, sizeof(long long) * PROF_SLOTS * c->n_slots);
@@ -415,7 +433,7 @@ const char* avm_last_error(const avm_ctx* c) { return c ? c->err.c_str() : "null
   do {                                                                                                      \
     ncclResult_t r__ = (call);                                                                              \
     if (r__ != ncclSuccess) {                                                                               \
-      (ctx)->err = std::string(#call) + ": " + rccl().GetErrorString(r__);                                  \
+      (ctx)->err = std::string(#call) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r__) : "rccl error");  \
       return AVM_ERR_HIP;                                                                                   \
     }                                                                                                       \
   } while (0)
@@ -516,6 +534,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   sa.pre_delta = c->pre_delta, sa.pre_jac = c->pre_jac, sa.pre_sqrt = c->pre_sqrt, sa.pre_sum_dt = c->pre_sum;
   sa.scratch = c->scratch, sa.iscratch = c->iscratch, sa.summary = d_sum, sa.n_slots = c->n_slots;
   sa.prof = c->prof;
+  sa.time_cap_ticks = opt->max_solver_time_s > 0.0 ? (long long)(opt->max_solver_time_s * c->wall_clock_hz) + 1 : 0;
   {
     const char* ns = getenv("AVM_NO_SPECULATE");
     sa.speculate = (ns && ns[0] == '1') ? 0 : 1;
@@ -584,13 +603,13 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   }
   if (marg_err) HIPCHK(c, hipMemcpyAsync(&marg_err_host, marg_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (mem == AVM_MEM_HOST) finish_window_states(batch, pinned_states);  // (also before a capacity error: the states WERE solved)
   if (marg_err_host != 0x7f7f7f7f) {
     c->err = "window " + std::to_string(marg_err_host) +
              ": the new prior does not fit (prior_out->max_prior / max_pblk too small, or more than 76 rows / 16 blocks to keep); "
              "the states were solved, prior_out is not valid";
     return AVM_ERR_CAPACITY;
   }
-  if (mem == AVM_MEM_HOST) finish_window_states(batch, pinned_states);
   if (po_pinned) {
     const size_t B = batch->n_windows, mp = prior_out->max_prior, mb = prior_out->max_pblk;
     std::memcpy(prior_out->n, po_pinned + po_offsets[0], sizeof(int32_t) * B);
@@ -608,6 +627,13 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   if (marg && hipEventElapsedTime(&ms, c->ev[6], c->ev[7]) == hipSuccess) c->last_ms["marginalize"] = ms;
   if (marg && hipEventElapsedTime(&ms, c->ev[7], c->ev[5]) == hipSuccess) c->last_ms["prior_eig"] = ms;
   return AVM_OK;
+}
+
+int avm_window_solve(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* window, avm_prior_out* prior_out,
+                     avm_solve_summary* summary) {
+  if (!c) return AVM_ERR_INVALID;
+  if (!window || window->n_windows != 1) return fail(c, AVM_ERR_INVALID, "avm_window_solve takes exactly one window (n_windows == 1)");
+  return avm_window_solve_batch(c, opt, mem, window, prior_out, summary);
 }
 
 int avm_imu_preintegrate_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, const avm_window_batch* batch, double* out_delta,
@@ -967,6 +993,12 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   // Every frame's greedy rounds in ONE launch (csrc/fsel.hip, fsel_frame_kernel): 2 = a team of workgroups per XCD, the teams
   // take frames from a queue; 1 = one team over all XCDs (a single frame only); 0 = one launch per round.  A kernel that reports
   // a timed-out wait, or that did not finish every frame, is re-run one mode down, and the ctx stays there.
+  // The downgrade is NOT sticky: a transient cause (an XCD busy with another ctx's solve, so that a team does not fill within
+  // its 2 ms) costs this call one re-run and the next AVM_FSEL_REPROBE_CALLS calls the slower mode; then the fast mode is
+  // probed again.  avm_fsel_fallback_stats() counts both.
+  constexpr int AVM_FSEL_REPROBE_CALLS = 16;
+  c->fsel_calls++;
+  if (c->fsel_cooldown > 0 && --c->fsel_cooldown == 0) c->fsel_frame_mode = 2;
   int mode = (d.max_cand <= 512 && mf < 4096) ? c->fsel_frame_mode : 0;  // (512: FS_FRAME_MAXC)
   if (mode == 1 && P != 1) mode = 0;  // (the one-team-over-all-XCDs form takes one frame)
   if (const char* e = getenv("AVM_FSEL_FRAME"))
@@ -995,11 +1027,28 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
               mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8], q[9], q[3]);
     }
     if (hsync[2] == 0 && hsync[4] == (int32_t)P) break;
-    c->fsel_frame_mode = --mode;  // (the outputs of the failed attempt are overwritten by the next one)
-    if (mode == 1 && P != 1) c->fsel_frame_mode = mode = 0;
+    // (the outputs of the failed attempt are overwritten by the next one)
+    c->fsel_failed_launches++, c->fsel_reruns++;
+    --mode;
+    c->fsel_frame_mode = std::min(c->fsel_frame_mode, std::max(mode, P != 1 ? 1 : 0));  // a failed batch leaves mode 1 to single frames
+    c->fsel_cooldown = AVM_FSEL_REPROBE_CALLS;
+    if (mode == 1 && P != 1) mode = 0;
   }
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->last_ms["fsel_select"] = ms;
+  return AVM_OK;
+}
+
+int avm_fsel_select(avm_ctx* c, avm_mem mem, const avm_fsel_batch* frame, int32_t* selected_ids, int32_t* n_selected, double* fvalues_opt) {
+  if (!c) return AVM_ERR_INVALID;
+  if (!frame || frame->n_problems != 1) return fail(c, AVM_ERR_INVALID, "avm_fsel_select takes exactly one frame (n_problems == 1)");
+  avm_fsel_out out{n_selected, selected_ids, fvalues_opt};
+  return avm_fsel_select_batch(c, mem, frame, &out);
+}
+
+int avm_fsel_fallback_stats(const avm_ctx* c, int64_t out[4]) {
+  if (!c || !out) return AVM_ERR_INVALID;
+  out[0] = c->fsel_reruns, out[1] = c->fsel_failed_launches, out[2] = c->fsel_frame_mode, out[3] = c->fsel_calls;
   return AVM_OK;
 }
 

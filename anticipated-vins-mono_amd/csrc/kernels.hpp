@@ -63,6 +63,7 @@ struct SolveArgs {
   int n_slots;
   long long* prof;  // optional [n_slots][PROF_SLOTS] per-phase shader-clock accumulators (debug)
   int speculate;    // 1: evaluate the Jacobian at the candidate directly while steps keep being accepted (window_solve.hip)
+  long long time_cap_ticks;  // avm_options::max_solver_time_s in ticks of the device wall clock (wall_clock64); 0 = no cap
 };
 
 struct EvalArgs {

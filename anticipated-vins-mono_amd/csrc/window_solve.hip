@@ -128,7 +128,7 @@ static_assert(L_S + SPP + ASM_WAVES * XSTG <= L_G, "assembly staging overlaps li
 // int carve (offsets in ints from L_INT)
 constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 546, I_PBLK = 560 /* kind,frame,off x16 */, I_FAIL = 620,
               I_NCOV = 624 /* [12] factors observed in frame b */, I_FRW = 636 /* [12] assembling wave of frame b */,
-              I_PMASK = 648 /* [12] start frames flushed by frame b */, I_END = 660;
+              I_PMASK = 648 /* [12] start frames flushed by frame b */, I_TIMEUP = 660 /* max_solver_time reached (set by thread 0) */, I_END = 661;
 static_assert(I_END <= 720, "int carve");
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -437,6 +437,7 @@ struct WinCtx {
   gcdouble* aux;      // [max_obs][4] velocity.x, velocity.y, cur_td, uv.y per observation slot (null unless estimate_td)
   gcdouble* relo_xy;  // [relo_n][2] match points
   int relo_n;         // > 0: the relocalization frame takes part (frame 11)
+  int has_relo;       // relocalization_info: relo_Pose is frame 11 of the state and goes through the gauge fix, even with no match (relo_n == 0)
   int est_ex, est_td;
 };
 
@@ -2234,7 +2235,8 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     cl.est_ex = A.opt.estimate_extrinsic != 0, cl.est_td = A.opt.estimate_td != 0;
     cl.aux = (cl.est_td && B.obs_vel_td) ? as_global(B.obs_vel_td + (size_t)w * B.max_obs * 4) : nullptr;
     if (!cl.aux) cl.est_td = 0;  // (the host refuses estimate_td without the per-observation data)
-    cl.relo_n = (B.relo_n && B.relo_feat && B.relo_xy && B.relo_pose) ? min(max(B.relo_n[w], 0), cl.nf) : 0;
+    cl.has_relo = B.relo_n && B.relo_feat && B.relo_xy && B.relo_pose;
+    cl.relo_n = cl.has_relo ? min(max(B.relo_n[w], 0), cl.nf) : 0;
     cl.relo_xy = cl.relo_n > 0 ? as_global(B.relo_xy + (size_t)w * B.max_feat * 2) : nullptr;
 #endif
     __syncthreads();  // the previous window's readers of the LDS context are done
@@ -2246,6 +2248,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     (void)pq__;
     PROFQ_T0();
     const long long pw__ = clock64();
+    const long long wall0 = A.time_cap_ticks > 0 ? wall_clock64() : 0;  // (only thread 0's copy is ever compared)
     // ---------------- load ----------------
     for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
     for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
@@ -2255,7 +2258,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     if (t < 7) {
       lds[L_X + XEX + t] = B.ex_pose[(size_t)w * 7 + t];
       // relo_Pose is frame 11 of the state; without a relocalization frame it mirrors pose 0 (never read by a factor)
-      lds[L_X + 7 * NFR + t] = c.relo_n > 0 ? B.relo_pose[(size_t)w * 7 + t] : B.pose[(size_t)w * 77 + t];
+      lds[L_X + 7 * NFR + t] = c.has_relo ? B.relo_pose[(size_t)w * 7 + t] : B.pose[(size_t)w * 77 + t];
     }
     if (t == 7) lds[L_X + XTD] = (c.est_td && B.td) ? B.td[w] : 0.0;
     if (t == 8) lds[L_X + XTD + 1] = 0.0;
@@ -2554,6 +2557,16 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           if (step_ok) accept_mask |= 1 << (iteration - 1);
         }
       }
+      if (A.time_cap_ticks > 0) {
+        // MaxSolverTimeReached (checked before the iteration limit, like Ceres): options.max_solver_time_in_seconds of
+        // estimator.cpp:803-806.  One thread reads the clock, the verdict goes through LDS so that it is workgroup-uniform.
+        if (t == 0) ids[I_TIMEUP] = wall_clock64() - wall0 >= A.time_cap_ticks;
+        __syncthreads();
+        if (ids[I_TIMEUP]) {
+          termination = AVM_TERM_NO_CONVERGENCE;
+          break;
+        }
+      }
       if (iteration >= o.max_num_iterations) {
         termination = AVM_TERM_NO_CONVERGENCE;
         break;
@@ -2835,7 +2848,8 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           for (int k = 3; k < 9; k++) so[k] = x[XSB + t * 9 + k];
         }
 #ifdef AVM_X
-        else if (c.relo_n > 0) {  // relo_t / relo_r of estimator.cpp:590-596 (frame 11 went through the same transformation)
+        else if (c.has_relo) {  // relo_t / relo_r of estimator.cpp:590-596 (frame 11 went through the same transformation; with
+                                // no matched feature it did not move in the solve, the gauge fix applies all the same)
           double* po = B.relo_pose + (size_t)w * 7;
           po[0] = P.x, po[1] = P.y, po[2] = P.z, po[3] = qo.x, po[4] = qo.y, po[5] = qo.z, po[6] = qo.w;
         }
@@ -3361,7 +3375,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     cl.nobs_tot = 0;
     cl.est_ex = 0, cl.est_td = (A.opt.estimate_td != 0 && B.obs_vel_td && B.td) ? 1 : 0;
     cl.aux = cl.est_td ? as_global(B.obs_vel_td + (size_t)w * B.max_obs * 4) : nullptr;
-    cl.relo_n = 0, cl.relo_xy = nullptr;  // (the relocalization factors take no part in the marginalization)
+    cl.relo_n = 0, cl.has_relo = 0, cl.relo_xy = nullptr;  // (the relocalization factors take no part in the marginalization)
     __syncthreads();  // the previous window's readers of the LDS context are done
     lds_store_ctx(cl, A.opt);
     const WinCtx& c = lds_ctx();

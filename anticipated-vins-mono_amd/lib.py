@@ -52,6 +52,9 @@ def lib():
         L.avm_last_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
         L.avm_window_solve_batch.argtypes = [vp, C.POINTER(abi.Options), C.c_int, C.POINTER(abi.WindowBatch),
                                              C.POINTER(abi.PriorOut), C.POINTER(abi.SolveSummary)]
+        L.avm_window_solve.argtypes = L.avm_window_solve_batch.argtypes
+        L.avm_fsel_select.argtypes = [vp, C.c_int, C.POINTER(abi.FselBatch), abi.c_ip, abi.c_ip, abi.c_dp]
+        L.avm_fsel_fallback_stats.argtypes = [vp, C.POINTER(C.c_int64)]
         L.avm_imu_preintegrate_batch.argtypes = [vp, C.POINTER(abi.Options), C.c_int, C.POINTER(abi.WindowBatch)] + [abi.c_dp] * 4
         L.avm_window_eval_factors.argtypes = [vp, C.POINTER(abi.Options), C.c_int, C.POINTER(abi.WindowBatch), C.c_int] + [abi.c_dp] * 6
         L.avm_triangulate_batch.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.c_double]
@@ -82,7 +85,7 @@ def lib():
 
 EXPORTS = [
     "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
-    "avm_window_solve_batch", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
+    "avm_window_solve_batch", "avm_window_solve", "avm_fsel_select", "avm_fsel_fallback_stats", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
     "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
     "avm_ctx_stream", "avm_comm_unique_id", "avm_comm_init", "avm_gather_states", "avm_comm_destroy", "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
 ]
@@ -133,6 +136,12 @@ class Context:
 
     def comm_destroy(self):
         self.check(self._L.avm_comm_destroy(self.h), "avm_comm_destroy")
+
+    def fsel_fallback_stats(self) -> dict:
+        """avm_fsel_fallback_stats: how often this ctx's selects fell back from the all-rounds-in-one-launch kernel."""
+        out = (C.c_int64 * 4)()
+        self.check(self._L.avm_fsel_fallback_stats(self.h, out), "avm_fsel_fallback_stats")
+        return {"reruns": int(out[0]), "failed_launches": int(out[1]), "mode": int(out[2]), "calls": int(out[3])}
 
     def kernel_ms(self, which: str) -> float:
         ms = C.c_float(0)

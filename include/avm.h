@@ -58,7 +58,8 @@ extern "C" {
 typedef enum avm_status {
   AVM_OK = 0,
   AVM_ERR_INVALID = -1,     /* bad argument / size */
-  AVM_ERR_UNSUPPORTED = -2, /* option combination not built (documented in DESIGN.md) */
+  AVM_ERR_UNSUPPORTED = -2, /* not available on this host: a selector HORIZON without a kernel instance (2,3,5,10,13 are built),
+                               or librccl.so.1 cannot be loaded for avm_comm_* */
   AVM_ERR_NO_DEVICE = -3,   /* no HIP device: there is NO CPU fallback */
   AVM_ERR_HIP = -4,         /* HIP runtime error, see avm_last_error() */
   AVM_ERR_CAPACITY = -5     /* problem larger than avm_config limits */
@@ -86,7 +87,7 @@ enum {
  * reference runs with: estimator.cpp:794-806, config/euroc/euroc_config.yaml:54-63,
  * parameters.cpp:11, estimator.cpp:17, and the Ceres defaults listed in SURVEY.md §5.9. */
 typedef struct avm_options {
-  int32_t max_num_iterations;        /* NUM_ITERATIONS = 8; wall-clock cap is NOT reproduced */
+  int32_t max_num_iterations;        /* NUM_ITERATIONS = 8 (the wall-clock cap: max_solver_time_s below) */
   int32_t estimate_extrinsic;        /* 0: ex_pose constant (SetParameterBlockConstant, estimator.cpp:677-681); != 0: a variable of the solve */
   int32_t estimate_td;               /* != 0: every vision factor is a ProjectionTdFactor and para_Td is a variable (estimator.cpp:684-688,732-747) */
   int32_t marginalization_flag;      /* AVM_MARGIN_* */
@@ -110,6 +111,12 @@ typedef struct avm_options {
   double marg_eps;                           /* 1e-8 marginalization_factor.h:70 */
   double tr, row;                            /* TR (rolling-shutter read-out time, 0 for a global shutter) and ROW (image height), parameters.cpp:
                                                 only read by the td factor (projection_td_factor.cpp:19-20,50-52) */
+  double max_solver_time_s;                  /* options.max_solver_time_in_seconds (estimator.cpp:803-806: SOLVER_TIME, x 4/5 under MARGIN_OLD;
+                                                config/euroc/euroc_config.yaml:54).  0 (the default) = no cap, which is what the parity
+                                                tests and the bench run with.  > 0: checked like Ceres' MaxSolverTimeReached at the top of
+                                                every iteration, before the iteration limit, against a device wall clock that starts when the
+                                                window's solve starts on the GPU (staging and pre-integration are not counted); the
+                                                minimizer then stops at the current point with AVM_TERM_NO_CONVERGENCE */
 } avm_options;
 
 /* A batch of independent sliding windows, struct-of-arrays over the window index.
@@ -158,9 +165,11 @@ typedef struct avm_window_batch {
    * (estimator.cpp:734-736) and para_Td */
   const double* obs_vel_td;      /* [B][max_obs][4] */
   double* td;                    /* [B] in/out */
-  /* relocalization factors (estimator.cpp:760-792): relo_n[w] > 0 <=> relocalization_info.  The loop over
+  /* relocalization (estimator.cpp:760-792, 588-604): these five arrays present <=> relocalization_info.  The loop over
    * f_manager.feature / match_points (ids ascending) is resolved by the host into feature INDICES of this batch
-   * (ascending, only features with start_frame <= relo_frame_local_index). */
+   * (ascending, only features with start_frame <= relo_frame_local_index).  relo_n[w] == 0 (no feature matched): no factor
+   * references relo_Pose and the solve leaves it alone, but it still comes back through double2vector's gauge fix
+   * (relo_t / relo_r of :590-596), as in the reference; a window without relocalization simply ignores its relo_pose. */
   const int32_t* relo_n;         /* [B] number of matched features */
   const int32_t* relo_frame;     /* [B] relo_frame_local_index (only needed by the host for the outputs of :598-604) */
   const int32_t* relo_feat;      /* [B][max_feat] feature index of match k */
@@ -305,6 +314,11 @@ int avm_window_solve_batch(avm_ctx* ctx, const avm_options* opt, avm_mem mem,
                            const avm_window_batch* batch, avm_prior_out* prior_out,
                            avm_solve_summary* summary /* [B], host or device per mem */);
 
+/* the single-call form, exactly one Estimator::optimization() (estimator.h:47): the same arguments with
+ * batch->n_windows == 1 (AVM_ERR_INVALID otherwise).  One window occupies one compute unit; see DESIGN.md for its latency. */
+int avm_window_solve(avm_ctx* ctx, const avm_options* opt, avm_mem mem, const avm_window_batch* window,
+                     avm_prior_out* prior_out, avm_solve_summary* summary);
+
 /* A4 only: IntegrationBase for every interval of every window (integration_base.h:13-158).
  * out_* are [B][10][...]: delta (p3,q4 xyzw,v3 = 10), jacobian 15x15, covariance 15x15, sum_dt. */
 int avm_imu_preintegrate_batch(avm_ctx* ctx, const avm_options* opt, avm_mem mem,
@@ -409,6 +423,17 @@ int avm_window_eval_factors(avm_ctx* ctx, const avm_options* opt, avm_mem mem,
 
 /* ---- HP-B: FeatureSelector::select() for a batch of independent frames ------- */
 int avm_fsel_select_batch(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, avm_fsel_out* out);
+/* the single-call form, one FeatureSelector::select() (feature_selector.h:49-50): frame->n_problems == 1
+ * (AVM_ERR_INVALID otherwise); selected_ids has room for frame->max_features ids (selection order), fvalues_opt may be NULL. */
+int avm_fsel_select(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* frame, int32_t* selected_ids, int32_t* n_selected,
+                    double* fvalues_opt);
+
+/* how often this ctx's select calls had to fall back from the all-rounds-in-one-launch kernel (csrc/fsel.hip): counters since
+ * avm_create.  out[0] = calls that were re-run one mode down, out[1] = launches that reported a timed-out wait or an unfinished
+ * frame, out[2] = the mode the next call starts in (2 = a team per XCD, 1 = one team over all XCDs, 0 = one launch per round),
+ * out[3] = select calls so far.  A degraded call costs at most the 20 ms spin time-out of the failed launch plus the slower
+ * mode's run time; the ctx probes the fast mode again after AVM_FSEL_REPROBE_CALLS (16) calls. */
+int avm_fsel_fallback_stats(const avm_ctx* ctx, int64_t out[4]);
 
 /* B5/B6 only: Omega_kkH (+prior) [P][N][N] and compact Delta_ell position blocks
  * [P][max_cand][3H][3H] (+ valid flag [P][max_cand]); for parity tests. */

@@ -270,6 +270,8 @@ class Estimator {
   IntegrationBase pre_integrations[AVM_NFRAMES];  // [j] spans frames j-1 .. j; [0] is unused by this path (estimator.cpp:702-709)
   MarginalizationInfo last_marginalization_info;
   avm_options options;        // NUM_ITERATIONS, noise densities, G, ... (parameters.cpp); marginalization_flag is set per call
+  double SOLVER_TIME = 0.0;   // parameters.cpp:97 / euroc_config.yaml:54 (0.04 s); 0 = no wall-clock cap (the default here: a cap makes
+                              // results depend on the clock, and one window takes ~1 ms on the device against the reference's 32-40 ms)
   avm_solve_summary summary;  // ceres::Solver::Summary subset of the last optimization()
 
   double para_Pose[AVM_NFRAMES][AVM_SIZE_POSE];
@@ -384,6 +386,8 @@ class Estimator {
   // HP-A (estimator.cpp:661-994): solve the window in place, leave the new prior in last_marginalization_info.
   void optimization() {
     options.marginalization_flag = marginalization_flag == MARGIN_OLD ? AVM_MARGIN_OLD : AVM_MARGIN_SECOND_NEW;
+    // estimator.cpp:803-806: max_solver_time_in_seconds = SOLVER_TIME * 4 / 5 under MARGIN_OLD, SOLVER_TIME otherwise
+    options.max_solver_time_s = SOLVER_TIME > 0.0 ? (marginalization_flag == MARGIN_OLD ? SOLVER_TIME * 4.0 / 5.0 : SOLVER_TIME) : 0.0;
     WindowTables t;
     t.use_td = options.estimate_td != 0, t.use_relo = relocalization_info, t.use_failure = failure_occur;
     marshal(t, [](const FeaturePerId& f) { return 1.0 / f.estimated_depth; });  // getDepthVector()
@@ -408,7 +412,8 @@ class Estimator {
       }
       t.relo_n = k, t.relo_frame = relo_frame_local_index;
       std::copy(relo_Pose, relo_Pose + 7, t.relo_pose.begin());
-      if (k == 0) t.use_relo = false;  // no factor references relo_Pose: Ceres would not move it either
+      // (k == 0: no factor references relo_Pose and the solve does not move it, but double2vector still takes it through the
+      //  gauge fix of the window, estimator.cpp:590-596 - the device does that whenever the relocalization arrays are there)
     }
     if (t.use_failure) {
       t.failure_occur = 1;
@@ -437,8 +442,9 @@ class Estimator {
     if (options.estimate_td) td = para_Td[0][0] = t.td;  // estimator.cpp:585-586
     failure_occur = false;                                 // estimator.cpp:530
     if (relocalization_info) {
-      // estimator.cpp:588-604: relo_t / relo_r come back gauge-fixed from the device (the untouched relo_Pose when no feature
-      // matched); the relative pose of the loop frame and the drift correction are host arithmetic on them
+      // estimator.cpp:588-604: relo_t / relo_r come back gauge-fixed from the device (also when no feature matched: the
+      // loop frame then did not move in the solve, the window's yaw / origin correction applies to it all the same); the
+      // relative pose of the loop frame and the drift correction are host arithmetic on them
       if (t.use_relo) std::copy(t.relo_pose.begin(), t.relo_pose.end(), relo_Pose);
       const Vector3d relo_t{relo_Pose[0], relo_Pose[1], relo_Pose[2]};
       const Quaterniond relo_r{relo_Pose[3], relo_Pose[4], relo_Pose[5], relo_Pose[6]};

@@ -62,9 +62,12 @@ void load_window(const avm_options& o, const avm_window_batch& B, int w, Window&
     else W.obs_aux.assign((size_t)B.max_obs * 4, 0.0);
     if (B.td) W.x.td = B.td[w];
   }
-  W.relo_n = (B.relo_n && B.relo_feat && B.relo_xy && B.relo_pose) ? B.relo_n[w] : 0;
+  // relocalization_info (estimator.cpp:588-604): relo_Pose goes through double2vector's gauge fix whether or not a feature
+  // matched; with no match (relo_n == 0) no factor references it and the solve leaves it where it was
+  W.has_relo = B.relo_n && B.relo_feat && B.relo_xy && B.relo_pose;
+  W.relo_n = W.has_relo ? std::max(B.relo_n[w], 0) : 0;
   W.relo_frame = B.relo_frame ? B.relo_frame[w] : 0;
-  if (W.relo_n > 0) {
+  if (W.has_relo) {
     W.relo_feat.assign(B.relo_feat + (size_t)w * B.max_feat, B.relo_feat + (size_t)w * B.max_feat + W.relo_n);
     W.relo_xy.assign(B.relo_xy + (size_t)w * B.max_feat * 2, B.relo_xy + ((size_t)w * B.max_feat + W.relo_n) * 2);
     std::memcpy(W.x.relo, B.relo_pose + (size_t)w * 7, 7 * sizeof(double));
@@ -210,6 +213,7 @@ int avmo_default_options(avm_options* o) {
   o->max_num_consecutive_invalid_steps = 5;
   o->jacobi_scaling = 1;
   o->marg_eps = 1e-8;
+  o->max_solver_time_s = 0.0;
   o->tr = 0.0, o->row = 480.0;  // global shutter (config/euroc/euroc_config.yaml:66), image_height
   return 0;
 }
@@ -226,14 +230,14 @@ int avmo_window_solve_batch(const avm_options* opt, const avm_window_batch* batc
     SolveResult R = trust_region_solve(P, W.x);
     State out;
     out.lam = R.x.lam;
-    gauge_fix_roundtrip(W.x, R.x, out, W.failure_occur ? W.last_pose0 : nullptr, W.relo_n > 0);
+    gauge_fix_roundtrip(W.x, R.x, out, W.failure_occur ? W.last_pose0 : nullptr, W.has_relo);
     if (summary) summary[w] = R.sum;
     if (opt->marginalization_flag != AVM_MARGIN_NONE && prior_out) {
       Prior np;
       marginalize(W, out, *opt, np);
       store_prior(*prior_out, w, np);
     }
-    store_state(*batch, w, out, opt->estimate_td != 0, W.relo_n > 0);
+    store_state(*batch, w, out, opt->estimate_td != 0, W.has_relo);
   });
   return 0;
 }

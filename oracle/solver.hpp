@@ -11,6 +11,7 @@
 // PARITY UNPINNED: no reference tests/golden vectors exist for this path and the
 // reference cannot be built in this image (no ROS/Ceres/Eigen/OpenCV).
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,7 @@ struct Window {
   // optional members of the problem (avm_window_batch)
   std::vector<double> obs_aux;  // [obs slot][4] velocity.x, velocity.y, cur_td, uv.y  (estimate_td)
   int relo_n = 0;               // relocalization_info: matched features (estimator.cpp:760-792)
+  bool has_relo = false;        // relocalization_info itself (relo_Pose is gauge-fixed even when no feature matched, :588-596)
   int relo_frame = 0;
   std::vector<int> relo_feat;
   std::vector<double> relo_xy;
@@ -570,6 +572,7 @@ inline SolveResult trust_region_solve(Problem& P, const State& x0) {
   };
 
   // ---- Minimize -----------------------------------------------------------------------
+  const auto t_minimize_start = std::chrono::steady_clock::now();
   x_norm = ambNorm(x);
   evalGradJac();  // IterationZero
   R.sum.initial_cost = x_cost;
@@ -587,6 +590,13 @@ inline SolveResult trust_region_solve(Problem& P, const State& x0) {
       R.sum.cost_trace[iteration - 1] = x_cost;
       R.sum.radius_trace[iteration - 1] = tr_radius_report;
       if (step_is_successful) R.sum.accept_mask |= (1 << (iteration - 1));
+    }
+    // MaxSolverTimeReached comes first (trust_region_minimizer.cc, FinalizeIterationAndCheckIfMinimizerCanContinue);
+    // options.max_solver_time_in_seconds = SOLVER_TIME (x 4/5 under MARGIN_OLD), estimator.cpp:803-806; 0 = no cap here
+    if (o.max_solver_time_s > 0.0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_minimize_start).count() >= o.max_solver_time_s) {
+      termination = AVM_TERM_NO_CONVERGENCE;
+      break;
     }
     if (iteration >= o.max_num_iterations) {
       termination = AVM_TERM_NO_CONVERGENCE;
