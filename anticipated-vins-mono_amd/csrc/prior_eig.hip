@@ -52,7 +52,9 @@ constexpr int P_PART = P_A + NMAX * LD;       // [2 buffers][2 values][NW][PL] p
 constexpr int P_B = P_PART + 2 * 2 * NW * PL;
 constexpr int P_DG = P_B + NMAX;              // running diagonal of the Cholesky factorization
 constexpr int P_PIV = P_DG + NMAX;            // pivot sequence of the Cholesky factorization (ints), then 4 doubles of verdicts
-constexpr int P_END = P_PIV + NMAX / 2 + 4;
+constexpr int P_D0 = P_PIV + NMAX / 2 + 4;     // the diagonal of A' as it came in (the scale of each variable, for the clamp's noise test)
+constexpr int P_END = P_D0 + NMAX;
+static_assert(3 * P_END * 8 <= 163840, "three workgroups per CU");
 
 __device__ __forceinline__ double nrm_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   for (int e = t; e < NMAX * NMAX; e += NT) A[e] = 0.0;
   if (t < NMAX) lds[P_B + t] = t < n ? gr[t] : 0.0;
   double dmine = t < n ? gJ[(size_t)t * ldj + t] : 0.0;  // threads 0..75 carry the running diagonal
-  if (t < NMAX) dgl[t] = dmine;
+  if (t < NMAX) dgl[t] = dmine, lds[P_D0 + t] = fmax(dmine, 0.0);
 #pragma unroll
   for (int q = 0; q < RW; q++) {
     const int i = wv + NW * q;
@@ -370,18 +372,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   }
 
   // ---- eigenvalues S = |g|^2 (fresh), g^T b', output
-  double lX, lY, vX, vY;
+  double lX, lY, vX, vY, wX, wY;  // w = g^T diag(A') g = S v^T diag(A') v: the scale of the variables this eigenvector lives on
   {
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0, d0 = 0, d1 = 0;
 #pragma unroll
     for (int r = 0; r < RW; r++) {
-      const double bb = lds[P_B + r0 + r];
+      const double bb = lds[P_B + r0 + r], dd = lds[P_D0 + r0 + r];
       a0 = fma(X[r], X[r], a0), a1 = fma(Y[r], Y[r], a1);
       b0 = fma(X[r], bb, b0), b1 = fma(Y[r], bb, b1);
+      d0 = fma(X[r] * X[r], dd, d0), d1 = fma(Y[r] * Y[r], dd, d1);
     }
     reduce2(a0, a1);
     reduce2(b0, b1);
-    lX = a0, lY = a1, vX = b0, vY = b1;
+    reduce2(d0, d1);
+    lX = a0, lY = a1, vX = b0, vY = b1, wX = d0, wY = d1;
   }
   // An odd n carries one pad index; its column is exactly zero and only ever got swapped around.  Any exactly-zero
   // column is as good as the pad (its output row would be zero anyway): the first one is skipped.
@@ -394,7 +398,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   if (lane < np) {
     const int qx = 2 * lane, qy = 2 * lane + 1;
     const int ox = qx < padpos ? qx : qx - 1, oy = qy < padpos ? qy : qy - 1;
-    const bool kx = lX > eps, ky = lY > eps;
+    // The clamp of marginalization_factor.cpp:284-285 (S > eps), applied as EXACT arithmetic would apply it: an eigenvalue
+    // that FP64 cannot tell from zero is zero.  A' reaches this kernel with componentwise errors of a few n u |A'_jj| (it
+    // is a difference of information matrices), so an eigenvalue S with eigenvector v carries an uncertainty of about
+    // n u v^T diag(A') v; the exact eigenvalues of the gauge directions of a window without a gauge-fixing prior are 0, in
+    // FP64 they come out as +-(1e-10 .. 1e-6), on either side of eps at random - and one that lands above eps puts
+    // (v^T b')^2 / S into |r0|^2 (measured against the binary128 statement of the reference's algorithm,
+    // tests/test_prior_truth.py: the prior's cost came out 3x too large in 1 of 6 such windows).  64 n u = 1e-12.
+    const bool kx = lX > eps && lX * lX > 1e-12 * wX, ky = lY > eps && lY * lY > 1e-12 * wY;
 #pragma unroll
     for (int r = 0; r < RW; r++) {
       if (r0 + r < n) {

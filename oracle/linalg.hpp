@@ -11,6 +11,10 @@
 #include <limits>
 #include <vector>
 
+#ifndef AVMO_EIG_EPS
+#define AVMO_EIG_EPS std::pow(2.0, -52.0)
+#endif
+
 namespace avmo {
 
 struct V3 {
@@ -387,7 +391,7 @@ inline void eig_sym(const Mat& A, std::vector<double>& d, Mat& V) {
   for (int i = 1; i < n; i++) e[i - 1] = e[i];
   e[n - 1] = 0.0;
   double f = 0.0, tst1 = 0.0;
-  const double eps = std::pow(2.0, -52.0);
+  const double eps = AVMO_EIG_EPS;  // unit roundoff of the scalar type (2^-52; the extended-precision build of avm_truth.cpp: 2^-112)
   for (int l = 0; l < n; l++) {
     tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
     int m = l;

@@ -768,7 +768,15 @@ struct MFactor {
   std::vector<int> drop;
 };
 
-inline void marginalize(const Window& win, const State& x, const avm_options& o, Prior& out) {
+// what the eigenvalue clamps of marginalization_factor.cpp:272,284-285 saw (diagnostics for the precision arbiter, tests/)
+struct MargDiag {
+  int m = 0, n = 0;
+  std::vector<double> ev_mm, ev_rr;  // eigenvalues of Amm and of the Schur complement, ascending
+  Mat A_rr;                          // the Schur complement A (n x n) and b before the square root
+  std::vector<double> b_rr;
+};
+
+inline void marginalize(const Window& win, const State& x, const avm_options& o, Prior& out, MargDiag* diag = nullptr) {
   const int flag = o.marginalization_flag;
   std::vector<MFactor> factors;
   const double sq = o.focal_length / 1.5;
@@ -957,6 +965,7 @@ inline void marginalize(const Window& win, const State& x, const avm_options& o,
   std::vector<double> ev2;
   Mat V2;
   eig_sym(S, ev2, V2);
+  if (diag) diag->m = m, diag->n = n, diag->ev_mm = ev, diag->ev_rr = ev2, diag->A_rr = S, diag->b_rr = bn;
   out = Prior();
   out.n = n;
   out.J = Mat(n, n);

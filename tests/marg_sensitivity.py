@@ -49,6 +49,13 @@ def ulp_perturbed(w, seed, keys=("pose", "speedbias", "inv_depth", "obs_xy", "pr
 def marginalize_only(w, opt, estimator=None):
     """The marginalization of optimization() at the state the windows are in (max_num_iterations = 0: the solve returns
     its starting point).  Through the oracle, or through the GPU when an Estimator class instance is given."""
+    return marginalize_at(w, opt, estimator)[0]
+
+
+def marginalize_at(w, opt, estimator=None):
+    """marginalize_only() plus the windows as the call left them: optimization() marginalizes at the state it RETURNS (the
+    gauge fix of double2vector / vector2double sits in between, and is the identity only up to the last bit), so that is the
+    state an exact evaluation of the same marginalization has to start from."""
     import oracle_py
 
     o0 = abi.Options.from_buffer_copy(bytes(opt))
@@ -57,14 +64,14 @@ def marginalize_only(w, opt, estimator=None):
     pr = buffers.PriorOutArrays.alloc(w.n_windows)
     if estimator is None:
         oracle_py.window_solve(o0, win, pr, buffers.summary_alloc(w.n_windows))
-        return pr
+        return pr, win
     old = estimator.options
     estimator.options = o0
     try:
         estimator.optimization(win, prior_out=pr)
     finally:
         estimator.options = old
-    return pr
+    return pr, win
 
 
 def install_prior(win, p):
@@ -72,3 +79,71 @@ def install_prior(win, p):
     a["prior_n"][:], a["prior_nblk"][:] = np.asarray(p.a["n"]).astype(np.int32), p.a["nblk"]
     a["prior_blk_kind"][:], a["prior_blk_frame"][:] = p.a["blk_kind"], p.a["blk_frame"]
     a["prior_J"][:], a["prior_r"][:], a["prior_x0"][:] = p.a["J"], p.a["r"], p.a["x0"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The extended-precision arbiter (oracle/avm_truth.cpp: the oracle's marginalization with __float128 as its scalar type,
+# following marginalization_factor.cpp:232-291 literally from the same FP64 inputs).  "How far is X from the value the
+# reference's algorithm defines" replaces "how far is X from the oracle, in units of the oracle's own scatter".
+_TRUTH = None
+
+
+def truth_lib():
+    global _TRUTH
+    if _TRUTH is None:
+        import ctypes as C
+        import os
+        import subprocess
+
+        here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+        path = os.path.join(here, "libavm_truth.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", here, "-s", "libavm_truth.so"])
+        _TRUTH = C.CDLL(path)
+    return _TRUTH
+
+
+def truth_marginalize(w, opt):
+    """The marginalization of every window of `w` at the state it is in, in binary128.  Returns (PriorOutArrays rounded to
+    FP64, diag) with diag[i] = dict(H, g, cost: J^T J, J^T r, |r|^2 / 2 formed in binary128 and rounded once; A, b: the
+    Schur complement; ev_mm / ev_rr: the eigenvalues the two clamps looked at)."""
+    import ctypes as C
+
+    L = truth_lib()
+    B = w.n_windows
+    pr = buffers.PriorOutArrays.alloc(B)
+    mp, mb = pr.dims["max_prior"], pr.dims["max_pblk"]
+    s = w.struct()
+    diag = []
+    for i in range(B):
+        n, nb, nmm = C.c_int32(), C.c_int32(), C.c_int32()
+        J, r, H, g = np.zeros(mp * mp), np.zeros(mp), np.zeros(mp * mp), np.zeros(mp)
+        A, b, ev_mm, ev_rr = np.zeros(mp * mp), np.zeros(mp), np.zeros(512), np.zeros(mp)
+        kind, frame, x0 = np.zeros(mb, np.int32), np.zeros(mb, np.int32), np.zeros((mb, 9))
+        cost = C.c_double()
+        rc = L.avmt_marginalize(C.byref(opt), C.byref(s), i, mb, C.byref(n), C.byref(nb), abi.iptr(kind), abi.iptr(frame), abi.dptr(x0),
+                                abi.dptr(J), abi.dptr(r), abi.dptr(H), abi.dptr(g), C.byref(cost), abi.dptr(A), abi.dptr(b),
+                                abi.dptr(ev_mm), 512, C.byref(nmm), abi.dptr(ev_rr))
+        nn = n.value
+        pr.a["n"][i] = nn
+        if rc != 0:
+            diag.append(None)
+            continue
+        pr.a["nblk"][i] = nb.value
+        pr.a["blk_kind"][i], pr.a["blk_frame"][i], pr.a["x0"][i] = kind, frame, x0
+        pr.a["J"][i, :nn, :nn] = J[: nn * nn].reshape(nn, nn)
+        pr.a["r"][i, :nn] = r[:nn]
+        diag.append(dict(n=nn, H=H[: nn * nn].reshape(nn, nn).copy(), g=g[:nn].copy(), cost=cost.value, A=A[: nn * nn].reshape(nn, nn).copy(),
+                         b=b[:nn].copy(), ev_mm=ev_mm[: nmm.value].copy(), ev_rr=ev_rr[:nn].copy()))
+    return pr, diag
+
+
+def distance_to_truth(p, diag, i):
+    """The four metrics of prior_metrics() for window i of prior `p`, against the binary128 H, g, cost of `diag[i]`."""
+    n, Hp, gp, cp = _quad(p, i)
+    t = diag[i]
+    assert n == t["n"]
+    Hq, gq, cq = t["H"], t["g"], t["cost"]
+    d = 1.0 / np.sqrt(np.maximum(np.diag(Hq), 1e-300))
+    return dict(H_rel=float(np.abs(Hp - Hq).max() / np.abs(Hq).max()), H_scaled=float(np.abs((Hp - Hq) * d[:, None] * d[None, :]).max()),
+                g_scaled=float(np.abs((gp - gq) * d).max() / max(1e-300, np.abs(gq * d).max())), cost_rel=abs(cp - cq) / max(cq, 1e-300))

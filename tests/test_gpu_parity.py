@@ -245,14 +245,21 @@ def test_window_solve_parity_over_random_track_structures(estimator, oracle):
             if flag == abi.MARGIN_SECOND_NEW:
                 assert rel(Hg, Ho) < 1e-9 and rel(bg, bo) < 1e-9, (flag, i, rel(Hg, Ho), rel(bg, bo))
         if flag == abi.MARGIN_OLD:
-            # MARGIN_OLD goes through the eigen pseudo-inverse of an ill-conditioned Amm (two-view tracks): the yardstick is the
-            # oracle's own spread when its inputs move by one ulp (tests/test_prior_parity.py), at the bit-identical state
-            from marg_sensitivity import marginalize_only, prior_metrics, ulp_perturbed
-            pg0, po0 = marginalize_only(wo2, o, estimator=E), marginalize_only(wo2, o)
-            gap = prior_metrics(pg0, po0)
-            own = [prior_metrics(marginalize_only(ulp_perturbed(wo2, sd), o), po0) for sd in range(6)]
-            for k in gap:
-                assert gap[k] <= 2.0 * max(x[k] for x in own), (k, gap[k], [x[k] for x in own])
+            # MARGIN_OLD goes through the eigen pseudo-inverse of an ill-conditioned Amm (two-view tracks), which FP64 only
+            # determines to 1e-5: the arbiter is the binary128 statement of the reference's algorithm (oracle/avm_truth.cpp,
+            # tests/test_prior_truth.py), each side against the exact result at the state it marginalized at
+            from marg_sensitivity import distance_to_truth, marginalize_at, truth_marginalize
+            (pg0, at_g), (po0, at_o) = marginalize_at(wo2, o, estimator=E), marginalize_at(wo2, o)
+            dg_t, do_t = truth_marginalize(at_g, o)[1], truth_marginalize(at_o, o)[1]
+            worst_g, worst_o = {}, {}
+            for i in range(B):
+                dg, do = distance_to_truth(pg0, dg_t, i), distance_to_truth(po0, do_t, i)
+                for k in dg:
+                    worst_g[k], worst_o[k] = max(worst_g.get(k, 0.0), dg[k]), max(worst_o.get(k, 0.0), do[k])
+            print("\n[random track structures, MARGIN_OLD prior vs truth] gpu", worst_g, "oracle", worst_o)
+            floor = dict(H_rel=1e-6, H_scaled=1e-5, g_scaled=1e-9, cost_rel=1e-6)
+            for k in worst_g:
+                assert worst_g[k] <= max(worst_o[k], floor[k]), (k, worst_g[k], worst_o[k])
 
 
 def test_window_solve_without_prior_and_mixed_batch(estimator, oracle):
@@ -768,19 +775,25 @@ def test_chained_solves_through_the_new_prior(ctx, oracle):
         win.a["prior_r"][:] = p.a["r"]
         win.a["prior_x0"][:] = p.a["x0"]
 
+    # the reference chain: the FP64 solver with the EXACT prior (the marginalization in binary128 at the oracle's solution,
+    # oracle/avm_truth.cpp).  The FP64 oracle's own prior leads 1e-7 .. 3e-6 away from it; the GPU's chain stays within the
+    # north-star 1e-6 (measured 2e-11 .. 4e-10, tests/test_prior_truth.py)
+    from marg_sensitivity import truth_marginalize
+    wt = wo.copy()
+    install(wt, truth_marginalize(wo, o)[0])
     install(wg, pg)
     install(wo, po)
     o2 = abi.default_options()
     o2.marginalization_flag = abi.MARGIN_NONE
     E2 = est_m.Estimator(ctx=ctx, options=o2)
     sg = E2.optimization(wg)
-    so = buffers.summary_alloc(2)
+    so, st = buffers.summary_alloc(2), buffers.summary_alloc(2)
     oracle.window_solve(o2, wo, None, so)
-    assert np.array_equal(buffers.summary_to_numpy(sg)["accept_mask"], so["accept_mask"])
+    oracle.window_solve(o2, wt, None, st)
+    assert np.array_equal(buffers.summary_to_numpy(sg)["accept_mask"], st["accept_mask"])
     for k in ("pose", "speedbias"):
-        # measured 1e-7 .. 3e-6 depending on the rounding of the marginalization; the oracle's own one-ulp spread of this
-        # chained solve is 1e-6 .. 1e-5 (tests/test_prior_parity.py::test_what_a_solve_sees_of_the_new_prior asserts against it)
-        assert rel(wg.a[k], wo.a[k]) < 5e-6, (k, rel(wg.a[k], wo.a[k]))
+        print(f"\n[chained solve vs exact-prior chain] {k}: gpu {rel(wg.a[k], wt.a[k]):.2e}  oracle {rel(wo.a[k], wt.a[k]):.2e}")
+        assert rel(wg.a[k], wt.a[k]) < 1e-6, (k, rel(wg.a[k], wt.a[k]))
 
 
 # ---------------------------------------------------------------- HP-B
@@ -1120,13 +1133,17 @@ def test_window_roll_matches_oracle_and_chains_solves(ctx, oracle):
     # GPU agrees with the chain through the oracle
     o = abi.default_options()
     w = synth.make_windows(3, tracks="sparse", n_feat=50, max_feat=150, max_samp=40)
+    from marg_sensitivity import truth_marginalize
     wg, wo = w.copy(), w.copy()
     E.optimization(wg)
     pg, po = E.last_marginalization_info, buffers.PriorOutArrays.alloc(3)
     oracle.window_solve(o, wo, po, buffers.summary_alloc(3))
+    wt = wo.copy()
+    pt = truth_marginalize(wo, o)[0]     # the exact prior (binary128) at the oracle's solution: the reference chain
     E.slideWindow(wg, abi.MARGIN_OLD, True, 5.0)
     assert oracle.slide_window(wo, abi.MARGIN_OLD, True, 5.0) == 0
-    for win, p in ((wg, pg), (wo, po)):
+    assert oracle.slide_window(wt, abi.MARGIN_OLD, True, 5.0) == 0
+    for win, p in ((wg, pg), (wo, po), (wt, pt)):
         a = win.a
         a["prior_n"][:], a["prior_nblk"][:] = p.a["n"].astype(np.int32), p.a["nblk"]
         a["prior_blk_kind"][:], a["prior_blk_frame"][:] = p.a["blk_kind"], p.a["blk_frame"]
@@ -1142,6 +1159,8 @@ def test_window_roll_matches_oracle_and_chains_solves(ctx, oracle):
     E2 = importlib_est().Estimator(ctx=ctx, options=o2)
     E2.optimization(wg)
     oracle.window_solve(o2, wo, None, buffers.summary_alloc(3))
+    oracle.window_solve(o2, wt, None, buffers.summary_alloc(3))
     for k in ("pose", "speedbias"):
-        # (1.2e-6 measured; the oracle's own one-ulp spread over such a chain is 2e-6 .. 1e-5, tests/test_prior_parity.py)
-        assert rel(wg.a[k], wo.a[k]) < 5e-6, (k, rel(wg.a[k], wo.a[k]))
+        # against the chain with the exact prior (the FP64 oracle's own chain sits 1e-6 .. 1e-5 away from it)
+        print(f"\n[solve -> roll -> solve vs exact-prior chain] {k}: gpu {rel(wg.a[k], wt.a[k]):.2e}  oracle {rel(wo.a[k], wt.a[k]):.2e}")
+        assert rel(wg.a[k], wt.a[k]) < 1e-6, (k, rel(wg.a[k], wt.a[k]))

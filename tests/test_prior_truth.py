@@ -1,0 +1,275 @@
+"""MARGIN_OLD prior parity against an extended-precision ARBITER.
+
+The reference computes the new prior through two symmetric eigen-decompositions of matrices whose entries span 1e12 .. 1e0
+(marginalization_factor.cpp:267-291), with a clamp at 1e-8 that sits far below the FP64 noise floor of that computation.  The
+FP64 oracle follows that algorithm literally and is therefore only reproducible to 1e-5 .. 1e-4; comparing the GPU with it says
+nothing about which of the two is right.  oracle/avm_truth.cpp is the same restatement compiled with __float128 as its scalar
+type, from the pre-integration on: the value the reference's algorithm DEFINES for the given FP64 inputs.  Every implementation
+is measured against the arbiter evaluated on exactly the state that implementation marginalized at (the state it returned).
+
+Measured (MI355X, 6 windows per row, worst window; profiles/r03_prior_truth.md):
+  with a prior:   |GPU - truth|  H 1.3e-7, Jacobi-scaled H 2.6e-6, scaled g 1e-12, cost 7e-8
+                  |oracle - truth|  H 2.0e-5,             1.4e-4,          5.6e-7,      1.4e-5
+The GPU's different algorithm (scalar pivots for the depths, Cholesky-based square root) is one to two
+orders of magnitude CLOSER to the exact result than the reference's algorithm run in FP64."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import abi, buffers, rel, synth
+from marg_sensitivity import distance_to_truth, install_prior, marginalize_at, truth_marginalize, ulp_perturbed
+
+est_m = importlib.import_module("anticipated-vins-mono_amd.estimator")
+METRICS = ("H_rel", "H_scaled", "g_scaled", "cost_rel")
+
+
+def _fmt(d):
+    return " ".join(f"{k} {v:.1e}" for k, v in d.items())
+
+
+# ---------------------------------------------------------------- CPU tier: the arbiter itself
+def test_truth_is_an_exact_square_root_of_its_own_schur_complement(oracle):
+    """J^T J and J^T r formed in binary128 reproduce the Schur complement A, b that went into the eigen square root to FP64
+    round-off (each side is rounded once): the two eigen-decompositions and the clamp lose nothing above 1e-15."""
+    o = abi.default_options()
+    w = synth.make_windows(3, first_id=300, tracks="sparse", n_feat=60, max_feat=150)
+    oracle.window_solve(o, w, buffers.PriorOutArrays.alloc(3), buffers.summary_alloc(3))
+    pt, diag = truth_marginalize(w, o)
+    for i in range(3):
+        t = diag[i]
+        assert (t["ev_mm"] > 1e-8).all()                                  # nothing clamped on the dropped side
+        d = 1.0 / np.sqrt(np.diag(t["A"]))
+        assert np.abs((t["H"] - t["A"]) * d[:, None] * d[None, :]).max() < 1e-12
+        assert np.abs((t["g"] - t["b"]) * d).max() < 1e-12 * np.abs(t["b"] * d).max()
+        n = t["n"]
+        J = pt.a["J"][i, :n, :n]
+        assert rel(J.T @ J, t["H"]) < 1e-13                               # the FP64 rounding of J is all that separates them
+
+
+def test_oracle_distance_to_truth(oracle):
+    """How far the reference's algorithm in FP64 (the oracle) lands from its own exact value: 1e-8 .. 2e-5 in H, up to
+    1.4e-4 in Jacobi-scaled entries.  This is the yardstick the GPU tier uses, and the reason a 1e-6 comparison
+    GPU-vs-oracle cannot be the criterion for the prior."""
+    o = abi.default_options()
+    worst = {k: 0.0 for k in METRICS}
+    for tracks, nf in (("sparse", 60), ("dense", 150)):
+        w = synth.make_windows(3, first_id=300, tracks=tracks, n_feat=nf, max_feat=150)
+        oracle.window_solve(o, w, buffers.PriorOutArrays.alloc(3), buffers.summary_alloc(3))
+        po, at = marginalize_at(w, o)
+        _, diag = truth_marginalize(at, o)
+        for i in range(3):
+            d = distance_to_truth(po, diag, i)
+            print(f"\n[oracle - truth] {tracks} {nf} window {i}: {_fmt(d)}")
+            for k in METRICS:
+                worst[k] = max(worst[k], d[k])
+    assert worst["H_rel"] < 2e-4 and worst["H_scaled"] < 2e-3 and worst["g_scaled"] < 1e-5 and worst["cost_rel"] < 2e-4, worst
+    assert worst["H_rel"] > 1e-9                                          # ... and it is not exact: the arbiter resolves the difference
+
+
+def test_which_eigenvalues_the_clamp_takes_is_rounding_dependent_in_fp64(oracle):
+    """A window without a prior has gauge freedom and unconstrained biases: exact zeros in the Schur complement.  The exact
+    computation clamps all of them; the FP64 oracle sees +-1e-10 .. 1e-4 there and keeps the ones that land above 1e-8."""
+    o = abi.default_options()
+    w = synth.make_windows(4, first_id=300, tracks="sparse", n_feat=80, max_feat=150, with_prior=False)
+    oracle.window_solve(o, w, buffers.PriorOutArrays.alloc(4), buffers.summary_alloc(4))
+    po, at = marginalize_at(w, o)
+    _, diag = truth_marginalize(at, o)
+    n_truth, n_oracle = [], []
+    for i in range(4):
+        n = diag[i]["n"]
+        n_truth.append(int((diag[i]["ev_rr"] <= 1e-8).sum()))
+        n_oracle.append(int((np.abs(po.a["J"][i, :n, :n]).max(1) == 0).sum()))   # a clamped eigenvalue leaves a zero row
+        assert np.abs(diag[i]["ev_rr"][: n_truth[-1]]).max() < 1e-15               # exact zeros, resolved as such in binary128
+    print("\n[clamped eigenvalues of A'] truth", n_truth, "oracle (FP64)", n_oracle)
+    assert min(n_truth) >= 4 and all(a <= b for a, b in zip(n_oracle, n_truth))
+    assert n_oracle != n_truth                                            # (measured: 2 .. 9 of them survive in FP64)
+
+
+# ---------------------------------------------------------------- GPU tier
+FLOOR = dict(H_rel=1e-6, H_scaled=1e-5, g_scaled=1e-9, cost_rel=1e-6)      # below these the comparison is moot
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracks,nf", [("sparse", 60), ("dense", 150), ("sparse", 150)])
+def test_gpu_prior_is_closer_to_the_truth_than_the_fp64_oracle(ctx, oracle, tracks, nf):
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    B = 6
+    w = synth.make_windows(B, first_id=300, tracks=tracks, n_feat=nf, max_feat=150)
+    oracle.window_solve(o, w, buffers.PriorOutArrays.alloc(B), buffers.summary_alloc(B))
+    po, at_o = marginalize_at(w, o)
+    pg, at_g = marginalize_at(w, o, estimator=E)
+    assert np.array_equal(pg.a["n"], po.a["n"]) and np.array_equal(pg.a["blk_kind"], po.a["blk_kind"]) and np.array_equal(pg.a["blk_frame"], po.a["blk_frame"])
+    _, diag_o = truth_marginalize(at_o, o)
+    _, diag_g = truth_marginalize(at_g, o)      # (each side against the exact result at the state IT marginalized at)
+    wo, wg = {k: 0.0 for k in METRICS}, {k: 0.0 for k in METRICS}
+    for i in range(B):
+        do, dg = distance_to_truth(po, diag_o, i), distance_to_truth(pg, diag_g, i)
+        print(f"\n[prior vs truth] {tracks} {nf} window {i}: clamped {int((diag_g[i]['ev_rr'] <= 1e-8).sum())} | oracle {_fmt(do)} | gpu {_fmt(dg)}")
+        for k in METRICS:
+            assert dg[k] <= max(do[k], FLOOR[k]), (i, k, dg[k], do[k])
+            wo[k], wg[k] = max(wo[k], do[k]), max(wg[k], dg[k])
+    for k in METRICS:
+        assert wg[k] <= wo[k], (k, wg[k], wo[k])                           # worst window: the GPU is the closer one, no floor
+    # the north-star tolerance, against the exact result
+    assert wg["H_rel"] < 1e-6 and wg["H_scaled"] < 1e-5 and wg["g_scaled"] < 1e-9 and wg["cost_rel"] < 1e-6, wg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracks,nf", [("sparse", 80), ("dense", 150)])
+def test_rank_deficient_prior_against_the_truth(ctx, oracle, tracks, nf):
+    """No prior yet (the first marginalization of a run): 16 .. 30 exact zeros in A' (gauge, unconstrained biases / extrinsic).
+    The exact computation clamps them all; in FP64 they come out as noise of up to 0.25 (oracle) / 0.02 (GPU), partly above the
+    smallest genuine eigenvalues, so no FP64 implementation can clamp exactly that set.  Asserted: the GPU is the closer one."""
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    B = 6
+    w = synth.make_windows(B, first_id=300, tracks=tracks, n_feat=nf, max_feat=150, with_prior=False)
+    oracle.window_solve(o, w, buffers.PriorOutArrays.alloc(B), buffers.summary_alloc(B))
+    po, at_o = marginalize_at(w, o)
+    pg, at_g = marginalize_at(w, o, estimator=E)
+    _, diag_o = truth_marginalize(at_o, o)
+    _, diag_g = truth_marginalize(at_g, o)
+    wo, wg = {k: 0.0 for k in METRICS}, {k: 0.0 for k in METRICS}
+    for i in range(B):
+        n = diag_g[i]["n"]
+        n_truth = int((diag_g[i]["ev_rr"] <= 1e-8).sum())
+        n_gpu = int((np.abs(pg.a["J"][i, :n, :n]).max(1) == 0).sum())
+        do, dg = distance_to_truth(po, diag_o, i), distance_to_truth(pg, diag_g, i)
+        print(f"\n[rank-deficient prior vs truth] {tracks} {nf} window {i}: clamped truth {n_truth} gpu {n_gpu} | oracle {_fmt(do)} | gpu {_fmt(dg)}")
+        n_oracle = int((np.abs(po.a["J"][i, :n, :n]).max(1) == 0).sum())
+        # FP64 cannot resolve all of the exact zeros (the unconstrained bias directions carry 1e-16 x 1e12 of noise, above
+        # the smallest genuine eigenvalues): the GPU recognises at least as many of them as the reference's algorithm in FP64
+        assert n_oracle <= n_gpu <= n_truth, (i, n_oracle, n_gpu, n_truth)
+        for k in METRICS:
+            wo[k], wg[k] = max(wo[k], do[k]), max(wg[k], dg[k])
+    for k in METRICS:
+        assert wg[k] <= wo[k], (k, wg[k], wo[k])
+    assert wg["H_rel"] < 1e-6, wg
+
+
+def _chained(start, prior, solve):
+    c = start.copy()
+    install_prior(c, prior)
+    return c, solve(c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tracks,nf", [("sparse", 60), ("dense", 150)])
+def test_what_a_solve_sees_of_the_prior_against_the_truth(ctx, oracle, tracks, nf):
+    """The next solve (the FP64 oracle's solver, from the same start) with the exact prior, with the oracle's prior and with
+    the GPU's prior: the GPU's prior leads to the solution of the exact prior within the north-star 1e-6 - the oracle's own
+    prior does not always - and the GPU's solver on the GPU's prior (the product end to end) is within 1e-6 as well."""
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    B = 4
+    w = synth.make_windows(B, first_id=300, tracks=tracks, n_feat=nf, max_feat=150)
+    wg, wo = w.copy(), w.copy()
+    E.optimization(wg)
+    pg, po = E.last_marginalization_info, buffers.PriorOutArrays.alloc(B)
+    oracle.window_solve(o, wo, po, buffers.summary_alloc(B))
+    assert rel(wg.a["pose"], wo.a["pose"]) < 1e-9                          # (the first solves agree far below what follows)
+    pt_o, _ = truth_marginalize(wo, o)     # exact prior at the oracle's solution
+    pt_g, _ = truth_marginalize(wg, o)     # exact prior at the GPU's solution
+    o2 = abi.default_options()
+    o2.marginalization_flag = abi.MARGIN_NONE
+    E2 = est_m.Estimator(ctx=ctx, options=o2)
+
+    def cpu(c):
+        s = buffers.summary_alloc(B)
+        oracle.window_solve(o2, c, None, s)
+        return s
+
+    def gpu(c):
+        return buffers.summary_to_numpy(E2.optimization(c)).copy()
+
+    tt, stt = _chained(wo, pt_o, cpu)      # the reference: exact prior, FP64 solver
+    oo, soo = _chained(wo, po, cpu)        # the oracle end to end
+    og, sog = _chained(wo, pg, cpu)        # GPU prior, oracle solver, oracle start
+    gt, sgt = _chained(wg, pt_g, gpu)      # exact prior at the GPU's state, GPU solver
+    gg, sgg = _chained(wg, pg, gpu)        # the product end to end
+    for k in ("pose", "speedbias"):
+        d_o, d_g, d_e = rel(oo.a[k], tt.a[k]), rel(og.a[k], tt.a[k]), rel(gg.a[k], gt.a[k])
+        print(f"\n[chained vs truth {tracks} {nf}] {k}: oracle prior {d_o:.2e}  gpu prior {d_g:.2e}  gpu end to end (vs exact prior at its own state) {d_e:.2e}"
+              f"  gpu end to end vs truth chain {rel(gg.a[k], tt.a[k]):.2e}")
+        assert d_g < 1e-6, (k, d_g)                                        # north-star tolerance, no escape clause
+        assert d_g <= max(d_o, 1e-8), (k, d_g, d_o)
+        assert d_e < 1e-6, (k, d_e)
+        assert rel(gg.a[k], tt.a[k]) < 1e-6, (k, rel(gg.a[k], tt.a[k]))
+    for s in (sog, sgg, sgt):
+        assert np.array_equal(s["accept_mask"], stt["accept_mask"]) and np.array_equal(s["num_iterations"], stt["num_iterations"])
+
+
+class _Oracle:
+    def __init__(self, oracle, opt, exact_prior=False):
+        self.o, self.opt, self.exact = oracle, opt, exact_prior
+
+    def solve(self, w):
+        p, s = buffers.PriorOutArrays.alloc(w.n_windows), buffers.summary_alloc(w.n_windows)
+        self.o.window_solve(self.opt, w, p, s)
+        if self.exact:                     # the FP64 solver, the marginalization in binary128 at the state it returned
+            p, _ = truth_marginalize(w, self.opt)
+        return p, s
+
+    def roll(self, w):
+        assert self.o.slide_window(w, abi.MARGIN_OLD, True, 5.0) == 0
+
+    def new_frame(self, w):
+        self.o.triangulate(w, 5.0)
+        self.o.imu_propagate(w, np.array(list(self.opt.g)))
+
+
+class _Gpu:
+    def __init__(self, ctx, opt):
+        self.E = est_m.Estimator(ctx=ctx, options=opt)
+
+    def solve(self, w):
+        s = buffers.summary_to_numpy(self.E.optimization(w))
+        return self.E.last_marginalization_info, s
+
+    def roll(self, w):
+        self.E.slideWindow(w, abi.MARGIN_OLD, True, 5.0)
+
+    def new_frame(self, w):
+        self.E.triangulate(w, 5.0)
+        self.E.imu_propagate(w)
+
+
+def _stream(seq_id, backend, n_frames):
+    seq = synth.Sequence(seq_id)
+    w, ids = seq.first_window()
+    out = []
+    for k in range(n_frames):
+        prior, s = backend.solve(w)
+        out.append(dict(pose=w.a["pose"].copy(), speedbias=w.a["speedbias"].copy(), n_feat=int(w.a["n_feat"][0]),
+                        it=int(s["num_iterations"][0]), acc=int(s["accept_mask"][0]), term=int(s["termination"][0])))
+        backend.roll(w)
+        ids = seq.next_image(w, ids, k)
+        install_prior(w, prior)
+        backend.new_frame(w)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq_id", [0, 1])
+def test_ten_frame_stream_against_the_exact_prior_stream(ctx, oracle, seq_id):
+    """Ten images through optimization() + slideWindow(), the prior handed from frame to frame (estimator.cpp:996-1107 in a
+    loop).  Three streams: T = FP64 solver with every marginalization done in binary128 (what the reference's algorithm defines,
+    up to the solver's 1e-11), O = the FP64 oracle, G = the GPU.  At every frame the GPU is at least as close to T as the
+    oracle is, and within the north-star 1e-6 of it."""
+    n = 10
+    o = abi.default_options()
+    T = _stream(seq_id, _Oracle(oracle, o, exact_prior=True), n)
+    O = _stream(seq_id, _Oracle(oracle, o), n)
+    G = _stream(seq_id, _Gpu(ctx, o), n)
+    worst_g = worst_o = 0.0
+    for k in range(n):
+        assert G[k]["n_feat"] == T[k]["n_feat"] and G[k]["it"] == T[k]["it"] and G[k]["acc"] == T[k]["acc"] and G[k]["term"] == T[k]["term"], (k, G[k], T[k])
+        for key in ("pose", "speedbias"):
+            dg, do = rel(G[k][key], T[k][key]), rel(O[k][key], T[k][key])
+            print(f"[stream {seq_id} vs exact-prior stream] frame {k} {key}: gpu {dg:.2e}  oracle {do:.2e}  features {T[k]['n_feat']}")
+            worst_g, worst_o = max(worst_g, dg), max(worst_o, do)
+            assert dg < 1e-6 or dg <= do, (k, key, dg, do)
+    print(f"[stream {seq_id}] worst distance to the exact-prior stream over {n} frames: gpu {worst_g:.2e}  oracle {worst_o:.2e}")
+    assert worst_g <= max(worst_o, 1e-6)
