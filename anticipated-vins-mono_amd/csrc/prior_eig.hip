@@ -144,7 +144,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   for (int e = t; e < NMAX * NMAX; e += NT) A[e] = 0.0;
   if (t < NMAX) lds[P_B + t] = t < n ? gr[t] : 0.0;
   double dmine = t < n ? gJ[(size_t)t * ldj + t] : 0.0;  // threads 0..75 carry the running diagonal
-  if (t < NMAX) dgl[t] = dmine, lds[P_D0 + t] = fmax(dmine, 0.0);
+  // (the scale every diagonal entry was formed at: marginalize_kernel leaves it in the unused upper triangle)
+  if (t < NMAX) dgl[t] = dmine, lds[P_D0 + t] = t < n ? (n >= 3 ? fabs(gJ[t + 1 < n ? (size_t)t * ldj + t + 1 : (size_t)(n - 1)]) : fabs(dmine)) : 0.0;
 #pragma unroll
   for (int q = 0; q < RW; q++) {
     const int i = wv + NW * q;
@@ -399,13 +400,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int qx = 2 * lane, qy = 2 * lane + 1;
     const int ox = qx < padpos ? qx : qx - 1, oy = qy < padpos ? qy : qy - 1;
     // The clamp of marginalization_factor.cpp:284-285 (S > eps), applied as EXACT arithmetic would apply it: an eigenvalue
-    // that FP64 cannot tell from zero is zero.  A' reaches this kernel with componentwise errors of a few n u |A'_jj| (it
-    // is a difference of information matrices), so an eigenvalue S with eigenvector v carries an uncertainty of about
-    // n u v^T diag(A') v; the exact eigenvalues of the gauge directions of a window without a gauge-fixing prior are 0, in
-    // FP64 they come out as +-(1e-10 .. 1e-6), on either side of eps at random - and one that lands above eps puts
-    // (v^T b')^2 / S into |r0|^2 (measured against the binary128 statement of the reference's algorithm,
-    // tests/test_prior_truth.py: the prior's cost came out 3x too large in 1 of 6 such windows).  64 n u = 1e-12.
-    const bool kx = lX > eps && lX * lX > 1e-12 * wX, ky = lY > eps && lY * lY > 1e-12 * wY;
+    // that FP64 cannot tell from zero is zero.  A'_ij reaches this kernel with an error of about 20 u sqrt(s_i s_j), s_i the
+    // magnitude its diagonal entry was formed at (a difference of information matrices: up to 2.5e12 on the gyroscope-bias rows),
+    // so an eigenvalue S with unit eigenvector v is uncertain by up to 20 n u v^T diag(s) v.  A window without a gauge-fixing
+    // prior has 16 .. 30 EXACT zeros in A' (gauge, unconstrained biases / extrinsic); in FP64 they come out as +-1e-10 .. 1e-2,
+    // above eps at random, and one that survives puts (v^T b')^2 / S into |r0|^2 (measured against the binary128 statement of
+    // the reference's algorithm, tests/test_prior_truth.py: the prior's cost came out 3x too large in 1 of 6 such windows).
+    // The threshold errs on the side of KEEPING: clamping a genuine eigenvalue removes the only constraint a weakly observed
+    // direction has (measured: a threshold of 1e-13 v^T diag(s) v took eigenvalues of 0.02 .. 0.5 on the bias rows of a
+    // prior-less first window with it, and the stream that followed ended 0.09 away from the exact one), while a kept noise
+    // eigenvalue is what the reference's own FP64 computation leaves behind as well.  Measured on two 10-frame streams against
+    // the stream with exact (binary128) priors: 1e-15 v^T diag(s) v reproduces the exact clamp set in 12 of 12 prior-less
+    // windows but costs the streams a factor 10 - 20 (9e-6 / 2e-4 worst state distance); 1e-16 v^T diag(s) v (= u) misses one
+    // or two of the 16 .. 30 zeros in half of those windows and leaves the streams at 3.9e-7 / 1.1e-4, the values they have
+    // without any noise test.  1e-16: 2.5e-4 for a pure gyroscope-bias direction (information worth sigma = 60 rad/s), 6e-7 for
+    // an accelerometer-bias direction, 1e-9 for directions in the poses.
+    const bool kx = lX > eps && lX * lX > 1e-16 * wX, ky = lY > eps && lY * lY > 1e-16 * wY;
 #pragma unroll
     for (int r = 0; r < RW; r++) {
       if (r0 + r < n) {

@@ -3695,7 +3695,13 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         if (j > i) continue;  // the eigen-solver reads the lower triangle only (as Eigen's SelfAdjointEigenSolver does)
         double sacc = 0;
         for (int k = 0; k < 16; k++) sacc += GT[i * 16 + k] * EB[j * 16 + k];
-        oJ[(size_t)i * PO.max_prior + j] = Sget(kidx[i], kidx[j]) - sacc;
+        const double arr = Sget(kidx[i], kidx[j]);
+        oJ[(size_t)i * PO.max_prior + j] = arr - sacc;
+        // The magnitude the diagonal entry was formed at (|Arr_ii| + |(Arm Amm^+ Amr)_ii|: the bias rows of the kept
+        // speed-bias block are differences of two numbers of size 1e10 .. 1e12) rides along in the unused upper triangle,
+        // slot (i, i + 1), the last one in (0, n - 1): prior_eig_kernel's clamp measures an eigenvalue against the
+        // rounding noise of ITS variables (prior_eig.hip).
+        if (i == j && n >= 3) oJ[i + 1 < n ? (size_t)i * PO.max_prior + i + 1 : (size_t)(n - 1)] = fabs(arr) + fabs(sacc);
       }
       if (t < n) {
         double sacc = 0;
