@@ -52,6 +52,31 @@ def flop_model(n_fac, n_feat, summ):
     return float((jac_evals * per_jac + lin_solves * per_lin + it * per_cand).sum())
 
 
+def kernel_source_sha256():
+    """Hash of the sources the window kernels are built from: a committed rocprofv3 --pmc summary (profiles/*_pmc_traffic.json) carries the
+    hash it was measured on, and roofline.traffic is only reported from a summary whose hash is the current one."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("window_solve.hip", "kernels.hpp", "devmath.hpp", "Makefile"):
+        h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def committed_profile():
+    """(dict of the newest profiles/*_pmc_traffic.json, its file name, why it cannot be used or None)."""
+    pd = os.path.join(ROOT, "profiles")
+    tp = sorted(p for p in os.listdir(pd) if p.endswith("_pmc_traffic.json"))
+    if not tp:
+        return None, None, "no profiles/*_pmc_traffic.json"
+    j = json.load(open(os.path.join(pd, tp[-1])))
+    have, want = j.get("_kernel_source_sha256"), kernel_source_sha256()
+    if have != want:
+        return j, tp[-1], (f"profiles/{tp[-1]} was measured on other kernel sources (sha256 {str(have)[:12]}... vs {want[:12]}... now): "
+                           "re-run scripts/gpu_profile.sh + scripts/summarize_rocprof.py")
+    return j, tp[-1], None
+
+
 def host_cpus():
     """(threads this process may run on, description): scheduler affinity, capped by the cgroup CPU quota."""
     n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -206,6 +231,7 @@ def main():
     ap.add_argument("--fsel-problems", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fsel", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (ragged tracks, single-window latency, selector at HORIZON 13)")
     ap.add_argument("--gather", default="library", choices=["library", "torch"], help="who issues the all-gather of the final poses (N > 1)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous of the N ranks on gloo and exit, before HIP is initialised")
     args = ap.parse_args()
@@ -237,6 +263,11 @@ def main():
     base = synth.make_windows_parallel(n_distinct, first_id=rank * W, tracks=args.tracks, procs=args.gen_procs or max(1, min(64, ncpu // max(world, 1))))
     host = base if n_distinct == W else synth.tile_windows(base, W)
     t_gen = time.perf_counter() - t_gen
+    extras = world == 1 and not args.no_extras and not args.launch_check
+    sparse_base = None
+    if extras and args.tracks == "dense":
+        # the ragged-track sub-record (a quarter of the batch generated, tiled: it is a sub-record, the headline batch is all distinct)
+        sparse_base = synth.make_windows_parallel(min(W, 1024), first_id=rank * W, tracks="sparse", procs=args.gen_procs or max(1, min(64, ncpu)))
 
     import torch
 
@@ -337,14 +368,18 @@ def main():
         flops = flop_model(n_fac, n_feat, s)
         k_ms = float(np.mean(kernel_ms))
         achieved = flops / (k_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        tp = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
-        tp = os.path.join(ROOT, "profiles", tp[-1]) if tp else ""  # newest committed rocprofv3 --pmc summary
-        if os.path.exists(tp) and W == 4096 and args.tracks == "dense" and opt.marginalization_flag == abi.MARGIN_OLD:
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (scripts/gpu_profile.sh), per launch
-            tj = json.load(open(tp))["window_solve_kernel"]
+        traffic, traffic_src, mfma_util, fabric_gbs, wait_any = None, None, None, None, None
+        prof_j, prof_name, prof_err = committed_profile()  # newest committed rocprofv3 --pmc summary, if it belongs to these kernel sources
+        if prof_err:
+            traffic_src = "UNAVAILABLE: " + prof_err
+            print("[bench] roofline.traffic not reported: " + prof_err, file=sys.stderr)
+        elif W == 4096 and args.tracks == "dense" and opt.marginalization_flag == abi.MARGIN_OLD:
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* passes of this same command (scripts/gpu_profile.sh), per launch
+            tj = prof_j["window_solve_kernel"]
             traffic = tj["traffic_bytes_per_launch"]
-            traffic_src = f"profiles/{os.path.basename(tp)}: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes"
+            mfma_util, fabric_gbs, wait_any = tj.get("mfma_util"), tj.get("fabric_GBs"), tj.get("wait_any_frac")
+            traffic_src = (f"profiles/{prof_name}: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / "
+                           "(dispatch ns x 2.4 GHz x 1024 SIMDs); measured on the kernel sources this run was built from (sha256 checked)")
         alg_bytes = W * (44.0 * n_fac + 23.0e3 + 45.6e3 + 3.0e3 + 2.6e3)  # ~140 KB / solve at K=1500
         peak_meas = None
         pm = os.path.join(ROOT, "profiles", "r02_fp64_peak.json")
@@ -388,6 +423,9 @@ def main():
                 "frac": achieved / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "mfma_util": mfma_util,          # rocprof: MFMA pipe busy / SIMD-cycles (FP64 MFMA and FP64 VALU share the pipe on gfx950)
+                "fabric_GBs": fabric_gbs,        # rocprof: L2 <-> fabric bytes per second (Infinity Cache hits included), peak ~8 TB/s HBM
+                "wait_any_frac": wait_any,       # rocprof: SQ_WAIT_ANY / SQ_WAVE_CYCLES
                 "kernel": "window_solve_kernel",
                 "kernel_ms": k_ms,
                 "flops_per_launch": flops,
@@ -396,7 +434,58 @@ def main():
                                   "peak_GBs": HBM_PEAK_GBS},
             },
             "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
+            # how far "parity" is pinned: the reference ships no tests / vectors and cannot be built here
+            "parity_pin": "unpinned at the Ceres / Eigen boundary (no reference vectors exist): the oracle is pinned by builder-written numpy "
+                          "restatements (tests/golden/), the marginalization prior by a binary128 arbiter (oracle/avm_truth.cpp, tests/test_prior_truth.py)",
         }
+
+    # ---- sub-records the headline line does not carry: ragged tracks, one-window latency
+    if extras and rank == 0:
+        if sparse_base is not None:
+            sh = synth.tile_windows(sparse_base, W)
+            sw = sh.to_device(dev)
+            sp = {k: sw.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
+            s_ms = {k: [] for k in ("preint", "window_solve", "marginalize", "prior_eig")}
+
+            def sstep():
+                for k, v in sp.items():
+                    sw.a[k].copy_(v)
+                return E.optimization(sw, want_summary=True, prior_out=prior_slots)
+
+            sstep()
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for _ in range(3):
+                ss = sstep()
+                for k in s_ms:
+                    s_ms[k].append(ctx.kernel_ms(k))
+            torch.cuda.synchronize()
+            tsp = (time.perf_counter() - ts0) / 3
+            s_np = buffers.summary_to_numpy(ss)
+            result["sparse_tracks"] = {
+                "workload": f"{W} windows, 150 features with ragged tracks (start ~ U{{0..7}}, length ~ U{{2..}}), "
+                            f"{float((sh.a['feat_nobs'] - 1).clip(min=0).sum(1).mean()):.0f} projection factors per window; "
+                            f"{sparse_base.n_windows} distinct windows tiled",
+                "value": W / tsp, "unit": "solves/s", "ms_per_step": tsp * 1e3, "kernel_ms": {k: float(np.mean(v)) for k, v in s_ms.items()},
+                "mean_iterations": float(s_np["num_iterations"].mean()),
+            }
+            del sw, sp
+        # one window per call, device-resident: the reference's own use (one optimization() per image)
+        one = host.slice(0, 1).copy().to_device(dev)
+        one0 = {k: one.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
+        po1 = buffers.PriorOutArrays.alloc(1, one.dims["max_prior"], one.dims["max_pblk"], dev) if marg else None
+        lat = []
+        for k in range(12):
+            for kk, v in one0.items():
+                one.a[kk].copy_(v)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            E.optimization(one, want_summary=False, prior_out=po1)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        result["latency_single_window_ms"] = {"value": statistics.median(lat[2:]) * 1e3, "what": "wall time of one avm_window_solve_batch call on one "
+                                              "dense window (pre-integration, solve, marginalization, prior), device-resident buffers, median of 10",
+                                              "kernel_ms": {k: ctx.kernel_ms(k) for k in ("preint", "window_solve", "marginalize", "prior_eig")}}
 
     # ---- feature selector: ms/frame (batch throughput), single-frame latency, FLOP/s of the scoring loop
     fsel_host = None
@@ -443,7 +532,28 @@ def main():
                     "kernel_ms": k_ms_f, "flops_per_launch": fl, "candidate_evaluations": evals,
                     "reference_flops_unhoisted": evals * ((9.0 * (fsel_host.dims["horizon"] + 1)) ** 3 / 3.0),
                 },
+                "fallback_stats": ctx.fsel_fallback_stats(),
             }
+            if extras:
+                # the reference's compiled HORIZON (utility/state_defs.h:8): 13
+                f13 = synth.make_fsel(P, first_id=rank * P, horizon=13).to_device(dev)
+                f13_1 = synth.make_fsel(1, first_id=rank * P, horizon=13).to_device(dev)
+                FS.select_batch(f13)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    FS.select_batch(f13)
+                torch.cuda.synchronize()
+                tb13 = (time.perf_counter() - t1) / reps
+                FS.select_batch(f13_1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    FS.select_batch(f13_1)
+                torch.cuda.synchronize()
+                tl13 = (time.perf_counter() - t1) / reps
+                result["feature_select"]["horizon_13"] = {"workload": "500 candidates -> 150 selected, HORIZON 13 (the reference's compiled value, utility/state_defs.h:8)",
+                                                          "ms_per_frame_batched": tb13 / P * 1e3, "batch": P, "ms_per_frame_single": tl13 * 1e3}
 
     # ---- CPU baseline (oracle = port of the reference algorithm), rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -478,6 +588,11 @@ def main():
             "threads_scaling": scaling,
             "build": build,
             "cpu": cpu_info,
+            # what a whole socket of this host would do, ASSUMING the linear thread scaling measured above continues
+            # (one independent single-threaded solve per core, no shared state): an extrapolation, not a measurement
+            "socket_extrapolated": {"value": r1 * 64, "unit": "solves/s", "cores": 64,
+                                    "how": f"value_1_core x 64 physical cores of one {cpu_info['model']} socket; measured up to {ncpu} threads",
+                                    "gpu_over_cpu_socket": value / (r1 * 64)},
         }
         result["gpu_over_cpu"] = value / rall
         result["gpu_over_cpu_1_core"] = value / r1

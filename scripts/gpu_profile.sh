@@ -5,6 +5,8 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT
+# what the numbers belong to: bench.py refuses a committed traffic figure whose kernel source has changed since
+python -c "import bench; print(bench.kernel_source_sha256())" > $OUT/kernel_source_sha256.txt
 # in-process input generation (forked workers under the profiler's signal handlers can hang) and, for the counter passes,
 # only the window kernels (the selector's thousands of small launches serialize under --pmc)
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fsel-problems 4 --gen-procs 1 --distinct 512"

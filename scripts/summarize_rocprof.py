@@ -65,6 +65,26 @@ for kn in fetch:
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 reports half of wide coalesced reads); WRITE_SIZE as reported; "
                 "counts L2<->fabric requests incl. Infinity-Cache hits",
     }
+sq = {}
+for cn in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA"):
+    db = os.path.join(src, "pmc_sq", "run_results.db")
+    if os.path.exists(db):
+        for kn, v, d in q(db, f"select kernel_name,avg(value),avg(duration) from counters_collection where counter_name='{cn}' group by kernel_name"):
+            short = kn.split("(")[0].split("::")[-1]
+            if short.endswith("_kernel"):
+                sq.setdefault(short, {})[cn] = v
+                sq[short]["dispatch_ns"] = d
+for short, c in sq.items():
+    if short in traffic and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        # MI355X: 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md); SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs
+        simd_cycles = c["dispatch_ns"] * 2.4 * 256 * 4
+        traffic[short]["sq"] = c
+        traffic[short]["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+        traffic[short]["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0)
+        traffic[short]["fabric_GBs"] = traffic[short]["traffic_bytes_per_launch"] / c["dispatch_ns"]
+hp = os.path.join(src, "kernel_source_sha256.txt")
+if traffic and os.path.exists(hp):
+    traffic["_kernel_source_sha256"] = open(hp).read().strip()
 if traffic:
     traffic["_command"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fsel-problems 4  (4096 windows, dense tracks, MARGIN_OLD)"
     json.dump(traffic, open(dst + "_pmc_traffic.json", "w"), indent=1)
