@@ -226,50 +226,70 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   // the two norms bounded from above by one triangular solve each with the comparison matrix M(G) (|diagonal|, -|off-diagonal|):
   // |G^-1| e <= M(G)^-1 e elementwise (Higham, Accuracy and Stability of Numerical Algorithms, section 8.2).  Typical windows with a
   // prior have lambda_min ~ 1e2 against the 1e-5 asked for.  Wavefront 0 solves for r0, wavefronts 1 and 2 for the two bounds.
+  //
+  // RANK-DEFICIENT A' (round 3).  When the factorization stopped at rank r < n - the window has directions nothing constrains
+  // (exact zeros of A': with ragged tracks two thirds of the windows have two or four of them, tests/test_prior_truth.py) - the
+  // same holds for the n x r factor G_r = [L11; L21] (pivot rows first): A' = G_r G_r^T up to the dropped remainder, which
+  // the eigen path drops as well (its input IS this factor), J = G_r^T with n - r zero rows is a square root of the clamped
+  // matrix, r0 = L11^-1 b'_pivots the matching residual, and no eigenvalue of the kept part is near the clamp when
+  //   lambda_min+(G_r G_r^T) = sigma_min(G_r)^2 >= sigma_min(L11)^2 = 1 / |L11^-1|_2^2 > threshold,
+  // bounded through the comparison matrix of L11 as before.  The threshold covers the eps clamp and the noise test of the
+  // eigen path (below): max(1000 eps, 1e-16 max_i s_i).
   double* verdict = lds + P_PIV + NMAX / 2;
-  if (!literal && rank == n) {
+  if (!literal && rank >= 1) {
+    const int nr = rank;
     // entries of G in pivot order: G[p_j][i] = g_{p_i}[p_j] = A[p_i * LD + p_j], zero for i > j (p_j was eliminated before p_i)
-    if (wv < 3) {
+    {
       const int i0 = lane, i1 = lane + 64;  // this lane's share of the dot products: pivots i0 and i1
-      const int pi0 = piv[min(i0, n - 1)], pi1 = piv[min(i1, n - 1)];
+      const int pi0 = piv[min(i0, nr - 1)], pi1 = piv[min(i1, nr - 1)];
       double y0 = 0.0, y1 = 0.0;  // solution entries of pivots i0, i1 (kept by their lanes)
-      if (wv < 2) {
-        // forward: y_j = (rhs_j -+ sum_{i < j} G[p_j][i] y_i) / G[p_j][j]   (wave 0: real entries and rhs = b'; wave 1: comparison matrix, rhs = 1)
-        for (int j = 0; j < n; j++) {
+      if (wv != 2) {
+        // forward: y_j = (rhs_j -+ sum_{i < j} G[p_j][i] y_i) / G[p_j][j]
+        //   wave 0: real entries, rhs = b'                               -> r0
+        //   wave 1: comparison matrix, rhs = 1                           -> |L11^-1|_inf
+        //   wave 3: comparison matrix of the ROW-SCALED factor diag(s)^-1/2 L11, i.e. rhs = sqrt(s_pj) -> |(diag(s)^-1/2 L11)^-1|_inf
+        for (int j = 0; j < nr; j++) {
           const int pj = piv[j];
           const double a0 = i0 < j ? A[pi0 * LD + pj] : 0.0, a1 = i1 < j ? A[pi1 * LD + pj] : 0.0;
           const double sacc = wv == 0 ? wave_sum(a0 * y0 + a1 * y1) : wave_sum(fabs(a0) * y0 + fabs(a1) * y1);
           const double d = A[pj * LD + pj];
-          const double yj = wv == 0 ? (lds[P_B + pj] - sacc) / d : (1.0 + sacc) / fabs(d);
+          const double rhs = wv == 1 ? 1.0 : sqrt(lds[P_D0 + pj]);
+          const double yj = wv == 0 ? (lds[P_B + pj] - sacc) / d : (rhs + sacc) / fabs(d);
           y0 = i0 == j ? yj : y0, y1 = i1 == j ? yj : y1;
         }
         if (wv == 0) {
-          if (i0 < n) gr[i0] = y0;
+          if (i0 < n) gr[i0] = y0;  // (zero beyond the rank: the rows of J there are zero)
           if (i1 < n) gr[i1] = y1;
         } else {
-          const double m = wave_max_pos(fmax(i0 < n ? y0 : 0.0, i1 < n ? y1 : 0.0));  // >= |G^-1|_inf
-          if (lane == 0) verdict[0] = m;
+          const double m = wave_max_pos(fmax(i0 < nr ? y0 : 0.0, i1 < nr ? y1 : 0.0));
+          if (lane == 0) verdict[wv == 1 ? 0 : 2] = m;
         }
       } else {
         // backward with the transposed comparison matrix: w_j = (1 + sum_{i > j} |G[p_i][j]| w_i) / |G[p_j][j]|, G[p_i][j] = A[p_j * LD + p_i]
-        for (int j = n - 1; j >= 0; j--) {
+        for (int j = nr - 1; j >= 0; j--) {
           const int pj = piv[j];
-          const double a0 = (i0 > j && i0 < n) ? fabs(A[pj * LD + pi0]) : 0.0, a1 = (i1 > j && i1 < n) ? fabs(A[pj * LD + pi1]) : 0.0;
+          const double a0 = (i0 > j && i0 < nr) ? fabs(A[pj * LD + pi0]) : 0.0, a1 = (i1 > j && i1 < nr) ? fabs(A[pj * LD + pi1]) : 0.0;
           const double sacc = wave_sum(a0 * y0 + a1 * y1);
           const double yj = (1.0 + sacc) / fabs(A[pj * LD + pj]);
           y0 = i0 == j ? yj : y0, y1 = i1 == j ? yj : y1;
         }
-        const double m = wave_max_pos(fmax(i0 < n ? y0 : 0.0, i1 < n ? y1 : 0.0));  // >= |G^-T|_inf = |G^-1|_1
-        if (lane == 0) verdict[1] = m;
+        const double m = wave_max_pos(fmax(i0 < nr ? y0 : 0.0, i1 < nr ? y1 : 0.0));  // >= |L11^-T|_inf = |L11^-1|_1
+        // (the transposed solve of the row-scaled factor is this one with its solution weighted by sqrt(s_p))
+        const double ms = wave_max_pos(fmax(i0 < nr ? y0 * sqrt(lds[P_D0 + pi0]) : 0.0, i1 < nr ? y1 * sqrt(lds[P_D0 + pi1]) : 0.0));
+        if (lane == 0) verdict[1] = m, verdict[3] = ms;
       }
     }
     __syncthreads();
-    const double inv_norm2_bound = verdict[0] * verdict[1];  // >= |G^-1|_2^2 = 1 / lambda_min(A')
-    if (inv_norm2_bound * (1000.0 * eps) < 1.0) {          // (NaN compares false)
-      // linearized_jacobians: row j = g_{p_j}^T
+    // 1 / (v0 v1) <= lambda_min+(A'): the eps clamp does not act on the kept part (factor 1000 to spare).
+    // 1 / (v2 v3) <= lambda_min of B = diag(s)^-1/2 L11 L11^T diag(s)^-1/2, and every eigenpair (S, v) of the kept part has
+    // S / v^T diag(s) v >= lambda_min(B): the noise test of the eigen path (S > 1e-16 v^T diag(s) v) passes for all of them.  The
+    // comparison-matrix bound is rigorous but 40 - 3400 x pessimistic, and the variables formed by cancellation (gyroscope bias:
+    // 1e2 left of 5e14) put lambda_min(B) at 1e-13 .. 1e-10, so this test gets a factor 4, not 1000.
+    if (verdict[0] * verdict[1] * (1000.0 * eps) < 1.0 && verdict[2] * verdict[3] * 4e-16 < 1.0) {  // (NaN compares false)
+      // linearized_jacobians: row j = g_{p_j}^T, zero rows beyond the rank
       for (int e = t; e < n * n; e += NT) {
         const int j = e / n, c = e - j * n;
-        gJ[(size_t)j * ldj + c] = A[piv[j] * LD + c];
+        gJ[(size_t)j * ldj + c] = j < nr ? A[piv[min(j, nr - 1)] * LD + c] : 0.0;
       }
       if (prof && t == 0) atomicAdd(reinterpret_cast<unsigned long long*>(prof + 25), (unsigned long long)((long long)__builtin_readcyclecounter() - t_start));
       return;
