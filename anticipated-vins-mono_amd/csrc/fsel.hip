@@ -1102,7 +1102,12 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
           for (;;) {
             fsel_rec_load2<true>(pf, pu, &rf, &ru);
             if (__all(cl[q] < 0 || (rf.tag == tag0 + k && ru.tag == tag0 + k))) break;
-            if (__hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > FS_SPIN_TICKS) {
+            // A record of THIS frame that already carries a later round's tag: its writer is two rounds ahead and has overwritten the
+            // value this workgroup still needed.  That can only happen to a workgroup none of whose own candidates is alive (nobody
+            // waits for its records, so nobody is held back by it); the value is gone - leave at once instead of spinning into the
+            // time-out (the host runs the call again one mode down, avm_fsel_fallback_stats counts it).
+            const bool overtaken = cl[q] >= 0 && (((rf.tag >> 12) == seq && rf.tag > tag0 + k) || ((ru.tag >> 12) == seq && ru.tag > tag0 + k));
+            if (__any(overtaken) || __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > FS_SPIN_TICKS) {
               give_up();
               s_fail = 1;
               break;
