@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--no-fsel", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (ragged tracks, single-window latency, selector at HORIZON 13)")
     ap.add_argument("--gather", default="library", choices=["library", "torch"], help="who issues the all-gather of the final poses (N > 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1.  gloo: the ranks may share a "
+                    "device (LOCAL_RANK modulo the visible devices) and the poses are gathered through the host - for exercising the N > 1 path "
+                    "end to end on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device); never the configuration to quote")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous of the N ranks on gloo and exit, before HIP is initialised")
     args = ap.parse_args()
 
@@ -276,7 +279,12 @@ def main():
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            if torch.cuda.is_available():
+                local_rank = local_rank % torch.cuda.device_count()
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -296,7 +304,8 @@ def main():
     win = host.to_device(dev)
     pristine = {k: win.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
     gathered = torch.empty((world * W, 11, 7), dtype=torch.float64, device=dev) if world > 1 else None
-    use_lib_gather = world > 1 and args.gather == "library" and hasattr(ctx, "gather_states")
+    use_lib_gather = world > 1 and args.gather == "library" and hasattr(ctx, "gather_states") and args.backend == "nccl"
+    gloo = world > 1 and args.backend == "gloo"
     if use_lib_gather:
         # the library's own communicator (raw rccl.h, avm_comm_*): the 128-byte unique id travels over torch.distributed
         uid = torch.zeros(128, dtype=torch.uint8)
@@ -326,6 +335,10 @@ def main():
         if world > 1:
             if use_lib_gather:
                 ctx.gather_states(win.a["pose"], gathered, W * 77)
+            elif gloo:  # (through the host: gloo has no device collectives)
+                hg = torch.empty(world * W * 77, dtype=torch.float64)
+                dist.all_gather_into_tensor(hg, win.a["pose"].cpu().reshape(-1))
+                gathered.copy_(hg.view(world * W, 11, 7))
             else:
                 dist.all_gather_into_tensor(gathered, win.a["pose"])
         return summ
@@ -349,16 +362,17 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = world * W * args.steps / elapsed
     per_rank_solve_ms = [float(np.mean(kernel_ms))]
     per_rank_gather_ms = None
     if world > 1:  # every rank's own solve-kernel time (HIP events on its ctx stream) and its last gather, for the scaling record
-        pr = torch.tensor([float(np.mean(kernel_ms)), ctx.kernel_ms("gather_states") if use_lib_gather else -1.0], dtype=torch.float64, device=dev)
-        allr = torch.empty((world, 2), dtype=torch.float64, device=dev)
+        pr = torch.tensor([float(np.mean(kernel_ms)), ctx.kernel_ms("gather_states") if use_lib_gather else -1.0], dtype=torch.float64, device="cpu" if gloo else dev)
+        allr = torch.empty(world * 2, dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_gather_into_tensor(allr, pr)
+        allr = allr.view(world, 2)
         per_rank_solve_ms = [float(x) for x in allr[:, 0].cpu()]
         per_rank_gather_ms = [float(x) for x in allr[:, 1].cpu()] if use_lib_gather else None
 
@@ -408,7 +422,8 @@ def main():
                 "mean_iterations": float(s["num_iterations"].mean()),
                 "mean_successful_steps": float(s["num_successful"].mean()),
                 "iterations_histogram": {int(k): int(v) for k, v in zip(*np.unique(s["num_iterations"], return_counts=True))},
-                "pose_gather": (("avm_gather_states (library, raw rccl.h)" if use_lib_gather else "torch.distributed all_gather") if world > 1 else "none (1 GPU)"),
+                "pose_gather": (("avm_gather_states (library, raw rccl.h)" if use_lib_gather else ("torch.distributed all_gather through the host (gloo; ranks may share a device: "
+                                "NOT a scaling measurement)" if gloo else "torch.distributed all_gather")) if world > 1 else "none (1 GPU)"),
                 "per_rank_window_solve_kernel_ms": per_rank_solve_ms,
                 "per_rank_gather_ms": per_rank_gather_ms,
                 "launch": ("self-launched (bench.py spawned its ranks)" if os.environ.get("AVM_BENCH_SELF_LAUNCHED") else

@@ -93,3 +93,17 @@ def test_self_launched_two_gpu_bench_line():
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["pose_gather"].startswith("avm_gather_states")
     assert len(j["config"]["per_rank_window_solve_kernel_ms"]) == 2 and j["config"]["launch"].startswith("self-launched")
+
+
+@pytest.mark.gpu
+def test_self_launched_two_rank_bench_end_to_end_on_whatever_devices_there_are():
+    """The whole N > 1 path of bench.py on real HIP work - launcher, per-rank window blocks, solve, the gather, max-over-ranks timing,
+    rank 0's JSON line - with the gloo backend, which lets two ranks share the one GPU of the test box (RCCL refuses that; the library's
+    own gather is covered by test_rccl.py and, on two devices, by the tests above).  Not a scaling measurement."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "128", "--no-fsel", "--backend", "gloo",
+                        "--gen-procs", "1"], env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["windows_per_gpu"] == 128 and j["value"] > 0
+    assert "gloo" in j["config"]["pose_gather"] and len(j["config"]["per_rank_window_solve_kernel_ms"]) == 2
+    assert j["config"]["launch"].startswith("self-launched") and "cpu_baseline" not in j

@@ -90,6 +90,58 @@ def test_which_eigenvalues_the_clamp_takes_is_rounding_dependent_in_fp64(oracle)
 FLOOR = dict(H_rel=1e-6, H_scaled=1e-5, g_scaled=1e-9, cost_rel=1e-6)      # below these the comparison is moot
 
 
+def _zero_baseline_window():
+    """Windows whose joint Amm (pose 0, speed-bias 0 AND the inverse depths of the features that start in frame 0) is rank deficient:
+    frame 1 has exactly frame 0's pose and a few start-0 features are seen in frames 0 and 1 only - no baseline, so the depth has
+    no influence on the residual (the point moves along its own ray): E^T E = 0 for them, exact zero eigenvalues of Amm."""
+    w = synth.make_windows(3, first_id=900, tracks="sparse", n_feat=60, max_feat=150)
+    for b in range(3):
+        w.a["pose"][b, 1] = w.a["pose"][b, 0]            # (the same camera centre needs the same attitude too: tic != 0)
+        n = int(w.a["n_feat"][b])
+        z = [e for e in range(n) if w.a["feat_start"][b, e] == 0][:3]
+        assert len(z) == 3
+        for e in z:
+            w.a["feat_nobs"][b, e] = 2
+    return w
+
+
+def test_rank_deficient_joint_amm_oracle_vs_truth(oracle):
+    """a deterministic case where the 1e-8 clamp of marginalization_factor.cpp:272 acts on the DROPPED side (feature block
+    included).  The exact computation finds the zero eigenvalues as exact zeros; the FP64 oracle's joint eigen-decomposition clamps them too
+    (they come out as +-1e-4 around 0, mostly below 1e-8 only by luck of the sign) and lands within its usual distance of the truth."""
+    o = abi.default_options()
+    w = _zero_baseline_window()
+    po, at = marginalize_at(w, o)
+    _, diag = truth_marginalize(at, o)
+    for i in range(3):
+        nz = int((diag[i]["ev_mm"] <= 1e-8).sum())   # (the three features above and every other two-view track between frames 0 and 1)
+        assert nz >= 3 and np.abs(diag[i]["ev_mm"][:nz]).max() < 1e-12 and diag[i]["ev_mm"][nz] > 1e-3   # exact zeros, resolved as such
+        d = distance_to_truth(po, diag, i)
+        print(f"\n[rank-deficient Amm] window {i}: oracle - truth {_fmt(d)}")
+        assert d["H_rel"] < 1e-3 and d["g_scaled"] < 1e-3, d
+
+
+@pytest.mark.gpu
+def test_rank_deficient_joint_amm_gpu_vs_truth(ctx, oracle):
+    """The GPU eliminates the inverse depths as scalar pivots (their block of Amm is diagonal) with the same clamp, then the 15 x 15 block:
+    on a rank-deficient joint Amm that is the joint pseudo-inverse of the reference - asserted against the exact result at a FIXED
+    tolerance, and against the FP64 oracle's distance."""
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    w = _zero_baseline_window()
+    po, at_o = marginalize_at(w, o)
+    pg, at_g = marginalize_at(w, o, estimator=E)
+    _, diag_o = truth_marginalize(at_o, o)
+    _, diag_g = truth_marginalize(at_g, o)
+    for i in range(3):
+        assert int((diag_g[i]["ev_mm"] <= 1e-8).sum()) >= 3
+        do, dg = distance_to_truth(po, diag_o, i), distance_to_truth(pg, diag_g, i)
+        print(f"\n[rank-deficient Amm] window {i}: oracle {_fmt(do)} | gpu {_fmt(dg)}")
+        assert dg["H_rel"] < 5e-6 and dg["H_scaled"] < 1e-5 and dg["g_scaled"] < 1e-8 and dg["cost_rel"] < 1e-6, dg   # (measured 1.2e-6 / 1.6e-6 / 1.4e-9 / 8.6e-9)
+        for k in METRICS:
+            assert dg[k] <= max(do[k], FLOOR[k]), (i, k, dg[k], do[k])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tracks,nf", [("sparse", 60), ("dense", 150), ("sparse", 150)])
 def test_gpu_prior_is_closer_to_the_truth_than_the_fp64_oracle(ctx, oracle, tracks, nf):
