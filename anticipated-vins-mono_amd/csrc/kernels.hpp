@@ -43,10 +43,10 @@ struct PreintArgs {
 // per-slot global scratch layout (doubles), one slot per resident workgroup (stays L2 resident)
 // (one layout for both builds of the solve kernel and the marginalization kernel: the slots are shared)
 struct Scratch {
-  static constexpr size_t PF = 0;                               // per-factor products: [14..15 quantities][frames][152] feature-major (solve), [15][MAXOBS] (marginalization)
+  static constexpr size_t PF = 0;                               // per-factor products, feature-major: [14..15 quantities][frames][152] (solve), [8 + 7][11][152] (marginalization)
   static constexpr size_t PART = PF + 17 * (size_t)MAXOBS;       // per (frame b, start a) partial blocks: [12][11][69] + [12][35]
   static constexpr size_t IJRAW = PART + 9600;                  // [10][15][31] IMU residual + Jacobian before sqrt_info
-  static constexpr size_t W = IJRAW + 4656;                     // E^T F: Wt[80][152] (solve), [MAXE][80] (marginalization)
+  static constexpr size_t W = IJRAW + 4656;                     // E^T F, feature-major: Wt[80][152] (solve), Wt[73][152] (marginalization)
   static constexpr size_t HP = W + (size_t)80 * 152;            // [MAXPRIOR][MAXPRIOR] J0^T J0
   static constexpr size_t TOTAL = HP + (size_t)MAXPRIOR * MAXPRIOR;
 };

@@ -2946,21 +2946,37 @@ AVM_DEV void marg_schur_macro_tile(int nf0) {
   d4 D[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
   for (int e0 = 0; e0 < nf0; e0 += 4 * KB) {
     double vr[2][KB], vc[2][KB], fe[KB], xe[KB];
+    // (the k index is a summation index: lane group lk takes the 8 consecutive features e0 + 8 lk .. + 7 = 64 contiguous bytes of a
+    //  column of Wt, as in schur_macro_tile; rows clamped, masked afterwards; the features beyond nf0 read stale but finite entries of
+    //  the region - WLE leaves room for the 8-feature granularity - and are masked out by `on`)
+#pragma unroll
+    for (int a = 0; a < NR; a++) {
+      gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)min(16 * RB[a] + li, NW - 1) * WLE + e0 + 8 * lk);
+#pragma unroll
+      for (int m2 = 0; m2 < KB / 2; m2++) {
+        const dv2 v = src[m2];
+        vr[a][2 * m2] = v.x, vr[a][2 * m2 + 1] = v.y;
+      }
+    }
+    if (!SAME) {
+#pragma unroll
+      for (int b = 0; b < NC; b++) {
+        gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)min(16 * CB[b] + li, NW - 1) * WLE + e0 + 8 * lk);
+#pragma unroll
+        for (int m2 = 0; m2 < KB / 2; m2++) {
+          const dv2 v = src[m2];
+          vc[b][2 * m2] = v.x, vc[b][2 * m2 + 1] = v.y;
+        }
+      }
+    }
 #pragma unroll
     for (int m = 0; m < KB; m++) {
-      const int e = e0 + 4 * m + lk, ec = min(e, nf0 - 1);
-      gcdouble* We = W + (size_t)ec * MWS;
-#pragma unroll
-      for (int a = 0; a < NR; a++) vr[a][m] = We[min(16 * RB[a] + li, NW - 1)];
-      if (!SAME) {
-#pragma unroll
-        for (int b = 0; b < NC; b++) vc[b][m] = We[min(16 * CB[b] + li, NW - 1)];
-      }
+      const int ec = min(e0 + 8 * lk + m, nf0 - 1);
       fe[m] = lds[L_HEE + ec], xe[m] = lds[L_HEE + ec] * lds[M_GE + ec];
     }
 #pragma unroll
     for (int m = 0; m < KB; m++) {
-      const bool on = e0 + 4 * m + lk < nf0;
+      const bool on = e0 + 8 * lk + m < nf0;
       double aop[2], bop[2];
 #pragma unroll
       for (int a = 0; a < NR; a++) {
@@ -3012,9 +3028,12 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
   Frames fr{lds + L_FR, lds + L_FR + 99};
   const double* xs = lds + L_X;
   const double sqi = o.focal_length / 1.5;
-  double* W = c.sc + Scratch::W;       // [MAXE][MWS] here
-  double* PF = c.sc + Scratch::PF;     // [8][MAXOBS] Ji^T Je (6), Je^T Je, Je^T r per observation slot
-  double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;  // [7][MAXOBS] Jex^T Je (6), Jtd^T Je
+  // FEATURE-MAJOR like the solve's slot (round 3): the lanes of a chunk are consecutive features of one frame, so W / PF / PF2 are
+  // written as whole cache lines (they were [feature][column] and [quantity][observation slot]: 8-byte stores 640 and 88 bytes
+  // apart, 80 K of this phase's 181 K cycles per window)
+  double* W = c.sc + Scratch::W;       // Wt[MNW][WLE]: E^T F, column-major over the features
+  double* PF = c.sc + Scratch::PF;     // [8][NFR][WLE] Ji^T Je (6), Je^T Je, Je^T r of the factor (feature e, frame b)
+  double* PF2 = c.sc + Scratch::PF + 8 * (size_t)NFR * WLE;  // [7][NFR][WLE] Jex^T Je (6), Jtd^T Je
   const double td = lds[L_RIC + 19];   // para_Td (0 unless estimate_td)
   d4 D00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, D11 = {0, 0, 0, 0}, E00 = {0, 0, 0, 0}, E10 = {0, 0, 0, 0}, E11 = {0, 0, 0, 0};
   const int drow = lane >> 4, dcol = lane & 15;
@@ -3066,13 +3085,13 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
       if (!c.est_td) Jt[0] = Jt[1] = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; k++) {
-        W[(size_t)e * MWS + 6 * b + k] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
-        PF[k * MAXOBS + s] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
-        PF2[k * MAXOBS + s] = Jx[k] * Je[0] + Jx[6 + k] * Je[1];
+        W[(size_t)(6 * b + k) * WLE + e] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
+        PF[(size_t)(k * NFR + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+        PF2[(size_t)(k * NFR + b) * WLE + e] = Jx[k] * Je[0] + Jx[6 + k] * Je[1];
       }
-      PF[6 * MAXOBS + s] = Je[0] * Je[0] + Je[1] * Je[1];
-      PF[7 * MAXOBS + s] = Je[0] * r[0] + Je[1] * r[1];
-      PF2[6 * MAXOBS + s] = Jt[0] * Je[0] + Jt[1] * Je[1];
+      PF[(size_t)(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
+      PF[(size_t)(7 * NFR + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
+      PF2[(size_t)(6 * NFR + b) * WLE + e] = Jt[0] * Je[0] + Jt[1] * Je[1];
     }
     // staged column-major like the solve kernel's frame tasks (Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18): one 16-byte store
     // per column, contiguous across the lanes; inactive lanes stage zeros, so no row needs masking.  The tile holds half
@@ -3460,7 +3479,8 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     {
       double* W = c.sc + Scratch::W;
       const double* PF = c.sc + Scratch::PF;
-      const double* PF2 = c.sc + Scratch::PF + 8 * (size_t)MAXOBS;
+      const double* PF2 = c.sc + Scratch::PF + 8 * (size_t)NFR * WLE;
+      // (the factor of feature e observed in frame k - these features start in frame 0 - sits at [quantity][k][e])
       // the two heavy items of a feature (f == 0: its own pose block, hee, g_e;  f == 11: the ex_pose / td columns) are dealt
       // densely to the threads; the structural zeros of the frames that do not observe it follow in a loop of their own
       for (int idx = t; idx < nf0 * 2; idx += NT) {
@@ -3474,21 +3494,21 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
 #pragma unroll
           for (int k = 1; k < NFR; k++)
 #pragma unroll
-            for (int q = 0; q < 7; q++) pv[q][k - 1] = P[min(q, f == 0 ? 5 : 6) * MAXOBS + s0 + min(k, max(no - 1, 0))];
+            for (int q = 0; q < 7; q++) pv[q][k - 1] = P[(size_t)(min(q, f == 0 ? 5 : 6) * NFR + min(k, max(no - 1, 0))) * WLE + e];
           double sacc[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int k = 1; k < NFR; k++)
 #pragma unroll
             for (int q = 0; q < 7; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
 #pragma unroll
-          for (int q = 0; q < 6; q++) W[(size_t)e * MWS + 6 * f + q] = sacc[q];
-          if (f == 11) W[(size_t)e * MWS + 72] = sacc[6];
+          for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = sacc[q];
+          if (f == 11) W[(size_t)72 * WLE + e] = sacc[6];
           if (f == 0) {
             double hv[2][NFR - 1];
 #pragma unroll
             for (int k = 1; k < NFR; k++) {
-              const int kk = s0 + min(k, max(no - 1, 0));
-              hv[0][k - 1] = PF[6 * MAXOBS + kk], hv[1][k - 1] = PF[7 * MAXOBS + kk];
+              const int kk = min(k, max(no - 1, 0));
+              hv[0][k - 1] = PF[(size_t)(6 * NFR + kk) * WLE + e], hv[1][k - 1] = PF[(size_t)(7 * NFR + kk) * WLE + e];
             }
             double he = 0, ge = 0;
 #pragma unroll
@@ -3502,7 +3522,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         const int e = idx / (NFR - 1), f = 1 + idx % (NFR - 1);
         if (f >= ids[I_FNOBS + e]) {
 #pragma unroll
-          for (int q = 0; q < 6; q++) W[(size_t)e * MWS + 6 * f + q] = 0.0;
+          for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = 0.0;
         }
       }
     }
