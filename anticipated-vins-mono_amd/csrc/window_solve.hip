@@ -3697,7 +3697,10 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       }
       __syncthreads();
     }
-    double* GT = c.sc + Scratch::W;   // T = Arm Amm^+ : n x 16, in the scratch slot
+    // T = Arm Amm^+ : n x 16, in the LDS range of the solve's gradient / scaling vectors (unused here; it was in the scratch slot:
+    // every entry of A' then waited for 16 trips to its memory)
+    static_assert(MAXKEEP * 16 <= L_X - L_G, "T fits the dead vectors");
+    double* GT = lds + L_G;
     for (int idx = t; idx < n * 16; idx += NT) {
       const int i = idx / 16, j = idx % 16;
       double sacc = 0;
