@@ -107,3 +107,17 @@ def test_self_launched_two_rank_bench_end_to_end_on_whatever_devices_there_are()
     assert j["n_gpus"] == 2 and j["config"]["windows_per_gpu"] == 128 and j["value"] > 0
     assert "gloo" in j["config"]["pose_gather"] and len(j["config"]["per_rank_window_solve_kernel_ms"]) == 2
     assert j["config"]["launch"].startswith("self-launched") and "cpu_baseline" not in j
+
+
+def test_the_committed_rocprof_summary_belongs_to_the_kernel_sources_in_the_tree():
+    """bench.py reports roofline.traffic / mfma_util / fabric_GBs from the newest profiles/*_pmc_traffic.json only if that summary was measured
+    on the kernel sources that are in the tree now (sha256 of csrc/window_solve.hip, kernels.hpp, devmath.hpp, Makefile stored with it):
+    a kernel change without a re-profile (scripts/gpu_profile.sh + scripts/summarize_rocprof.py) fails here instead of reporting stale traffic."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    prof, name, err = b.committed_profile()
+    assert err is None, err
+    assert prof["window_solve_kernel"]["traffic_bytes_per_launch"] > 0 and 0 < prof["window_solve_kernel"]["mfma_util"] < 1
