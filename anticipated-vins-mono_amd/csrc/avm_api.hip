@@ -575,7 +575,9 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_marginalize(sa, dpo, marg_err, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-    HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, c->prof, c->stream));
+    int* pe_done = static_cast<int*>(pool_get(c, "pe_done", sizeof(int) * B));
+    if (!pe_done) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior flags)");
+    HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, c->prof, pe_done, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     if (mem == AVM_MEM_HOST) {
       if (po_bytes <= PACK_LIMIT) {

@@ -160,7 +160,7 @@ int window_solve_x_lds_bytes();
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream);
 // second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior
-hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, hipStream_t stream);
+hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, int* done /* [n_windows] device scratch, may be null */, hipStream_t stream);
 int window_solve_lds_bytes();
 
 }  // namespace avm

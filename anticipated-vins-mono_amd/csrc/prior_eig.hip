@@ -114,14 +114,203 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// ---- the well-conditioned case on ONE wavefront (round 3) ------------------------------------------------------------------------
+// Most windows of a run - every window whose prior already pins all its directions - leave an A' that is positive definite with
+// lambda_min ~ 1e2: no eigenvalue anywhere near the clamp, and ANY square root J^T J = A' with r0 = J^-T b' is the prior
+// (marginalization_factor.cpp:283-301 only ever hands J and r0 to consumers that see J^T J, J^T r0 and |r0|^2, see below).  For those
+// windows prior_eig_kernel's four cooperating wavefronts, two barriers per pivot and rank-revealing pivot search are the wrong tool:
+// it is latency bound at ~4 K cycles per pivot (0.88 ms per 4096 windows).  Here one wavefront takes one window, the matrix lives in
+// its registers as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4 and never goes back to memory:
+//   * A' is held as its UPPER tiles U[k][i] (k <= i): register r of lane (lk = lane / 16, lr = lane % 16) is entry (lk + 4 r, lr) of
+//     the tile.  With the k index of a product running as lk + 4 r, a tile in this layout IS a B operand and, read as an A operand, its
+//     transpose - so (like the selector's evaluation on the 4 x 4 x 4 form) nothing is transposed or moved between lanes:
+//   * block column k:  L_kk from the diagonal tile (through a 2 KB LDS patch into lane = row form: a 16-pivot chain of v_readlane
+//     broadcasts, with the rows of the identity riding along in lanes 16..31 and ending as L_kk^-T, the scheme of chol_diag_block in
+//     window_solve.hip);  W_i = L_kk^-1 U[k][i] (A operand = L_kk^-1 from LDS, B = the tile);  U[j][i] -= W_j^T W_i (both operands
+//     straight from registers).  W_i = L_ik^T is block (k, i) of J = L^T: the factor is the output.
+//   * r0 = L^-1 b' by blocks (tile^T x vector products reduced over the four row groups, the diagonal solves through L_kk^-1).
+//   * certification with the EXPLICIT inverse (120 more MFMAs, column block by column block, only its norms are kept):
+//     lambda_min(A') >= 1 / |L^-1|_F^2 for the eps clamp (factor 1000 to spare) and lambda_min of the row-scaled form >= 1 / |L^-1 diag(s)^1/2|_F^2
+//     for the noise test of the eigen path (see the clamp below) - sqrt(n) pessimistic at worst, where the comparison-matrix bound of
+//     the pivoted path is 40 - 3400 x.
+// A window that fails any of it - a non-positive or non-finite pivot (rank deficient: no prior yet, ragged tracks), a bound that
+// does not clear the thresholds - is left untouched (done[w] = 0) and taken by prior_eig_kernel afterwards.
+constexpr int PC_T = 5;                                 // tiles per dimension: n <= 80
+constexpr int PC_NT = PC_T * (PC_T + 1) / 2;            // 15 upper tiles
+constexpr int PC_LDS = 256 + PC_T * 256 + 4 * 80;       // doubles: the diagonal patch | L_kk^-1 of every block | b', y, s, a 16-vector
+typedef double pd4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ constexpr int pc_ti(int k, int i) { return k * PC_T - k * (k - 1) / 2 + (i - k); }
+__device__ __forceinline__ double pc_readlane(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ void pc_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_windows, double eps, int* done) {
+  __shared__ double pc_lds[PC_LDS];
+  const int w = blockIdx.x, lane = threadIdx.x, lk = lane >> 4, lr = lane & 15;
+  if (w >= n_windows) return;
+  if (lane == 0) done[w] = 0;
+  const int n = PO.n[w];
+  if (n < 3 || n > 16 * PC_T) return;
+  double* gJ = PO.J + (size_t)w * PO.max_prior * PO.max_prior;
+  double* gr = PO.r + (size_t)w * PO.max_prior;
+  const int ldj = PO.max_prior;
+  double* blk = pc_lds;                 // [16][16]
+  double* Linv = pc_lds + 256;          // [PC_T][16][16]: L_kk^-1, row-major
+  double* vb = Linv + PC_T * 256;       // b' (80)
+  double* vy = vb + 80;                 // y = L^-1 b' (80)
+  double* vs = vy + 80;                 // s: the magnitude every diagonal entry was formed at (marginalize_kernel), 0 on the pad
+  double* vt = vs + 80;                 // a 16-vector in transit
+  // ---- load: upper tiles (A' is symmetric and stored as its lower triangle), identity on the pad
+  pd4 U[PC_NT];
+#pragma unroll
+  for (int k = 0; k < PC_T; k++)
+#pragma unroll
+    for (int i = k; i < PC_T; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * k + lk + 4 * r, col = 16 * i + lr;
+        const int rc = min(row, n - 1), cc = min(col, n - 1);
+        const double v = gJ[(size_t)max(rc, cc) * ldj + min(rc, cc)];
+        U[pc_ti(k, i)][r] = (row < n && col < n) ? v : (row == col ? 1.0 : 0.0);
+      }
+  for (int c = lane; c < 80; c += 64) {
+    vb[c] = c < n ? gr[c] : 0.0;
+    vs[c] = c < n ? fabs(gJ[c + 1 < n ? (size_t)c * ldj + c + 1 : (size_t)(n - 1)]) : 0.0;
+  }
+  pc_sync();
+  bool bad = false;
+  // ---- factorization
+#pragma unroll
+  for (int k = 0; k < PC_T; k++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) blk[(lk + 4 * r) * 16 + lr] = U[pc_ti(k, k)][r];
+    pc_sync();
+    {
+      // lane = row (lanes 0..15), lanes 16..31: the rows of the identity (they end as the rows of L_kk^-T); the others carry junk
+      double a[16];
+      const bool idl = (lane & 48) == 16;
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = idl ? (lr == c ? 1.0 : 0.0) : blk[lr * 16 + c];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const double pj = pc_readlane(a[j], j);
+        bad |= !(pj > 0.0) || !(pj < 1e300);
+        a[j] *= nrm_rsqrt(pj);
+#pragma unroll
+        for (int c = j + 1; c < 16; c++) a[c] = fma(-a[j], pc_readlane(a[j], c), a[c]);
+      }
+      pc_sync();  // (every lane has read its row of the patch)
+      // L_kk (lower) back into the patch; L_kk^-1[c][i] = (L_kk^-T)[i][c] = a[c] of lane 16 + i
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (lane < 16) blk[lr * 16 + c] = c <= lr ? a[c] : 0.0;
+        if (idl) Linv[k * 256 + c * 16 + lr] = c >= lr ? a[c] : 0.0;
+      }
+    }
+    pc_sync();
+    // J_kk = L_kk^T in the tile layout: entry (row, col) = L[col][row]
+#pragma unroll
+    for (int r = 0; r < 4; r++) U[pc_ti(k, k)][r] = blk[lr * 16 + lk + 4 * r];
+    if (k + 1 < PC_T) {
+      double ao[4];  // A operand L_kk^-1[i' = lr][k' = lk + 4 r]
+#pragma unroll
+      for (int r = 0; r < 4; r++) ao[r] = Linv[k * 256 + lr * 16 + lk + 4 * r];
+#pragma unroll
+      for (int i = k + 1; i < PC_T; i++) {
+        pd4 W = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) W = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[r], U[pc_ti(k, i)][r], W, 0, 0, 0);
+        U[pc_ti(k, i)] = W;  // = L_ik^T = block (k, i) of J
+      }
+#pragma unroll
+      for (int j = k + 1; j < PC_T; j++)
+#pragma unroll
+        for (int i = j; i < PC_T; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            U[pc_ti(j, i)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[pc_ti(k, j)][r], U[pc_ti(k, i)][r], U[pc_ti(j, i)], 0, 0, 0);
+    }
+    pc_sync();  // (the patch is rewritten by the next block column)
+  }
+  // ---- y = L^-1 b' by blocks: v_k = b_k - sum_{i < k} L_ki y_i with L_ki = (J block (i, k))^T, then y_k = L_kk^-1 v_k
+#pragma unroll
+  for (int k = 0; k < PC_T; k++) {
+    double p = 0.0;
+#pragma unroll
+    for (int i = 0; i < k; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) p = fma(U[pc_ti(i, k)][r], vy[16 * i + lk + 4 * r], p);
+    p += __shfl_xor(p, 16, 64);
+    p += __shfl_xor(p, 32, 64);
+    if (lk == 0) vt[lr] = vb[16 * k + lr] - p;
+    pc_sync();
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc = fma(Linv[k * 256 + lr * 16 + q], vt[q], acc);
+    if (lk == 0) vy[16 * k + lr] = acc;
+    pc_sync();
+  }
+  // ---- |L^-1|_F^2 and |L^-1 diag(s)^1/2|_F^2 from the explicit inverse, one column block at a time
+  double f2 = 0.0, fs2 = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < PC_T; kk++) {
+    pd4 X[PC_T];  // X[i] = (L^-1) block (i, kk), i >= kk
+    const double sc = vs[16 * kk + lr];
+    const bool cin = 16 * kk + lr < n;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      X[kk][r] = Linv[kk * 256 + (lk + 4 * r) * 16 + lr];
+      const double e2 = (cin && 16 * kk + lk + 4 * r < n) ? X[kk][r] * X[kk][r] : 0.0;
+      f2 += e2, fs2 = fma(e2, sc, fs2);
+    }
+#pragma unroll
+    for (int i = kk + 1; i < PC_T; i++) {
+      pd4 Sacc = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = kk; j < i; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[pc_ti(j, i)][r], X[j][r], Sacc, 0, 0, 0);  // L_ij X_j
+      pd4 Xi = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-Linv[i * 256 + lr * 16 + lk + 4 * r], Sacc[r], Xi, 0, 0, 0);
+      X[i] = Xi;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const double e2 = (cin && 16 * i + lk + 4 * r < n) ? Xi[r] * Xi[r] : 0.0;
+        f2 += e2, fs2 = fma(e2, sc, fs2);
+      }
+    }
+  }
+  f2 = wave_sum(f2), fs2 = wave_sum(fs2);
+  const bool ok = !__any(bad) && f2 * (1000.0 * eps) < 1.0 && fs2 * 4e-16 < 1.0;  // (NaN compares false)
+  if (!ok) return;
+  // ---- the prior: linearized_jacobians = J = L^T (upper triangular), linearized_residuals = y
+#pragma unroll
+  for (int k = 0; k < PC_T; k++)
+#pragma unroll
+    for (int i = 0; i < PC_T; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * k + lk + 4 * r, col = 16 * i + lr;
+        if (row < n && col < n) gJ[(size_t)row * ldj + col] = i >= k ? U[pc_ti(min(k, i), max(k, i))][r] : 0.0;
+      }
+  for (int c = lane; c < n; c += 64) gr[c] = vy[c];
+  if (lane == 0) done[w] = 1;
+}
+
 // `literal` != 0 forces the eigen-decomposition even where the Cholesky factor would do (AVM_PRIOR_LITERAL=1, for A/B tests)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof, int literal) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof, int literal, const int* done) {
   extern __shared__ char pe_smem[];
   double* lds = reinterpret_cast<double*>(pe_smem);
   double* A = lds + P_A;
   const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;  // wv: provably uniform
   const int w = blockIdx.x;
   if (w >= n_windows) return;
+  if (done && done[w]) return;     // prior_chol_kernel has written this window's prior (a well-conditioned A')
   const int n = PO.n[w];
   if (n <= 0 || n > NMAX) return;  // n == -1: MARGIN_SECOND_NEW had nothing to drop (the caller keeps the old prior)
   const long long t_start = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -456,7 +645,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 }  // namespace pe
 
-hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, hipStream_t stream) {
+hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, int* done, hipStream_t stream) {
   static bool attr_set = false;
   const char* lit = getenv("AVM_PRIOR_LITERAL");  // (read per call: the A/B test flips it inside one process)
   const int literal = (lit && lit[0] == '1') ? 1 : 0;
@@ -470,7 +659,12 @@ hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, 
       fprintf(stderr, "[avm] prior_eig_kernel: %d workgroups / CU (LDS %d B)\n", nb, pe::P_END * 8);
     }
   }
-  hipLaunchKernelGGL(pe::prior_eig_kernel, dim3(n_windows), dim3(pe::NT), pe::P_END * 8, stream, po, n_windows, eps, prof, literal);
+  // the well-conditioned windows on one wavefront each; what that kernel leaves (done[w] == 0) goes through the pivoted path
+  // (AVM_PRIOR_LITERAL=1 / AVM_PRIOR_NO_FAST=1: everything through the pivoted path, for A/B tests)
+  const char* nf = getenv("AVM_PRIOR_NO_FAST");
+  const bool fast = done && !literal && !(nf && nf[0] == '1');
+  if (fast) hipLaunchKernelGGL(pe::prior_chol_kernel, dim3(n_windows), dim3(64), 0, stream, po, n_windows, eps, done);
+  hipLaunchKernelGGL(pe::prior_eig_kernel, dim3(n_windows), dim3(pe::NT), pe::P_END * 8, stream, po, n_windows, eps, prof, literal, fast ? (const int*)done : (const int*)nullptr);
   return hipGetLastError();
 }
 
