@@ -11,7 +11,7 @@ python -c "import bench; print(bench.kernel_source_sha256())" > $OUT/kernel_sour
 # only the window kernels (the selector's thousands of small launches serialize under --pmc)
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --fsel-problems 4 --gen-procs 1 --distinct 512"
 PMCCMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-fsel --gen-procs 1 --distinct 512"
-KF='--kernel-include-regex (window_solve|marginalize|prior_eig|preint)' 
+KF='--kernel-include-regex (window_solve|marginalize|prior_eig|prior_chol|preint)' 
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 timeout 300 rocprofv3 --kernel-trace $KF --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- $PMCCMD > /dev/null 2> $OUT/pmc_fetch.log
 timeout 300 rocprofv3 --kernel-trace $KF --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- $PMCCMD > /dev/null 2> $OUT/pmc_write.log
