@@ -79,6 +79,39 @@ int avmt_marginalize(const avm_options* opt, const avm_window_batch* batch, int 
   return 0;
 }
 
+// The solve of window w in the wide scalar type: Problem::build + trust_region_solve (the restated Ceres 1.14 dogleg minimizer,
+// oracle/solver.hpp) + the gauge-fix round trip of double2vector (estimator.cpp:206-284), from the pre-integration on, on the
+// same FP64 inputs.  What comes back, rounded once to FP64, is the state the reference's ALGORITHM defines for these inputs when
+// no arithmetic error is made on the way; the FP64 oracle and the GPU are both measured against it (tests/test_solve_truth.py).
+// Outputs (any pointer may be NULL): pose [11][7], speedbias [11][9], ex_pose [7], td [1], relo_pose [7], inv_depth [n_feat];
+// summary: the oracle's record (costs, iterations, termination), its doubles rounded from binary128.
+int avmt_solve(const avm_options* opt, const avm_window_batch* batch, int w, double* pose, double* speedbias, double* ex_pose, double* td,
+               double* relo_pose, double* inv_depth, avm_solve_summary* summary) {
+  Window W;
+  load_window(*opt, *batch, w, W);
+  Problem P;
+  P.build(W, *opt);
+  SolveResult R = trust_region_solve(P, W.x);
+  State out;
+  out.lam = R.x.lam;
+  gauge_fix_roundtrip(W.x, R.x, out, W.failure_occur ? W.last_pose0 : nullptr, W.has_relo);
+  for (int f = 0; f < AVM_NFRAMES; f++) {
+    if (pose)
+      for (int k = 0; k < 7; k++) pose[f * 7 + k] = (double)out.pose[f][k];
+    if (speedbias)
+      for (int k = 0; k < 9; k++) speedbias[f * 9 + k] = (double)out.sb[f][k];
+  }
+  for (int k = 0; k < 7; k++) {
+    if (ex_pose) ex_pose[k] = (double)out.ex[k];
+    if (relo_pose && W.has_relo) relo_pose[k] = (double)out.relo[k];
+  }
+  if (td) *td = (double)out.td;
+  if (inv_depth)
+    for (size_t e = 0; e < out.lam.size(); e++) inv_depth[e] = (double)out.lam[e];
+  if (summary) *summary = R.sum;
+  return 0;
+}
+
 int avmt_digits(void) { return FLT128_DIG; }
 
 }  // extern "C"

@@ -147,3 +147,32 @@ def distance_to_truth(p, diag, i):
     d = 1.0 / np.sqrt(np.maximum(np.diag(Hq), 1e-300))
     return dict(H_rel=float(np.abs(Hp - Hq).max() / np.abs(Hq).max()), H_scaled=float(np.abs((Hp - Hq) * d[:, None] * d[None, :]).max()),
                 g_scaled=float(np.abs((gp - gq) * d).max() / max(1e-300, np.abs(gq * d).max())), cost_rel=abs(cp - cq) / max(cq, 1e-300))
+
+
+def truth_solve(w, opt):
+    """Estimator::optimization()'s solve (no marginalization) of every window of `w` in binary128 (oracle/avm_truth.cpp:
+    avmt_solve - the restated Ceres dogleg minimizer and the gauge-fix round trip, from the pre-integration on, on the same FP64
+    inputs).  Returns (a copy of `w` holding the resulting states rounded once to FP64, the summaries)."""
+    import ctypes as C
+
+    L = truth_lib()
+    out = w.copy()
+    s = w.struct()
+    B = w.n_windows
+    summ = buffers.summary_alloc(B)
+    for i in range(B):
+        pose, sb, ex, lam = np.zeros(11 * 7), np.zeros(11 * 9), np.zeros(7), np.zeros(w.dims["max_feat"])
+        td, relo = np.zeros(1), np.zeros(7)
+        one = buffers.summary_alloc(1)
+        rc = L.avmt_solve(C.byref(opt), C.byref(s), i, abi.dptr(pose), abi.dptr(sb), abi.dptr(ex), abi.dptr(td), abi.dptr(relo), abi.dptr(lam),
+                          one.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        nf = int(w.a["n_feat"][i])
+        out.a["pose"][i], out.a["speedbias"][i], out.a["ex_pose"][i] = pose.reshape(11, 7), sb.reshape(11, 9), ex
+        out.a["inv_depth"][i, :nf] = lam[:nf]
+        if opt.estimate_td and "td" in out.a:
+            out.a["td"][i] = td[0]
+        if "relo_pose" in out.a:
+            out.a["relo_pose"][i] = relo
+        summ[i] = one[0]
+    return out, summ
