@@ -14,6 +14,7 @@
 #include "quad_prelude.hpp"
 
 #include "window_io.hpp"  // (-> solver.hpp -> factors.hpp -> linalg.hpp, all in the wide scalar type from here on)
+#include "fsel_io.hpp"    // (-> fsel.hpp)
 
 #undef double
 
@@ -109,6 +110,40 @@ int avmt_solve(const avm_options* opt, const avm_window_batch* batch, int w, dou
   if (inv_depth)
     for (size_t e = 0; e < out.lam.size(); e++) inv_depth[e] = (double)out.lam[e];
   if (summary) *summary = R.sum;
+  return 0;
+}
+
+// FeatureSelector::select of frame p of the batch in the wide scalar type (oracle/fsel.hpp: calcInfoFromRobotMotion,
+// calcInfoFromFeatures, the lazy greedy of selectInformativeFeatures with sortedlogDetUB's std::map, Utility::logdet by Cholesky -
+// feature_selector.cpp:239-728): the ids the reference's algorithm selects when no logdet comparison is decided by rounding.
+// selected_ids [max_features], fvalues [max_features] (rounded to FP64; may be NULL); returns the number selected.
+int avmt_fsel_select(const avm_fsel_batch* batch, int p, int32_t* selected_ids, double* fvalues) {
+  FselProblem P;
+  load_fsel(*batch, p, P);
+  FselResult R = fsel_select(P);
+  for (size_t i = 0; i < R.selected.size(); i++) {
+    selected_ids[i] = R.selected[i];
+    if (fvalues) fvalues[i] = (double)R.fvalues[i];
+  }
+  return (int)R.selected.size();
+}
+
+// Omega (calcInfoFromRobotMotion incl. addOmegaPrior) [N][N] and every candidate's Delta [max_cand][N][N] (zero when the
+// candidate is not triangulable) of frame p, formed in binary128 and rounded to FP64 (either pointer may be NULL).
+int avmt_fsel_information(const avm_fsel_batch* batch, int p, double* omega, double* delta_full) {
+  FselProblem P;
+  load_fsel(*batch, p, P);
+  const int N = 9 * (P.H + 1);
+  Mat Om = calcInfoFromRobotMotion(P);
+  if (omega)
+    for (int i = 0; i < N * N; i++) omega[i] = (double)Om.a[i];
+  if (delta_full) {
+    std::map<int, Mat> D = calcInfoFromFeatures(P, P.cand_id, P.cand_x, P.cand_y);
+    for (size_t c = 0; c < P.cand_id.size(); c++) {
+      auto it = D.find(P.cand_id[c]);
+      for (int i = 0; i < N * N; i++) delta_full[c * N * N + i] = it == D.end() ? 0.0 : (double)it->second.a[i];
+    }
+  }
   return 0;
 }
 

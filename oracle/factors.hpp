@@ -376,7 +376,7 @@ inline void cauchy_loss(double a, double s, double rho[3]) {
   const double sum = 1.0 + s * c;
   const double inv = 1.0 / sum;
   rho[0] = b * std::log(sum);
-  rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+  rho[1] = std::max(AVMO_NUM_MIN, inv);
   rho[2] = -c * (inv * inv);
 }
 // Ceres Corrector == marginalization_factor.cpp:37-68

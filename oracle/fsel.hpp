@@ -114,7 +114,7 @@ inline Mat calcInfoFromRobotMotion(const FselProblem& p) {
 inline double findNNDepth(const FselProblem& p, double x, double y) {
   if (p.cloud_d.empty()) return 1.0;
   size_t best = 0;
-  double bd = std::numeric_limits<double>::max();
+  double bd = AVMO_NUM_MAX;
   for (size_t i = 0; i < p.cloud_d.size(); i++) {
     double dx = x - p.cloud_x[i], dy = y - p.cloud_y[i];
     double d = dx * dx + dy * dy;
@@ -175,7 +175,7 @@ inline std::map<int, Mat> calcInfoFromFeatures(const FselProblem& p, const std::
 // Utility::logdet(M, true), utility.h:144-167 — NaN on a failed factorisation (documented)
 inline double logdet_chol(const Mat& M) {
   Mat L = M;
-  if (!llt_lower(L)) return std::numeric_limits<double>::quiet_NaN();
+  if (!llt_lower(L)) return AVMO_NUM_NAN;
   double ld = 0;
   for (int i = 0; i < M.r; i++) ld += std::log(L(i, i));
   return ld * 2;

@@ -14,6 +14,16 @@
 #ifndef AVMO_EIG_EPS
 #define AVMO_EIG_EPS std::pow(2.0, -52.0)
 #endif
+// The limits of the scalar type.  (Not std::numeric_limits<double> in the text of these headers: the extended-precision build
+// re-defines `double`, and libstdc++ 11 has no numeric_limits<__float128> - the primary template answers 0 to everything.
+// quad_prelude.hpp defines the binary128 values.)
+#ifndef AVMO_NUM_MAX
+#define AVMO_NUM_MAX std::numeric_limits<double>::max()
+#define AVMO_NUM_MIN std::numeric_limits<double>::min()
+#define AVMO_NUM_EPSILON std::numeric_limits<double>::epsilon()
+#define AVMO_NUM_INF std::numeric_limits<double>::infinity()
+#define AVMO_NUM_NAN std::numeric_limits<double>::quiet_NaN()
+#endif
 
 namespace avmo {
 
@@ -181,7 +191,7 @@ inline Q fromR(const M3& R) {
 }
 // Eigen slerp: linear weights when |d| >= 1-eps, sign flip if d<0, no renormalisation
 inline Q slerp(const Q& a, double t, const Q& b) {
-  const double one = 1.0 - std::numeric_limits<double>::epsilon();
+  const double one = 1.0 - AVMO_NUM_EPSILON;
   double d = a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z;
   double absD = std::fabs(d);
   double s0, s1;

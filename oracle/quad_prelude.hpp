@@ -47,4 +47,11 @@ inline avmo_real min(double a, avmo_real b) { return b < a ? b : (avmo_real)a; }
 }  // namespace std
 
 #define AVMO_EIG_EPS scalbnq((avmo_real)1, -112)
+// (the scalar type's limits: see oracle/linalg.hpp.  The unit roundoff that Eigen's slerp compares with stays FP64's: the
+//  branch `|d| >= 1 - eps` is part of the algorithm, the inputs are FP64 quaternions)
+#define AVMO_NUM_MAX FLT128_MAX
+#define AVMO_NUM_MIN FLT128_MIN
+#define AVMO_NUM_EPSILON ((avmo_real)2.220446049250313e-16)
+#define AVMO_NUM_INF ((avmo_real)HUGE_VAL)
+#define AVMO_NUM_NAN nanq("")
 #define double avmo_real

@@ -40,7 +40,7 @@ inline void smallest_right_singular_vector(std::vector<double> A, int n, double 
     if (!rotated) break;
   }
   int best = 0;
-  double bn = std::numeric_limits<double>::infinity();
+  double bn = AVMO_NUM_INF;
   for (int j = 0; j < 4; j++) {
     double s = 0;
     for (int i = 0; i < n; i++) s += A[i * 4 + j] * A[i * 4 + j];

@@ -176,3 +176,19 @@ def truth_solve(w, opt):
             out.a["relo_pose"][i] = relo
         summ[i] = one[0]
     return out, summ
+
+
+def truth_fsel_select(fsel):
+    """FeatureSelector::select of every frame of `fsel` in binary128 (oracle/avm_truth.cpp: avmt_fsel_select).  Returns
+    FselOutArrays (fvalues rounded to FP64)."""
+    import ctypes as C
+
+    L = truth_lib()
+    P, mf = fsel.n_problems, fsel.dims["max_features"]
+    out = buffers.FselOutArrays.alloc(P, mf)
+    s = fsel.struct()
+    for p in range(P):
+        ids, fv = np.full(mf, -1, np.int32), np.zeros(mf)
+        n = L.avmt_fsel_select(C.byref(s), p, abi.iptr(ids), abi.dptr(fv))
+        out.a["n_selected"][p], out.a["selected_ids"][p], out.a["fvalues"][p] = n, ids, fv
+    return out
