@@ -133,11 +133,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 //     lambda_min(A') >= 1 / |L^-1|_F^2 for the eps clamp (factor 1000 to spare) and lambda_min of the row-scaled form >= 1 / |L^-1 diag(s)^1/2|_F^2
 //     for the noise test of the eigen path (see the clamp below) - sqrt(n) pessimistic at worst, where the comparison-matrix bound of
 //     the pivoted path is 40 - 3400 x.
-// A window that fails any of it - a non-positive or non-finite pivot (rank deficient: no prior yet, ragged tracks), a bound that
-// does not clear the thresholds - is left untouched (done[w] = 0) and taken by prior_eig_kernel afterwards.
+//   * EXACT ZEROS of A' (ragged tracks: two thirds of the windows have two to four directions nothing constrains).  In natural order
+//     such a direction shows up as ONE pivot that is zero up to the noise it was formed with, |p_j| <= pc_zero(s_j, s_j) (s_j: the
+//     magnitude the diagonal entry was formed at, from marginalize_kernel).  The pivot is DELETED: column j of L is set to
+//     zero (row j of J, entry j of r0 - exactly what the eigen path and the pivoted path do with a direction under the clamp), the
+//     factorization continues, the inverse norms above are those of the kept part (row / column j of every L_kk^-1 are zero).  What
+//     that drops is checked afterwards, row by row: |A'[j][c] - (J^T J)[j][c]| <= pc_zero(s_j, s_c) for every c - the deleted row
+//     of the remainder is formation noise, not a small genuine direction (whose column would not be small: |a_jc| <= sqrt(p_j a_cc)
+//     only).  A pivot between noise and genuine stays, makes |L^-1| huge and fails the certification.
+// A window that fails any of it - a negative or non-finite pivot, more than PC_MAXDEL deleted pivots (no prior yet), a deleted row
+// that is not noise, a bound that does not clear the thresholds - is left untouched (done[w] = 0) and taken by prior_eig_kernel.
 constexpr int PC_T = 5;                                 // tiles per dimension: n <= 80
 constexpr int PC_NT = PC_T * (PC_T + 1) / 2;            // 15 upper tiles
-constexpr int PC_LDS = 256 + PC_T * 256 + 4 * 80;       // doubles: the diagonal patch | L_kk^-1 of every block | b', y, s, a 16-vector
+constexpr int PC_LDS = 256 + PC_T * 256 + 5 * 80;       // doubles: the diagonal patch | L_kk^-1 of every block | b', y, s, a 16-vector, a column of J
+constexpr int PC_MAXDEL = 8;                            // deleted pivots per window
 typedef double pd4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ constexpr int pc_ti(int k, int i) { return k * PC_T - k * (k - 1) / 2 + (i - k); }
 __device__ __forceinline__ double pc_readlane(double v, int src) {
@@ -147,6 +156,14 @@ __device__ __forceinline__ void pc_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// what counts as zero for entry (i, j) of A' given the magnitudes s_i, s_j its two diagonal entries were formed at: 4000 unit roundoffs of
+// sqrt(s_i s_j) - plain formation noise - or, for the small magnitudes, 1e-7 (s_i s_j)^1/4: the level the eigen path's own noise test
+// works at (it drops S when S^2 <= 1e-16 g^T diag(s) g, i.e. S <= 1e-8 sqrt(s) for a coordinate direction; a factor 10 on top because
+// the noise of a pivot that follows a small genuine pivot is amplified by their ratio - measured: 5e-6 at s = 3e4 behind a pivot of 0.05)
+__device__ __forceinline__ double pc_zero(double si, double sj) {
+  const double g = sqrt(si * sj);
+  return fmax(1e-12 * g, 1e-7 * sqrt(g));
 }
 __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_windows, double eps, int* done) {
   __shared__ double pc_lds[PC_LDS];
@@ -164,6 +181,7 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
   double* vy = vb + 80;                 // y = L^-1 b' (80)
   double* vs = vy + 80;                 // s: the magnitude every diagonal entry was formed at (marginalize_kernel), 0 on the pad
   double* vt = vs + 80;                 // a 16-vector in transit
+  double* vc = vt + 80;                 // column j of J (the check of a deleted pivot)
   // ---- load: upper tiles (A' is symmetric and stored as its lower triangle), identity on the pad
   pd4 U[PC_NT];
 #pragma unroll
@@ -183,6 +201,7 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
   }
   pc_sync();
   bool bad = false;
+  unsigned long long dm0 = 0, dm1 = 0;  // the deleted pivots, a bit each (wave-uniform; no branch inside the pivot chain)
   // ---- factorization
 #pragma unroll
   for (int k = 0; k < PC_T; k++) {
@@ -195,11 +214,16 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
       const bool idl = (lane & 48) == 16;
 #pragma unroll
       for (int c = 0; c < 16; c++) a[c] = idl ? (lr == c ? 1.0 : 0.0) : blk[lr * 16 + c];
+      const double thr_l = pc_zero(vs[16 * k + lr], vs[16 * k + lr]);  // (off the pivot chain: lane j holds pivot j's threshold)
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const double pj = pc_readlane(a[j], j);
-        bad |= !(pj > 0.0) || !(pj < 1e300);
-        a[j] *= nrm_rsqrt(pj);
+        const double thr = pc_readlane(thr_l, j);
+        const bool del = fabs(pj) <= thr;  // zero up to formation noise: the direction is dropped (pads: s = 0, pivot 1)
+        bad |= !(del || pj > 0.0) || !(pj < 1e300);
+        if (16 * k + j < 64) dm0 |= del ? 1ull << ((16 * k + j) & 63) : 0ull;
+        else dm1 |= del ? 1ull << ((16 * k + j) & 63) : 0ull;
+        a[j] *= del ? 0.0 : nrm_rsqrt(pj);
 #pragma unroll
         for (int c = j + 1; c < 16; c++) a[c] = fma(-a[j], pc_readlane(a[j], c), a[c]);
       }
@@ -286,7 +310,50 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
     }
   }
   f2 = wave_sum(f2), fs2 = wave_sum(fs2);
-  const bool ok = !__any(bad) && f2 * (1000.0 * eps) < 1.0 && fs2 * 4e-16 < 1.0;  // (NaN compares false)
+  const int ndel = __popcll(dm0) + __popcll(dm1);
+  bool ok = !__any(bad) && ndel <= PC_MAXDEL && f2 * (1000.0 * eps) < 1.0 && fs2 * 4e-16 < 1.0;  // (NaN compares false)
+  if (!ok) return;
+  // ---- the deleted pivots: row d of A' - J^T J has to be formation noise
+  for (int q = 0; q < ndel; q++) {
+    int d;
+    if (dm0) d = __builtin_ctzll(dm0), dm0 &= dm0 - 1;
+    else d = 64 + __builtin_ctzll(dm1), dm1 &= dm1 - 1;
+    d = __builtin_amdgcn_readfirstlane(d);
+    const int kd = d >> 4, cd = d & 15;
+    // column d of J into LDS: J[row][d], rows < d (row d itself is zero, the rows below are below the diagonal)
+    for (int c = lane; c < 80; c += 64) vc[c] = 0.0;
+    pc_sync();
+#pragma unroll
+    for (int k = 0; k < PC_T; k++)
+      if (k <= kd && lr == cd) {
+#pragma unroll
+        for (int i = k; i < PC_T; i++)
+          if (i == kd) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) vc[16 * k + lk + 4 * r] = U[pc_ti(k, i)][r];
+          }
+      }
+    pc_sync();
+    const double sd = vs[d];
+    bool viol = false;
+#pragma unroll
+    for (int i = 0; i < PC_T; i++) {
+      double pacc = 0.0;
+#pragma unroll
+      for (int k = 0; k <= i; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) pacc = fma(U[pc_ti(k, i)][r], vc[16 * k + lk + 4 * r], pacc);
+      pacc += __shfl_xor(pacc, 16, 64);
+      pacc += __shfl_xor(pacc, 32, 64);
+      const int c = 16 * i + lr;
+      if (c < n) {
+        const double orig = gJ[(size_t)max(d, c) * ldj + min(d, c)];
+        viol |= !(fabs(orig - pacc) <= pc_zero(sd, vs[c]));
+      }
+    }
+    ok = ok && !__any(viol);
+    pc_sync();
+  }
   if (!ok) return;
   // ---- the prior: linearized_jacobians = J = L^T (upper triangular), linearized_residuals = y
 #pragma unroll

@@ -62,3 +62,46 @@ def test_cholesky_square_root_is_the_same_prior_as_the_eigen_square_root(ctx, or
         assert np.array_equal(sa["accept_mask"], sb["accept_mask"])
         for k in ("pose", "speedbias", "inv_depth"):
             assert rel(ca.a[k], cb.a[k]) < 1e-8, (k, rel(ca.a[k], cb.a[k]))
+
+
+def test_one_wavefront_factorization_with_deleted_pivots_is_the_pivoted_path_s_prior(ctx, monkeypatch):
+    """Ragged tracks: two thirds of the windows leave an A' with two or four exact zeros.  prior_chol_kernel (one wavefront per
+    window, natural order) deletes the pivots that are zero up to formation noise and checks what that drops; prior_eig_kernel (four
+    wavefronts, diagonal pivoting, AVM_PRIOR_NO_FAST=1 forces it) stops at the rank.  256 windows: the same number of dropped
+    directions in both, the same prior through everything a consumer sees of it (J^T J, J^T r0, |r0|^2), and the next solve cannot
+    tell them apart."""
+    o = abi.default_options()
+    E = est_m.Estimator(ctx=ctx, options=o)
+    B = 256
+    w = synth.make_windows(B, first_id=7000, tracks="sparse", n_feat=150, max_feat=150)
+    wa, wb = w.copy(), w.copy()
+    monkeypatch.setenv("AVM_PRIOR_NO_FAST", "1")
+    E.optimization(wa)
+    pa = E.last_marginalization_info
+    monkeypatch.delenv("AVM_PRIOR_NO_FAST")
+    E.optimization(wb)
+    pb = E.last_marginalization_info
+    assert np.array_equal(wa.a["pose"], wb.a["pose"]) and np.array_equal(pa.a["n"], pb.a["n"])
+    n_deleted = n_natural = 0
+    for i in range(B):
+        n = int(pa.a["n"][i])
+        Ja, Jb = pa.a["J"][i, :n, :n], pb.a["J"][i, :n, :n]
+        za, zb = int((np.abs(Ja).max(1) == 0).sum()), int((np.abs(Jb).max(1) == 0).sum())
+        assert za == zb, (i, za, zb)
+        natural = bool(np.array_equal(Jb, np.triu(Jb)))       # an upper triangle in natural order: the one-wavefront form
+        n_natural += natural
+        n_deleted += natural and zb > 0
+    m = prior_metrics(pb, pa)
+    print("\n[one-wavefront vs pivoted prior]", m, "natural-order form:", n_natural, "of", B, "with deleted pivots:", n_deleted)
+    assert n_natural >= 0.95 * B and n_deleted >= 0.4 * B
+    assert m["H_rel"] < 1e-9 and m["H_scaled"] < 1e-6 and m["g_scaled"] < 1e-7 and m["cost_rel"] < 1e-6, m
+    o2 = abi.default_options()
+    o2.marginalization_flag = abi.MARGIN_NONE
+    E2 = est_m.Estimator(ctx=ctx, options=o2)
+    ca, cb = wa.copy(), wb.copy()
+    install_prior(ca, pa), install_prior(cb, pb)
+    sa = buffers.summary_to_numpy(E2.optimization(ca)).copy()
+    sb = buffers.summary_to_numpy(E2.optimization(cb))
+    assert np.array_equal(sa["accept_mask"], sb["accept_mask"])
+    for k in ("pose", "speedbias", "inv_depth"):
+        assert rel(ca.a[k], cb.a[k]) < 1e-8, (k, rel(ca.a[k], cb.a[k]))
