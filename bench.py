@@ -305,6 +305,7 @@ def main():
     pristine = {k: win.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
     gathered = torch.empty((world * W, 11, 7), dtype=torch.float64, device=dev) if world > 1 else None
     use_lib_gather = world > 1 and args.gather == "library" and hasattr(ctx, "gather_states") and args.backend == "nccl"
+    gather_checked = False
     gloo = world > 1 and args.backend == "gloo"
     if use_lib_gather:
         # the library's own communicator (raw rccl.h, avm_comm_*): the 128-byte unique id travels over torch.distributed
@@ -322,6 +323,24 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         use_lib_gather = bool(flag.item())
+        if use_lib_gather:
+            # one untimed self-check of the library's collective against torch.distributed's on the same buffer: a rank that gets
+            # an error or different bytes sends every rank to the torch.distributed gather together
+            ok = 1
+            try:
+                probe = torch.arange(W * 77, dtype=torch.float64, device=dev).reshape(W, 11, 7) + rank * 1.0e6
+                want = torch.empty_like(gathered)
+                ctx.gather_states(probe, gathered, W * 77)
+                torch.cuda.synchronize()
+                dist.all_gather_into_tensor(want, probe)
+                ok = int(torch.equal(want, gathered))
+            except Exception as e:
+                ok = 0
+                print(f"[bench] rank {rank}: avm_gather_states self-check failed ({e}); falling back to torch.distributed", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_lib_gather = bool(flag.item())
+            gather_checked = use_lib_gather
 
     marg = opt.marginalization_flag != abi.MARGIN_NONE
     prior_slots = buffers.PriorOutArrays.alloc(W, win.dims["max_prior"], win.dims["max_pblk"], dev) if marg else None
@@ -422,7 +441,7 @@ def main():
                 "mean_iterations": float(s["num_iterations"].mean()),
                 "mean_successful_steps": float(s["num_successful"].mean()),
                 "iterations_histogram": {int(k): int(v) for k, v in zip(*np.unique(s["num_iterations"], return_counts=True))},
-                "pose_gather": (("avm_gather_states (library, raw rccl.h)" if use_lib_gather else ("torch.distributed all_gather through the host (gloo; ranks may share a device: "
+                "pose_gather": (("avm_gather_states (library, raw rccl.h; checked against torch.distributed's all_gather before the timed region)" if use_lib_gather and gather_checked else "avm_gather_states (library, raw rccl.h)" if use_lib_gather else ("torch.distributed all_gather through the host (gloo; ranks may share a device: "
                                 "NOT a scaling measurement)" if gloo else "torch.distributed all_gather")) if world > 1 else "none (1 GPU)"),
                 "per_rank_window_solve_kernel_ms": per_rank_solve_ms,
                 "per_rank_gather_ms": per_rank_gather_ms,
