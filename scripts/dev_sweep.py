@@ -1,0 +1,43 @@
+"""Development sweep (GPU box): the one-wavefront prior (with deleted pivots) against the pivoted path, the next solve with either prior, and the
+solve against the oracle, over 5120 windows of four track shapes.  Results: profiles/r03_experiments.md, section 5."""
+import importlib, sys, os, time
+import numpy as np
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+from helpers import abi, buffers, rel, synth
+from marg_sensitivity import prior_metrics, install_prior
+from oracle import oracle_py
+est_m = importlib.import_module("anticipated-vins-mono_amd.estimator")
+libm = importlib.import_module("anticipated-vins-mono_amd.lib")
+ctx = libm.Context(0)
+o = abi.default_options()
+E = est_m.Estimator(ctx=ctx, options=o)
+o2 = abi.default_options(); o2.marginalization_flag = abi.MARGIN_NONE
+E2 = est_m.Estimator(ctx=ctx, options=o2)
+for tracks, nf, B, fid in (("sparse", 150, 2048, 20000), ("sparse", 70, 1024, 30000), ("dense", 150, 1024, 40000), ("sparse", 110, 1024, 50000)):
+    w = synth.make_windows_parallel(B, first_id=fid, procs=16, tracks=tracks, n_feat=nf, max_feat=150)
+    wa, wb = w.copy(), w.copy()
+    os.environ["AVM_PRIOR_NO_FAST"] = "1"
+    E.optimization(wa); pa = E.last_marginalization_info
+    del os.environ["AVM_PRIOR_NO_FAST"]
+    E.optimization(wb); pb = E.last_marginalization_info
+    assert np.array_equal(wa.a["pose"], wb.a["pose"])
+    worst = dict(H_rel=0, H_scaled=0, g_scaled=0, cost_rel=0); nat = dele = zdiff = 0
+    for i in range(B):
+        n = int(pa.a["n"][i])
+        Ja, Jb = pa.a["J"][i,:n,:n], pb.a["J"][i,:n,:n]
+        za, zb = int((np.abs(Ja).max(1)==0).sum()), int((np.abs(Jb).max(1)==0).sum())
+        zdiff += za != zb
+        natural = bool(np.array_equal(Jb, np.triu(Jb))); nat += natural; dele += natural and zb > 0
+    m = prior_metrics(pb, pa)
+    print(tracks, nf, B, "natural", nat, "deleted", dele, "zero-row count differs in", zdiff, "windows; metrics", {k: float(f"{v:.2e}") for k,v in m.items()}, flush=True)
+    # chained solve A/B
+    ca, cb = wa.copy(), wb.copy(); install_prior(ca, pa); install_prior(cb, pb)
+    sa = buffers.summary_to_numpy(E2.optimization(ca)).copy(); sb = buffers.summary_to_numpy(E2.optimization(cb))
+    print("   next solve: accept masks equal", np.array_equal(sa["accept_mask"], sb["accept_mask"]), "pose rel", rel(ca.a["pose"], cb.a["pose"]), "sb", rel(ca.a["speedbias"], cb.a["speedbias"]), flush=True)
+    # GPU vs oracle solve parity
+    wo = w.copy(); so = buffers.summary_alloc(B)
+    t=time.time(); oracle_py.window_solve(o2, wo, None, so, n_threads=16) if "n_threads" in oracle_py.window_solve.__code__.co_varnames else oracle_py.window_solve(o2, wo, None, so)
+    wg = w.copy(); sg = buffers.summary_to_numpy(E2.optimization(wg))
+    dec = np.array_equal(sg["num_iterations"], so["num_iterations"]) and np.array_equal(sg["accept_mask"], so["accept_mask"]) and np.array_equal(sg["termination"], so["termination"])
+    per = np.abs(wg.a["pose"] - wo.a["pose"]).reshape(B,-1).max(1) / np.abs(wo.a["pose"]).max()
+    print("   solve vs oracle (", round(time.time()-t,1), "s ): decisions equal", dec, "mismatching windows", int((sg["accept_mask"] != so["accept_mask"]).sum()), "pose rel worst", per.max(), "sb", rel(wg.a["speedbias"], wo.a["speedbias"]), "lam", rel(wg.a["inv_depth"], wo.a["inv_depth"]), flush=True)
