@@ -3414,23 +3414,29 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     }
     if (t < 7) lds[L_RIC + 12 + t] = B.ex_pose[(size_t)w * 7 + t];
     if (t == 7) lds[L_RIC + 19] = c.est_td ? B.td[w] : 0.0;  // para_Td
+    if (t >= 256 && t < 256 + c.pnblk) {  // the prior's block table (one round trip instead of one per block, as in the solve)
+      const int k = t - 256;
+      ids[I_PBLK + k * 3] = B.prior_blk_kind[(size_t)w * B.max_pblk + k], ids[I_PBLK + k * 3 + 1] = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
+    }
     if (t == 0) {
       const double* ex = B.ex_pose + (size_t)w * 7;
       double R[9];
       q2R(quat{ex[6], ex[3], ex[4], ex[5]}, R);
       for (int k = 0; k < 9; k++) lds[L_RIC + k] = R[k];
       for (int k = 0; k < 3; k++) lds[L_RIC + 9 + k] = ex[k];
+    }
+    __syncthreads();
+    if (t == 0) {  // offsets and state columns of the prior's blocks (read after the barrier that precedes phase A)
       int off = 0;
       for (int k = 0; k < c.pnblk; k++) {
-        const int kind = B.prior_blk_kind[(size_t)w * B.max_pblk + k], fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
-        ids[I_PBLK + k * 3] = kind, ids[I_PBLK + k * 3 + 1] = fr, ids[I_PBLK + k * 3 + 2] = off;
+        const int kind = ids[I_PBLK + k * 3], fr = ids[I_PBLK + k * 3 + 1];
+        ids[I_PBLK + k * 3 + 2] = off;
         const int n = kind == AVM_BLK_SPEEDBIAS ? 9 : (kind == AVM_BLK_TD ? 1 : 6);
         for (int q = 0; q < n; q++)
           ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q : (kind == AVM_BLK_TD ? MTD : MEX0 + q));
         off += n;
       }
     }
-    __syncthreads();
     // does the prior take part?  MARGIN_SECOND_NEW needs pose[WINDOW_SIZE-1] in it (estimator.cpp:926-927)
     bool use_prior = c.pn > 0;
     bool has9 = false;
