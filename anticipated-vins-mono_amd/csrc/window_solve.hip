@@ -3037,9 +3037,36 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
   const double td = lds[L_RIC + 19];   // para_Td (0 unless estimate_td)
   d4 D00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, D11 = {0, 0, 0, 0}, E00 = {0, 0, 0, 0}, E10 = {0, 0, 0, 0}, E11 = {0, 0, 0, 0};
   const int drow = lane >> 4, dcol = lane & 15;
+  // COMPACT (no time offset in the problem: the reference's default): Jj's translation columns are minus Ji's (projection_factor.cpp:
+  // 81-95: both are +-reduce ric^T Rj^T), so the staged row is [Jj_r 0-2 | Ji_t 3-5 | Ji_r 6-8 | r 9 | Jex 10-15] - ONE 16-column tile
+  // and ONE X^T X product per k-step instead of three; the three Gram tiles the scatter below works on are read back out of it
+  // (entries of other lanes through ds_bpermute, signs for the columns that stand for Jj_t) when a frame ends.
+  const bool cp = !c.est_td;
+  auto gram_get = [&](const d4& G, int Rs, int Cs) {  // entry (Rs, Cs) of a 16 x 16 accumulator tile, for every lane its own
+    const int src = (Rs & 3) * 16 + Cs, q = Rs >> 2;
+    const double v0 = __shfl(G[0], src, 64), v1 = __shfl(G[1], src, 64), v2 = __shfl(G[2], src, 64), v3 = __shfl(G[3], src, 64);
+    return q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+  };
+  auto cmap = [](int p, double& sg) {  // column p of [Jj | Ji | r] -> its column in the compact row, and its sign
+    sg = p < 3 ? -1.0 : 1.0;
+    return p < 3 ? 3 + p : (p < 6 ? p - 3 : (p < 9 ? p - 3 : (p < 12 ? p - 3 : 9)));
+  };
   auto end_frame = [&](int b) {  // the blocks frame b owns, from the accumulators
     double* PART = c.sc + Scratch::PART + (size_t)b * PARTW;
     D00 += E00, D10 += E10, D11 += E11;
+    if (cp) {
+      const d4 G = D00 + D10;  // (all four chains of the one tile)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = drow + 4 * r;
+        double sr, sc2;
+        const int mr = cmap(min(row, 12), sr), mc = cmap(min(dcol, 12), sc2);
+        const double g00 = gram_get(G, mr, mc), g10 = gram_get(G, 10 + min(row, 5), mc), g11 = gram_get(G, 10 + min(row, 5), 10 + min(dcol, 5));
+        D00[r] = (row < 13 && dcol < 13) ? sr * sc2 * g00 : 0.0;
+        D10[r] = (row < 6 && dcol < 13) ? sc2 * g10 : 0.0;
+        D11[r] = (row < 6 && dcol < 6) ? g11 : 0.0;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = drow + 4 * r;
@@ -3103,14 +3130,26 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
       if (nh == 0) break;  // (uniform)
       if ((lane >> 5) == half) {
         dv2* st = reinterpret_cast<dv2*>(stage) + (lane & 31);
+        if (cp) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-          st[k * (MXRS / 2)] = dv2{Jj[k], Jj[6 + k]};
-          st[(6 + k) * (MXRS / 2)] = dv2{Ji[k], Ji[6 + k]};
-          st[(13 + k) * (MXRS / 2)] = dv2{Jx[k], Jx[6 + k]};
+          for (int k = 0; k < 3; k++) {
+            st[k * (MXRS / 2)] = dv2{Jj[3 + k], Jj[9 + k]};
+            st[(3 + k) * (MXRS / 2)] = dv2{Ji[k], Ji[6 + k]};
+            st[(6 + k) * (MXRS / 2)] = dv2{Ji[3 + k], Ji[9 + k]};
+          }
+          st[9 * (MXRS / 2)] = dv2{r[0], r[1]};
+#pragma unroll
+          for (int k = 0; k < 6; k++) st[(10 + k) * (MXRS / 2)] = dv2{Jx[k], Jx[6 + k]};
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            st[k * (MXRS / 2)] = dv2{Jj[k], Jj[6 + k]};
+            st[(6 + k) * (MXRS / 2)] = dv2{Ji[k], Ji[6 + k]};
+            st[(13 + k) * (MXRS / 2)] = dv2{Jx[k], Jx[6 + k]};
+          }
+          st[12 * (MXRS / 2)] = dv2{r[0], r[1]};
+          st[19 * (MXRS / 2)] = dv2{Jt[0], Jt[1]};
         }
-        st[12 * (MXRS / 2)] = dv2{r[0], r[1]};
-        st[19 * (MXRS / 2)] = dv2{Jt[0], Jt[1]};
       }
       wave_lds_sync();
       // the factors of frame b0 in this half, then those of b1 (either may be empty)
@@ -3124,6 +3163,28 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
         // lane group drow takes the two rows of factor 4 j + drow (one 16-byte read per tile), four j at a time: 24 MFMAs on
         // six independent chains; factors outside the run are masked out by their index
         const int j_end = (l_end + 3) >> 2;
+        if (cp) {  // one tile: two MFMAs (the two residual rows) per k-step, eight in flight
+#pragma unroll 1
+          for (int j0 = l >> 2; j0 < j_end; j0 += 4) {
+            dv2 u0[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) u0[u] = *reinterpret_cast<const dv2*>(stage + dcol * MXRS + 8 * min(j0 + u, 7) + 2 * drow);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int f = 4 * (j0 + u) + drow;
+              const bool on = f >= l && f < l_end;
+              const double a0 = on ? u0[u][0] : 0.0, a1 = on ? u0[u][1] : 0.0;
+              if (u & 1) {
+                D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D10, 0, 0, 0);  // (D10 / E10: the second pair of chains of the
+                E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E10, 0, 0, 0);  //  same tile, folded into D00 below)
+              } else {
+                D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
+                E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
+              }
+            }
+          }
+          continue;
+        }
 #pragma unroll 1
         for (int j0 = l >> 2; j0 < j_end; j0 += 4) {
           dv2 u0[4], u1[4];
