@@ -3599,10 +3599,15 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     if (flag == AVM_MARGIN_OLD && t < PARTW) {
       const double* PART = c.sc + Scratch::PART;
       const int q = t;  // (rows MEX0 .. MEX0 + 6 = the six ex_pose variables and td)
+      // (every frame's PART row was written by its frame task - zeros for a frame without factors -, so all ten loads go out at once:
+      //  behind the `I_NCOV > 0` test they were ten dependent trips to the slot)
+      double pv[NFR - 1];
+#pragma unroll
+      for (int b = 1; b < NFR; b++) pv[b - 1] = PART[(size_t)b * PARTW + q];
       if (q < 104) {
         double sacc = 0;
-        for (int b = 1; b < NFR; b++)
-          if (ids[I_NCOV + b] > 0) sacc += PART[(size_t)b * PARTW + q];
+#pragma unroll
+        for (int b = 1; b < NFR; b++) sacc += ids[I_NCOV + b] > 0 ? pv[b - 1] : 0.0;
         if (q < 21) {
           int i = 0;
           while ((i + 1) * (i + 2) / 2 <= q) i++;
@@ -3621,8 +3626,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         }
       } else {
         const int k = q - 104;
+#pragma unroll
         for (int b = 1; b < NFR; b++)
-          if (ids[I_NCOV + b] > 0) lds[L_S + roff(MEX0 + k / 6) + 6 * b + k % 6] = PART[(size_t)b * PARTW + q];
+          if (ids[I_NCOV + b] > 0) lds[L_S + roff(MEX0 + k / 6) + 6 * b + k % 6] = pv[b - 1];
       }
     }
     __syncthreads();
@@ -3780,18 +3786,33 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     {
       double* oJ = PO.J + (size_t)w * PO.max_prior * PO.max_prior;
       double* orr = PO.r + (size_t)w * PO.max_prior;
-      for (int idx = t; idx < n * n; idx += NT) {
-        const int i = idx / n, j = idx % n;
-        if (j > i) continue;  // the eigen-solver reads the lower triangle only (as Eigen's SelfAdjointEigenSolver does)
-        double sacc = 0;
-        for (int k = 0; k < 16; k++) sacc += GT[i * 16 + k] * EB[j * 16 + k];
-        const double arr = Sget(kidx[i], kidx[j]);
-        oJ[(size_t)i * PO.max_prior + j] = arr - sacc;
-        // The magnitude the diagonal entry was formed at (|Arr_ii| + |(Arm Amm^+ Amr)_ii|: the bias rows of the kept
-        // speed-bias block are differences of two numbers of size 1e10 .. 1e12) rides along in the unused upper triangle,
-        // slot (i, i + 1), the last one in (0, n - 1): prior_eig_kernel's clamp measures an eigenvalue against the
-        // rounding noise of ITS variables (prior_eig.hip).
-        if (i == j && n >= 3) oJ[i + 1 < n ? (size_t)i * PO.max_prior + i + 1 : (size_t)(n - 1)] = fabs(arr) + fabs(sacc);
+      // T Amr by 16 x 16 tiles on the matrix cores (K = the 16 dropped columns): lower tiles only - the eigen-solver reads the lower
+      // triangle only, as Eigen's SelfAdjointEigenSolver does - dealt to the wavefronts; operands straight from LDS (the scalar form
+      // read 32 LDS words per entry: 11 K cycles per window)
+      {
+        const int lr = lane & 15, lk = lane >> 4, ntl = (n + 15) >> 4;
+        for (int tile = wv; tile < ntl * (ntl + 1) / 2; tile += NT / 64) {
+          int ti = 0;
+          while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+          const int tj = tile - ti * (ti + 1) / 2;
+          const int ra = min(16 * ti + lr, n - 1), rb = min(16 * tj + lr, n - 1);
+          d4 D = {0, 0, 0, 0};
+#pragma unroll
+          for (int mq = 0; mq < 4; mq++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(GT[ra * 16 + lk + 4 * mq], EB[rb * 16 + lk + 4 * mq], D, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int i = 16 * ti + lk + 4 * r, j = 16 * tj + lr;
+            if (i < n && j <= i) {
+              const double arr = Sget(kidx[i], kidx[j]), sacc = D[r];
+              oJ[(size_t)i * PO.max_prior + j] = arr - sacc;
+              // The magnitude the diagonal entry was formed at (|Arr_ii| + |(Arm Amm^+ Amr)_ii|: the bias rows of the kept
+              // speed-bias block are differences of two numbers of size 1e10 .. 1e12) rides along in the unused upper triangle,
+              // slot (i, i + 1), the last one in (0, n - 1): prior_eig_kernel's clamp measures an eigenvalue against the
+              // rounding noise of ITS variables (prior_eig.hip).
+              if (i == j && n >= 3) oJ[i + 1 < n ? (size_t)i * PO.max_prior + i + 1 : (size_t)(n - 1)] = fabs(arr) + fabs(sacc);
+            }
+          }
+        }
       }
       if (t < n) {
         double sacc = 0;
