@@ -708,8 +708,11 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
   if (t < 150) {
     const int i = t / 15, r = t % 15;
     if (c.psum[i] <= o.max_sum_dt) {
-      double s = 0;
-      for (int k = r; k < 15; k++) s += c.psqrt[i * 225 + r * 15 + k] * lds[L_S + i * 465 + k * 31];
+      double ps[15], s = 0;  // (all fifteen loads in flight: from k = r every step was a trip to memory of its own)
+#pragma unroll
+      for (int k = 0; k < 15; k++) ps[k] = c.psqrt[i * 225 + r * 15 + k];
+#pragma unroll
+      for (int k = 0; k < 15; k++) s += k >= r ? ps[k] * lds[L_S + i * 465 + k * 31] : 0.0;
       acc += 0.5 * s * s;
     }
   }
@@ -1560,29 +1563,54 @@ AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
     acc += y0 * y0 + y1 * y1;
   }
 #endif
-  if (t < 150) {  // IMU: y = sqrt_info * (raw_J * v), raw Jacobians of the last eval_jac are still in the scratch slot
-    const int i = t / 15, r = t % 15;
-    if (c.psum[i] <= o.max_sum_dt) {
-      const double* IJR = c.sc + Scratch::IJRAW + i * 465;
-      double y = 0;
-      for (int k = r; k < 15; k++) {
-        double rv = 0;
-        for (int p = 0; p < 30; p++) {
-          const int col = imu_col(i, p);
-          rv += IJR[k * 31 + 1 + p] * (u[col] * scl[col]);
-        }
-        y += c.psqrt[i * 225 + r * 15 + k] * rv;
-      }
-      acc += y * y;
+  // IMU: y = sqrt_info * (raw_J * v), raw Jacobians of the last eval_jac are still in the scratch slot.  Two steps with one trip to
+  // the slot each (thread (i, k): row k of raw_J times v, thirty loads in flight; thread (i, r): row r of sqrt_info times that) - as
+  // nested loops from k = r every thread made up to fifteen trips of its own, and every row of raw_J v was computed up to 15 times
+  double* rvb = lds + L_WCH;  // [150] (the factorization's scratch is dead here)
+  if (t < 150) {
+    const int i = t / 15, k = t % 15;
+    const double* IJR = c.sc + Scratch::IJRAW + i * 465;
+    double jv[30];
+#pragma unroll
+    for (int p = 0; p < 30; p++) jv[p] = IJR[k * 31 + 1 + p];
+    double rv = 0;
+#pragma unroll
+    for (int p = 0; p < 30; p++) {
+      const int col = imu_col(i, p);
+      rv += jv[p] * (u[col] * scl[col]);
     }
+    rvb[t] = rv;
   }
+  // the prior's rows meanwhile: J0 row i times v, sixteen loads in flight (behind `pidx[k] >= 0` they were up to 75 trips)
   if (c.pn > 0 && t >= 192 && t < 192 + c.pn) {
     const int i = t - 192;
     const int* pidx = ids + I_PIDX;
+    const int pn1 = c.pn - 1;
     double y = 0;
-    for (int k = 0; k < c.pn; k++)
-      if (pidx[k] >= 0) y += c.pJ[(size_t)i * c.ldp + k] * (u[pidx[k]] * scl[pidx[k]]);
+    for (int k0 = 0; k0 < c.pn; k0 += 16) {
+      double pj[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) pj[q] = c.pJ[(size_t)i * c.ldp + min(k0 + q, pn1)];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int ix = pidx[min(k0 + q, pn1)], ic = max(ix, 0);
+        y += (k0 + q <= pn1 && ix >= 0) ? pj[q] * (u[ic] * scl[ic]) : 0.0;
+      }
+    }
     acc += y * y;
+  }
+  __syncthreads();
+  if (t < 150) {
+    const int i = t / 15, r = t % 15;
+    if (c.psum[i] <= o.max_sum_dt) {
+      double ps[15];
+#pragma unroll
+      for (int k = 0; k < 15; k++) ps[k] = c.psqrt[i * 225 + r * 15 + k];
+      double y = 0;
+#pragma unroll
+      for (int k = 0; k < 15; k++) y += k >= r ? ps[k] * rvb[i * 15 + k] : 0.0;
+      acc += y * y;
+    }
   }
   return block_sum1(acc);
 }
@@ -3638,8 +3666,14 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       double* IJ = lds + M_WCH;
       for (int idx = t; idx < 465; idx += NT) {
         const int r = idx / 31, cc = idx % 31;
+        // (sqrt_info is stored with zeros below its diagonal: all fifteen products, their thirty loads in flight at once - as a loop
+        //  from k = r every step was a trip to the slot of its own)
+        double ps[15], ij[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) ps[k] = c.psqrt[r * 15 + k], ij[k] = IJR[k * 31 + cc];
         double sacc = 0;
-        for (int k = r; k < 15; k++) sacc += c.psqrt[r * 15 + k] * IJR[k * 31 + cc];
+#pragma unroll
+        for (int k = 0; k < 15; k++) sacc += k >= r ? ps[k] * ij[k] : 0.0;
         IJ[idx] = sacc;
       }
       __syncthreads();
