@@ -1,8 +1,10 @@
-"""Development sweep (GPU box): the one-wavefront prior (with deleted pivots) against the pivoted path, the next solve with either prior, and the
+"""TEST INFRASTRUCTURE (uses oracle/).  Development sweep (GPU box): the one-wavefront prior (with deleted pivots) against the pivoted path, the next solve with either prior, and the
 solve against the oracle, over 5120 windows of four track shapes.  Results: profiles/r03_experiments.md, section 5."""
 import importlib, sys, os, time
 import numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os as _os
+_root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+sys.path.insert(0, _root); sys.path.insert(0, _os.path.join(_root, 'tests'))
 from helpers import abi, buffers, rel, synth
 from marg_sensitivity import prior_metrics, install_prior
 from oracle import oracle_py
