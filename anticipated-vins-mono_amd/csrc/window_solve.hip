@@ -83,6 +83,9 @@ constexpr int XSTG = 128 * XLD;    // 64 factors x 2 residual rows (>= 13 * XRS)
 static_assert(13 * XRS <= XSTG, "column-major staging tile fits");
 constexpr int ASM_WAVES = 6;       // wavefronts assembling projection factors (wavefront 6: the raw IMU Jacobians, 7: the prior)
 #endif
+#ifndef AVM_LPT_RUNW
+#define AVM_LPT_RUNW 16
+#endif
 constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diagonal block); trailing tiles stay 16x16
 constexpr int TLAST = NF / 16;     // last 16-row tile of the packed matrix incl. the augmented row NF: 10 (11)
 constexpr int FRS = 18 * NFRP;     // one frames slot: R (NFRP x 9) then A = ric^T R^T (NFRP x 9)
@@ -128,7 +131,8 @@ static_assert(L_S + SPP + ASM_WAVES * XSTG <= L_G, "assembly staging overlaps li
 // int carve (offsets in ints from L_INT)
 constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 546, I_PBLK = 560 /* kind,frame,off x16 */, I_FAIL = 620,
               I_NCOV = 624 /* [12] factors observed in frame b */, I_FRW = 636 /* [12] assembling wave of frame b */,
-              I_PMASK = 648 /* [12] start frames flushed by frame b */, I_TIMEUP = 660 /* max_solver_time reached (set by thread 0) */, I_END = 661;
+              I_PMASK = 648 /* [12] start frames flushed by frame b */, I_TIMEUP = 660 /* max_solver_time reached (set by thread 0) */,
+              I_NRUN = 661 /* [12] distinct start frames among the factors observed in frame b */, I_END = 673;
 static_assert(I_END <= 720, "int carve");
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -2352,14 +2356,17 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     for (int f = 1 + (t >> 6); f < NFR; f += NT / 64) {  // features observed in frame f (as imu_j), in feature order
       const int ln = t & 63;
       int n = 0;
+      unsigned am = 0;  // start frames that occur among the frame's factors (one accumulation run of the frame task each)
       for (int e0 = 0; e0 < c.nf; e0 += 64) {
         const int e = min(e0 + ln, MAXE - 1), a = ids[I_FSTART + e];
         const bool in = e0 + ln < c.nf && a < f && f < a + ids[I_FNOBS + e];
         const unsigned long long m = __ballot(in);
         if (in) c.cov[f * MAXE + n + __popcll(m & ((1ull << ln) - 1ull))] = e;
         n += __popcll(m);
+#pragma unroll
+        for (int aa = 0; aa < NFR - 1; aa++) am |= __any(in && a == aa) ? 1u << aa : 0u;
       }
-      if (ln == 0) ids[I_NCOV + f] = n;
+      if (ln == 0) ids[I_NCOV + f] = n, ids[I_NRUN + f] = __popc(am);
     }
     if (t == 0) ids[I_NCOV] = 0;
 #ifdef AVM_X
@@ -2397,9 +2404,13 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       int fc = 0, done = 0;
       if (t == 0) ids[I_FRW] = -1;
       for (int k = 1; k < NFRP; k++) {
+        // (a frame weighs its factors plus RUNW factors' worth for every accumulation run beyond the first - a run costs a flush of
+        //  the partial blocks and a group of eight MFMAs however short it is: with ragged tracks a frame has up to ten runs of a
+        //  handful of factors each, and by factor counts alone two wavefronts ended up with twice the others' time)
+        constexpr int RUNW = AVM_LPT_RUNW;
         int bb = -1, bn = -1;
         for (int f = 1; f < NFRP; f++) {
-          const int n = ids[I_NCOV + f];
+          const int n = ids[I_NCOV + f] + RUNW * max(ids[I_NRUN + f] - 1, 0);
           if (!(done & (1 << f)) && n > bn) bn = n, bb = f;
         }
         const int own = (fc + 63) >> 6, with = (fc + bn + 63) >> 6;
