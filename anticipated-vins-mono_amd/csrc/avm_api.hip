@@ -63,6 +63,8 @@ struct avm_ctx {
   // device buffers owned by the ctx
   double* scratch = nullptr;
   int32_t* iscratch = nullptr;
+  bool last_solve_tp = false;  // which form of the solve kernel the last avm_window_solve_batch took (avm_debug_last_solve_form)
+  int scratch_slots = 0;  // slots allocated (n_slots, or 2 n_slots once a batch has taken the throughput form of the solve)
   double *pre_delta = nullptr, *pre_jac = nullptr, *pre_cov = nullptr, *pre_sqrt = nullptr, *pre_sum = nullptr;
   size_t pre_cap = 0;  // windows
   avm_solve_summary* d_summary = nullptr;
@@ -142,7 +144,9 @@ int report_bad(avm_ctx* c, int first_bad, const char* unit) {
 
 // Runs before any kernel indexes with the caller's tables: host tables are checked on the host, device-resident ones by a
 // one-thread-per-window kernel whose 4-byte verdict is read back (the only extra synchronization of a device-mode call).
-int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int what) {
+// tp_fits (optional, with CHK_PRIOR): false when some window's prior does not fit the throughput form of the solve (kernels.hpp)
+int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int what, bool* tp_fits = nullptr) {
+  if (tp_fits) *tp_fits = true;
   if ((what & CHK_TRACKS) && (!b->n_feat || !b->feat_start || !b->feat_nobs || !b->feat_obs_begin)) return fail(c, AVM_ERR_INVALID, "null feature table");
   if ((what & CHK_IMU) && !b->imu_n) return fail(c, AVM_ERR_INVALID, "null imu_n");
   if ((what & CHK_PRIOR) && b->prior_n && (!b->prior_nblk || !b->prior_blk_kind || !b->prior_blk_frame)) return fail(c, AVM_ERR_INVALID, "null prior table");
@@ -150,17 +154,20 @@ int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int wha
     for (int w = 0; w < b->n_windows; w++) {
       const int rule = check_window_tables(*b, w, what);
       if (rule) return report_bad(c, w * 8 + rule, "window");
+      if (tp_fits && (what & CHK_PRIOR) && !window_prior_fits_tp(*b, w)) *tp_fits = false;
     }
     return AVM_OK;
   }
-  int* flag = static_cast<int*>(pool_get(c, "v_flag", sizeof(int)));
+  int* flag = static_cast<int*>(pool_get(c, "v_flag", 2 * sizeof(int)));
   if (!flag) return fail(c, AVM_ERR_HIP, "hipMalloc failed (validation flag)");
   HIPCHK(c, hipMemsetAsync(flag, 0x7f, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(flag + 1, 0, sizeof(int), c->stream));
   HIPCHK(c, launch_validate_windows(*b, what, flag, c->stream));
-  int h = 0;
-  HIPCHK(c, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  int h[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(h, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return h == 0x7f7f7f7f ? AVM_OK : report_bad(c, h, "window");
+  if (tp_fits) *tp_fits = h[1] == 0;
+  return h[0] == 0x7f7f7f7f ? AVM_OK : report_bad(c, h[0], "window");
 }
 
 int validate_fsel(avm_ctx* c, avm_mem mem, const avm_fsel_batch* b) {
@@ -172,7 +179,7 @@ int validate_fsel(avm_ctx* c, avm_mem mem, const avm_fsel_batch* b) {
     }
     return AVM_OK;
   }
-  int* flag = static_cast<int*>(pool_get(c, "v_flag", sizeof(int)));
+  int* flag = static_cast<int*>(pool_get(c, "v_flag", 2 * sizeof(int)));
   if (!flag) return fail(c, AVM_ERR_HIP, "hipMalloc failed (validation flag)");
   HIPCHK(c, hipMemsetAsync(flag, 0x7f, sizeof(int), c->stream));
   HIPCHK(c, launch_validate_fsel(*b, flag, c->stream));
@@ -195,12 +202,18 @@ int stage_in(avm_ctx* c, const char* name, const T* host, size_t count, const T*
   return AVM_OK;
 }
 
-int ensure_window_buffers(avm_ctx* c, int n_windows) {
-  if (!c->scratch) {
-    HIPCHK(c, hipMalloc(&c->scratch, sizeof(double) * Scratch::TOTAL * c->n_slots));
-    HIPCHK(c, hipMalloc(&c->iscratch, sizeof(int32_t) * ISCRATCH * c->n_slots));
-    HIPCHK(c, hipMemsetAsync(c->scratch, 0, sizeof(double) * Scratch::TOTAL * c->n_slots, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->iscratch, 0, sizeof(int32_t) * ISCRATCH * c->n_slots, c->stream));
+int ensure_window_buffers(avm_ctx* c, int n_windows, bool tp = false) {
+  // (the throughput form of the solve runs two workgroups per CU: twice the slots; allocated when a batch first takes it)
+  const int want = tp ? 2 * c->n_slots : c->n_slots;
+  if (!c->scratch || c->scratch_slots < want) {
+    if (c->scratch) (void)hipFree(c->scratch), c->scratch = nullptr;
+    if (c->iscratch) (void)hipFree(c->iscratch), c->iscratch = nullptr;
+    c->scratch_slots = 0;
+    HIPCHK(c, hipMalloc(&c->scratch, sizeof(double) * Scratch::TOTAL * want));
+    HIPCHK(c, hipMalloc(&c->iscratch, sizeof(int32_t) * ISCRATCH * want));
+    HIPCHK(c, hipMemsetAsync(c->scratch, 0, sizeof(double) * Scratch::TOTAL * want, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->iscratch, 0, sizeof(int32_t) * ISCRATCH * want, c->stream));
+    c->scratch_slots = want;
   }
   if ((size_t)n_windows > c->pre_cap) {
     c->pre_cap = 0;  // a failed hipMalloc below must not leave the old capacity next to freed / partial buffers
@@ -512,8 +525,17 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     if (prior_out->max_prior > MAXPRIOR || prior_out->max_prior < 1 || prior_out->max_pblk < 1) return fail(c, AVM_ERR_CAPACITY, "prior_out dims");
   }
   if (batch->n_windows == 0) return AVM_OK;
-  if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR)) != AVM_OK) return rc;
-  if ((rc = ensure_window_buffers(c, batch->n_windows)) != AVM_OK) return rc;
+  bool tp_fits = true;
+  if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR, &tp_fits)) != AVM_OK) return rc;
+  // Which form of the solve kernel: the throughput form (two 256-thread workgroups per CU, window_solve_tp.o) for batches that give
+  // every CU more than one window, the latency form (one 512-thread workgroup per CU) otherwise - and always for the extended
+  // problem, a wall-clock cap (its clock is per window), the phase profile, or a prior the structural form cannot hold.
+  // AVM_SOLVE_TP=0 / 1 forces the choice where both are possible (tests, A/B runs).
+  const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || batch->relo_n != nullptr;
+  bool use_tp = batch->n_windows > c->n_slots;
+  if (const char* e = getenv("AVM_SOLVE_TP")) use_tp = e[0] == '1' ? true : (e[0] == '0' ? false : use_tp);
+  use_tp = use_tp && !extended && tp_fits && !c->prof && !(opt->max_solver_time_s > 0.0);
+  if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp)) != AVM_OK) return rc;
   avm_window_batch d;
   avm_solve_summary* d_sum = nullptr;
   if (mem == AVM_MEM_HOST) {
@@ -541,8 +563,14 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   }
   if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * PROF_SLOTS * c->n_slots, c->stream));
   // ex_pose / td as variables, relocalization factors: the build of the solve kernel with the wider dense block
-  const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || d.relo_n != nullptr;
-  HIPCHK(c, extended ? launch_window_solve_x(sa, c->stream) : launch_window_solve(sa, c->stream));
+  if (use_tp) {
+    sa.n_slots = 2 * c->n_slots;
+    HIPCHK(c, launch_window_solve_tp(sa, c->stream));
+    sa.n_slots = c->n_slots;  // (the marginalization below runs one workgroup per CU)
+  } else {
+    HIPCHK(c, extended ? launch_window_solve_x(sa, c->stream) : launch_window_solve(sa, c->stream));
+  }
+  c->last_solve_tp = use_tp;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   avm_prior_out dpo;
   int* marg_err = nullptr;
@@ -674,6 +702,9 @@ int avm_debug_copy_profile(avm_ctx* c, long long* host_out) {
     for (int k = 0; k < PROF_SLOTS; k++) host_out[k] += h[(size_t)s * PROF_SLOTS + k];
   return AVM_OK;
 }
+
+// test / bench hook (not in avm.h): 1 when the last avm_window_solve_batch ran the throughput form of the solve kernel
+int avm_debug_last_solve_form(const avm_ctx* c) { return c ? (c->last_solve_tp ? 1 : 0) : -1; }
 
 // test hook (not in avm.h): sizeof of every ABI struct, for the ctypes mirror check
 int avm_debug_struct_sizes(int* out) {

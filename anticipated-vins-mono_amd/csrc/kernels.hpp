@@ -139,7 +139,19 @@ __host__ __device__ inline int check_fsel_tables(const avm_fsel_batch& b, int p)
   return 0;
 }
 
-// first_bad: one int, INT_MAX when every window / problem passes, else (index * 8 + rule) of the lowest failing index
+// The throughput form of the solve (window_solve_tp.o) keeps the speed-bias rows of the system in their structural form plus ONE strip
+// "the prior's speed-bias block x every pose" (window_solve.hip, s_off): a prior with more than one speed-bias block does not fit it.
+// The reference never builds one (estimator.cpp:904-916 keeps para_SpeedBias[1] only); such a batch simply takes the other kernel.
+__host__ __device__ inline bool window_prior_fits_tp(const avm_window_batch& B, int w) {
+  if (!B.prior_n || B.prior_n[w] <= 0) return true;
+  int nsb = 0;
+  const int nb = B.prior_nblk[w];
+  for (int k = 0; k < nb && k < B.max_pblk; k++) nsb += B.prior_blk_kind[(size_t)w * B.max_pblk + k] == AVM_BLK_SPEEDBIAS;
+  return nsb <= 1;
+}
+
+// first_bad: TWO ints.  [0]: INT_MAX when every window / problem passes, else (index * 8 + rule) of the lowest failing index;
+// [1] (windows, with CHK_PRIOR): set to 1 when some window's prior does not fit the throughput kernel (left alone otherwise)
 hipError_t launch_validate_windows(const avm_window_batch& b, int what, int* first_bad, hipStream_t stream);
 hipError_t launch_validate_fsel(const avm_fsel_batch& b, int* first_bad, hipStream_t stream);
 
@@ -157,6 +169,8 @@ hipError_t launch_projection_td_eval(const avm_td_factor_batch& f, double* resid
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream);
 hipError_t launch_window_solve_x(const SolveArgs& a, hipStream_t stream);  // window_solve_x.o: estimate_extrinsic / estimate_td / relocalization
 int window_solve_x_lds_bytes();
+hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream);  // window_solve_tp.o: two 256-thread workgroups per CU (large batches)
+int window_solve_tp_lds_bytes();
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream);
 // second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior

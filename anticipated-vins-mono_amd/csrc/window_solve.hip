@@ -19,6 +19,7 @@
 // All arithmetic FP64.  Every reduction has a fixed order, so results are bit-reproducible
 // run to run and independent of how windows are sharded over ranks.
 #include <cfloat>
+#include <utility>
 
 #include "devmath.hpp"
 #include "kernels.hpp"
@@ -53,7 +54,18 @@ AVM_DEV void lds_base_check() {
 #define PROFQ_T0() pq__ = clock64()
 #define PROFQ(c, k) do { if ((c).prof && threadIdx.x == 0) { long long n__ = clock64(); (c).prof[k] += n__ - pq__; pq__ = n__; } } while (0)
 
+#ifdef AVM_TP
+// THROUGHPUT build (window_solve_tp.o, -DAVM_TP): the same minimizer as a 256-thread workgroup (four wavefronts, one per SIMD) with at most
+// 80 KB of LDS, so that TWO windows are resident per CU and the dependent chains of one overlap the other's.  What makes it fit:
+//   * only the dense pose-pose rows of S (66 packed rows, 18 KB) stay in LDS as they are; the speed-bias rows are kept in their
+//     structural form (per 9-row block the 18 pose and 18 speed-bias columns an IMU factor can reach, plus the prior's speed-bias x pose
+//     strip), in the range the frame tasks' staging occupies during phase A;
+//   * the factorization runs on REGISTER tiles distributed over the four wavefronts (chol_regs below), fed from those two forms;
+//   * the frame tasks stage half a chunk (32 factors) at a time.
+constexpr int NT = 256;
+#else
 constexpr int NT = 512;          // threads per workgroup (8 wavefronts)
+#endif
 constexpr int croff(int i) { return 2 * ((i >> 1) + 1) * ((i >> 1) + (i & 1)); }  // roff() at compile time
 constexpr int SROWS = croff(NF + 1);  // padded packed lower triangle of the NF x NF matrix + one augmented row (the RHS): 13944 (16200)
 constexpr int VEC = (NCOL + 7) & ~7;  // padded NCOL: 320 (328)
@@ -76,6 +88,10 @@ constexpr int WCH = 8;             // rows of the scratch tile at L_WCH (x 80 co
 constexpr int XCOLS = 20;          // staged factor row: Jj(6) | Ji(6) | r | Jex(6) | Jtd
 constexpr int XSTG = XCOLS * XRS;
 constexpr int ASM_WAVES = 5;       // wavefronts assembling projection factors
+#elif defined(AVM_TP)
+constexpr int XRS_H = 68;          // column stride of the HALF-chunk staging tile: 32 factors x 2 residual rows + 4 (bank spread)
+constexpr int XSTG = 13 * XRS_H;   // 884
+constexpr int ASM_WAVES = 4;       // every wavefront assembles; wavefront 2 then takes the raw IMU Jacobians, wavefront 3 the prior
 #else
 constexpr int WCH = 32;
 constexpr int XLD = 14;            // staged factor row: Jj(6) | Ji(6) | r (+1 pad)
@@ -90,12 +106,39 @@ constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diag
 constexpr int TLAST = NF / 16;     // last 16-row tile of the packed matrix incl. the augmented row NF: 10 (11)
 constexpr int FRS = 18 * NFRP;     // one frames slot: R (NFRP x 9) then A = ric^T R^T (NFRP x 9)
 constexpr int L_S = 0;
+#ifdef AVM_TP
+// rows 0..65 of S packed as in the other builds, then the union region U: phase A: 4 staging tiles; from phase D on: the speed-bias
+// rows in structural form + the prior's strip; during the factorization: diagonal patch, L_kk^-T (two buffers), the published row of W
+constexpr int SBW = 36;                       // compact speed-bias row: 18 pose columns (poses i-1, i, i+1) | 18 speed-bias columns (i-1, i)
+constexpr int L_U = L_S + SPP;
+constexpr int L_SBC = L_U;                    // [99][SBW]
+constexpr int L_STRIP = L_SBC + 99 * SBW;     // [9][66]: rows of the prior's speed-bias block x every pose column
+constexpr int USZ = 99 * SBW + 9 * NPOSE + 2; // 4160
+static_assert(ASM_WAVES * XSTG <= USZ, "staging fits the union region");
+constexpr int L_PATCH = L_U;                  // factorization: [16][16] diagonal block in lane = row form
+constexpr int L_LINV = L_PATCH + 256;         // [2][256 + 16]: L_kk^-T (unscaled, see chol_diag_block) and the pivots
+constexpr int L_WROW = L_LINV + 2 * 272;      // [10][256]: row k of W, tile column i at index i - 1, in the accumulator layout [r][lane]
+constexpr int L_PARTV = L_WROW + 10 * 256;    // back substitution: [4][176] partial sums of the four wavefronts
+static_assert(L_PARTV + 4 * 176 <= L_U + USZ, "factorization scratch fits the union region");
+constexpr int L_Y = L_U + USZ;                // Gauss-Newton solution y; until the solve writes it: the right-hand side (row NF of the other builds)
+constexpr int L_RHS = L_Y;
+constexpr int WCH_TP = 224;                   // doubles: ys of back_substitute / rvb of jac_times_vec_sq (<= 150), then 64 dump slots
+constexpr int L_ST = L_Y + VEC;
+constexpr int L_XC = L_ST + VEC;
+constexpr int L_WCH = L_XC + XN;
+constexpr int L_DUMP = L_WCH + 160;
+constexpr int L_G = L_WCH + WCH_TP;
+constexpr int L_DD = L_G + VEC;               // (g / D is recomputed where it is needed, as in the extended build)
+#else
 constexpr int L_Y = L_S + SROWS;   // Gauss-Newton solution y of (H + mu D^2) y = g
 constexpr int L_ST = L_Y + VEC;    // trust region step (scaled space)
 constexpr int L_XC = L_ST + VEC;   // candidate state
 constexpr int L_WCH = L_XC + XN;   // [WCH][80] scratch tile
+constexpr int L_DUMP = L_WCH + 512;     // per-lane dump slots of the masked-out stores
 constexpr int L_G = L_WCH + WCH * WLD;  // scaled gradient g (f | e)
-#ifdef AVM_X
+#endif
+#ifdef AVM_TP
+#elif defined(AVM_X)
 constexpr int L_DD = L_G + VEC;    // D   (g / D is recomputed where it is needed: no room for a fourth vector next to the 178 x 178 system)
 #else
 constexpr int L_DG = L_G + VEC;    // g / D
@@ -126,13 +169,18 @@ constexpr int L_SUM = L_INT + 360;  // cost_trace[16], radius_trace[16]
 constexpr int L_CTX = L_SUM + 32;   // WinCtx of the window being solved (32 doubles)
 constexpr int L_OPT = L_CTX + 32;   // avm_options (copied from the kernel arguments)
 constexpr int L_END = L_OPT + (int)((sizeof(avm_options) + 7) / 8);
+#ifdef AVM_TP
+static_assert(L_END * 8 <= 81920, "two workgroups per CU: 80 KB each");
+#else
 static_assert(L_END * 8 <= 163840, "LDS budget exceeded");
+#endif
 static_assert(L_S + SPP + ASM_WAVES * XSTG <= L_G, "assembly staging overlaps live data");
 // int carve (offsets in ints from L_INT)
 constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 546, I_PBLK = 560 /* kind,frame,off x16 */, I_FAIL = 620,
               I_NCOV = 624 /* [12] factors observed in frame b */, I_FRW = 636 /* [12] assembling wave of frame b */,
               I_PMASK = 648 /* [12] start frames flushed by frame b */, I_TIMEUP = 660 /* max_solver_time reached (set by thread 0) */,
-              I_NRUN = 661 /* [12] distinct start frames among the factors observed in frame b */, I_END = 673;
+              I_NRUN = 661 /* [12] distinct start frames among the factors observed in frame b */,
+              I_PSB = 673 /* throughput build: frame of the prior's speed-bias block (its rows x every pose column: the strip) */, I_END = 674;
 static_assert(I_END <= 720, "int carve");
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -189,6 +237,26 @@ AVM_DEV int roff(int i) {  // even i = 2q: 2q(q+1); odd i = 2q+1: 2(q+1)^2 -> ev
   const int q = i >> 1;
   return 2 * __mul24(q + 1, q + (i & 1));  // 24-bit multiply: full rate (v_mul_lo_u32 is quarter rate)
 }
+
+#ifdef AVM_TP
+// Throughput build: offset (doubles from lds[0]) of entry (r, c), c <= r < NF, of the assembled system, or -1 where the entry is
+// structurally zero.  Pose rows: the packed triangle; speed-bias rows: the compact row [poses i-1, i, i+1 | speed-biases i-1, i] of
+// block i, except that the pose columns of the prior's speed-bias block live in the strip (the prior couples it to every pose).
+AVM_DEV int s_off(int r, int c) {
+  if (r < NPOSE) return L_S + roff(r) + c;
+  const int q = r - NPOSE, i = q / 9;
+  if (c < NPOSE) {
+    if (i == reinterpret_cast<const int*>(LDS() + L_INT)[I_PSB]) return L_STRIP + (q - 9 * i) * NPOSE + c;
+    const int p = c - 6 * (i - 1);
+    return (p >= 0 && p < 18) ? L_SBC + q * SBW + p : -1;
+  }
+  const int p = c - (NPOSE + 9 * (i - 1));
+  return (p >= 0 && p < 18) ? L_SBC + q * SBW + 18 + p : -1;
+}
+#define S_OFF(r, c) s_off(r, c)
+#else
+#define S_OFF(r, c) (L_S + roff(r) + (c))
+#endif
 
 // reciprocal / reciprocal square root from the hardware estimate + two Newton steps (about one ulp; the library forms spend
 // two to three times as long on range handling that the operands here - depths, squared norms >= 1 - never need)
@@ -505,6 +573,7 @@ AVM_DEV void td_shift(double* ob, const double* ai, const double* aj, double td,
   ob[0] -= si * ai[0], ob[1] -= si * ai[1], ob[2] -= sj * aj[0], ob[3] -= sj * aj[1];
 }
 
+#ifndef AVM_TP
 // prior residual r_p = r0 + J0 * dx(xs) into lds[L_RP]; returns (to all threads) nothing; needs syncs by caller
 AVM_NOINL void prior_residual_dev(const WinCtx&, int xs_off) {
   const WinCtx& c = lds_ctx();
@@ -548,6 +617,8 @@ AVM_NOINL void prior_residual_dev(const WinCtx&, int xs_off) {
   }
   __syncthreads();
 }
+
+#endif  // !AVM_TP
 
 // The prior's share of an evaluation on ONE wavefront, with wave-level synchronisation only, so that it runs beside the
 // projection factors (whose wavefronts do not touch these LDS ranges) instead of in a phase of its own:
@@ -724,6 +795,7 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
   return block_sum1(acc);
 }
 
+#ifndef AVM_TP
 // Prior J0^T J0 on the matrix cores (16x16 tiles, K = prior rows), marginalization-kernel variant: the tiles are
 // added straight into the packed system in LDS at the
 // columns pidx[] maps the prior's columns to (every lower entry is produced exactly once, so the wavefronts never
@@ -760,6 +832,8 @@ AVM_NOINL void prior_jtj_add_lds(gcdouble* pJ, int ldp, int pn, int s_off) {
     }
   }
 }
+
+#endif  // !AVM_TP
 
 // Solve-kernel variant: lower triangle packed by idx = p (p + 1) / 2 + q into HPk, plus the destination of every
 // entry inside the packed S (or -1 if the prior column is not a state of the solve) - the per-iteration add is then
@@ -816,7 +890,11 @@ AVM_NOINL void prior_jtj_packed(gcdouble* pJ, int ldp, int pn, gdouble* HPk, gin
         const int idx = gi * (gi + 1) / 2 + gj;
         const int ip = pidx[gi], iq = pidx[gj];
         HPk[idx] = D[r];
+#ifdef AVM_TP
+        dst[idx] = (ip < 0 || iq < 0) ? -1 : s_off(max(ip, iq), min(ip, iq)) - L_S;  // (-1 also where the structural form has no slot: see tp_prior_ok)
+#else
         dst[idx] = (ip < 0 || iq < 0) ? -1 : roff(max(ip, iq)) + min(ip, iq);
+#endif
       }
     }
   }
@@ -948,6 +1026,60 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int wvi, int stage_
       PF[(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
       PF[(7 * NFR + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
     }
+#ifdef AVM_TP
+    // Throughput build: the staging tile holds HALF a chunk (lanes 0-31 stage and the wavefront multiplies, then lanes 32-63; the
+    // scheme of marg_frame_task).  A run that straddles the two halves simply continues: the switches below only act on a new key.
+    const int nact = min(64, ntot - chunk0);
+    const int key = (b << 4) | fa;  // frames ascending, start frames ascending inside a frame: equal keys are consecutive
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+      const int h0 = 32 * half, lim = min(nact, h0 + 32);
+      if (h0 >= nact) break;  // (uniform)
+      if ((lane >> 5) == half) {
+        dv2* st = reinterpret_cast<dv2*>(stage) + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 6; k++) st[k * (XRS_H / 2)] = dv2{Jj[k], Jj[6 + k]}, st[(6 + k) * (XRS_H / 2)] = dv2{Ji[k], Ji[6 + k]};
+        st[12 * (XRS_H / 2)] = dv2{r[0], r[1]};
+      }
+      wave_lds_sync();
+      int l = h0;
+      while (l < lim) {
+        const int k_cur = __shfl(key, l, 64);
+        const int l_end = min(l + __popcll(__ballot(act && key == k_cur && lane >= l)), lim);
+        if ((k_cur >> 4) != b_run) {
+          end_frame();
+          b_run = k_cur >> 4;
+        }
+        if ((k_cur & 15) != a_run) {
+          flush();
+          a_run = k_cur & 15;
+        }
+        const int j_end = (l_end - h0 + 3) >> 2;
+#pragma unroll 1
+        for (int j0 = (l - h0) >> 2; j0 < j_end; j0 += 4) {
+          dv2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS_H + 8 * min(j0 + u, 7) + 2 * drow);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int f = h0 + 4 * (j0 + u) + drow;
+            const bool in = dcol < 13 && f >= l && f < l_end;
+            const double a0 = in ? v[u][0] : 0.0, a1 = in ? v[u][1] : 0.0;
+            if (u & 1) {
+              Drun2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, Drun2, 0, 0, 0);
+              Drun3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, Drun3, 0, 0, 0);
+            } else {
+              Drun = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, Drun, 0, 0, 0);
+              Drun1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, Drun1, 0, 0, 0);
+            }
+          }
+        }
+        l = l_end;
+      }
+      wave_lds_sync();
+    }
+  }
+#else
     // staged column-major, X^T[col][row], row = 2 lane + residual row: one 16-byte store per column, contiguous
     // across the lanes (a row-major [row][14] tile puts the 64 lanes of a store on 8 banks)
     {
@@ -1000,6 +1132,7 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int wvi, int stage_
     }
     wave_lds_sync();
   }
+#endif
   end_frame();
   return cost;
 }
@@ -1224,7 +1357,7 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
 #endif
   const int ccol0 = li > 0 ? imu_col(i, li - 1) : -1;          // state column of combined column li
   const int ccol1 = li < 15 ? imu_col(i, 15 + li) : -1;        // ... of combined column 16 + li
-  const int dump = L_WCH + 512 + lane;
+  const int dump = L_DUMP + lane;
   int off[12];
   double val[12];
 #pragma unroll
@@ -1235,15 +1368,15 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
     // G00: rows / columns 0..15, lower part; row 0 is the residual row (its (0,0) entry is r^T r)
     if (R0 == 0 && li == 0) half_rr = 0.5 * G00[r];
     const bool v00 = R0 > 0 && li <= R0;
-    off[3 * r] = !v00 ? dump : (li == 0 ? L_G + sr0 : L_S + roff(max(sr0, ccol0)) + min(sr0, ccol0));
+    off[3 * r] = !v00 ? dump : (li == 0 ? L_G + sr0 : S_OFF(max(sr0, ccol0), min(sr0, ccol0)));
     val[3 * r] = G00[r] * (li == 0 ? 1.0 : SCL(sr0) * SCL(ccol0));
     // G10: rows 16..30, columns 0..15
     const bool v10 = R1 < 31;
-    off[3 * r + 1] = !v10 ? dump : (li == 0 ? L_G + sr1 : L_S + roff(max(sr1, ccol0)) + min(sr1, ccol0));
+    off[3 * r + 1] = !v10 ? dump : (li == 0 ? L_G + sr1 : S_OFF(max(sr1, ccol0), min(sr1, ccol0)));
     val[3 * r + 1] = G10[r] * (li == 0 ? 1.0 : SCL(sr1) * SCL(ccol0));
     // G11: rows / columns 16..30, lower part
     const bool v11 = R1 < 31 && li < 15 && 16 + li <= R1;
-    off[3 * r + 2] = !v11 ? dump : L_S + roff(max(sr1, ccol1)) + min(sr1, ccol1);
+    off[3 * r + 2] = !v11 ? dump : S_OFF(max(sr1, ccol1), min(sr1, ccol1));
     val[3 * r + 2] = G11[r] * (SCL(sr1) * SCL(ccol1));
   }
 #undef SCL
@@ -1276,6 +1409,11 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   double acc = 0;
   // ---- phase A: projection factors (wavefronts 0..ASM_WAVES-1) || raw IMU Jacobians (the next wavefront) || the prior
   const long long pa__ = c.prof ? clock64() : 0;
+#ifdef AVM_TP
+  constexpr int IMUW = 2;  // (every wavefront assembles; wavefronts 2 and 3 get fewer frames and take the raw IMU Jacobians and the prior afterwards)
+#else
+  constexpr int IMUW = ASM_WAVES;
+#endif
   if (wv < ASM_WAVES) {
 #ifdef AVM_X
     for (int b = 1; b < NFRP; b++)
@@ -1283,7 +1421,12 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
 #else
     acc += frame_task(c, o, wv, L_S + SPP + wv * XSTG);  // all the frames of this wavefront as one list
 #endif
-  } else if (wv == ASM_WAVES && lane < 10) {
+  }
+#ifdef AVM_TP
+  if (wv == IMUW && lane < 10) {
+#else
+  else if (wv == ASM_WAVES && lane < 10) {
+#endif
     const int i = lane;
     if (c.psum[i] <= o.max_sum_dt)
       imu_raw<true>(xs, fr.R, o, c.pdelta + i * 10, c.pjac + i * 225, c.psum[i], c.lba + i * 3, c.lbg + i * 3, i, IJR + i * 465);
@@ -1297,9 +1440,9 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
 #else
   // (the raw-IMU wavefront takes the last two fifths of the prior's rows once it is done: each of the two reads J0 along its
   //  own rows only)
-  if (wv >= ASM_WAVES && c.pn > 0) {
+  if (wv >= IMUW && c.pn > 0) {
     const int h = (3 * c.pn + 2) / 5;
-    const double pc = wv == ASM_WAVES ? prior_wave<true>(xs_off, h, c.pn, L_DX2) : prior_wave<true>(xs_off, 0, h, L_DXP);
+    const double pc = wv == IMUW ? prior_wave<true>(xs_off, h, c.pn, L_DX2) : prior_wave<true>(xs_off, 0, h, L_DXP);
     if (lane == 0) acc += pc;
   }
 #endif
@@ -1335,12 +1478,24 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     }
 #ifndef AVM_X
     // the partial (a,a) blocks of the frame tasks, summed further down, are requested now as well
+#ifdef AVM_TP
+    constexpr int NPR = (NFR * 27 + NT - 1) / NT;  // 297 sums on 256 threads: two rounds
+    double pp[NPR][NFR - 1];
+#pragma unroll
+    for (int u = 0; u < NPR; u++) {
+      const int tt = min(t + u * NT, NFR * 27 - 1);
+      const int f = tt / 27, q = tt % 27;
+#pragma unroll
+      for (int b = 1; b < NFR; b++) pp[u][b - 1] = (c.sc + Scratch::PART)[((size_t)b * NFR + f) * 27 + q];  // unconditional, masked below
+    }
+#else
     double pp[NFR - 1];
     if (t < NFR * 27) {
       const int f = t / 27, q = t % 27;
 #pragma unroll
       for (int b = 1; b < NFR; b++) pp[b - 1] = (c.sc + Scratch::PART)[((size_t)b * NFR + f) * 27 + q];  // unconditional, masked below
     }
+#endif
 #endif
 #pragma unroll
     for (int u = 0; u < NRND; u++) {
@@ -1418,6 +1573,25 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       const bool on = t < 6 ? c.relo_n > 0 : (t < 12 ? c.est_ex != 0 : c.est_td != 0);
       if (!on) lds[L_S + roff(col) + col] = 1.0;
     }
+#elif defined(AVM_TP)
+#pragma unroll
+    for (int u = 0; u < NPR; u++) {
+      const int tt = t + u * NT;
+      if (tt >= NFR * 27) break;
+      const int f = tt / 27, q = tt % 27;
+      double sacc = 0;
+#pragma unroll
+      for (int b = 1; b < NFR; b++)
+        if (b > f && (ids[I_PMASK + b] & (1 << f))) sacc += pp[u][b - 1];
+      if (q < 21) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= q) i++;
+        const int j = q - i * (i + 1) / 2;
+        lds[L_S + roff(6 * f + i) + 6 * f + j] += sacc * (lds[L_SC + 6 * f + i] * lds[L_SC + 6 * f + j]);
+      } else {
+        lds[L_G + 6 * f + (q - 21)] += sacc;
+      }
+    }
 #else
     if (t < NFR * 27) {
       const int f = t / 27, q = t % 27;
@@ -1439,9 +1613,20 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   PROF(c, 1);
   // phase D's operands (sqrt_info, the raw Jacobians wave ASM_WAVES left in the slot during phase A) and phase E's packed
   // prior are fetched now: their trip to the slot's memory overlaps the zeroing and the barriers in between
+#ifdef AVM_TP
+  // ten factors on four wavefronts: three rounds of factors that share no frame - {0 2 4 6}, {8 1 3 5}, {7 9}
+  constexpr int NIMR = 3;
+  auto imu_of = [&](int rd) { return rd == 0 ? 2 * wv : (rd == 1 ? (wv == 0 ? 8 : 2 * wv - 1) : (wv == 0 ? 7 : (wv == 1 ? 9 : -1))); };
+  ImuOperands io[NIMR];
+#pragma unroll
+  for (int rd = 0; rd < NIMR; rd++)
+    if (imu_of(rd) >= 0) imu_factor_load(imu_of(rd), io[rd]);
+  constexpr int NIT = 12;  // rounds fetched ahead: they cover a prior of up to 77 rows (the tail of a larger one is added straight from the slot)
+#else
   ImuOperands io[2];
   if (wv < 5) imu_factor_load(2 * wv, io[0]), imu_factor_load(2 * wv + 1, io[1]);
   constexpr int NIT = (HPK_MAX + NT - 1) / NT;  // 10 rounds cover the largest prior
+#endif
   const int npk = c.pn * (c.pn + 1) / 2;
   int dd[NIT];
   double hv[NIT];
@@ -1455,11 +1640,23 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     }
   }
   // rows 66.. of S (the staging area is dead now)
+#ifdef AVM_TP
+  for (int i = t; i < 99 * SBW + 9 * NPOSE; i += NT) lds[L_SBC + i] = 0.0;  // the speed-bias rows in structural form + the prior's strip
+#else
   for (int i = SPP + t; i < SROWS; i += NT) lds[L_S + i] = 0.0;
+#endif
   __syncthreads();
   PROF(c, 3);
   // ---- phase D: IMU factors on MFMA, one wavefront per factor; even factors then odd ones (neighbours share a frame)
   {
+#ifdef AVM_TP
+#pragma unroll
+    for (int rd = 0; rd < NIMR; rd++) {
+      const int i = imu_of(rd);
+      if (i >= 0 && c.psum[max(i, 0)] <= o.max_sum_dt) acc += imu_factor_mfma(c, i, io[rd]);
+      __syncthreads();
+    }
+#else
 #pragma unroll
     for (int par = 0; par < 2; par++) {
       if (wv < 5) {
@@ -1468,6 +1665,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       }
       __syncthreads();
     }
+#endif
   }
   PROF(c, 7);
   // ---- phase E: prior  H += Hp (packed values + destinations prepared once per solve), g += J0^T r_p
@@ -1477,6 +1675,12 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
 #pragma unroll
       for (int u = 0; u < NIT; u++)
         if (t + u * NT < npk && dd[u] >= 0) lds[L_S + dd[u]] += hv[u];
+#ifdef AVM_TP
+      for (int idx = t + NIT * NT; idx < npk; idx += NT) {
+        const int d = reinterpret_cast<const gint*>(c.sc + Scratch::HP + HPK_MAX)[idx];
+        if (d >= 0) lds[L_S + d] += (c.sc + Scratch::HP)[idx];
+      }
+#endif
     }
     {
       const int* pidx = ids + I_PIDX;
@@ -1586,8 +1790,13 @@ AVM_NOINL double jac_times_vec_sq(const WinCtx&, const avm_options&) {
     rvb[t] = rv;
   }
   // the prior's rows meanwhile: J0 row i times v, sixteen loads in flight (behind `pidx[k] >= 0` they were up to 75 trips)
-  if (c.pn > 0 && t >= 192 && t < 192 + c.pn) {
-    const int i = t - 192;
+#ifdef AVM_TP
+  constexpr int PT0 = 160;  // (256 threads: the prior's rows sit right behind the 150 IMU rows)
+#else
+  constexpr int PT0 = 192;
+#endif
+  if (c.pn > 0 && t >= PT0 && t < PT0 + c.pn) {
+    const int i = t - PT0;
     const int* pidx = ids + I_PIDX;
     const int pn1 = c.pn - 1;
     double y = 0;
@@ -1626,6 +1835,318 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
+#ifdef AVM_TP
+// =====================================================================================================================
+// Throughput build: the factorization on REGISTER tiles, distributed over the workgroup's four wavefronts.
+//
+// The augmented (NF + 1) x (NF + 1) system [H' + mu D^2, g'; g'^T, .] is cut into 11 x 11 tiles of 16 x 16 and held as its UPPER
+// tiles U(k, i), k <= i (U(k, i) = L(i, k)^T once factored), in the accumulator layout of v_mfma_f64_16x16x4: register r of lane
+// (lk = lane / 16, lr = lane % 16) is entry (lk + 4 r, lr).  With the k index of a product running as lk + 4 r such a tile IS a B
+// operand and, read as an A operand, its transpose (the scheme of prior_chol_kernel, prior_eig.hip), so nothing is transposed or
+// moved between lanes.  The right-hand side is column NF (tile column 10, local column 5): the forward substitution rides along.
+//   * ownership by tile COLUMN: wavefront tp_owner(i) holds U(0..i, i) - column sizes {11 5} {10 6} {9 7 1} {8 4 3 2}: at most 17
+//     tiles = 136 registers per lane, and the trailing updates of every step are spread almost evenly;
+//   * step k:  [owner of column k] 16-pivot chain on the diagonal tile (through a 2 KB LDS patch into lane = row form: the
+//     square-root-free chain of chol_diag_block, L_kk^-T riding along in lanes 16..31) ............................. barrier
+//              [every wavefront] W(k, i) = L_kk^-1 U(k, i) for its columns i > k, published to LDS ................. barrier
+//              [every wavefront] U(j, i) -= W(k, j)^T W(k, i) for its columns, the owner of column k + 1 taking tile (k + 1, k + 1)
+//              first and running the next chain while the others still update (look-ahead): two barriers per step.
+//   * backward substitution L^T x = z by tile columns, last to first: the owner of column i solves x_i from z_i minus the four
+//     wavefronts' partial sums, folds x_i into element-wise accumulators E_k += U(k, i) .* x_i (k < i, no reduction), and every
+//     wavefront reduces its E_{i-1} over the 16-lane rows (DPP) into its partial vector: one barrier per column.
+// Nothing of the factor ever goes to memory; the LDS traffic is the published row of W (<= 20 KB per step).
+constexpr int TPT = 11;
+constexpr int TP_NBL = NF - 16 * (TPT - 1);  // state columns in the last tile column: 5 (+ the right-hand side at local column 5)
+static_assert(TP_NBL >= 1 && TP_NBL < 16, "the right-hand side fits the last tile column");
+__host__ __device__ constexpr int tp_owner(int i) {
+  return i == 10 || i == 4 ? 0 : (i == 9 || i == 5 ? 1 : (i == 8 || i == 6 || i == 0 ? 2 : 3));
+}
+__host__ __device__ constexpr int tp_base(int wv, int i) {  // index of tile (0, i) in wavefront wv's array
+  int n = 0;
+  for (int c = 0; c < i; c++) n += tp_owner(c) == wv ? c + 1 : 0;
+  return n;
+}
+__host__ __device__ constexpr int tp_ntiles(int wv) { return tp_base(wv, TPT); }
+
+// entry (R, C) of the augmented symmetric system as the evaluation + schur_reduce left it (structural zeros included)
+AVM_DEV double tp_entry(int R, int C) {
+  double* lds = LDS();
+  const int hi = max(R, C), lo = min(R, C);
+  const int o = s_off(min(hi, NF - 1), min(lo, NF - 1));
+  const double v = lds[max(o, 0)], rhs = lds[L_RHS + min(lo, NF - 1)];
+  return hi > NF ? 0.0 : (hi == NF ? (lo < NF ? rhs : 0.0) : (o >= 0 ? v : 0.0));
+}
+
+// 16-pivot chain on the diagonal block in the LDS patch ([row][16], symmetric): chol_diag_block with the patch as its source and
+// destination.  Leaves L~ (lower, unscaled: times sqrt(d_c) per column c, the pivot d_c on the diagonal) in the patch and
+// L~^-T in buffer `buf`.
+AVM_DEV void tp_diag_chain(int nb, int buf) {
+  constexpr int NB = 16;
+  double* lds = LDS();
+  const int r = threadIdx.x & 63;
+  __builtin_amdgcn_s_setprio(3);
+  double a[NB];
+  const bool idl = (r & 48) == 16;
+  const int rc = min(r, nb - 1);
+  double* row = lds + L_PATCH + (rc & 15) * NB;
+  {
+#pragma unroll
+    for (int k = 0; k < NB; k++) a[k] = row[k];
+#pragma unroll
+    for (int k = 0; k < NB; k++) a[k] = idl ? ((r & 15) == k ? 1.0 : 0.0) : a[k];  // lanes 16..31: the identity's rows
+  }
+  wave_lds_sync();  // (every lane holds its row: the stores below go to the same patch)
+  double uprev = 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    if (j > 0) a[j] = fma(-uprev, readlane_d(a[j - 1], j), a[j]);
+    const double djj = readlane_d(a[j], j);
+    double y = __builtin_amdgcn_rcp(djj), e = 0;
+#define AVM_TAIL(slot)                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  if (j > 0) {                                                                                                         \
+    double sk[3];                                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 3; q++) sk[q] = readlane_d(a[j - 1], min(j + 1 + (slot) + 5 * q, NB - 1));   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 3; q++)                                                                      \
+      if (j + 1 + (slot) + 5 * q < NB) a[j + 1 + (slot) + 5 * q] = fma(-uprev, sk[q], a[j + 1 + (slot) + 5 * q]);      \
+  }                                                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+    AVM_TAIL(0)
+    e = fma(-djj, y, 1.0);
+    AVM_TAIL(1)
+    y = fma(y, e, y);
+    AVM_TAIL(2)
+    e = fma(-djj, y, 1.0);
+    AVM_TAIL(3)
+    y = fma(y, e, y);
+    AVM_TAIL(4)
+#undef AVM_TAIL
+    uprev = a[j] * y;
+  }
+  {
+    double* dst = idl ? lds + L_LINV + buf * 272 + (r & 15) * NB : row;
+    double* dump = lds + L_DUMP + r;
+    const int kmax = idl ? NB - 1 : (r < nb ? r : -1);
+#pragma unroll
+    for (int k = 0; k < NB; k++) *(k <= kmax ? dst + k : dump) = a[k];
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// sum over the 16 lanes of a DPP row; the result is valid in lane 15 of every row (row_shr with bound_ctrl: a lane without a source adds 0)
+AVM_DEV double tp_row_sum(double v) {
+#define AVM_DPP_ADD(ctrl)                                                                      \
+  {                                                                                            \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);    \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);    \
+    v += __hiloint2double(hi, lo);                                                             \
+  }
+  AVM_DPP_ADD(0x111)
+  AVM_DPP_ADD(0x112)
+  AVM_DPP_ADD(0x114)
+  AVM_DPP_ADD(0x118)
+#undef AVM_DPP_ADD
+  return v;
+}
+
+// compile-time loops: every tile index below has to be a constant, or the tile array would live in scratch memory
+template <class F, int... Is>
+AVM_DEV void tp_sfor_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+AVM_DEV void tp_sfor(F&& f) {
+  tp_sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Factor the assembled system and solve it: (H' + mu D^2) y = g', y -> lds[L_Y .. L_Y + NF).  Returns false on a non-positive pivot
+// (uniform over the workgroup).  Called by all four wavefronts, WV = the caller's wavefront.
+template <int WV>
+AVM_NOINL bool chol_regs() {
+  double* lds = LDS();
+  const int lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
+  int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
+  constexpr int NTL = tp_ntiles(WV);
+  d4 T[NTL];
+  // ---- load (structural zeros included)
+  tp_sfor<TPT>([&](auto I) {
+    constexpr int i = I;
+    if constexpr (tp_owner(i) == WV) {
+      tp_sfor<i + 1>([&](auto K) {
+        constexpr int k = K;
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[tp_base(WV, i) + k][r] = tp_entry(16 * k + lk + 4 * r, 16 * i + lr);
+      });
+    }
+  });
+  if (threadIdx.x == 0) *s_fail = 0;
+  __syncthreads();  // every tile is in registers: the union region becomes the factorization's scratch
+  for (int q = threadIdx.x; q < 4 * 176; q += NT) lds[L_PARTV + q] = 0.0;
+  // by the owner of column k: diagonal tile -> patch -> chain (L~_kk in the patch, L~_kk^-T in buffer k & 1)
+  auto run_chain = [&](auto K) {
+    constexpr int k = K;
+    const d4& D = T[tp_base(WV, k) + k];
+#pragma unroll
+    for (int r = 0; r < 4; r++) lds[L_PATCH + (lk + 4 * r) * 16 + lr] = D[r];
+    wave_lds_sync();
+    tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, k & 1);
+    wave_lds_sync();
+  };
+  d4 Dlast = {0, 0, 0, 0};  // the last diagonal tile as it was before its chain (its column TP_NBL is the right-hand side)
+  if constexpr (tp_owner(0) == WV) run_chain(std::integral_constant<int, 0>{});
+  bool failed = false;
+  tp_sfor<TPT>([&](auto K) {
+    constexpr int k = K;
+    constexpr int nb = k == TPT - 1 ? TP_NBL : 16;
+    if (failed) return;  // (uniform)
+    __syncthreads();  // (b) L~_kk and L~_kk^-T are published; every wavefront is done with step k - 1
+    // A operand of the solves: L_kk^-1[i' = lr][k' = lk + 4 m] = L~^-T[k'][i'] / sqrt(d_i'); the row scaling is applied to the product
+    double aop[4], isq4[4];
+    {
+      const double* LT = lds + L_LINV + (k & 1) * 272;
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const double v = LT[(lk + 4 * m) * 16 + lr];
+        aop[m] = (lk + 4 * m < nb && lr < nb) ? v : 0.0;
+        const double dc = lds[L_PATCH + min(lk + 4 * m, nb - 1) * 17];
+        if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront sees the same values
+        isq4[m] = fast_rsqrt_pe(dc);
+      }
+    }
+    if constexpr (tp_owner(k) == WV) {
+      // the diagonal tile becomes L~_kk^T (entry (a, b) = L~[b][a]); the last one first gives up the right-hand side: z_10 = L^-1 b
+      d4& D = T[tp_base(WV, k) + k];
+      if constexpr (k == TPT - 1) {
+        d4 Za = {0, 0, 0, 0}, Zb = {0, 0, 0, 0};
+        Za = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], Dlast[0], Za, 0, 0, 0);
+        Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], Dlast[1], Zb, 0, 0, 0);
+        Za = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], Dlast[2], Za, 0, 0, 0);
+        Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], Dlast[3], Zb, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (lr == TP_NBL && lk + 4 * r < TP_NBL) lds[L_Y + 16 * k + lk + 4 * r] = (Za[r] + Zb[r]) * isq4[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + lr * 16 + lk + 4 * r];
+    }
+    // (c) W(k, i) = L_kk^-1 U(k, i) for this wavefront's columns i > k: the final factor tiles, published for the others' updates
+    tp_sfor<TPT - 1 - k>([&](auto II) {
+      constexpr int i = k + 1 + II;
+      if constexpr (tp_owner(i) == WV) {
+        d4& U = T[tp_base(WV, i) + k];
+        d4 Wa = {0, 0, 0, 0}, Wb = {0, 0, 0, 0};
+        Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], U[0], Wa, 0, 0, 0);
+        Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], U[1], Wb, 0, 0, 0);
+        Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], U[2], Wa, 0, 0, 0);
+        Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], U[3], Wb, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          U[r] = (Wa[r] + Wb[r]) * isq4[r];
+          lds[L_WROW + (i - 1) * 256 + r * 64 + lane] = U[r];
+        }
+        if constexpr (i == TPT - 1) {  // the right-hand side column of tile column 10 is z_k
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (lr == TP_NBL) lds[L_Y + 16 * k + lk + 4 * r] = U[r];
+        }
+      }
+    });
+    if constexpr (k < TPT - 1) {
+      __syncthreads();  // (d) row k of W is published
+      if (*s_fail) {
+        failed = true;
+        return;
+      }
+      // (e) trailing update U(j, i) -= W(k, j)^T W(k, i), k < j <= i.  The owner of column k + 1 starts with tile (k + 1, k + 1) and
+      // runs the next chain right away: the other wavefronts update meanwhile (look-ahead).
+      auto update_col = [&](auto II, auto J0) {
+        constexpr int i = II, j0 = J0;
+        const d4& Wi = T[tp_base(WV, i) + k];
+        tp_sfor<i - j0 + 1>([&](auto JJ) {
+          constexpr int j = j0 + JJ;
+          d4 Wj;
+          if constexpr (tp_owner(j) == WV) {
+            Wj = T[tp_base(WV, j) + k];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Wj[r] = lds[L_WROW + (j - 1) * 256 + r * 64 + lane];
+          }
+          d4& U = T[tp_base(WV, i) + j];
+#pragma unroll
+          for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wj[r], Wi[r], U, 0, 0, 0);
+        });
+      };
+      if constexpr (tp_owner(k + 1) == WV) {
+        update_col(std::integral_constant<int, k + 1>{}, std::integral_constant<int, k + 1>{});  // one tile: (k + 1, k + 1)
+        if constexpr (k + 1 == TPT - 1) Dlast = T[tp_base(WV, k + 1) + k + 1];
+        run_chain(std::integral_constant<int, k + 1>{});
+      }
+      tp_sfor<TPT - 2 - k>([&](auto II) {
+        constexpr int i = k + 2 + II;
+        if constexpr (tp_owner(i) == WV) update_col(std::integral_constant<int, i>{}, std::integral_constant<int, k + 1>{});
+      });
+    }
+  });
+  if (failed) return false;
+  __syncthreads();  // z is complete in lds[L_Y]
+  if (*s_fail) return false;
+  // ---- backward substitution L^T x = z by tile columns, last to first
+  d4 E[TPT - 1];  // E[k] += U(k, i) .* x_i over this wavefront's columns i > k (element-wise: reduced once, when block k is due)
+#pragma unroll
+  for (int k = 0; k < TPT - 1; k++) E[k] = d4{0, 0, 0, 0};
+  tp_sfor<TPT>([&](auto IR) {
+    constexpr int i = TPT - 1 - IR;
+    constexpr int nb = i == TPT - 1 ? TP_NBL : 16;
+    if constexpr (tp_owner(i) == WV) {
+      // v = z_i - the four partial sums; L~_ii back into the patch in [row][column] form; the 16-step chain of chol_solve_block
+      const d4& D = T[tp_base(WV, i) + i];
+#pragma unroll
+      for (int r = 0; r < 4; r++) lds[L_PATCH + lr * 16 + lk + 4 * r] = D[r];
+      const int rr = min(lr, nb - 1);
+      double bv = lds[L_Y + 16 * i + rr];
+#pragma unroll
+      for (int w = 0; w < 4; w++) bv -= lds[L_PARTV + w * 176 + 16 * i + rr];
+      wave_lds_sync();
+      double colv[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) colv[q] = lds[L_PATCH + q * 16 + rr];
+      const double isq = fast_rsqrt_pe(lds[L_PATCH + rr * 17]), di2 = isq * isq;
+      bv *= isq;
+#pragma unroll
+      for (int q = 0; q < 16; q++) colv[q] *= di2;
+      double xout = 0.0;
+#pragma unroll
+      for (int jj = nb - 1; jj >= 0; jj--) {
+        const double xj = readlane_d(bv, jj);
+        bv = fma(-colv[jj], xj, bv);
+        xout = lane == jj ? xj : xout;
+      }
+      if (lane < nb) lds[L_Y + 16 * i + lane] = xout;
+      wave_lds_sync();
+      // fold x_i into the element-wise accumulators of the blocks above (lane (lk, lr): column lr of every tile)
+      const double xl = lr < nb ? lds[L_Y + 16 * i + min(lr, nb - 1)] : 0.0;
+      tp_sfor<i>([&](auto K) {
+        constexpr int k = K;
+        const d4& U = T[tp_base(WV, i) + k];
+#pragma unroll
+        for (int r = 0; r < 4; r++) E[k][r] = fma(U[r], xl, E[k][r]);
+      });
+    }
+    if constexpr (i > 0) {
+      // every wavefront: its share of block i - 1 is complete (all its columns > i - 1 have been folded in)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const double sacc = tp_row_sum(E[i - 1][r]);
+        if (lr == 15) lds[L_PARTV + WV * 176 + 16 * (i - 1) + lk + 4 * r] = sacc;
+      }
+      __syncthreads();
+    }
+  });
+  __syncthreads();
+  return true;
+}
+#else  // the other builds: left-looking factorization of the packed system in LDS
 // Scratch of the factorization inside the tile at L_WCH (dead while S is being factored): L^-T of the current and of the
 // next diagonal block, and a per-lane dump slot for the masked-out stores.
 constexpr int L_CLT = L_WCH /* two buffers of 256: block j's L^-T in buffer j & 1 */, L_CDUMP = L_WCH + 512;
@@ -1949,6 +2470,8 @@ AVM_NOINL void chol_solve_lds(int vec) {
   __syncthreads();
 }
 
+#endif  // AVM_TP / LDS factorization
+
 // One wavefront's share of the Schur update: the tiles (R, C), R in {R0, R1}, C in {C0, C1}, C <= R, of the 5x5
 // grid (-1 = absent).  Every 16-column block of W is loaded once per k-step and feeds all the tiles that use it.
 template <int R0, int R1, int C0, int C1>
@@ -2027,7 +2550,11 @@ AVM_DEV void schur_macro_tile(const WinCtx&) {
       for (int r = 0; r < 4; r++) {
         const int gi = 16 * RB[a] + lk + 4 * r, gj = 16 * CB[b] + li;
         const bool body = gi < NPOSE && gj <= gi, rhs = gi == NPOSE && gj < NPOSE;
-        off[r] = body ? L_S + roff(gi) + gj : (rhs ? L_S + roff(NF) + gj : L_WCH + 512 + (threadIdx.x & 63));
+#ifdef AVM_TP
+        off[r] = body ? L_S + roff(gi) + gj : (rhs ? L_RHS + gj : L_DUMP + (threadIdx.x & 63));
+#else
+        off[r] = body ? L_S + roff(gi) + gj : (rhs ? L_S + roff(NF) + gj : L_DUMP + (threadIdx.x & 63));
+#endif
         sc[r] = (body ? scl[min(gi, NPOSE - 1)] : 1.0) * scl[min(gj, NPOSE - 1)];
         cur[r] = lds[off[r]];
       }
@@ -2050,8 +2577,13 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
   double* lds = LDS();
   const int t = threadIdx.x;
   const double* scl = lds + L_SC;
+#ifdef AVM_TP
+  if (t < NF) lds[s_off(t, t)] += mu * lds[L_DD + t] * lds[L_DD + t];
+  for (int i = t; i < NF; i += NT) lds[L_RHS + i] = lds[L_G + i];  // the right-hand side (column NF of the register tiles; L_Y is free until the solve)
+#else
   if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
   for (int i = t; i < NF; i += NT) lds[L_S + roff(NF) + i] = lds[L_G + i];  // RHS rides along as row NF
+#endif
   // per feature: f_e = s_e^2 / (hee' + mu D_e^2) and x_e = s_e g'_e / (hee' + mu D_e^2)   (L_ST is dead here)
   if (t < MAXE + 2) {
     double f = 0, x = 0;
@@ -2063,6 +2595,16 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
     lds[L_ST + t] = f, lds[L_ST + 152 + t] = x;
   }
   __syncthreads();
+#ifdef AVM_TP
+  switch (t >> 6) {  // four wavefronts, one per SIMD: 4 | 3 + 1 | 3 + 1... tiles (the 15 lower tiles of the 5 x 5 grid)
+    case 0: schur_macro_tile<2, 3, 0, 1>(c); break;                                       // 4 tiles
+    case 1: schur_macro_tile<0, 1, 0, 1>(c); schur_macro_tile<4, -1, 4, -1>(c); break;    // 3 + 1
+    case 2: schur_macro_tile<2, 3, 2, 3>(c); break;                                       // 3
+    default: schur_macro_tile<4, -1, 0, 1>(c); schur_macro_tile<4, -1, 2, 3>(c); break;   // 2 + 2
+  }
+  __syncthreads();
+  return;
+#endif
   switch (t >> 6) {
     case 0: schur_macro_tile<2, 3, 0, 1>(c); break;  // 4 tiles
     case 1: schur_macro_tile<0, 1, 0, 1>(c); break;  // 3 tiles
@@ -2090,8 +2632,8 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
   __syncthreads();
   const int part = t & 3;
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int e = (t >> 2) + 128 * pass;
+  for (int pass = 0; pass < (MAXE + NT / 4 - 1) / (NT / 4); pass++) {
+    const int e = (t >> 2) + (NT / 4) * pass;
     double sacc = 0;
     if (e < c.nf) {
       gcdouble* We = W + e;  // Wt[c][e]
@@ -2139,6 +2681,25 @@ AVM_NOINL void scale_system(const WinCtx&, bool matrix) {
     }
   }
 #endif
+#ifdef AVM_TP
+  if (matrix) {
+    // once per solve: the pose rows of the packed triangle entry by entry, then the speed-bias rows in their structural form
+    for (int idx = t; idx < NPOSE * NPOSE; idx += NT) {
+      const int r = idx / NPOSE, cc = idx - r * NPOSE;
+      if (cc <= r) lds[L_S + roff(r) + cc] *= scl[r] * scl[cc];
+    }
+    for (int idx = t; idx < 99 * SBW; idx += NT) {
+      const int q = idx / SBW, p = idx - q * SBW, i = q / 9;
+      const int cc = p < 18 ? 6 * (i - 1) + p : NPOSE + 9 * (i - 1) + (p - 18);
+      if (cc >= 0 && (p >= 18 || cc < NPOSE)) lds[L_SBC + idx] *= scl[NPOSE + q] * scl[cc];
+    }
+    const int psb = reinterpret_cast<const int*>(lds + L_INT)[I_PSB];
+    for (int idx = t; idx < 9 * NPOSE; idx += NT) {
+      const int a = idx / NPOSE, cc = idx - a * NPOSE;
+      lds[L_STRIP + idx] *= scl[NPOSE + 9 * psb + a] * scl[cc];
+    }
+  }
+#else
   if (matrix)
   // 16x16 tiles of the packed lower triangle dealt to the wavefronts, 4 entries per lane and tile (the same lane <-> entry
   // map as the accumulators of the factorization): every lane has the same amount of work; three tiles per round with
@@ -2166,7 +2727,7 @@ AVM_NOINL void scale_system(const WinCtx&, bool matrix) {
         for (int r = 0; r < 4; r++) {
           const int gi = 16 * ti + lk + 4 * r;
           const bool ok = tv && gi < NF && gj <= gi;
-          off[u][r] = ok ? L_S + roff(gi) + gj : L_WCH + 512 + lane;
+          off[u][r] = ok ? L_S + roff(gi) + gj : L_DUMP + lane;
           f[u][r] = scl[min(gi, NF - 1)] * sj;
           v[u][r] = lds[off[u][r]];
         }
@@ -2177,6 +2738,7 @@ AVM_NOINL void scale_system(const WinCtx&, bool matrix) {
         for (int r = 0; r < 4; r++) lds[off[u][r]] = v[u][r] * f[u][r];
     }
   }
+#endif
   if (t < c.nf) lds[L_HEE + t] *= scl[NF + t] * scl[NF + t];
   for (int i = t; i < NF + c.nf; i += NT) lds[L_G + i] *= scl[i];
   __syncthreads();
@@ -2201,10 +2763,14 @@ AVM_DEV void state_plus() {
     const int k = t - 64;
     xc[XSB + k] = x[XSB + k] + st[SB0 + k] * scl[SB0 + k];
   }
+#ifdef AVM_TP
+  for (int e = t; e < MAXE; e += NT) xc[XLAM + e] = x[XLAM + e] + st[NF + e] * scl[NF + e];
+#else
   if (t >= 192 && t < 192 + MAXE) {
     const int e = t - 192;
     xc[XLAM + e] = x[XLAM + e] + st[NF + e] * scl[NF + e];
   }
+#endif
 #ifdef AVM_X
   // relo_Pose (frame 11) / ex_pose: PoseLocalParameterization::Plus when they are variables, else carried over untouched
   const WinCtx& c = lds_ctx();
@@ -2228,10 +2794,15 @@ AVM_DEV void state_plus() {
 
 #ifdef AVM_X
 #define AVM_SOLVE_KERNEL window_solve_x_kernel
+#define AVM_SOLVE_OCC
+#elif defined(AVM_TP)
+#define AVM_SOLVE_KERNEL window_solve_tp_kernel
+#define AVM_SOLVE_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))  // two four-wavefront workgroups per CU: 256 registers each
 #else
 #define AVM_SOLVE_KERNEL window_solve_kernel
+#define AVM_SOLVE_OCC
 #endif
-__global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
+__global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A) {
   lds_base_check();
   red_init();
   double* lds = LDS();
@@ -2294,6 +2865,8 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     }
     if (t == 7) lds[L_X + XTD] = (c.est_td && B.td) ? B.td[w] : 0.0;
     if (t == 8) lds[L_X + XTD + 1] = 0.0;
+#elif defined(AVM_TP)
+    for (int i = t; i < VEC; i += NT) lds[L_SC + i] = 1.0, lds[L_ST + i] = 0.0, lds[L_Y + i] = 0.0, lds[L_DD + i] = 1.0;
 #else
     for (int i = t; i < VEC; i += NT) lds[L_SC + i] = 1.0, lds[L_ST + i] = 0.0, lds[L_Y + i] = 0.0, lds[L_DG + i] = 0.0, lds[L_DD + i] = 1.0;
 #endif
@@ -2303,8 +2876,13 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       ids[I_FNOBS + t] = B.feat_nobs[(size_t)w * B.max_feat + t];
       ids[I_FOBS + t] = B.feat_obs_begin[(size_t)w * B.max_feat + t];
     }
-    if (t >= 256 && t < 256 + c.pnblk) {  // the prior's block table (one round trip instead of one per block)
-      const int k = t - 256;
+#ifdef AVM_TP
+    constexpr int PBT0 = 160;
+#else
+    constexpr int PBT0 = 256;
+#endif
+    if (t >= PBT0 && t < PBT0 + c.pnblk) {  // the prior's block table (one round trip instead of one per block)
+      const int k = t - PBT0;
       ids[I_PBLK + k * 3] = B.prior_blk_kind[(size_t)w * B.max_pblk + k], ids[I_PBLK + k * 3 + 1] = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
     }
 #ifndef AVM_X
@@ -2338,6 +2916,9 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     }
     if (t == 0) {
       int off = 0;
+#ifdef AVM_TP
+      int psb_ = 0;
+#endif
       for (int k = 0; k < c.pnblk; k++) {
         const int kind = ids[I_PBLK + k * 3], fr = ids[I_PBLK + k * 3 + 1];  // (loaded by 16 lanes at once above)
         ids[I_PBLK + k * 3 + 2] = off;
@@ -2350,8 +2931,14 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
 #else
         for (int q = 0; q < n; q++) ids[I_PIDX + off + q] = kind == AVM_BLK_POSE ? fr * 6 + q : (kind == AVM_BLK_SPEEDBIAS ? SB0 + fr * 9 + q : -1);
 #endif
+#ifdef AVM_TP
+        if (kind == AVM_BLK_SPEEDBIAS) psb_ = fr;  // (at most one such block: the host checks it before it chooses this kernel)
+#endif
         off += n;
       }
+#ifdef AVM_TP
+      ids[I_PSB] = psb_;
+#endif
     }
     for (int f = 1 + (t >> 6); f < NFR; f += NT / 64) {  // features observed in frame f (as imu_j), in feature order
       const int ln = t & 63;
@@ -2391,6 +2978,37 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           if (load[q] < load[bw]) bw = q;
         ids[I_FRW + bb] = bw;
         load[bw] += ((bn + 63) / 64) * 64 + 8;
+        done |= 1 << bb;
+      }
+    }
+#elif defined(AVM_TP)
+    if (t < 64) {
+      // Longest-processing-time assignment of the frames to the four wavefronts (lane q keeps the load of wavefront q, in factors).
+      // Every wavefront has a SIMD to itself within the workgroup; wavefront 2 also evaluates the raw IMU Jacobians (about two
+      // chunks' worth) and two fifths of the prior's rows, wavefront 3 the other three fifths: they start with that load.
+#ifndef AVM_TP_WIMU
+#define AVM_TP_WIMU 128
+#endif
+#ifndef AVM_TP_WPRI
+#define AVM_TP_WPRI 512
+#endif
+      int fc = t == 2 ? AVM_TP_WIMU + (c.pn > 0 ? 2 * AVM_TP_WPRI / 5 : 0) : (t == 3 && c.pn > 0 ? 3 * AVM_TP_WPRI / 5 : 0), done = 0;
+      if (t == 0) ids[I_FRW] = -1;
+      for (int k = 1; k < NFRP; k++) {
+        constexpr int RUNW = AVM_LPT_RUNW;
+        int bb = -1, bn = -1;
+        for (int f = 1; f < NFRP; f++) {
+          const int n = ids[I_NCOV + f] + RUNW * max(ids[I_NRUN + f] - 1, 0);
+          if (!(done & (1 << f)) && n > bn) bn = n, bb = f;
+        }
+        const int own = (fc + 63) >> 6, with = (fc + bn + 63) >> 6;
+        int key = (with << 16) | (own << 8) | t;
+        if (t >= ASM_WAVES) key = 0x7fffffff;
+#pragma unroll
+        for (int o = 2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, 64));
+        const int bw = __builtin_amdgcn_readfirstlane(key) & 255;
+        if (t == bw) fc += bn;
+        if (t == 0) ids[I_FRW + bb] = bw;
         done |= 1 << bb;
       }
     }
@@ -2463,7 +3081,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     double radius = o.initial_trust_region_radius, mu = 1e-8;
     const double min_mu = 1e-8, max_mu = 1.0, mu_inc = 10.0;
     bool reuse = false, first = true, have_alpha = false;
-#ifdef AVM_X
+#if defined(AVM_X) || defined(AVM_TP)
     auto DG = [&](int i) { return lds[L_G + i] / lds[L_DD + i]; };  // g / D, recomputed (the same division every time)
 #else
     auto DG = [&](int i) { return lds[L_DG + i]; };
@@ -2507,8 +3125,13 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
       (void)was_first;
       if (first) {
         if (o.jacobi_scaling) {
+#ifdef AVM_TP
+          if (t < NF) lds[L_SC + t] = 1.0 / (1.0 + sqrt(lds[s_off(t, t)]));
+          for (int e = t; e < c.nf; e += NT) lds[L_SC + NF + e] = 1.0 / (1.0 + sqrt(lds[L_HEE + e]));
+#else
           if (t < NF) lds[L_SC + t] = 1.0 / (1.0 + sqrt(lds[L_S + roff(t) + t]));
           if (t >= 192 && t < 192 + c.nf) lds[L_SC + NF + t - 192] = 1.0 / (1.0 + sqrt(lds[L_HEE + t - 192]));
+#endif
         }
         first = false;
       }
@@ -2524,7 +3147,11 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           gm = fmax(gm, fmax(fmax(fabs(q.x - r.x), fabs(q.y - r.y)), fmax(fabs(q.z - r.z), fabs(q.w - r.w))));
         }
         if (t >= 64 && t < 64 + 99) gm = fmax(gm, fabs(g[SB0 + t - 64]));
+#ifdef AVM_TP
+        for (int e = t; e < c.nf; e += NT) gm = fmax(gm, fabs(g[NF + e]));
+#else
         if (t >= 192 && t < 192 + c.nf) gm = fmax(gm, fabs(g[NF + t - 192]));
+#endif
 #ifdef AVM_X
         if ((t == 400 && c.relo_n > 0) || (t == 401 && c.est_ex)) {  // relo_Pose / ex_pose: pose blocks like the others
           const int xo = t == 401 ? XEX : 7 * NFR, go = t == 401 ? XC_EX : 6 * NFR;
@@ -2625,13 +3252,18 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
         reuse = true;
         have_alpha = false;
         // D = sqrt(clamp(diag(J'^T J'))), g/D
+#ifdef AVM_TP
+        if (t < NF) lds[L_DD + t] = sqrt(fmin(fmax(lds[s_off(t, t)], o.min_lm_diagonal), o.max_lm_diagonal));
+        for (int e = t; e < c.nf; e += NT) lds[L_DD + NF + e] = sqrt(fmin(fmax(lds[L_HEE + e], o.min_lm_diagonal), o.max_lm_diagonal));
+#else
         if (t < NF) lds[L_DD + t] = sqrt(fmin(fmax(lds[L_S + roff(t) + t], o.min_lm_diagonal), o.max_lm_diagonal));
         if (t >= 192 && t < 192 + c.nf) lds[L_DD + NF + t - 192] = sqrt(fmin(fmax(lds[L_HEE + t - 192], o.min_lm_diagonal), o.max_lm_diagonal));
+#endif
         __syncthreads();
         double g2 = 0;
         for (int i = t; i < NF + c.nf; i += NT) {
           const double v = lds[L_G + i] / lds[L_DD + i];
-#ifndef AVM_X
+#if !defined(AVM_X) && !defined(AVM_TP)
           lds[L_DG + i] = v;
 #endif
           g2 += v * v;
@@ -2649,6 +3281,22 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           PROF_T0();
           schur_reduce(c, mu);
           PROF(c, 11);
+#ifdef AVM_TP
+          // factorization + both triangular solves on the register tiles of the four wavefronts (y -> lds[L_Y])
+          bool ok;
+          switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+            case 0: ok = chol_regs<0>(); break;
+            case 1: ok = chol_regs<1>(); break;
+            case 2: ok = chol_regs<2>(); break;
+            default: ok = chol_regs<3>(); break;
+          }
+          PROF(c, 12);
+          if (!ok) {
+            mu *= mu_inc;
+            rebuilt = false;
+            continue;
+          }
+#else
           const bool ok = cholesky_lds(c.prof);
           PROF(c, 12);
           if (!ok) {
@@ -2658,6 +3306,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
           }
           chol_solve_lds(L_Y);
           PROF(c, 13);
+#endif
           const double bad_y = back_substitute(c, mu);
           PROF(c, 14);
           if (bad_y > 0) {
@@ -2830,7 +3479,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
     // ---------------- double2vector + vector2double (estimator.cpp:521-587, 477-519) ----------------
     {
       // rot_diff from yaw of frame 0 before / after ; stored in lds[L_GF..+9], origin_P0 in +9..12
-#ifdef AVM_X
+#if defined(AVM_X) || defined(AVM_TP)
       constexpr int L_GF = L_Y;  // (the Gauss-Newton step is dead after the loop)
 #else
       constexpr int L_GF = L_DG;
@@ -2910,10 +3559,14 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
 #ifdef AVM_X
       if (t == 65 && c.est_td && B.td) B.td[w] = lds[L_X + XTD];
 #endif
+#ifdef AVM_TP
+      for (int e = t; e < c.nf; e += NT) B.inv_depth[(size_t)w * B.max_feat + e] = 1.0 / (1.0 / lds[L_X + XLAM + e]);
+#else
       if (t >= 128 && t < 128 + c.nf) {
         const int e = t - 128;
         B.inv_depth[(size_t)w * B.max_feat + e] = 1.0 / (1.0 / lds[L_X + XLAM + e]);
       }
+#endif
     }
     PROFQ(c, 37);
     if (c.prof && t == 0) c.prof[31] += 1, c.prof[42] += clock64() - pw__;
@@ -2931,7 +3584,7 @@ __global__ __launch_bounds__(NT) void AVM_SOLVE_KERNEL(SolveArgs A) {
   }
 }
 
-#ifndef AVM_X
+#if !defined(AVM_X) && !defined(AVM_TP)
 // =====================================================================================
 // Post-solve marginalization: MarginalizationInfo::addResidualBlockInfo / preMarginalize /
 // marginalize / getParameterBlocks (vins_estimator/src/factor/marginalization_factor.cpp:89-319)
@@ -3989,7 +4642,22 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
 
 #endif  // !AVM_X (marginalization + per-factor evaluation kernels: base build only)
 
-#ifndef AVM_X
+#ifdef AVM_TP
+int window_solve_tp_lds_bytes() { return L_END * 8; }
+
+// Throughput form of the solve (window_solve_tp.o): two 256-thread workgroups per CU, a.n_slots = 2 x CUs scratch slots.
+hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_solve_tp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 8);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = a.b.n_windows < a.n_slots ? a.b.n_windows : a.n_slots;
+  hipLaunchKernelGGL(window_solve_tp_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a);
+  return hipGetLastError();
+}
+#elif !defined(AVM_X)
 int window_solve_lds_bytes() { return L_END * 8; }
 
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream) {

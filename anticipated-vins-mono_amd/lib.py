@@ -65,6 +65,7 @@ def lib():
         L.avm_projection_td_eval.argtypes = [vp, C.c_int, C.POINTER(abi.TdFactorBatch), abi.c_dp, abi.c_dp]
         L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
         L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
+        L.avm_debug_last_solve_form.argtypes = [vp]
         L.avm_slide_window.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.c_int32, C.c_int32, C.c_double]
         L.avm_comm_unique_id.argtypes = [vp, C.c_void_p]
         L.avm_comm_init.argtypes = [vp, C.c_int32, C.c_int32, C.c_void_p]
@@ -142,6 +143,11 @@ class Context:
         out = (C.c_int64 * 4)()
         self.check(self._L.avm_fsel_fallback_stats(self.h, out), "avm_fsel_fallback_stats")
         return {"reruns": int(out[0]), "failed_launches": int(out[1]), "mode": int(out[2]), "calls": int(out[3])}
+
+    def last_solve_form(self) -> str:
+        """Which form of the solve kernel the last optimization() took: 'throughput' (two 256-thread workgroups per CU,
+        batches larger than the CU count) or 'latency' (one 512-thread workgroup per CU).  AVM_SOLVE_TP=0/1 forces it."""
+        return "throughput" if self._L.avm_debug_last_solve_form(self.h) == 1 else "latency"
 
     def kernel_ms(self, which: str) -> float:
         ms = C.c_float(0)

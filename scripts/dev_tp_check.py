@@ -1,0 +1,56 @@
+"""Dev check of the throughput form of the solve kernel against the latency form and the oracle (GPU box)."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+PKG = "anticipated-vins-mono_amd"
+mod = lambda n: importlib.import_module(PKG + "." + n)
+abi, synth, buffers = mod("abi"), mod("synth"), mod("buffers")
+ctx = mod("lib").Context(0)
+opt = abi.default_options()
+opt.marginalization_flag = abi.MARGIN_NONE
+E = mod("estimator").Estimator(ctx=ctx, options=opt)
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def run(w, form):
+    os.environ["AVM_SOLVE_TP"] = form
+    g = w.copy()
+    t0 = time.time()
+    s = buffers.summary_to_numpy(E.optimization(g))
+    return g, s, ctx.last_solve_form(), time.time() - t0
+
+
+for tracks, nf, prior in (("dense", 150, True), ("sparse", 60, True), ("sparse", 150, False), ("dense", 12, True)):
+    w = synth.make_windows(8, tracks=tracks, n_feat=nf, max_feat=150, with_prior=prior)
+    g0, s0, f0, _ = run(w, "0")
+    g1, s1, f1, dt = run(w, "1")
+    print(tracks, nf, prior, f0, f1, "iters", s0["num_iterations"][:4], s1["num_iterations"][:4], "term", s0["termination"][:4], s1["termination"][:4],
+          "accept", s0["accept_mask"][:4], s1["accept_mask"][:4])
+    for k in ("pose", "speedbias", "inv_depth"):
+        print("   ", k, rel(g1.a[k], g0.a[k]))
+    print("    cost", s0["final_cost"][:3], s1["final_cost"][:3], "wall %.3f" % dt, flush=True)
+if "--oracle" in sys.argv:
+    import oracle_py
+    w = synth.make_windows(8, tracks="dense", n_feat=150, max_feat=150)
+    wo, so = w.copy(), buffers.summary_alloc(8)
+    oracle_py.window_solve(opt, wo, None, so, n_threads=8)
+    g1, s1, f1, _ = run(w, "1")
+    for k in ("pose", "speedbias", "inv_depth"):
+        print("oracle", k, rel(g1.a[k], wo.a[k]))
+if "--bench" in sys.argv:
+    base = synth.make_windows(64, tracks="dense")
+    big = synth.tile_windows(base, 4096).to_device("cuda:0")
+    for form in ("0", "1", "0", "1"):
+        os.environ["AVM_SOLVE_TP"] = form
+        b = big.copy() if hasattr(big, "copy") else big
+        E.optimization(b)
+        print("bench form", form, ctx.last_solve_form(), "window_solve ms", ctx.kernel_ms("window_solve"), flush=True)
