@@ -417,7 +417,7 @@ int avm_create(const avm_config* cfg, avm_ctx** out) {
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
   if (const char* pe = getenv("AVM_PROFILE"))
-    if (pe[0] == '1') (void)hipMalloc(&c->prof, sizeof(long long) * PROF_SLOTS * c->n_slots);
+    if (pe[0] == '1') (void)hipMalloc(&c->prof, sizeof(long long) * PROF_SLOTS * 2 * c->n_slots);  // (two workgroups per CU in the throughput form)
   *out = c;
   return AVM_OK;
 }
@@ -529,12 +529,12 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR, &tp_fits)) != AVM_OK) return rc;
   // Which form of the solve kernel: the throughput form (two 256-thread workgroups per CU, window_solve_tp.o) for batches that give
   // every CU more than one window, the latency form (one 512-thread workgroup per CU) otherwise - and always for the extended
-  // problem, a wall-clock cap (its clock is per window), the phase profile, or a prior the structural form cannot hold.
+  // problem, a wall-clock cap (its clock is per window), or a prior the structural form cannot hold.
   // AVM_SOLVE_TP=0 / 1 forces the choice where both are possible (tests, A/B runs).
   const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || batch->relo_n != nullptr;
   bool use_tp = batch->n_windows > c->n_slots;
   if (const char* e = getenv("AVM_SOLVE_TP")) use_tp = e[0] == '1' ? true : (e[0] == '0' ? false : use_tp);
-  use_tp = use_tp && !extended && tp_fits && !c->prof && !(opt->max_solver_time_s > 0.0);
+  use_tp = use_tp && !extended && tp_fits && !(opt->max_solver_time_s > 0.0);
   if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp)) != AVM_OK) return rc;
   avm_window_batch d;
   avm_solve_summary* d_sum = nullptr;
@@ -561,10 +561,11 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     const char* ns = getenv("AVM_NO_SPECULATE");
     sa.speculate = (ns && ns[0] == '1') ? 0 : 1;
   }
-  if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * PROF_SLOTS * c->n_slots, c->stream));
+  if (c->prof) HIPCHK(c, hipMemsetAsync(c->prof, 0, sizeof(long long) * PROF_SLOTS * 2 * c->n_slots, c->stream));
   // ex_pose / td as variables, relocalization factors: the build of the solve kernel with the wider dense block
   if (use_tp) {
     sa.n_slots = 2 * c->n_slots;
+    if (const char* e = getenv("AVM_TP_GRID")) sa.n_slots = std::max(1, std::min(atoi(e), 2 * c->n_slots));  // (experiments: fewer resident workgroups)
     HIPCHK(c, launch_window_solve_tp(sa, c->stream));
     sa.n_slots = c->n_slots;  // (the marginalization below runs one workgroup per CU)
   } else {
@@ -695,16 +696,22 @@ int avm_imu_preintegrate_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, 
 // debug hook (not in avm.h): per-phase shader clocks of the last solve, summed over slots, [PROF_SLOTS = 64]
 int avm_debug_copy_profile(avm_ctx* c, long long* host_out) {
   if (!c || !c->prof) return AVM_ERR_INVALID;
-  std::vector<long long> h((size_t)PROF_SLOTS * c->n_slots);
+  std::vector<long long> h((size_t)PROF_SLOTS * 2 * c->n_slots);
   HIPCHK(c, hipMemcpy(h.data(), c->prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
   for (int k = 0; k < PROF_SLOTS; k++) host_out[k] = 0;
-  for (int s = 0; s < c->n_slots; s++)
+  for (int s = 0; s < 2 * c->n_slots; s++)
     for (int k = 0; k < PROF_SLOTS; k++) host_out[k] += h[(size_t)s * PROF_SLOTS + k];
   return AVM_OK;
 }
 
 // test / bench hook (not in avm.h): 1 when the last avm_window_solve_batch ran the throughput form of the solve kernel
 int avm_debug_last_solve_form(const avm_ctx* c) { return c ? (c->last_solve_tp ? 1 : 0) : -1; }
+
+// test / bench hook (not in avm.h): out[0] = workgroups of the throughput kernel per CU (runtime's occupancy query), out[1] = its LDS bytes
+int avm_debug_solve_tp_occupancy(int* out) {
+  out[0] = window_solve_tp_occupancy(), out[1] = window_solve_tp_lds_bytes();
+  return 2;
+}
 
 // test hook (not in avm.h): sizeof of every ABI struct, for the ctypes mirror check
 int avm_debug_struct_sizes(int* out) {

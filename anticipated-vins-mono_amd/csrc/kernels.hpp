@@ -171,6 +171,7 @@ hipError_t launch_window_solve_x(const SolveArgs& a, hipStream_t stream);  // wi
 int window_solve_x_lds_bytes();
 hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream);  // window_solve_tp.o: two 256-thread workgroups per CU (large batches)
 int window_solve_tp_lds_bytes();
+int window_solve_tp_occupancy();
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream);
 // second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior

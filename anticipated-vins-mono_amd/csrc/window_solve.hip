@@ -1981,7 +1981,10 @@ AVM_NOINL bool chol_regs() {
     }
   });
   if (threadIdx.x == 0) *s_fail = 0;
+  const WinCtx& c = lds_ctx();
+  PROF_T0();
   __syncthreads();  // every tile is in registers: the union region becomes the factorization's scratch
+  PROF(c, 4);
   for (int q = threadIdx.x; q < 4 * 176; q += NT) lds[L_PARTV + q] = 0.0;
   // by the owner of column k: diagonal tile -> patch -> chain (L~_kk in the patch, L~_kk^-T in buffer k & 1)
   auto run_chain = [&](auto K) {
@@ -2090,6 +2093,7 @@ AVM_NOINL bool chol_regs() {
   });
   if (failed) return false;
   __syncthreads();  // z is complete in lds[L_Y]
+  PROF(c, 5);
   if (*s_fail) return false;
   // ---- backward substitution L^T x = z by tile columns, last to first
   d4 E[TPT - 1];  // E[k] += U(k, i) .* x_i over this wavefront's columns i > k (element-wise: reduced once, when block k is due)
@@ -2144,6 +2148,7 @@ AVM_NOINL bool chol_regs() {
     }
   });
   __syncthreads();
+  PROF(c, 6);
   return true;
 }
 #else  // the other builds: left-looking factorization of the packed system in LDS
@@ -2987,10 +2992,10 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
       // Every wavefront has a SIMD to itself within the workgroup; wavefront 2 also evaluates the raw IMU Jacobians (about two
       // chunks' worth) and two fifths of the prior's rows, wavefront 3 the other three fifths: they start with that load.
 #ifndef AVM_TP_WIMU
-#define AVM_TP_WIMU 128
+#define AVM_TP_WIMU 88
 #endif
 #ifndef AVM_TP_WPRI
-#define AVM_TP_WPRI 512
+#define AVM_TP_WPRI 380
 #endif
       int fc = t == 2 ? AVM_TP_WIMU + (c.pn > 0 ? 2 * AVM_TP_WPRI / 5 : 0) : (t == 3 && c.pn > 0 ? 3 * AVM_TP_WPRI / 5 : 0), done = 0;
       if (t == 0) ids[I_FRW] = -1;
@@ -4644,6 +4649,13 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
 
 #ifdef AVM_TP
 int window_solve_tp_lds_bytes() { return L_END * 8; }
+// workgroups of the throughput kernel the runtime says a CU can hold (2 is what the kernel is built for)
+int window_solve_tp_occupancy() {
+  int n = 0;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_solve_tp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 8);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, window_solve_tp_kernel, NT, L_END * 8) != hipSuccess) return -1;
+  return n;
+}
 
 // Throughput form of the solve (window_solve_tp.o): two 256-thread workgroups per CU, a.n_slots = 2 x CUs scratch slots.
 hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream) {

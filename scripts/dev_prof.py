@@ -7,7 +7,7 @@ import numpy as np
 pkg = "anticipated-vins-mono_amd"
 synth = importlib.import_module(pkg + ".synth"); abi = importlib.import_module(pkg + ".abi")
 est_m = importlib.import_module(pkg + ".estimator")
-NAMES = ["A: frames(MFMA)+imu raw", "B: feat sums+diag", "prior resid", "zero S rows", "  chol: diag block", "  chol: panel solve", "  chol: trailing MFMA", "D: imu sqrt+JtJ", "E: prior + cost", "load+Hp", "scale/gmax", "schur(MFMA)", "cholesky", "tri solve", "backsub", "cand eval"]
+NAMES = ["A: frames(MFMA)+imu raw", "B: feat sums+diag", "prior resid", "zero S rows", "  chol: diag block | tp: tile load", "  chol: panel solve | tp: factorization", "  chol: trailing MFMA | tp: back substitution", "D: imu sqrt+JtJ", "E: prior + cost", "load+Hp", "scale/gmax", "schur(MFMA)", "cholesky", "tri solve", "backsub", "cand eval"]
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 tracks = sys.argv[2] if len(sys.argv) > 2 else "dense"
 opt = abi.default_options()

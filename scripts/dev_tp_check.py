@@ -54,3 +54,7 @@ if "--bench" in sys.argv:
         b = big.copy() if hasattr(big, "copy") else big
         E.optimization(b)
         print("bench form", form, ctx.last_solve_form(), "window_solve ms", ctx.kernel_ms("window_solve"), flush=True)
+import ctypes as C
+o = (C.c_int * 2)()
+ctx._L.avm_debug_solve_tp_occupancy(o)
+print("tp occupancy (workgroups per CU)", o[0], "lds bytes", o[1])
