@@ -84,6 +84,7 @@ struct avm_ctx {
   // fallbacks of the selector's all-rounds-in-one-launch kernel (avm_fsel_fallback_stats)
   int64_t fsel_calls = 0, fsel_reruns = 0, fsel_failed_launches = 0;
   int fsel_cooldown = 0;  // calls left before a degraded ctx probes the fast mode again
+  int fsel_backoff = 16;  // the next cool-down (doubles with every failed probe up to 4096 calls, back to 16 after a fast-mode call that went through)
 };
 
 namespace {
@@ -383,6 +384,7 @@ int avm_default_options(avm_options* o) {
   o->marg_eps = 1e-8;
   o->tr = 0.0, o->row = 480.0;  // global shutter (config/euroc/euroc_config.yaml:66), image_height
   o->max_solver_time_s = 0.0;   // no wall-clock cap (the host sets SOLVER_TIME, estimator.cpp:803-806; avm_host.hpp does)
+  o->marg_noise_rel = 1e-16;    // the eigenvalue clamp also tests against the rounding noise of the eigenvector's variables (0: literal)
   return AVM_OK;
 }
 
@@ -534,7 +536,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || batch->relo_n != nullptr;
   bool use_tp = batch->n_windows > c->n_slots;
   if (const char* e = getenv("AVM_SOLVE_TP")) use_tp = e[0] == '1' ? true : (e[0] == '0' ? false : use_tp);
-  use_tp = use_tp && !extended && tp_fits && !(opt->max_solver_time_s > 0.0);
+  use_tp = use_tp && !extended && tp_fits && !(opt->max_solver_time_s > 0.0 && opt->max_solver_time_s <= 1.0e9);
   if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp)) != AVM_OK) return rc;
   avm_window_batch d;
   avm_solve_summary* d_sum = nullptr;
@@ -556,7 +558,8 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   sa.pre_delta = c->pre_delta, sa.pre_jac = c->pre_jac, sa.pre_sqrt = c->pre_sqrt, sa.pre_sum_dt = c->pre_sum;
   sa.scratch = c->scratch, sa.iscratch = c->iscratch, sa.summary = d_sum, sa.n_slots = c->n_slots;
   sa.prof = c->prof;
-  sa.time_cap_ticks = opt->max_solver_time_s > 0.0 ? (long long)(opt->max_solver_time_s * c->wall_clock_hz) + 1 : 0;
+  // (a cap that is not finite, or beyond 1e9 s, means "no cap": the conversion to device ticks must not overflow)
+  sa.time_cap_ticks = (opt->max_solver_time_s > 0.0 && opt->max_solver_time_s <= 1.0e9) ? (long long)(opt->max_solver_time_s * c->wall_clock_hz) + 1 : 0;
   {
     const char* ns = getenv("AVM_NO_SPECULATE");
     sa.speculate = (ns && ns[0] == '1') ? 0 : 1;
@@ -601,12 +604,16 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     marg_err = static_cast<int*>(pool_get(c, "marg_err", sizeof(int)));
     if (!marg_err) return fail(c, AVM_ERR_HIP, "hipMalloc failed (marginalization flag)");
     HIPCHK(c, hipMemsetAsync(marg_err, 0x7f, sizeof(int), c->stream));
+    // the magnitude every diagonal entry of A' was formed at (marginalize_kernel -> the eigenvalue clamp's noise test): the ctx's own array
+    double* marg_scale = static_cast<double*>(pool_get(c, "marg_scale", sizeof(double) * B * mp));
+    if (!marg_scale) return fail(c, AVM_ERR_HIP, "hipMalloc failed (marginalization scales)");
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    HIPCHK(c, launch_marginalize(sa, dpo, marg_err, c->stream));
+    HIPCHK(c, launch_marginalize(sa, dpo, marg_err, marg_scale, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     int* pe_done = static_cast<int*>(pool_get(c, "pe_done", sizeof(int) * B));
     if (!pe_done) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior flags)");
-    HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, c->prof, pe_done, c->stream));
+    const double noise_rel = (opt->marg_noise_rel > 0.0 && opt->marg_noise_rel < 1.0) ? opt->marg_noise_rel : 0.0;
+    HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, noise_rel, marg_scale, c->prof, pe_done, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     if (mem == AVM_MEM_HOST) {
       if (po_bytes <= PACK_LIMIT) {
@@ -1036,9 +1043,11 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   // The downgrade is NOT sticky: a transient cause (an XCD busy with another ctx's solve, so that a team does not fill within
   // its 2 ms) costs this call one re-run and the next AVM_FSEL_REPROBE_CALLS calls the slower mode; then the fast mode is
   // probed again.  avm_fsel_fallback_stats() counts both.
-  constexpr int AVM_FSEL_REPROBE_CALLS = 16;
+  constexpr int AVM_FSEL_REPROBE_CALLS = 16, AVM_FSEL_REPROBE_MAX = 4096;
   c->fsel_calls++;
-  if (c->fsel_cooldown > 0 && --c->fsel_cooldown == 0) c->fsel_frame_mode = 2;
+  const bool probing = c->fsel_cooldown > 0 && --c->fsel_cooldown == 0;  // this call tries the fast mode again
+  if (probing) c->fsel_frame_mode = 2;
+  bool rerun = false;
   int mode = (d.max_cand <= 512 && mf < 4096) ? c->fsel_frame_mode : 0;  // (512: FS_FRAME_MAXC)
   if (mode == 1 && P != 1) mode = 0;  // (the one-team-over-all-XCDs form takes one frame)
   if (const char* e = getenv("AVM_FSEL_FRAME"))
@@ -1066,14 +1075,23 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
       fprintf(stderr, "fsel frame kernel, mode %d (cycles): pick %lld update %lld eval %lld wait %lld | eval: loads %lld bound %lld elimination %lld logdet %lld | setup: before the elimination %lld, elimination %lld\n",
               mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8], q[9], q[3]);
     }
-    if (hsync[2] == 0 && hsync[4] == (int32_t)P) break;
+    if (hsync[2] == 0 && hsync[4] == (int32_t)P) {
+      // a fast-mode call that went through: the back-off starts from the beginning next time
+      if (mode == 2 || (mode == c->fsel_frame_mode && !rerun)) c->fsel_backoff = AVM_FSEL_REPROBE_CALLS;
+      break;
+    }
     // (the outputs of the failed attempt are overwritten by the next one)
-    c->fsel_failed_launches++, c->fsel_reruns++;
+    c->fsel_failed_launches++;  // one per launch that did not finish; the call counts once, below
+    rerun = true;
     --mode;
     c->fsel_frame_mode = std::min(c->fsel_frame_mode, std::max(mode, P != 1 ? 1 : 0));  // a failed batch leaves mode 1 to single frames
-    c->fsel_cooldown = AVM_FSEL_REPROBE_CALLS;
+    // exponential back-off of the re-probe: a host where the fast mode can never become resident pays a failed launch (up to its
+    // 20 ms spin time-out) after 16, 32, 64 ... 4096 calls instead of every 16
+    c->fsel_cooldown = c->fsel_backoff;
+    c->fsel_backoff = std::min(2 * c->fsel_backoff, AVM_FSEL_REPROBE_MAX);
     if (mode == 1 && P != 1) mode = 0;
   }
+  if (rerun) c->fsel_reruns++;
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->last_ms["fsel_select"] = ms;
   return AVM_OK;

@@ -173,9 +173,12 @@ hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream);  // w
 int window_solve_tp_lds_bytes();
 int window_solve_tp_occupancy();
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
-hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream);
+// scale: [n_windows][po.max_prior] device array: the magnitude every diagonal entry of A' was formed at (for launch_prior_eig's noise test)
+hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, double* scale, hipStream_t stream);
 // second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior
-hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, int* done /* [n_windows] device scratch, may be null */, hipStream_t stream);
+// noise_rel: avm_options::marg_noise_rel (0 = the reference-literal clamp S > eps and nothing else)
+hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, double noise_rel, const double* scale, long long* prof,
+                            int* done /* [n_windows] device scratch, may be null */, hipStream_t stream);
 int window_solve_lds_bytes();
 
 }  // namespace avm

@@ -161,11 +161,12 @@ __device__ __forceinline__ void pc_sync() {
 // sqrt(s_i s_j) - plain formation noise - or, for the small magnitudes, 1e-7 (s_i s_j)^1/4: the level the eigen path's own noise test
 // works at (it drops S when S^2 <= 1e-16 g^T diag(s) g, i.e. S <= 1e-8 sqrt(s) for a coordinate direction; a factor 10 on top because
 // the noise of a pivot that follows a small genuine pivot is amplified by their ratio - measured: 5e-6 at s = 3e4 behind a pivot of 0.05)
-__device__ __forceinline__ double pc_zero(double si, double sj) {
-  const double g = sqrt(si * sj);
-  return fmax(1e-12 * g, 1e-7 * sqrt(g));
+// (noise_rel = avm_options::marg_noise_rel: the constants belong to its default 1e-16 and scale with its square root; 0 switches the test off)
+__device__ __forceinline__ double pc_zero(double si, double sj, double noise_rel) {
+  const double g = sqrt(si * sj), f = sqrt(noise_rel * 1e16);
+  return f * fmax(1e-12 * g, 1e-7 * sqrt(g));
 }
-__global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_windows, double eps, int* done) {
+__global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_windows, double eps, double noise_rel, const double* scale, int* done) {
   __shared__ double pc_lds[PC_LDS];
   const int w = blockIdx.x, lane = threadIdx.x, lk = lane >> 4, lr = lane & 15;
   if (w >= n_windows) return;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
       }
   for (int c = lane; c < 80; c += 64) {
     vb[c] = c < n ? gr[c] : 0.0;
-    vs[c] = c < n ? fabs(gJ[c + 1 < n ? (size_t)c * ldj + c + 1 : (size_t)(n - 1)]) : 0.0;
+    vs[c] = c < n ? scale[(size_t)w * ldj + c] : 0.0;
   }
   pc_sync();
   bool bad = false;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
       const bool idl = (lane & 48) == 16;
 #pragma unroll
       for (int c = 0; c < 16; c++) a[c] = idl ? (lr == c ? 1.0 : 0.0) : blk[lr * 16 + c];
-      const double thr_l = pc_zero(vs[16 * k + lr], vs[16 * k + lr]);  // (off the pivot chain: lane j holds pivot j's threshold)
+      const double thr_l = pc_zero(vs[16 * k + lr], vs[16 * k + lr], noise_rel);  // (off the pivot chain: lane j holds pivot j's threshold)
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const double pj = pc_readlane(a[j], j);
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
   }
   f2 = wave_sum(f2), fs2 = wave_sum(fs2);
   const int ndel = __popcll(dm0) + __popcll(dm1);
-  bool ok = !__any(bad) && ndel <= PC_MAXDEL && f2 * (1000.0 * eps) < 1.0 && fs2 * 4e-16 < 1.0;  // (NaN compares false)
+  bool ok = !__any(bad) && ndel <= PC_MAXDEL && f2 * (1000.0 * eps) < 1.0 && fs2 * (4.0 * noise_rel) < 1.0;  // (NaN compares false)
   if (!ok) return;
   // ---- the deleted pivots: row d of A' - J^T J has to be formation noise
   for (int q = 0; q < ndel; q++) {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
       const int c = 16 * i + lr;
       if (c < n) {
         const double orig = gJ[(size_t)max(d, c) * ldj + min(d, c)];
-        viol |= !(fabs(orig - pacc) <= pc_zero(sd, vs[c]));
+        viol |= !(fabs(orig - pacc) <= pc_zero(sd, vs[c], noise_rel));
       }
     }
     ok = ok && !__any(viol);
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
   if (lane == 0) done[w] = 1;
 }
 
-// `literal` != 0 forces the eigen-decomposition even where the Cholesky factor would do (AVM_PRIOR_LITERAL=1, for A/B tests)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, long long* prof, int literal, const int* done) {
+// `literal` != 0 forces the eigen-decomposition even where the Cholesky factor would do (AVM_PRIOR_LITERAL=1 / AVM_PRIOR_FORCE_EIG=1)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void prior_eig_kernel(avm_prior_out PO, int n_windows, double eps, double noise_rel, const double* scale, long long* prof, int literal, const int* done) {
   extern __shared__ char pe_smem[];
   double* lds = reinterpret_cast<double*>(pe_smem);
   double* A = lds + P_A;
@@ -400,8 +401,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   for (int e = t; e < NMAX * NMAX; e += NT) A[e] = 0.0;
   if (t < NMAX) lds[P_B + t] = t < n ? gr[t] : 0.0;
   double dmine = t < n ? gJ[(size_t)t * ldj + t] : 0.0;  // threads 0..75 carry the running diagonal
-  // (the scale every diagonal entry was formed at: marginalize_kernel leaves it in the unused upper triangle)
-  if (t < NMAX) dgl[t] = dmine, lds[P_D0 + t] = t < n ? (n >= 3 ? fabs(gJ[t + 1 < n ? (size_t)t * ldj + t + 1 : (size_t)(n - 1)]) : fabs(dmine)) : 0.0;
+  // (the scale every diagonal entry was formed at: marginalize_kernel leaves it in the ctx's scale array)
+  if (t < NMAX) dgl[t] = dmine, lds[P_D0 + t] = t < n ? scale[(size_t)w * ldj + t] : 0.0;
 #pragma unroll
   for (int q = 0; q < RW; q++) {
     const int i = wv + NW * q;
@@ -492,7 +493,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   // bounded through the comparison matrix of L11 as before.  The threshold covers the eps clamp and the noise test of the
   // eigen path (below): max(1000 eps, 1e-16 max_i s_i).
   double* verdict = lds + P_PIV + NMAX / 2;
-  if (!literal && rank >= 1) {
+  // (with the reference-literal clamp, marg_noise_rel = 0, only the FULL-rank factor is the same prior: the rank-r form drops the
+  //  remainder, which the literal eigen form keeps wherever FP64 leaves it above eps)
+  if (!literal && rank >= 1 && (rank == n || noise_rel > 0.0)) {
     const int nr = rank;
     // entries of G in pivot order: G[p_j][i] = g_{p_i}[p_j] = A[p_i * LD + p_j], zero for i > j (p_j was eliminated before p_i)
     {
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // S / v^T diag(s) v >= lambda_min(B): the noise test of the eigen path (S > 1e-16 v^T diag(s) v) passes for all of them.  The
     // comparison-matrix bound is rigorous but 40 - 3400 x pessimistic, and the variables formed by cancellation (gyroscope bias:
     // 1e2 left of 5e14) put lambda_min(B) at 1e-13 .. 1e-10, so this test gets a factor 4, not 1000.
-    if (verdict[0] * verdict[1] * (1000.0 * eps) < 1.0 && verdict[2] * verdict[3] * 4e-16 < 1.0) {  // (NaN compares false)
+    if (verdict[0] * verdict[1] * (1000.0 * eps) < 1.0 && verdict[2] * verdict[3] * (4.0 * noise_rel) < 1.0) {  // (NaN compares false)
       // linearized_jacobians: row j = g_{p_j}^T, zero rows beyond the rank
       for (int e = t; e < n * n; e += NT) {
         const int j = e / n, c = e - j * n;
@@ -691,7 +694,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // or two of the 16 .. 30 zeros in half of those windows and leaves the streams at 3.9e-7 / 1.1e-4, the values they have
     // without any noise test.  1e-16: 2.5e-4 for a pure gyroscope-bias direction (information worth sigma = 60 rad/s), 6e-7 for
     // an accelerometer-bias direction, 1e-9 for directions in the poses.
-    const bool kx = lX > eps && lX * lX > 1e-16 * wX, ky = lY > eps && lY * lY > 1e-16 * wY;
+    // (avm_options::marg_noise_rel, default 1e-16; 0 - also under AVM_PRIOR_LITERAL=1 - leaves the reference's S > eps alone)
+    const bool kx = lX > eps && lX * lX > noise_rel * wX, ky = lY > eps && lY * lY > noise_rel * wY;
 #pragma unroll
     for (int r = 0; r < RW; r++) {
       if (r0 + r < n) {
@@ -712,10 +716,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 }  // namespace pe
 
-hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, long long* prof, int* done, hipStream_t stream) {
+hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, double noise_rel, const double* scale, long long* prof, int* done,
+                            hipStream_t stream) {
   static bool attr_set = false;
-  const char* lit = getenv("AVM_PRIOR_LITERAL");  // (read per call: the A/B test flips it inside one process)
-  const int literal = (lit && lit[0] == '1') ? 1 : 0;
+  // AVM_PRIOR_LITERAL=1: the reference's square root, literally - the eigen-decomposition for every window and the clamp S > eps and
+  // nothing else (as avm_options::marg_noise_rel = 0).  AVM_PRIOR_FORCE_EIG=1: the eigen-decomposition for every window, the clamp as
+  // the options say (A/B tests of the two forms of the square root).  Read per call: the tests flip them inside one process.
+  const char* lit = getenv("AVM_PRIOR_LITERAL");
+  const char* fe = getenv("AVM_PRIOR_FORCE_EIG");
+  const bool lit1 = lit && lit[0] == '1';
+  const int literal = (lit1 || (fe && fe[0] == '1')) ? 1 : 0;
+  if (lit1) noise_rel = 0.0;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe::prior_eig_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pe::P_END * 8);
     if (e != hipSuccess) return e;
@@ -727,11 +738,12 @@ hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, 
     }
   }
   // the well-conditioned windows on one wavefront each; what that kernel leaves (done[w] == 0) goes through the pivoted path
-  // (AVM_PRIOR_LITERAL=1 / AVM_PRIOR_NO_FAST=1: everything through the pivoted path, for A/B tests)
+  // (AVM_PRIOR_LITERAL=1 / AVM_PRIOR_FORCE_EIG=1 / AVM_PRIOR_NO_FAST=1: everything through the pivoted path, for A/B tests)
   const char* nf = getenv("AVM_PRIOR_NO_FAST");
   const bool fast = done && !literal && !(nf && nf[0] == '1');
-  if (fast) hipLaunchKernelGGL(pe::prior_chol_kernel, dim3(n_windows), dim3(64), 0, stream, po, n_windows, eps, done);
-  hipLaunchKernelGGL(pe::prior_eig_kernel, dim3(n_windows), dim3(pe::NT), pe::P_END * 8, stream, po, n_windows, eps, prof, literal, fast ? (const int*)done : (const int*)nullptr);
+  if (fast) hipLaunchKernelGGL(pe::prior_chol_kernel, dim3(n_windows), dim3(64), 0, stream, po, n_windows, eps, noise_rel, scale, done);
+  hipLaunchKernelGGL(pe::prior_eig_kernel, dim3(n_windows), dim3(pe::NT), pe::P_END * 8, stream, po, n_windows, eps, noise_rel, scale, prof, literal,
+                     fast ? (const int*)done : (const int*)nullptr);
   return hipGetLastError();
 }
 

@@ -4122,7 +4122,7 @@ AVM_DEV bool pinv16_cholesky(double* EA, double* EV, int m, double eps) {
   return fast;
 }
 
-__global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO, int* err) {
+__global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO, int* err, double* scale_out) {
   lds_base_check();
   using namespace mg;
   double* lds = LDS();
@@ -4509,10 +4509,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
               const double arr = Sget(kidx[i], kidx[j]), sacc = D[r];
               oJ[(size_t)i * PO.max_prior + j] = arr - sacc;
               // The magnitude the diagonal entry was formed at (|Arr_ii| + |(Arm Amm^+ Amr)_ii|: the bias rows of the kept
-              // speed-bias block are differences of two numbers of size 1e10 .. 1e12) rides along in the unused upper triangle,
-              // slot (i, i + 1), the last one in (0, n - 1): prior_eig_kernel's clamp measures an eigenvalue against the
-              // rounding noise of ITS variables (prior_eig.hip).
-              if (i == j && n >= 3) oJ[i + 1 < n ? (size_t)i * PO.max_prior + i + 1 : (size_t)(n - 1)] = fabs(arr) + fabs(sacc);
+              // speed-bias block are differences of two numbers of size 1e10 .. 1e12) goes to the ctx's scale array:
+              // prior_eig_kernel's clamp measures an eigenvalue against the rounding noise of ITS variables (prior_eig.hip).
+              if (i == j) scale_out[(size_t)w * PO.max_prior + i] = fabs(arr) + fabs(sacc);
             }
           }
         }
@@ -4684,7 +4683,7 @@ hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, hipStream_t stream) {
+hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, double* scale, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(marginalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 8);
@@ -4692,7 +4691,7 @@ hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* 
     attr_set = true;
   }
   const int grid = a.b.n_windows < a.n_slots ? a.b.n_windows : a.n_slots;
-  hipLaunchKernelGGL(marginalize_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a, po, err);
+  hipLaunchKernelGGL(marginalize_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a, po, err, scale);
   return hipGetLastError();
 }
 

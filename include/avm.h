@@ -116,7 +116,16 @@ typedef struct avm_options {
                                                 tests and the bench run with.  > 0: checked like Ceres' MaxSolverTimeReached at the top of
                                                 every iteration, before the iteration limit, against a device wall clock that starts when the
                                                 window's solve starts on the GPU (staging and pre-integration are not counted); the
-                                                minimizer then stops at the current point with AVM_TERM_NO_CONVERGENCE */
+                                                minimizer then stops at the current point with AVM_TERM_NO_CONVERGENCE.  Non-finite values
+                                                and anything above 1e9 s mean "no cap" */
+  double marg_noise_rel;                     /* The eigenvalue clamp of marginalization_factor.cpp:284-285 keeps S > marg_eps.  With
+                                                marg_noise_rel > 0 (default 1e-16, about one unit roundoff) an eigenvalue is kept only
+                                                if it ALSO exceeds the rounding noise of the variables its eigenvector lives on,
+                                                S^2 > marg_noise_rel * v^T diag(s) v, s_i the magnitude the diagonal entry A'_ii was
+                                                formed at: the clamp as exact arithmetic would apply it (the reference's own FP64 run
+                                                keeps eigenvalues that are pure rounding noise).  0 = the
+                                                reference-literal clamp, nothing but S > marg_eps (AVM_PRIOR_LITERAL=1 does the same and
+                                                also forces the eigen-decomposition path) */
 } avm_options;
 
 /* A batch of independent sliding windows, struct-of-arrays over the window index.
@@ -429,10 +438,11 @@ int avm_fsel_select(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* frame, int3
                     double* fvalues_opt);
 
 /* how often this ctx's select calls had to fall back from the all-rounds-in-one-launch kernel (csrc/fsel.hip): counters since
- * avm_create.  out[0] = calls that were re-run one mode down, out[1] = launches that reported a timed-out wait or an unfinished
- * frame, out[2] = the mode the next call starts in (2 = a team per XCD, 1 = one team over all XCDs, 0 = one launch per round),
- * out[3] = select calls so far.  A degraded call costs at most the 20 ms spin time-out of the failed launch plus the slower
- * mode's run time; the ctx probes the fast mode again after AVM_FSEL_REPROBE_CALLS (16) calls. */
+ * avm_create.  out[0] = CALLS that had to be re-run in a slower mode (once per call), out[1] = LAUNCHES that reported a timed-out
+ * wait or an unfinished frame (a call that falls two modes counts twice here), out[2] = the mode the next call starts in (2 = a
+ * team per XCD, 1 = one team over all XCDs, 0 = one launch per round), out[3] = select calls so far.  A degraded call costs at most
+ * the 20 ms spin time-out of the failed launch plus the slower mode's run time; the ctx probes the fast mode again after 16 calls,
+ * and after 32, 64 ... 4096 if the probes keep failing (back to 16 once a fast-mode call has gone through). */
 int avm_fsel_fallback_stats(const avm_ctx* ctx, int64_t out[4]);
 
 /* B5/B6 only: Omega_kkH (+prior) [P][N][N] and compact Delta_ell position blocks

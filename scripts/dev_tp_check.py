@@ -1,4 +1,4 @@
-"""Dev check of the throughput form of the solve kernel against the latency form and the oracle (GPU box)."""
+"""Dev check of the throughput form of the solve kernel against the latency form (GPU box); the parity tests proper: tests/test_solve_tp.py."""
 import importlib
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 PKG = "anticipated-vins-mono_amd"
 mod = lambda n: importlib.import_module(PKG + "." + n)
 abi, synth, buffers = mod("abi"), mod("synth"), mod("buffers")
@@ -38,14 +38,6 @@ for tracks, nf, prior in (("dense", 150, True), ("sparse", 60, True), ("sparse",
     for k in ("pose", "speedbias", "inv_depth"):
         print("   ", k, rel(g1.a[k], g0.a[k]))
     print("    cost", s0["final_cost"][:3], s1["final_cost"][:3], "wall %.3f" % dt, flush=True)
-if "--oracle" in sys.argv:
-    import oracle_py
-    w = synth.make_windows(8, tracks="dense", n_feat=150, max_feat=150)
-    wo, so = w.copy(), buffers.summary_alloc(8)
-    oracle_py.window_solve(opt, wo, None, so, n_threads=8)
-    g1, s1, f1, _ = run(w, "1")
-    for k in ("pose", "speedbias", "inv_depth"):
-        print("oracle", k, rel(g1.a[k], wo.a[k]))
 if "--bench" in sys.argv:
     base = synth.make_windows(64, tracks="dense")
     big = synth.tile_windows(base, 4096).to_device("cuda:0")
