@@ -63,6 +63,8 @@ struct avm_ctx {
   // device buffers owned by the ctx
   double* scratch = nullptr;
   int32_t* iscratch = nullptr;
+  int64_t n_allocs = 0;       // device / pinned (re)allocations since avm_create (avm_debug_counters: a timed region should see none)
+  int last_marg_windows = 0;  // batch size of the last marginalization (its per-window "the one-wavefront kernel finished it" flags: pool "pe_done")
   bool last_solve_tp = false;  // which form of the solve kernel the last avm_window_solve_batch took (avm_debug_last_solve_form)
   int scratch_slots = 0;  // slots allocated (n_slots, or 2 n_slots once a batch has taken the throughput form of the solve)
   double *pre_delta = nullptr, *pre_jac = nullptr, *pre_cov = nullptr, *pre_sqrt = nullptr, *pre_sum = nullptr;
@@ -106,6 +108,7 @@ int fail(avm_ctx* c, int code, const char* msg) {
 void* pool_get(avm_ctx* c, const std::string& name, size_t bytes) {
   auto& e = c->pool[name];
   if (e.second < bytes || e.first == nullptr) {
+    c->n_allocs++;
     if (e.first) (void)hipFree(e.first);
     e.first = nullptr;
     if (hipMalloc(&e.first, bytes ? bytes : 8) != hipSuccess) return nullptr;
@@ -117,6 +120,7 @@ void* pool_get(avm_ctx* c, const std::string& name, size_t bytes) {
 void* pinned_get(avm_ctx* c, const std::string& name, size_t bytes) {
   auto& e = c->pinned[name];
   if (e.second < bytes || e.first == nullptr) {
+    c->n_allocs++;
     if (e.first) (void)hipHostFree(e.first);
     e.first = nullptr;
     if (hipHostMalloc(&e.first, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) return nullptr;
@@ -206,6 +210,7 @@ int stage_in(avm_ctx* c, const char* name, const T* host, size_t count, const T*
 int ensure_window_buffers(avm_ctx* c, int n_windows, bool tp = false) {
   // (the throughput form of the solve runs two workgroups per CU: twice the slots; allocated when a batch first takes it)
   const int want = tp ? 2 * c->n_slots : c->n_slots;
+  if (!c->scratch || c->scratch_slots < want || (size_t)n_windows > c->pre_cap) c->n_allocs++;
   if (!c->scratch || c->scratch_slots < want) {
     if (c->scratch) (void)hipFree(c->scratch), c->scratch = nullptr;
     if (c->iscratch) (void)hipFree(c->iscratch), c->iscratch = nullptr;
@@ -614,6 +619,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     if (!pe_done) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior flags)");
     const double noise_rel = (opt->marg_noise_rel > 0.0 && opt->marg_noise_rel < 1.0) ? opt->marg_noise_rel : 0.0;
     HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, noise_rel, marg_scale, c->prof, pe_done, c->stream));
+    c->last_marg_windows = (int)B;
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     if (mem == AVM_MEM_HOST) {
       if (po_bytes <= PACK_LIMIT) {
@@ -718,6 +724,21 @@ int avm_debug_last_solve_form(const avm_ctx* c) { return c ? (c->last_solve_tp ?
 int avm_debug_solve_tp_occupancy(int* out) {
   out[0] = window_solve_tp_occupancy(), out[1] = window_solve_tp_lds_bytes();
   return 2;
+}
+
+// test / bench hook (not in avm.h): out[0] = device / pinned (re)allocations of this ctx so far, out[1] = windows of the last
+// marginalization whose square root the one-wavefront kernel (prior_chol_kernel) finished, out[2] = windows of that marginalization
+// (out[2] - out[1] went through prior_eig_kernel's pivoted path), out[3] = 1 if the last solve took the throughput form
+int avm_debug_counters(avm_ctx* c, int64_t* out) {
+  if (!c || !out) return AVM_ERR_INVALID;
+  out[0] = c->n_allocs, out[1] = 0, out[2] = c->last_marg_windows, out[3] = c->last_solve_tp ? 1 : 0;
+  auto it = c->pool.find("pe_done");
+  if (c->last_marg_windows > 0 && it != c->pool.end() && it->second.first) {
+    std::vector<int> h((size_t)c->last_marg_windows);
+    HIPCHK(c, hipMemcpy(h.data(), it->second.first, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+    for (int v : h) out[1] += v != 0;
+  }
+  return AVM_OK;
 }
 
 // test hook (not in avm.h): sizeof of every ABI struct, for the ctypes mirror check

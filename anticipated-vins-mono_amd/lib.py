@@ -66,6 +66,8 @@ def lib():
         L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
         L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
         L.avm_debug_last_solve_form.argtypes = [vp]
+        L.avm_debug_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.avm_debug_solve_tp_occupancy.argtypes = [C.POINTER(C.c_int)]
         L.avm_slide_window.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.c_int32, C.c_int32, C.c_double]
         L.avm_comm_unique_id.argtypes = [vp, C.c_void_p]
         L.avm_comm_init.argtypes = [vp, C.c_int32, C.c_int32, C.c_void_p]
@@ -148,6 +150,13 @@ class Context:
         """Which form of the solve kernel the last optimization() took: 'throughput' (two 256-thread workgroups per CU,
         batches larger than the CU count) or 'latency' (one 512-thread workgroup per CU).  AVM_SOLVE_TP=0/1 forces it."""
         return "throughput" if self._L.avm_debug_last_solve_form(self.h) == 1 else "latency"
+
+    def counters(self) -> dict:
+        """Debug counters of this ctx: device / pinned (re)allocations so far, and how the last marginalization's square roots were taken."""
+        out = (C.c_int64 * 4)()
+        self.check(self._L.avm_debug_counters(self.h, out), "avm_debug_counters")
+        return {"allocations": int(out[0]), "prior_one_wavefront": int(out[1]), "prior_windows": int(out[2]),
+                "prior_pivoted_path": int(out[2] - out[1]), "solve_form": "throughput" if out[3] else "latency"}
 
     def kernel_ms(self, which: str) -> float:
         ms = C.c_float(0)

@@ -52,13 +52,38 @@ def flop_model(n_fac, n_feat, summ):
     return float((jac_evals * per_jac + lin_solves * per_lin + it * per_cand).sum())
 
 
+def flop_models_other(host, n_windows):
+    """Algorithmic FP64 FLOPs per launch of the kernels around the solve, from the batch's own counts.
+    preint + sqrt_info : per IMU sample the reference's dense products jacobian = F jacobian (2 x 15^3), covariance = F cov F^T +
+                         V noise V^T (2 x 2 x 15^3 + 2 x 15 x 18 x 18 + 2 x 15 x 18 x 15) + ~600 for the midpoint integration; per interval
+                         the 15 x 15 inverse and its LLT (~1.0e4)
+    marginalize        : per projection factor of a start-0 feature 2600 (r, J with the ex_pose block, its Gram products), IMU factor 0
+                         4.3e4, the old prior 2 n^2 + n^2 (n + 1), one rank-1 update of the 73 x 73 pose block per eliminated depth
+                         (73 x 74), the 15 x 15 pseudo-inverse and A' = Arr - T Amr (2.4e5)
+    prior_chol         : n^3 / 3 + 2 n^2 at n = 75 (the factor IS the square root; the certification's inverse is overhead, not counted)"""
+    import numpy as np
+
+    a = host.a
+    samples = float(a["imu_n"].sum()) * n_windows / a["imu_n"].shape[0]
+    preint = samples * (3 * 2 * 15.0**3 + 2 * 15 * 18 * 18 + 2 * 15 * 18 * 15 + 600.0) + n_windows * 10 * 1.0e4
+    nobs, start, nf = a["feat_nobs"], a["feat_start"], a["n_feat"]
+    live = np.arange(nobs.shape[1])[None, :] < nf[:, None]
+    s0 = live & (start == 0)
+    k0 = float(((nobs - 1).clip(min=0) * s0).sum()) * n_windows / nobs.shape[0]
+    m0 = float(s0.sum()) * n_windows / nobs.shape[0]
+    n = 75.0
+    marg = k0 * 2600.0 + m0 * 73.0 * 74.0 + n_windows * (4.3e4 + 2 * n * n + n * n * (n + 1) + 2.4e5)
+    chol = n_windows * (n**3 / 3.0 + 2 * n * n)
+    return {"preint": preint, "marginalize": marg, "prior_eig": chol}
+
+
 def kernel_source_sha256():
     """Hash of the sources the window kernels are built from: a committed rocprofv3 --pmc summary (profiles/*_pmc_traffic.json) carries the
     hash it was measured on, and roofline.traffic is only reported from a summary whose hash is the current one."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("window_solve.hip", "kernels.hpp", "devmath.hpp", "Makefile"):
+    for f in ("window_solve.hip", "prior_eig.hip", "preint.hip", "kernels.hpp", "devmath.hpp", "Makefile"):
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -400,6 +425,8 @@ def main():
         s = buffers.summary_to_numpy(summ)
         flops = flop_model(n_fac, n_feat, s)
         k_ms = float(np.mean(kernel_ms))
+        solve_form = ctx.last_solve_form() if hasattr(ctx, "last_solve_form") else "latency"
+        solve_kernel = "window_solve_tp_kernel" if solve_form == "throughput" else "window_solve_kernel"
         achieved = flops / (k_ms * 1e-3) / 1e12
         traffic, traffic_src, mfma_util, fabric_gbs, wait_any = None, None, None, None, None
         prof_j, prof_name, prof_err = committed_profile()  # newest committed rocprofv3 --pmc summary, if it belongs to these kernel sources
@@ -408,16 +435,54 @@ def main():
             print("[bench] roofline.traffic not reported: " + prof_err, file=sys.stderr)
         elif W == 4096 and args.tracks == "dense" and opt.marginalization_flag == abi.MARGIN_OLD:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* passes of this same command (scripts/gpu_profile.sh), per launch
-            tj = prof_j["window_solve_kernel"]
+            tj = prof_j.get(solve_kernel)
+            if tj is None:
+                prof_err = f"profiles/{prof_name} has no entry for {solve_kernel}"
+                traffic_src = "UNAVAILABLE: " + prof_err
+                tj = {"traffic_bytes_per_launch": None}
             traffic = tj["traffic_bytes_per_launch"]
             mfma_util, fabric_gbs, wait_any = tj.get("mfma_util"), tj.get("fabric_GBs"), tj.get("wait_any_frac")
             traffic_src = (f"profiles/{prof_name}: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / "
                            "(dispatch ns x 2.4 GHz x 1024 SIMDs); measured on the kernel sources this run was built from (sha256 checked)")
         alg_bytes = W * (44.0 * n_fac + 23.0e3 + 45.6e3 + 3.0e3 + 2.6e3)  # ~140 KB / solve at K=1500
+        # the FP64 peak of THIS device, re-measured in the run when the micro-benchmark is built (scripts/ubench/peak, made by
+        # __graft_entry__.build()); else the committed measurement of round 2
         peak_meas = None
+        pk = os.path.join(ROOT, "scripts", "ubench", "peak")
+        if os.path.exists(pk) and not args.no_extras:
+            try:
+                out = subprocess.run([pk], capture_output=True, text=True, timeout=120).stdout
+                peak_meas = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+                if "error" in peak_meas:
+                    peak_meas = None
+                else:
+                    peak_meas["measured_in_this_run"] = True
+            except Exception as e:  # noqa
+                print(f"[bench] scripts/ubench/peak failed: {e}", file=sys.stderr)
         pm = os.path.join(ROOT, "profiles", "r02_fp64_peak.json")
-        if os.path.exists(pm):
+        if peak_meas is None and os.path.exists(pm):
             peak_meas = json.load(open(pm))
+        # ---- the kernels around the solve: the same roofline entry each (FLOP models: flop_models_other; counters: the committed profile)
+        other = flop_models_other(host, W)
+        kernels = {}
+        for key, names in (("preint", ("preint_kernel", "sqrt_info_kernel")), ("marginalize", ("marginalize_kernel",)),
+                           ("prior_eig", ("prior_chol_kernel", "prior_eig_kernel"))):
+            ms_k = float(np.mean(all_ms[key])) if all_ms[key] else 0.0
+            if ms_k <= 0.0:
+                continue
+            ach = other[key] / (ms_k * 1e-3) / 1e12
+            ent = {"kernels": list(names), "kernel_ms": ms_k, "flops_per_launch": other[key], "achieved": ach, "unit": "TFLOP/s",
+                   "peak": FP64_PEAK_TFLOPS, "frac": ach / FP64_PEAK_TFLOPS, "bound": "mfma"}
+            if prof_j is not None and not prof_err and W == 4096 and args.tracks == "dense":
+                pj = prof_j.get(names[0])
+                if pj:
+                    ent.update({"traffic": pj.get("traffic_bytes_per_launch"), "mfma_util": pj.get("mfma_util"), "wait_any_frac": pj.get("wait_any_frac"),
+                                "fabric_GBs": pj.get("fabric_GBs")})
+            kernels[key] = ent
+        kernels["window_solve"] = {"kernels": [solve_kernel], "kernel_ms": k_ms, "flops_per_launch": flops, "achieved": achieved, "unit": "TFLOP/s",
+                                   "peak": FP64_PEAK_TFLOPS, "frac": achieved / FP64_PEAK_TFLOPS, "bound": "mfma", "traffic": traffic,
+                                   "mfma_util": mfma_util, "wait_any_frac": wait_any, "fabric_GBs": fabric_gbs}
+        furthest = min(kernels.items(), key=lambda kv: kv[1]["frac"])[0]
         result = {
             "metric": "sliding-window solves/sec (10 KF, 150 feats)",
             "value": value,
@@ -448,6 +513,8 @@ def main():
                 "launch": ("self-launched (bench.py spawned its ranks)" if os.environ.get("AVM_BENCH_SELF_LAUNCHED") else
                            ("external launcher (torch.distributed.run)" if world > 1 else "single process")),
                 "input_generation_s": t_gen,
+                "solve_form": solve_form + (" (two 256-thread workgroups per CU, window_solve_tp.o)" if solve_form == "throughput" else
+                                            " (one 512-thread workgroup per CU)"),
             },
             "roofline": {
                 "bound": "mfma",
@@ -460,7 +527,7 @@ def main():
                 "mfma_util": mfma_util,          # rocprof: MFMA pipe busy / SIMD-cycles (FP64 MFMA and FP64 VALU share the pipe on gfx950)
                 "fabric_GBs": fabric_gbs,        # rocprof: L2 <-> fabric bytes per second (Infinity Cache hits included), peak ~8 TB/s HBM
                 "wait_any_frac": wait_any,       # rocprof: SQ_WAIT_ANY / SQ_WAVE_CYCLES
-                "kernel": "window_solve_kernel",
+                "kernel": solve_kernel,
                 "kernel_ms": k_ms,
                 "flops_per_launch": flops,
                 "peak_measured": peak_meas,
@@ -468,6 +535,9 @@ def main():
                                   "peak_GBs": HBM_PEAK_GBS},
             },
             "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
+            # every kernel of the step against the same FP64 roofline; "furthest_below_roofline" names the one to work on next
+            "kernel_rooflines": kernels,
+            "furthest_below_roofline": furthest,
             # how far "parity" is pinned: the reference ships no tests / vectors and cannot be built here
             "parity_pin": "unpinned at the Ceres / Eigen boundary (no reference vectors exist): the oracle is pinned by builder-written numpy "
                           "restatements (tests/golden/), the marginalization prior by a binary128 arbiter (oracle/avm_truth.cpp, tests/test_prior_truth.py)",
@@ -475,35 +545,81 @@ def main():
 
     # ---- sub-records the headline line does not carry: ragged tracks, one-window latency
     if extras and rank == 0:
+        def timed_record(E_, win_, slots_, n_warm=3, n_timed=10):
+            """A robust sub-record of a batch: n_warm untimed steps, then n_timed steps timed ONE BY ONE (a synchronization on
+            both sides of each): median / min / max wall time, the per-step window_solve list, device allocations inside the
+            timed region (none expected), and how the marginalization's square roots were taken."""
+            keep = {k: win_.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
+            for opt_k in ("td", "relo_pose"):
+                if opt_k in win_.a and win_.a[opt_k] is not None and hasattr(win_.a[opt_k], "clone"):
+                    keep[opt_k] = win_.a[opt_k].clone()
+            ms_k = {k: [] for k in ("preint", "window_solve", "marginalize", "prior_eig")}
+            walls, ss_ = [], None
+
+            def one():
+                for k, v in keep.items():
+                    win_.a[k].copy_(v)
+                return E_.optimization(win_, want_summary=True, prior_out=slots_)
+
+            for _ in range(n_warm):
+                one()
+            torch.cuda.synchronize()
+            c0 = ctx.counters() if hasattr(ctx, "counters") else None
+            for _ in range(n_timed):
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                ss_ = one()
+                torch.cuda.synchronize()
+                walls.append(time.perf_counter() - t_)
+                for k in ms_k:
+                    ms_k[k].append(ctx.kernel_ms(k))
+            c1 = ctx.counters() if hasattr(ctx, "counters") else None
+            med = statistics.median(walls)
+            rec = {"value": win_.n_windows / med, "unit": "solves/s", "ms_per_step": med * 1e3, "ms_per_step_min": min(walls) * 1e3,
+                   "ms_per_step_max": max(walls) * 1e3, "steps": n_timed, "warmup": n_warm,
+                   "kernel_ms": {k: float(statistics.median(v)) for k, v in ms_k.items()},
+                   "window_solve_ms_per_step": [round(float(x), 4) for x in ms_k["window_solve"]],
+                   "mean_iterations": float(buffers.summary_to_numpy(ss_)["num_iterations"].mean())}
+            if c0 is not None:
+                rec["allocations_inside_timed_region"] = c1["allocations"] - c0["allocations"]
+                rec["solve_form"] = c1["solve_form"]
+                if c1["prior_windows"]:
+                    rec["prior_square_roots"] = {"one_wavefront_kernel": c1["prior_one_wavefront"], "pivoted_path": c1["prior_pivoted_path"]}
+            return rec
+
         if sparse_base is not None:
             sh = synth.tile_windows(sparse_base, W)
             sw = sh.to_device(dev)
-            sp = {k: sw.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
-            s_ms = {k: [] for k in ("preint", "window_solve", "marginalize", "prior_eig")}
-
-            def sstep():
-                for k, v in sp.items():
-                    sw.a[k].copy_(v)
-                return E.optimization(sw, want_summary=True, prior_out=prior_slots)
-
-            sstep()
-            torch.cuda.synchronize()
-            ts0 = time.perf_counter()
-            for _ in range(3):
-                ss = sstep()
-                for k in s_ms:
-                    s_ms[k].append(ctx.kernel_ms(k))
-            torch.cuda.synchronize()
-            tsp = (time.perf_counter() - ts0) / 3
-            s_np = buffers.summary_to_numpy(ss)
-            result["sparse_tracks"] = {
-                "workload": f"{W} windows, 150 features with ragged tracks (start ~ U{{0..7}}, length ~ U{{2..}}), "
-                            f"{float((sh.a['feat_nobs'] - 1).clip(min=0).sum(1).mean()):.0f} projection factors per window; "
-                            f"{sparse_base.n_windows} distinct windows tiled",
-                "value": W / tsp, "unit": "solves/s", "ms_per_step": tsp * 1e3, "kernel_ms": {k: float(np.mean(v)) for k, v in s_ms.items()},
-                "mean_iterations": float(s_np["num_iterations"].mean()),
-            }
-            del sw, sp
+            rec = timed_record(E, sw, prior_slots)
+            rec["workload"] = (f"{W} windows, 150 features with ragged tracks (start ~ U{{0..7}}, length ~ U{{2..}}), "
+                               f"{float((sh.a['feat_nobs'] - 1).clip(min=0).sum(1).mean()):.0f} projection factors per window; "
+                               f"{sparse_base.n_windows} distinct windows tiled")
+            result["sparse_tracks"] = rec
+            del sw
+        if marg and W >= 1024:
+            # the branch estimator.cpp:924-990 (MARGIN_SECOND_NEW) and the extended problem (estimator.cpp:672-688, 732-747, 760-792:
+            # ex_pose and td as variables, a relocalization frame) on a quarter batch each: timed, not part of `value`
+            o_sn = abi.default_options()
+            o_sn.marginalization_flag = abi.MARGIN_SECOND_NEW
+            qb = host.slice(0, W // 4).copy().to_device(dev)
+            slots_q = buffers.PriorOutArrays.alloc(W // 4, qb.dims["max_prior"], qb.dims["max_pblk"], dev)
+            rec = timed_record(est_m.Estimator(ctx=ctx, options=o_sn), qb, slots_q, n_warm=2, n_timed=5)
+            rec["workload"] = f"{W // 4} of the headline windows, marginalization_flag = MARGIN_SECOND_NEW"
+            result["margin_second_new"] = rec
+            try:
+                xh = synth.make_windows_parallel(min(W // 4, 256), first_id=rank * W, tracks="dense", procs=1, td_true=0.004, relo=True)
+                xw = synth.tile_windows(xh, W // 4).to_device(dev)
+                o_x = abi.default_options()
+                o_x.estimate_extrinsic, o_x.estimate_td = 1, 1
+                slots_x = buffers.PriorOutArrays.alloc(W // 4, xw.dims["max_prior"], xw.dims["max_pblk"], dev)
+                rec = timed_record(est_m.Estimator(ctx=ctx, options=o_x), xw, slots_x, n_warm=2, n_timed=5)
+                rec["workload"] = (f"{W // 4} dense windows with estimate_extrinsic = estimate_td = 1 and a relocalization frame: the -DAVM_X build of "
+                                   "the solve kernel (178 x 178 reduced system, always the latency form)")
+                # same FLOP model with the wider dense block: per linear solve 79 x 80 x F + 178^3 / 3
+                result["extended_problem"] = rec
+            except Exception as e:  # (a generator without the optional members: say so instead of failing the bench)
+                result["extended_problem"] = {"unavailable": f"{type(e).__name__}: {e}"}
+            del qb
         # one window per call, device-resident: the reference's own use (one optimization() per image)
         one = host.slice(0, 1).copy().to_device(dev)
         one0 = {k: one.a[k].clone() for k in ("pose", "speedbias", "ex_pose", "inv_depth")}
