@@ -1214,6 +1214,30 @@ int avm_fsel_build_cloud(avm_ctx* c, avm_mem mem, const avm_window_batch* window
   return AVM_OK;
 }
 
+int avm_fsel_nn_depth(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, double* depth) {
+  if (!c) return AVM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  int rc = check_fsel(c, batch);
+  if (rc != AVM_OK) return rc;
+  if (!depth) return fail(c, AVM_ERR_INVALID, "null depth");
+  if (batch->n_problems == 0) return AVM_OK;
+  if ((rc = validate_fsel(c, mem, batch)) != AVM_OK) return rc;
+  avm_fsel_batch d;
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = stage_fsel(c, batch, &d)) != AVM_OK) return rc;
+  } else {
+    d = *batch;
+  }
+  const size_t n = (size_t)batch->n_problems * batch->max_cand;
+  double* dd = mem == AVM_MEM_HOST ? static_cast<double*>(pool_get(c, "fi_nn", sizeof(double) * n)) : depth;
+  if (!dd) return fail(c, AVM_ERR_HIP, "hipMalloc failed (nn depth)");
+  HIPCHK(c, hipMemsetAsync(dd, 0, sizeof(double) * n, c->stream));
+  HIPCHK(c, launch_fsel_nn_depth(d, dd, c->stream));
+  if (mem == AVM_MEM_HOST) HIPCHK(c, hipMemcpyAsync(depth, dd, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return AVM_OK;
+}
+
 int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, double* omega, double* delta_cand, int32_t* cand_valid) {
   if (!c) return AVM_ERR_INVALID;
   (void)hipSetDevice(c->device);

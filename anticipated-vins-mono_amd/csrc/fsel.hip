@@ -76,9 +76,11 @@ AVM_DEV quat slerp_eigen(quat a, double t, quat b) {
 // cam[h] (h = 1..H): t_WC (3), R of q_WC^-1 (9), R of (q_WC * q_IC)^-1 (9)  => 21 doubles per h
 // front part: per-frame blocks C_h (Ch, 6 per h), W = (sum C_h)^-1 (Wm); false if the feature is seen in no future frame
 // WAVE: called by all 64 lanes of a wavefront for the same feature - the nearest-neighbour search is split over the lanes
+// findNNDepth (feature_selector.cpp:437-459): the depth of the cloud point nearest to (fx_, fy_) - exact 1-NN, first strictly
+// smaller distance wins (the lowest index among points at bit-identical distances; the reference's kd-tree takes whichever of those
+// its traversal meets first: tests/test_nanoflann_nn.py), 1.0 for an empty cloud.
 template <bool WAVE>
-AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* Ch /*13*6*/, double* Wm /*9*/) {
-  // findNNDepth: exact 1-NN, first strictly smaller distance wins
+AVM_DEV double nn_depth(const avm_fsel_batch& b, int p, double fx_, double fy_) {
   double dep = 1.0;
   const int ncl = b.n_cloud ? b.n_cloud[p] : 0;
   if (ncl > 0) {
@@ -111,6 +113,12 @@ AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, do
     }
     dep = b.cloud_depth[(size_t)p * b.max_cloud + best];
   }
+  return dep;
+}
+
+template <bool WAVE>
+AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* Ch /*13*6*/, double* Wm /*9*/) {
+  const double dep = nn_depth<WAVE>(b, p, fx_, fy_);
   const double nrm = sqrt(fx_ * fx_ + fy_ * fy_ + 1.0);
   const v3 fn = mk3(fx_ / nrm, fy_ / nrm, 1.0 / nrm);  // feature.normalized()
   const v3 feat = dep * fn;
@@ -1515,6 +1523,22 @@ __global__ __launch_bounds__(64) void fsel_build_cloud_kernel(avm_window_batch B
     n++;
   }
   n_cloud[w] = n;
+}
+
+// B8, second half as a parity surface: findNNDepth of every candidate, one wavefront per (frame, candidate) - the search the setup
+// kernel runs inside calcInfoFromFeatures (nn_depth<true>)
+__global__ __launch_bounds__(256) void fsel_nn_depth_kernel(avm_fsel_batch b, double* depth_out) {
+  const int p = blockIdx.y, cnd = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cnd >= b.n_cand[p]) return;  // (wave-uniform)
+  const double* xy = b.cand_xy + ((size_t)p * b.max_cand + cnd) * 2;
+  const double d = nn_depth<true>(b, p, xy[0], xy[1]);
+  if ((threadIdx.x & 63) == 0) depth_out[(size_t)p * b.max_cand + cnd] = d;
+}
+
+hipError_t launch_fsel_nn_depth(const avm_fsel_batch& b, double* depth_out, hipStream_t stream) {
+  if (b.n_problems == 0 || b.max_cand == 0) return hipSuccess;
+  hipLaunchKernelGGL(fsel_nn_depth_kernel, dim3((b.max_cand + 3) / 4, b.n_problems), dim3(256), 0, stream, b, depth_out);
+  return hipGetLastError();
 }
 
 hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,

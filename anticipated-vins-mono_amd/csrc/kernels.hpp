@@ -161,6 +161,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
 bool fsel_horizon_supported(int H);
 hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,
                                    double* cloud_xy, double* cloud_depth, hipStream_t stream);
+hipError_t launch_fsel_nn_depth(const avm_fsel_batch& b, double* depth_out, hipStream_t stream);
 hipError_t launch_fsel_horizon_imu(const avm_fsel_horizon_in& in, double* hor_pos, double* hor_quat, hipStream_t stream);
 hipError_t launch_triangulate(const avm_window_batch& b, double init_depth, hipStream_t stream);
 hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipStream_t stream);

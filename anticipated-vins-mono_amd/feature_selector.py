@@ -66,6 +66,14 @@ class FeatureSelector:
         self.ctx.check(rc, "avm_fsel_information")
         return om, dl, va
 
+    def nn_depth(self, problems: buffers.FselArrays):
+        """FeatureSelector::findNNDepth (feature_selector.cpp:437-459) of every candidate: [P, max_cand] (host array)."""
+        assert not problems.on_device
+        out = np.zeros((problems.n_problems, problems.dims["max_cand"]))
+        s = problems.struct()
+        self.ctx.check(self.ctx._L.avm_fsel_nn_depth(self.ctx.h, problems.mem, C.byref(s), abi.dptr(out)), "avm_fsel_nn_depth")
+        return out
+
     def setParameters(self, enable=True, maxFeatures=150, initThresh=0):
         """The bookkeeping half of FeatureSelector::setParameters (feature_selector.cpp:24-34); the noise parameters and
         the horizon mode travel with the FselArrays the problem_builder returns."""

@@ -61,6 +61,7 @@ def lib():
         L.avm_imu_propagate_batch.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.POINTER(C.c_double)]
         L.avm_fsel_select_batch.argtypes = [vp, C.c_int, C.POINTER(abi.FselBatch), C.POINTER(abi.FselOut)]
         L.avm_fsel_information.argtypes = [vp, C.c_int, C.POINTER(abi.FselBatch), abi.c_dp, abi.c_dp, abi.c_ip]
+        L.avm_fsel_nn_depth.argtypes = [vp, C.c_int, C.POINTER(abi.FselBatch), abi.c_dp]
         L.avm_fsel_horizon_imu.argtypes = [vp, C.c_int, C.POINTER(abi.FselHorizonIn), abi.c_dp, abi.c_dp]
         L.avm_projection_td_eval.argtypes = [vp, C.c_int, C.POINTER(abi.TdFactorBatch), abi.c_dp, abi.c_dp]
         L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
@@ -89,7 +90,7 @@ def lib():
 EXPORTS = [
     "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
     "avm_window_solve_batch", "avm_window_solve", "avm_fsel_select", "avm_fsel_fallback_stats", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
-    "avm_fsel_select_batch", "avm_fsel_information", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
+    "avm_fsel_select_batch", "avm_fsel_information", "avm_fsel_nn_depth", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
     "avm_ctx_stream", "avm_comm_unique_id", "avm_comm_init", "avm_gather_states", "avm_comm_destroy", "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
 ]
 

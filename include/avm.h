@@ -445,6 +445,14 @@ int avm_fsel_select(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* frame, int3
  * and after 32, 64 ... 4096 if the probes keep failing (back to 16 once a fast-mode call has gone through). */
 int avm_fsel_fallback_stats(const avm_ctx* ctx, int64_t out[4]);
 
+/* B8, second half as a parity surface: FeatureSelector::findNNDepth (feature_selector.cpp:437-459) for every candidate of every
+ * frame - the depth of the cloud point nearest to the candidate on the normalized plane (exact 1-NN, squared Euclidean distance
+ * as nanoflann's L2_Simple_Adaptor, feature_selector.h:143; 1.0 for an empty cloud, feature_selector.cpp:444).  depth
+ * [P][max_cand] (entries beyond n_cand: 0).  The same search runs inside avm_fsel_select_batch / avm_fsel_information; this
+ * entry exists so that it can be checked against the reference's own nanoflann (tests/golden/nanoflann_nn.npz).  Among cloud
+ * points at bit-identical distances the lowest index wins here; nanoflann takes the one its kd-tree traversal meets first. */
+int avm_fsel_nn_depth(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, double* depth);
+
 /* B5/B6 only: Omega_kkH (+prior) [P][N][N] and compact Delta_ell position blocks
  * [P][max_cand][3H][3H] (+ valid flag [P][max_cand]); for parity tests. */
 int avm_fsel_information(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, double* omega,

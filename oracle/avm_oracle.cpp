@@ -264,6 +264,17 @@ int avmo_fsel_information(const avm_fsel_batch* batch, double* omega, double* de
   return 0;
 }
 
+// findNNDepth (feature_selector.cpp:437-459) of every candidate: depth_out[P][max_cand]; pinned against the reference's own nanoflann
+// (tests/golden/nanoflann_nn.npz)
+int avmo_fsel_nn_depth(const avm_fsel_batch* batch, double* depth_out) {
+  for (int p = 0; p < batch->n_problems; p++) {
+    FselProblem P;
+    load_fsel(*batch, p, P);
+    for (size_t c = 0; c < P.cand_id.size(); c++) depth_out[(size_t)p * batch->max_cand + c] = findNNDepth(P, P.cand_x[c], P.cand_y[c]);
+  }
+  return 0;
+}
+
 // createLinearImuMatrices exported for the MATLAB known-answer test; quaternions x,y,z,w
 int avmo_linear_imu_matrices(const double* qi, const double* qj, double nr, double delta, double accVar, double biasVar, double* Omega,
                              double* Ablk) {

@@ -91,6 +91,16 @@ def fsel_information(fsel):
     return om, dl, va
 
 
+def fsel_nn_depth(fsel):
+    """findNNDepth of every candidate, [P, max_cand]."""
+    import numpy as np
+    abi = importlib.import_module("anticipated-vins-mono_amd.abi")
+    out = np.zeros((fsel.n_problems, fsel.dims["max_cand"]))
+    s = fsel.struct()
+    assert lib().avmo_fsel_nn_depth(C.byref(s), abi.dptr(out)) == 0
+    return out
+
+
 def triangulate(win, init_depth=5.0, n_threads=1):
     """FeatureManager::triangulate in place on host WindowArrays (inverse depths <= 0 are replaced)."""
     s = win.struct()

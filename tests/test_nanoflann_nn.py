@@ -1,0 +1,77 @@
+"""B8 (feature_selector.cpp:380-459) against the REFERENCE'S OWN nearest-neighbour search: the vendored, header-only nanoflann is
+the one piece of the reference that compiles in the build container.  tests/golden/gen_nanoflann_nn.cpp runs
+it - adaptor, tree type, leaf size and search parameters as feature_selector.h:118-146 / feature_selector.cpp:424-455 - on
+seeded clouds; tests/golden/nanoflann_nn.npz holds, for 10 500 queries, the index it returned, its squared distance and the depth
+findNNDepth hands back.  Empty clouds (the "return 1.0" branch), clouds around the leaf size, queries ON cloud points, and
+EXACT TIES (dyadic grid points, queries at midpoints and cell centres: two resp. four points at bit-identical distances).
+
+What is asserted: on every query without a tie the oracle's and the GPU's 1-NN return nanoflann's depth bit for bit (10 422
+queries); the squared distance of the winner is bit-identical always; on the 78 exact ties the depth returned belongs to one of
+the tied points - the lowest index, where nanoflann takes the point its kd-tree traversal meets first (40 of the 78 differ).  That
+deviation is documented (include/avm.h): ties have measure zero in real data, and restating the tree's traversal order
+would be restating nanoflann."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import synth
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "nanoflann_nn.npz"))
+NC = int(GOLD["n_clouds"])
+
+
+def _problems():
+    """The fixture's clouds and queries as avm_fsel_batch frames: one frame per cloud, the queries as its candidates."""
+    out = []
+    for c in range(NC):
+        xy, dep, q = GOLD[f"cloud_xy_{c}"], GOLD[f"cloud_depth_{c}"], GOLD[f"query_xy_{c}"]
+        p = synth.make_fsel(1, horizon=3, n_cand=len(q), n_used=0, n_cloud=max(len(xy), 1), max_features=4)
+        p.a["n_cloud"][0] = len(xy)
+        p.a["cloud_xy"][0, :len(xy)] = xy
+        p.a["cloud_depth"][0, :len(xy)] = dep
+        p.a["cand_xy"][0, :len(q)] = q
+        out.append(p)
+    return out
+
+
+def _check(depths_of):
+    n_plain = n_tie = n_tie_other = 0
+    for c, p in enumerate(_problems()):
+        xy, dep, q = GOLD[f"cloud_xy_{c}"], GOLD[f"cloud_depth_{c}"], GOLD[f"query_xy_{c}"]
+        want, d2 = GOLD[f"nn_depth_{c}"], GOLD[f"nn_dist2_{c}"]
+        got = depths_of(p)[0, :len(q)]
+        if len(xy) == 0:
+            assert (got == 1.0).all() and (want == 1.0).all()      # feature_selector.cpp:444
+            n_plain += len(q)
+            continue
+        D = (q[:, None, 0] - xy[None, :, 0]) ** 2 + (q[:, None, 1] - xy[None, :, 1]) ** 2
+        assert np.array_equal(D.min(1), d2)                         # nanoflann's L2_Simple distance, bit for bit
+        tied = (D == d2[:, None]).sum(1) > 1
+        assert np.array_equal(got[~tied], want[~tied]), c           # no tie: the reference's answer exactly
+        for i in np.nonzero(tied)[0]:
+            assert got[i] in dep[D[i] == d2[i]], (c, i)            # a tie: one of the tied points (the lowest index)
+            assert got[i] == dep[np.argmin(D[i])]
+        n_plain += int((~tied).sum())
+        n_tie += int(tied.sum())
+        n_tie_other += int((got[tied] != want[tied]).sum())
+    return n_plain, n_tie, n_tie_other
+
+
+def test_the_fixture_is_what_the_docstring_says():
+    tot = sum(len(GOLD[f"query_xy_{c}"]) for c in range(NC))
+    assert NC == 14 and tot >= 10000
+    assert sorted({len(GOLD[f"cloud_xy_{c}"]) for c in range(NC)}) == [0, 1, 9, 10, 11, 64, 150]
+
+
+def test_oracle_find_nn_depth_against_the_reference_nanoflann(oracle):
+    n_plain, n_tie, n_other = _check(oracle.fsel_nn_depth)
+    print(f"\n[nanoflann] oracle: {n_plain} queries without a tie identical; {n_tie} exact ties, {n_other} of them answered with another tied point")
+    assert n_plain >= 10000 and n_tie >= 50
+
+
+@pytest.mark.gpu
+def test_gpu_find_nn_depth_against_the_reference_nanoflann(selector):
+    n_plain, n_tie, n_other = _check(selector.nn_depth)
+    print(f"\n[nanoflann] gpu: {n_plain} queries without a tie identical; {n_tie} exact ties, {n_other} of them answered with another tied point")
+    assert n_plain >= 10000 and n_tie >= 50
