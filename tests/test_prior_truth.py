@@ -288,12 +288,49 @@ class _Gpu:
         self.E.imu_propagate(w)
 
 
-def _stream(seq_id, backend, n_frames):
-    seq = synth.Sequence(seq_id)
+AMP_EPS = 1e-8
+
+
+def _perturbed_state(w, eps=AMP_EPS, seed=777):
+    """A copy of the window with its solved states moved by eps (positions, velocities: absolute, they are O(1); attitudes: a
+    rotation of eps rad; biases: eps of their scales 0.02 / 0.002)."""
+    rng = np.random.default_rng(seed)
+    p = w.copy()
+    p.a["pose"][..., :3] += eps * rng.uniform(-1, 1, p.a["pose"][..., :3].shape)
+    for f in range(p.a["pose"].shape[1]):
+        R = synth.R_from_quat(p.a["pose"][0, f, 3:]) @ synth._rot_zyx(*(eps * rng.uniform(-1, 1, 3)))
+        p.a["pose"][0, f, 3:] = synth.quat_from_R(R)
+    sc = np.array([1.0] * 3 + [0.02] * 3 + [0.002] * 3)
+    p.a["speedbias"] += eps * sc * rng.uniform(-1, 1, p.a["speedbias"].shape)
+    return p
+
+
+def _stream(seq_id, backend, n_images, amplification=None, **seq_kw):
+    """amplification (a list, T stream only): per frame k >= 1 the one-frame propagation factor of a state deviation - the solved
+    state of frame k - 1 moved by AMP_EPS, the same frame transition (exact marginalization at the moved state, roll, new image,
+    triangulation, dead-reckoning) and the FP64 solve of frame k, against the unmoved stream: |delta state_k| / AMP_EPS.  Below 1 a
+    stream forgets what separated two implementations; far above 1 it multiplies it."""
+    seq = synth.Sequence(seq_id, **seq_kw)
     w, ids = seq.first_window()
     out = []
-    for k in range(n_frames):
+    pending = None
+    for k in range(n_images):
         prior, s = backend.solve(w)
+        if amplification is not None:
+            amplification.append(0.0 if pending is None else
+                                 max(rel(pending.a["pose"], w.a["pose"]), rel(pending.a["speedbias"], w.a["speedbias"])) / AMP_EPS)
+            pending = None
+            if k + 1 < n_images:
+                wp = _perturbed_state(w)
+                pp, _ = truth_marginalize(wp, backend.opt)
+                backend.roll(wp)
+                seq.next_image(wp, ids, k)
+                install_prior(wp, pp)
+                backend.new_frame(wp)
+                o2 = abi.Options.from_buffer_copy(bytes(backend.opt))
+                o2.marginalization_flag = abi.MARGIN_NONE
+                backend.o.window_solve(o2, wp, None, buffers.summary_alloc(1))
+                pending = wp
         out.append(dict(pose=w.a["pose"].copy(), speedbias=w.a["speedbias"].copy(), n_feat=int(w.a["n_feat"][0]),
                         it=int(s["num_iterations"][0]), acc=int(s["accept_mask"][0]), term=int(s["termination"][0])))
         backend.roll(w)
@@ -325,3 +362,56 @@ def test_ten_frame_stream_against_the_exact_prior_stream(ctx, oracle, seq_id):
             assert dg < 1e-6 or dg <= do, (k, key, dg, do)
     print(f"[stream {seq_id}] worst distance to the exact-prior stream over {n} frames: gpu {worst_g:.2e}  oracle {worst_o:.2e}")
     assert worst_g <= max(worst_o, 1e-6)
+
+
+@pytest.mark.gpu
+def test_eight_twenty_frame_streams_against_the_exact_prior_stream(ctx, oracle):
+    """Eight sequences, twenty images each, through optimization() + slideWindow() with the prior handed from frame to frame.
+    Streams as above: T (FP64 solver, every marginalization in binary128), O (the FP64 oracle), G (the GPU).
+
+    What round 4 measured (VERDICT r3 item 3b asked for a per-frame amplification to sort the frames by): the one-frame
+    propagation factor of a state deviation (_stream) is 1 .. 2e3 on these sequences and does NOT predict where a stream leaves T -
+    stream 2 jumps from 6e-8 to 1e-5 at a frame whose factor is 6, whatever form the square root takes and whichever clamp is used
+    (tests/tools/dev_stream_probe.py): what separates the streams enters through weakly determined directions of the prior itself,
+    from the first, prior-less marginalization on.  A sensitivity of the solve to a Jacobi-scaled perturbation of J^T J (2e1 .. 7e3)
+    does not sort the frames either.  So there is no `amplification below a bound` class to assert 1e-6 on; what is asserted is
+    what holds: identical decisions at every frame; |G - T| < 1e-6 on the first frames (k <= 1) of every stream; at every frame
+    |G - T| < 1e-6, or |G - T| <= |O - T|, or - the third class, counted and bounded - |G - T| <= 5 |O - T| and < 5e-5.
+    Measured: 160 frames, G within 1e-6 of T on about half, closer to T than the oracle on all but ~15 frames (stream 2), worst
+    |G - T| 2e-5 (oracle 5e-4).  The north-star 1e-6 is therefore NOT met along whole streams by either implementation: the
+    exact-prior stream is itself only defined to ~1e-5 in FP64."""
+    n, n_seq = 20, 8
+    o = abi.default_options()
+    kw = dict(n_frames=34, n_landmarks=600)
+    tot = within = by_oracle = third = 0
+    worst_g = worst_o = worst_ratio = 0.0
+    failures = []
+    for sid in range(n_seq):
+        amp = []
+        T = _stream(sid, _Oracle(oracle, o, exact_prior=True), n, amplification=amp, **kw)
+        O = _stream(sid, _Oracle(oracle, o), n, **kw)
+        G = _stream(sid, _Gpu(ctx, o), n, **kw)
+        line = []
+        for k in range(n):
+            assert G[k]["n_feat"] == T[k]["n_feat"] and G[k]["it"] == T[k]["it"] and G[k]["acc"] == T[k]["acc"] and G[k]["term"] == T[k]["term"], (sid, k, G[k], T[k])
+            dg = max(rel(G[k][key], T[k][key]) for key in ("pose", "speedbias"))
+            do = max(rel(O[k][key], T[k][key]) for key in ("pose", "speedbias"))
+            line.append(f"{k}:{amp[k]:.0e}/{dg:.0e}/{do:.0e}")
+            tot += 1
+            worst_g, worst_o = max(worst_g, dg), max(worst_o, do)
+            if dg < 1e-6:
+                within += 1
+            elif dg <= do:
+                by_oracle += 1
+            else:
+                third += 1
+                worst_ratio = max(worst_ratio, dg / do)
+                if not (dg <= 5.0 * do and dg < 5e-5):
+                    failures.append((sid, k, dg, do))
+            if k <= 1 and not dg < 1e-6:
+                failures.append((sid, k, "first frames", dg, do))
+        print(f"\n[stream {sid}] frame:propagation factor/|G-T|/|O-T|  " + " ".join(line))
+    print(f"\n[streams] {tot} frames: |G-T| < 1e-6 on {within}; beyond 1e-6 but <= |O-T| on {by_oracle}; beyond the oracle on {third} "
+          f"(worst ratio {worst_ratio:.1f}); worst |G-T| {worst_g:.1e}, worst |O-T| {worst_o:.1e}")
+    assert not failures, failures
+    assert third <= tot // 6 and within >= tot // 4
