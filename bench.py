@@ -723,6 +723,19 @@ def main():
         r1, p1 = median_rate(solve_sample(n1, 1), n1, passes=5, budget_s=6.0)
         nall = min(W, max(2 * ncpu, 16))
         rall, pall = median_rate(solve_sample(nall, ncpu), nall, passes=5, budget_s=12.0)
+        # second leg, "port_blocked": the same port with its Schur update / Cholesky / forward substitution in a form the compiler
+        # vectorises (oracle/linalg.hpp, bit-for-bit the same operations in the same order; asserted against the literal loops in the CPU tier)
+        blocked = None
+        if hasattr(oracle_py, "set_fast_linalg"):
+            oracle_py.set_fast_linalg(True)
+            try:
+                rb1, _ = median_rate(solve_sample(n1, 1), n1, passes=5, budget_s=6.0)
+                rball, pball = median_rate(solve_sample(nall, ncpu), nall, passes=5, budget_s=12.0)
+            finally:
+                oracle_py.set_fast_linalg(False)
+            blocked = {"value": rball, "unit": "solves/s", "cores": ncpu, "kind": "port_blocked", "value_1_core": rb1,
+                       "sample": f"as the literal port ({nall} windows per pass on {ncpu} threads, median of {pball} passes)",
+                       "socket_extrapolated": {"value": rb1 * 64, "unit": "solves/s", "cores": 64, "gpu_over_cpu_socket": value / (rb1 * 64)}}
         scaling = {}
         for th in sorted({max(1, ncpu // 4), max(1, ncpu // 2)} - {1, ncpu}):
             nn = min(W, max(2 * th, 16))
@@ -744,6 +757,12 @@ def main():
                                     "how": f"value_1_core x 64 physical cores of one {cpu_info['model']} socket; measured up to {ncpu} threads",
                                     "gpu_over_cpu_socket": value / (r1 * 64)},
         }
+        if blocked is not None:
+            result["cpu_baseline"]["port_blocked"] = blocked
+            # the ratio the >= 50x target is quoted against: the FASTER of the two ports, a whole socket (extrapolated from one core)
+            best1 = max(r1, blocked["value_1_core"])
+            result["gpu_over_cpu_socket"] = {"value": value / (best1 * 64), "against": "port_blocked" if blocked["value_1_core"] >= r1 else "port",
+                                             "how": "value / (the faster port's 1-core rate x 64 cores): an extrapolation, stated as one"}
         result["gpu_over_cpu"] = value / rall
         result["gpu_over_cpu_1_core"] = value / r1
         if fsel_host is not None:

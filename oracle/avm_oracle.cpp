@@ -264,6 +264,13 @@ int avmo_fsel_information(const avm_fsel_batch* batch, double* omega, double* de
   return 0;
 }
 
+// bench leg only: the vectorisable forms of the Schur update, the Cholesky factorization and the forward substitution (linalg.hpp);
+// bit-identical results, off by default
+int avmo_set_fast_linalg(int on) {
+  fast_linalg() = on != 0;
+  return 0;
+}
+
 // findNNDepth (feature_selector.cpp:437-459) of every candidate: depth_out[P][max_cand]; pinned against the reference's own nanoflann
 // (tests/golden/nanoflann_nn.npz)
 int avmo_fsel_nn_depth(const avm_fsel_batch* batch, double* depth_out) {

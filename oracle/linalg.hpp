@@ -272,6 +272,51 @@ inline bool llt_lower(Mat& A) {
   }
   return true;
 }
+// ---- bench leg only: the same factorization and forward substitution in a form the compiler can vectorise.
+// The literal loops above are dot products (a reduction: no SIMD without reassociation); below the SAME subtractions happen in the
+// SAME order (k ascending for every entry) as row updates of the upper factor U = L^T, whose rows are contiguous: bit-identical
+// results (tests/test_oracle.py), a few times faster with -march=native.  Switched on by avmo_set_fast_linalg(1); never by default.
+inline bool& fast_linalg() {
+  static bool f = false;
+  return f;
+}
+inline bool llt_lower_fast(Mat& A, Mat& U) {  // A: lower triangle in / out as llt_lower; U: the upper factor (rows contiguous) for llt_solve_fast
+  const int n = A.r;
+  U = Mat(n, n);
+  for (int i = 0; i < n; i++)
+    for (int j = i; j < n; j++) U(i, j) = A(j, i);
+  for (int k = 0; k < n; k++) {
+    double x = U(k, k);
+    if (!(x > 0.0)) return false;
+    x = std::sqrt(x);
+    U(k, k) = x;
+    double* uk = &U.a[(size_t)k * n];
+    for (int j = k + 1; j < n; j++) uk[j] = uk[j] / x;
+    for (int i = k + 1; i < n; i++) {
+      const double uki = uk[i];
+      double* ui = &U.a[(size_t)i * n];
+      for (int j = i; j < n; j++) ui[j] -= uki * uk[j];
+    }
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) A(i, j) = U(j, i);
+  return true;
+}
+inline void llt_solve_fast(const Mat& U, std::vector<double>& b) {
+  const int n = U.r;
+  for (int j = 0; j < n; j++) {  // forward, column-oriented: b[i] loses its terms in j-ascending order, as in llt_solve
+    const double* uj = &U.a[(size_t)j * n];
+    b[j] = b[j] / uj[j];
+    const double bj = b[j];
+    for (int i = j + 1; i < n; i++) b[i] -= uj[i] * bj;
+  }
+  for (int i = n - 1; i >= 0; i--) {  // backward: the literal loop (row i of U is column i of L)
+    const double* ui = &U.a[(size_t)i * n];
+    double s = b[i];
+    for (int j = i + 1; j < n; j++) s -= ui[j] * b[j];
+    b[i] = s / ui[i];
+  }
+}
 // Solve L L^T x = b given lower factor
 inline void llt_solve(const Mat& L, std::vector<double>& b) {
   const int n = L.r;

@@ -91,6 +91,11 @@ def fsel_information(fsel):
     return om, dl, va
 
 
+def set_fast_linalg(on: bool):
+    """bench.py's second CPU leg ("port_blocked"): vectorisable Schur / Cholesky / forward-substitution loops, bit-identical results."""
+    lib().avmo_set_fast_linalg(1 if on else 0)
+
+
 def fsel_nn_depth(fsel):
     """findNNDepth of every candidate, [P, max_cand]."""
     import numpy as np

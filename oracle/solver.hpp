@@ -359,6 +359,24 @@ struct Problem {
     // lhs -= buf^T ete^-1 buf ; rhs -= buf^T ete^-1 ge   (only pose columns can be non-zero)
     const int npose = AVM_NFRAMES * 6;
     std::vector<int> cols;
+    if (fast_linalg()) {
+      // (bench leg: the same updates over the dense pose range - a zero column subtracts an exact zero -, contiguous inner loop)
+      for (int e = 0; e < ne; e++) {
+        const double inv = 1.0 / ete[e];
+        const double* be = &buf.a[(size_t)e * nf_];
+        int c0 = nf_, c1 = -1;  // the feature's range of touched columns (its frames' poses; ex_pose / td / relo_Pose when they are variables)
+        for (int c = 0; c < nf_; c++)
+          if (be[c] != 0.0) c0 = c < c0 ? c : c0, c1 = c;
+        (void)npose;
+        for (int a = c0; a <= c1; a++) {
+          if (be[a] == 0.0) continue;
+          const double va = be[a] * inv;
+          double* la = &lhs.a[(size_t)a * nf_];
+          for (int c = c0; c <= c1; c++) la[c] -= va * be[c];
+          rhs[a] -= va * ge[e];
+        }
+      }
+    } else {
     for (int e = 0; e < ne; e++) {
       double inv = 1.0 / ete[e];
       cols.clear();
@@ -371,10 +389,17 @@ struct Problem {
         rhs[a] -= va * ge[e];
       }
     }
+    }
     Mat L = lhs;
-    if (!llt_lower(L)) return false;
     std::vector<double> yf = rhs;
-    llt_solve(L, yf);
+    if (fast_linalg()) {
+      Mat U;
+      if (!llt_lower_fast(L, U)) return false;
+      llt_solve_fast(U, yf);
+    } else {
+      if (!llt_lower(L)) return false;
+      llt_solve(L, yf);
+    }
     y.assign(n_local, 0.0);
     for (int i = 0; i < nf_; i++) y[i] = yf[i];
     for (int e = 0; e < ne; e++) {

@@ -945,3 +945,28 @@ def test_window_roll_matches_python_lists(oracle):
     w = _roll_inputs()
     w.a["imu_n"][:, 8], w.a["imu_n"][:, 9] = 30, 20
     assert oracle.slide_window(w, abi.MARGIN_SECOND_NEW, True, 5.0) == -3    # 50 samples do not fit max_samp = 40
+
+
+def test_vectorisable_linear_algebra_of_the_bench_leg_is_the_literal_one_to_rounding(oracle):
+    """bench.py's second CPU baseline ("port_blocked") switches the oracle's Schur update, Cholesky factorization and
+    forward substitution to loops the compiler can vectorise (oracle/linalg.hpp: llt_lower_fast - the same subtractions in the same
+    order, as row updates of the upper factor instead of dot products).  Same decisions, states within 1e-11 of the literal path."""
+    import numpy as np
+
+    from helpers import abi, buffers, rel, synth
+
+    o = abi.default_options()
+    o.marginalization_flag = abi.MARGIN_NONE
+    for tracks, nf, prior in (("dense", 150, True), ("sparse", 70, False)):
+        w = synth.make_windows(3, first_id=77, tracks=tracks, n_feat=nf, max_feat=150, with_prior=prior)
+        a, b = w.copy(), w.copy()
+        sa, sb = buffers.summary_alloc(3), buffers.summary_alloc(3)
+        oracle.window_solve(o, a, None, sa)
+        oracle.set_fast_linalg(True)
+        try:
+            oracle.window_solve(o, b, None, sb)
+        finally:
+            oracle.set_fast_linalg(False)
+        assert np.array_equal(sa["accept_mask"], sb["accept_mask"]) and np.array_equal(sa["num_iterations"], sb["num_iterations"])
+        for k in ("pose", "speedbias", "inv_depth"):
+            assert rel(b.a[k], a.a[k]) < 1e-11, (k, rel(b.a[k], a.a[k]))
