@@ -950,7 +950,9 @@ def test_window_roll_matches_python_lists(oracle):
 def test_vectorisable_linear_algebra_of_the_bench_leg_is_the_literal_one_to_rounding(oracle):
     """bench.py's second CPU baseline ("port_blocked") switches the oracle's Schur update, Cholesky factorization and
     forward substitution to loops the compiler can vectorise (oracle/linalg.hpp: llt_lower_fast - the same subtractions in the same
-    order, as row updates of the upper factor instead of dot products).  Same decisions, states within 1e-11 of the literal path."""
+    order, as row updates of the upper factor instead of dot products; the compiler's vector code rounds a few last bits differently).
+    Same decisions; states within 1e-11 of the literal path on a window with a prior, 1e-8 on a prior-less one (its gauge directions
+    carry rounding differences into the states: measured 2e-10)."""
     import numpy as np
 
     from helpers import abi, buffers, rel, synth
@@ -969,4 +971,4 @@ def test_vectorisable_linear_algebra_of_the_bench_leg_is_the_literal_one_to_roun
             oracle.set_fast_linalg(False)
         assert np.array_equal(sa["accept_mask"], sb["accept_mask"]) and np.array_equal(sa["num_iterations"], sb["num_iterations"])
         for k in ("pose", "speedbias", "inv_depth"):
-            assert rel(b.a[k], a.a[k]) < 1e-11, (k, rel(b.a[k], a.a[k]))
+            assert rel(b.a[k], a.a[k]) < (1e-11 if prior else 1e-8), (k, rel(b.a[k], a.a[k]))
