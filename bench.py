@@ -702,6 +702,53 @@ def main():
                     FS.select_batch(f13_1)
                 torch.cuda.synchronize()
                 tl13 = (time.perf_counter() - t1) / reps
+                # larger batches (eight GPUs' worth of frames on one): where the issue rate, not the round's latency, is the limit
+                big_b = {}
+                for Pb in (64, 256):
+                    fb = synth.make_fsel(min(Pb, 64), first_id=rank * P)
+                    if Pb > 64:  # (tiled: the generator is the slow part)
+                        fb = type(fb)(dict(fb.dims, n_problems=Pb), {k: np.ascontiguousarray(v[np.arange(Pb) % 64]) for k, v in fb.a.items()}, fb.scalars)
+                    fbd = fb.to_device(dev)
+                    FS.select_batch(fbd)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(2):
+                        FS.select_batch(fbd)
+                    torch.cuda.synchronize()
+                    big_b[str(Pb)] = (time.perf_counter() - t1) / 2 / Pb * 1e3
+                    del fbd
+                result["feature_select"]["ms_per_frame_by_batch"] = big_b
+                # the pipelined deployment: single-frame selects while ANOTHER ctx runs the 4096-window solve on the same device
+                import threading
+
+                ctx2 = lib_m.Context(local_rank)
+                E2c = est_m.Estimator(ctx=ctx2, options=opt)
+                stop_ev, n_solves = threading.Event(), [0]
+
+                def _solver():
+                    pr2 = buffers.PriorOutArrays.alloc(W, win.dims["max_prior"], win.dims["max_pblk"], dev) if marg else None
+                    while not stop_ev.is_set():
+                        E2c.optimization(win, want_summary=False, prior_out=pr2)
+                        n_solves[0] += 1
+
+                th = threading.Thread(target=_solver)
+                th.start()
+                lat_c = []
+                try:
+                    while n_solves[0] < 1:
+                        time.sleep(0.005)
+                    for _ in range(12):
+                        t1 = time.perf_counter()
+                        FS.select_batch(f1)
+                        torch.cuda.synchronize()
+                        lat_c.append(time.perf_counter() - t1)
+                finally:
+                    stop_ev.set()
+                    th.join(timeout=120)
+                result["feature_select"]["ms_per_frame_single_beside_a_solve"] = {
+                    "median": statistics.median(lat_c) * 1e3, "min": min(lat_c) * 1e3, "max": max(lat_c) * 1e3,
+                    "what": f"12 single-frame selects while a second ctx loops the {W}-window solve on the same device ({n_solves[0]} solves meanwhile): "
+                            "the select queues behind the solve's kernels (they fill every CU)", "fallback_stats": ctx.fsel_fallback_stats()}
                 result["feature_select"]["horizon_13"] = {"workload": "500 candidates -> 150 selected, HORIZON 13 (the reference's compiled value, utility/state_defs.h:8)",
                                                           "ms_per_frame_batched": tb13 / P * 1e3, "batch": P, "ms_per_frame_single": tl13 * 1e3}
 

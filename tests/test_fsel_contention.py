@@ -77,7 +77,7 @@ def test_selects_are_exact_while_another_ctx_solves_4096_windows(oracle):
           f"contended median {np.median(lat_single) * 1e3:.2f} worst {max(lat_single) * 1e3:.2f} ms; batch of 8: median {np.median(lat_batch) * 1e3:.2f} "
           f"worst {max(lat_batch) * 1e3:.2f} ms; fall-backs {st}")
     assert solves[0] >= 2                                             # the contention was real
-    assert st["reruns"] == st["failed_launches"] and st["calls"] >= 4 * 4 + 4
+    assert st["reruns"] <= st["failed_launches"] and st["calls"] >= 4 * 4 + 4   # (re-run CALLS against failed LAUNCHES: a call can fall two modes)
     # a degraded call costs at most the failed launch's 20 ms spin time-out (2 ms if a team did not form) plus the slower mode's run,
     # on top of waiting for the other ctx's kernels (one 4096-window step is ~20 ms): well under a second either way
     assert max(lat_single) < 1.0 and max(lat_batch) < 1.0
