@@ -31,9 +31,14 @@ AVM_DEV void wsync() {
   __builtin_amdgcn_sched_barrier(0);  // keep the phases of a sample from being interleaved (register pressure)
 }
 
+// Row strides of the two images: 17 and 22 doubles (34 and 44 banks).  The operand reads below take, per half wavefront, rows 0..8 at
+// two k offsets each: with the natural strides 16 / 20 (32 / 40 banks) rows 0, 2, 4, 6, 8 of F - and rows 0 and 8 of V - fall on the
+// same banks (a five-way conflict on every operand read: 10 conflict cycles per LDS instruction in profiles/r03f.md); with 17 / 22
+// the nine rows of a half wavefront hit 18 distinct bank pairs.
+constexpr int FS = 17, VS = 22;
 struct PreLds {
-  double Fi[9 * 16];  // rows 0..8 of F, 16 columns (column 15 = 0); rows 9..14 are rows of the identity
-  double Vi[9 * 20];  // rows 0..8 of V, 20 columns (18-19 = 0); rows 9..14 hold I dt in the columns row + 3
+  double Fi[9 * FS];  // rows 0..8 of F, 16 columns (column 15 = 0) + 1 pad; rows 9..14 are rows of the identity
+  double Vi[9 * VS];  // rows 0..8 of V, 20 columns (18-19 = 0) + 2 pad; rows 9..14 hold I dt in the columns row + 3
   double m[72];       // Rd, Rr, Ra0, Ra1, IRw (I - Rw*dt), T1=Rd*Ra0, T2=Rr*Ra1, T3=T2*IRw
 };
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -78,8 +83,8 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
   const v3 lbg = mk3(a.imu_lin_bg[iv * 3], a.imu_lin_bg[iv * 3 + 1], a.imu_lin_bg[iv * 3 + 2]);
 
   // static part of the images: zeros, the identity blocks of F's rows 0..8 (16 lanes per image)
-  for (int i = li; i < 9 * 16; i += 16) L.Fi[i] = (i / 16 == i % 16) ? 1.0 : 0.0;
-  for (int i = li; i < 9 * 20; i += 16) L.Vi[i] = 0.0;
+  for (int i = li; i < 9 * FS; i += 16) L.Fi[i] = (i / FS == i % FS) ? 1.0 : 0.0;
+  for (int i = li; i < 9 * VS; i += 16) L.Vi[i] = 0.0;
   d4 Jb[PG], Pb[PG];
 #pragma unroll
   for (int g = 0; g < PG; g++) {
@@ -155,28 +160,28 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
       const double I = (r == c) ? 1.0 : 0.0;
       const double dt2 = dt * dt;
       // F (integration_base.h:90-105)
-      L.Fi[(0 + r) * 16 + 3 + c] = -0.25 * T1 * dt2 + -0.25 * T3 * dt2;
-      L.Fi[(0 + r) * 16 + 6 + c] = I * dt;
-      L.Fi[(0 + r) * 16 + 9 + c] = -0.25 * (Rd + Rr) * dt2;
-      L.Fi[(0 + r) * 16 + 12 + c] = -0.25 * T2 * dt2 * -dt;
-      L.Fi[(3 + r) * 16 + 3 + c] = L.m[36 + li];
-      L.Fi[(3 + r) * 16 + 12 + c] = -1.0 * I * dt;
-      L.Fi[(6 + r) * 16 + 3 + c] = -0.5 * T1 * dt + -0.5 * T3 * dt;
-      L.Fi[(6 + r) * 16 + 9 + c] = -0.5 * (Rd + Rr) * dt;
-      L.Fi[(6 + r) * 16 + 12 + c] = -0.5 * T2 * dt * -dt;
+      L.Fi[(0 + r) * FS + 3 + c] = -0.25 * T1 * dt2 + -0.25 * T3 * dt2;
+      L.Fi[(0 + r) * FS + 6 + c] = I * dt;
+      L.Fi[(0 + r) * FS + 9 + c] = -0.25 * (Rd + Rr) * dt2;
+      L.Fi[(0 + r) * FS + 12 + c] = -0.25 * T2 * dt2 * -dt;
+      L.Fi[(3 + r) * FS + 3 + c] = L.m[36 + li];
+      L.Fi[(3 + r) * FS + 12 + c] = -1.0 * I * dt;
+      L.Fi[(6 + r) * FS + 3 + c] = -0.5 * T1 * dt + -0.5 * T3 * dt;
+      L.Fi[(6 + r) * FS + 9 + c] = -0.5 * (Rd + Rr) * dt;
+      L.Fi[(6 + r) * FS + 12 + c] = -0.5 * T2 * dt * -dt;
       // V (integration_base.h:108-120)
       const double v03 = 0.25 * -T2 * dt2 * 0.5 * dt;
       const double v63 = 0.5 * -T2 * dt * 0.5 * dt;
-      L.Vi[(0 + r) * 20 + 0 + c] = 0.25 * Rd * dt2;
-      L.Vi[(0 + r) * 20 + 3 + c] = v03;
-      L.Vi[(0 + r) * 20 + 6 + c] = 0.25 * Rr * dt2;
-      L.Vi[(0 + r) * 20 + 9 + c] = v03;
-      L.Vi[(3 + r) * 20 + 3 + c] = 0.5 * I * dt;
-      L.Vi[(3 + r) * 20 + 9 + c] = 0.5 * I * dt;
-      L.Vi[(6 + r) * 20 + 0 + c] = 0.5 * Rd * dt;
-      L.Vi[(6 + r) * 20 + 3 + c] = v63;
-      L.Vi[(6 + r) * 20 + 6 + c] = 0.5 * Rr * dt;
-      L.Vi[(6 + r) * 20 + 9 + c] = v63;
+      L.Vi[(0 + r) * VS + 0 + c] = 0.25 * Rd * dt2;
+      L.Vi[(0 + r) * VS + 3 + c] = v03;
+      L.Vi[(0 + r) * VS + 6 + c] = 0.25 * Rr * dt2;
+      L.Vi[(0 + r) * VS + 9 + c] = v03;
+      L.Vi[(3 + r) * VS + 3 + c] = 0.5 * I * dt;
+      L.Vi[(3 + r) * VS + 9 + c] = 0.5 * I * dt;
+      L.Vi[(6 + r) * VS + 0 + c] = 0.5 * Rd * dt;
+      L.Vi[(6 + r) * VS + 3 + c] = v63;
+      L.Vi[(6 + r) * VS + 6 + c] = 0.5 * Rr * dt;
+      L.Vi[(6 + r) * VS + 9 + c] = v63;
     }
     wsync();
     // ---- matrix side: the four intervals in turn, all 64 lanes each.  Rows 9..14 of the operands do not depend on the
@@ -189,9 +194,9 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
       const double dtg = readlane_f64(dt, 16 * g);
       double fa[4], va[5];
 #pragma unroll
-      for (int m = 0; m < 4; m++) fa[m] = G.Fi[lic * 16 + lk + 4 * m];
+      for (int m = 0; m < 4; m++) fa[m] = G.Fi[lic * FS + lk + 4 * m];
 #pragma unroll
-      for (int m = 0; m < 5; m++) va[m] = G.Vi[lic * 20 + lk + 4 * m];
+      for (int m = 0; m < 5; m++) va[m] = G.Vi[lic * VS + lk + 4 * m];
 #pragma unroll
       for (int m = 0; m < 4; m++) fa[m] = li < 9 ? fa[m] : ((li < 15 && lk + 4 * m == li) ? 1.0 : 0.0);
 #pragma unroll
