@@ -467,6 +467,7 @@ struct Problem {
 struct SolveResult {
   avm_solve_summary sum;
   State x;
+  std::vector<double> cost_after;  // the cost after every iteration in the oracle's own scalar type (the summary's trace is the ABI's FP64)
 };
 
 inline SolveResult trust_region_solve(Problem& P, const State& x0) {
@@ -613,6 +614,7 @@ inline SolveResult trust_region_solve(Problem& P, const State& x0) {
     tr_radius_report = radius;
     if (iteration > 0 && iteration <= AVM_MAX_ITER_TRACE) {
       R.sum.cost_trace[iteration - 1] = x_cost;
+      R.cost_after.push_back(x_cost);
       R.sum.radius_trace[iteration - 1] = tr_radius_report;
       if (step_is_successful) R.sum.accept_mask |= (1 << (iteration - 1));
     }
