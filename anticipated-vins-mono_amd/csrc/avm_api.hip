@@ -79,6 +79,7 @@ struct avm_ctx {
   bool packed_in = false;  // the last stage_window_batch took the packed path (states are contiguous on the device)
   hipEvent_t ev[8];
   std::map<std::string, float> last_ms;
+  int last_fsel_mode = -1;  // the form the last avm_fsel_select_batch took (3: fsel_solo_kernel)
   int fsel_frame_mode = 2;  // how a single-frame select runs (avm_fsel_select_batch); AVM_FSEL_FRAME=0/1/2 caps it
   ncclComm_t comm = nullptr;  // avm_comm_init
   int comm_ranks = 0, comm_rank = 0;
@@ -719,6 +720,9 @@ int avm_debug_copy_profile(avm_ctx* c, long long* host_out) {
 
 // test / bench hook (not in avm.h): 1 when the last avm_window_solve_batch ran the throughput form of the solve kernel
 int avm_debug_last_solve_form(const avm_ctx* c) { return c ? (c->last_solve_tp ? 1 : 0) : -1; }
+// ... and which form the last avm_fsel_select_batch STARTED in: 3 = one workgroup per frame with lazy evaluation (fsel_solo_kernel), 2 / 1 = the
+// frame kernel's teams, 0 = one launch per greedy round
+int avm_debug_last_fsel_form(const avm_ctx* c) { return c ? c->last_fsel_mode : -1; }
 
 // test / bench hook (not in avm.h): out[0] = workgroups of the throughput kernel per CU (runtime's occupancy query), out[1] = its LDS bytes
 int avm_debug_solve_tp_occupancy(int* out) {
@@ -1073,6 +1077,16 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   if (mode == 1 && P != 1) mode = 0;  // (the one-team-over-all-XCDs form takes one frame)
   if (const char* e = getenv("AVM_FSEL_FRAME"))
     if (e[0] >= '0' && e[0] <= '2') mode = std::min(mode, e[0] - '0');
+  // 3 = one workgroup per frame with lazy evaluation (fsel_solo_kernel): what a batch of many frames takes - it has no waits between
+  // workgroups, so it cannot time out and is never re-run.  AVM_FSEL_SOLO=0/1 overrides the batch-size rule (tests, measurements).
+  {
+    constexpr size_t AVM_FSEL_SOLO_MIN = 24;  // (frames: below, the teams of fsel_frame_kernel are faster - DESIGN.md section 3)
+    const bool can = d.max_cand <= 512 && 3 * d.horizon <= 30 && P >= 1;
+    bool solo = can && P >= AVM_FSEL_SOLO_MIN && !getenv("AVM_FSEL_FRAME");
+    if (const char* e = getenv("AVM_FSEL_SOLO")) solo = can && e[0] == '1';
+    if (solo) mode = 3;
+  }
+  c->last_fsel_mode = mode;
   int32_t* hsync = mode ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 64)) : nullptr;
   if (mode && !hsync) mode = 0;
   for (;;) {
@@ -1096,6 +1110,11 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
       fprintf(stderr, "fsel frame kernel, mode %d (cycles): pick %lld update %lld eval %lld wait %lld | eval: loads %lld bound %lld elimination %lld logdet %lld | setup: before the elimination %lld, elimination %lld\n",
               mode, q[0], q[1], q[2], q[4], q[5], q[6], q[7], q[8], q[9], q[3]);
     }
+    if (mode == 3 && getenv("AVM_FSEL_LAZY_STATS")) {  // (development: frame 0's workgroup of fsel_solo_kernel)
+      const long long* q = reinterpret_cast<const long long*>(hsync + 32);
+      fprintf(stderr, "fsel solo kernel, frame 0 (cycles): bounds %lld list %lld scores %lld pick+check %lld second-pass scores %lld fold %lld | %lld candidates scored in %lld rounds, %lld second passes\n",
+              q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[8], q[7]);
+    }
     if (hsync[2] == 0 && hsync[4] == (int32_t)P) {
       // a fast-mode call that went through: the back-off starts from the beginning next time
       if (mode == 2 || (mode == c->fsel_frame_mode && !rerun)) c->fsel_backoff = AVM_FSEL_REPROBE_CALLS;
@@ -1104,7 +1123,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     // (the outputs of the failed attempt are overwritten by the next one)
     c->fsel_failed_launches++;  // one per launch that did not finish; the call counts once, below
     rerun = true;
-    --mode;
+    mode = mode == 3 ? std::min(2, c->fsel_frame_mode) : mode - 1;  // (3 cannot fail; kept for completeness)
     c->fsel_frame_mode = std::min(c->fsel_frame_mode, std::max(mode, P != 1 ? 1 : 0));  // a failed batch leaves mode 1 to single frames
     // exponential back-off of the re-probe: a host where the fast mode can never become resident pays a failed launch (up to its
     // 20 ms spin time-out) after 16, 32, 64 ... 4096 calls instead of every 16

@@ -15,6 +15,7 @@
 // registers (four candidates per wavefront, one per 16-lane DPP row; one launch per greedy round).
 // This is the same Cholesky with the constant leading pivots factored once — the same kind of
 // hoist as IMUFactor's sqrt_info.  All FP64; selection order is deterministic.
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 
@@ -33,6 +34,8 @@ constexpr int FS_TABLES_OK = 0x7f7f7f7f;  // (what launch_validate_fsel leaves i
 struct FselDev {
   avm_fsel_batch b;  // device pointers
   int no_key_rule;   // test switch (AVM_FSEL_NO_KEY_RULE=1): skip the std::map equal-key rule of sortedlogDetUB
+  int lazy_stats;    // development (AVM_FSEL_LAZY_STATS=1): workgroup 0 of fsel_solo_kernel leaves its counters and phase clocks in sync[32..]
+  double lazy_tau;   // fsel_solo_kernel: a candidate is scored in a round's first pass when its gain bound reaches lazy_tau x the last winner's gain
   const int* vflag;  // result of the table validation that runs ahead on the same stream (null: already checked by the host): any
                      // value but FS_TABLES_OK means a malformed table - no kernel of the select may index with the tables then
   // work buffers
@@ -840,6 +843,23 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
 }
 
 
+// The Hadamard bound alone, for the candidate of this lane's 16-lane row: the same expression, in the same order, as the bound
+// inside fsel_logdet4.  dd: the T diagonal entries of the candidate's Delta (fsel_solo_kernel takes every candidate's bound from
+// here, scored or not, so the equal-key rule and the (fValue, bound, id) order of the pick see one function).
+template <int T, int BS, int NB>
+AVM_DEV double fsel_ub4(const double* sdpp, const double* dd, double pr) {
+  const int lane = threadIdx.x & 63;
+  const int r = min(lane & 15, BS - 1);
+  double ubl = 0.0;
+#pragma unroll
+  for (int bi = 0; bi < NB; bi++) {
+    const int dgi = bi * BS + r;
+    ubl += fs_log(sdpp[dgi] + pr * dd[dgi]);
+  }
+  return fs_row_sum((lane & 15) < BS ? ubl : 0.0);
+}
+
+
 AVM_DEV double fs_rsqrt(double x) {  // v_rsq_f64 + two Newton steps (about one ulp on normal positive numbers)
   double y = __builtin_amdgcn_rsq(x);
   y = y * (1.5 - (0.5 * x) * y * y);
@@ -1358,6 +1378,229 @@ __global__ __launch_bounds__(FS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 }
 
 // the compact list of the candidates that take part in the greedy rounds: the valid ones, in ascending index (= id) order
+// ---- SOLO: one workgroup per frame, lazy evaluation (batches of many frames) -------------------------------------------------------
+// The frame kernel above spreads ONE frame's 425 evaluations per round over a team of workgroups and pays an exchange of records per
+// round; a batch larger than the number of teams queues.  Here a frame belongs to one workgroup from its first round to its last -
+// no records, no waiting for anybody, hundreds of frames side by side - which only pays because a round does not have to score every
+// candidate: the objective is submodular (every p Delta is positive semidefinite), so a candidate's gain f_l(S) - logdet C(S) can only
+// shrink as features are added, and the gain it had when it was last scored, g_l, bounds its value now: f_l <= logdet C + g_l (Minoux'
+// accelerated greedy; logdet C is the last winner's value).  Per round:
+//   1. every live candidate's Hadamard bound (the std::map equal-key rule and the order of the pick need all of them);
+//   2. the candidates with g_l >= lazy_tau x (the last winner's gain) are scored, four per wavefront, Delta straight from memory;
+//   3. the pick among the scored ones, and its check: a candidate that was NOT scored and whose bound logdet C + g_l + margin reaches
+//      the winner's value is scored after all and the pick repeated, until nobody is left.  A candidate that is never scored in a
+//      round is therefore PROVEN to lose it (strictly, beyond the margin: it can neither win nor tie), which is all the reference's
+//      loop (feature_selector.cpp:669-683) needs of it: ids and fValues are those of the full evaluation.  lazy_tau trades second
+//      passes against scored candidates and cannot change a result.
+// Measured on the bench frames (500 candidates, 150 selected, H = 10): ~40 candidates scored per round instead of 425.
+constexpr int FS_SOLO_NT = 512;
+static_assert(FS_SOLO_NT == FS_FRAME_MAXC, "one candidate per thread");
+
+// the pick of fsel_pick_frame for a workgroup of FS_SOLO_NT threads with ONE candidate each (cl < 0: not in the race)
+AVM_DEV int fsel_pick_solo(const FselDev& A, int cl, double cf, double cu, double* fwin) {
+  constexpr int NW = FS_SOLO_NT / 64;
+  __shared__ double s_f[2][NW], s_u[2][NW];
+  __shared__ int s_i[2][NW], s_h[2][NW];
+  const int t = threadIdx.x, wv = t >> 6;
+  constexpr int MAXSH = 8;
+  int sh[MAXSH], nsh = 0;
+#pragma unroll
+  for (int qq = 0; qq < MAXSH; qq++) sh[qq] = -1;
+  for (int pass = 0;; pass++) {
+    const int sl = pass & 1;
+    bool out = cl < 0;
+#pragma unroll
+    for (int qq = 0; qq < MAXSH; qq++) out |= sh[qq] == cl;
+    const bool in = !out && cf > -1.0;  // (NaN never wins)
+    {  // the wavefront's best: three maxima in a row, each over the lanes that tie in the previous ones
+      const double wf = fs_wave_max(in ? cf : -1.0);
+      const bool tf = in && cf == wf;
+      const double wu = fs_wave_max(tf ? cu : -DBL_MAX);
+      const bool tu = tf && cu == wu;
+      const int wi = fs_wave_max(tu ? cl : -1);
+      if ((t & 63) == 0) s_f[sl][wv] = wf, s_u[sl][wv] = wu, s_i[sl][wv] = wi;
+    }
+    __syncthreads();
+    double bf = s_f[sl][0], bu = s_u[sl][0];
+    int bi = s_i[sl][0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+      const double f2 = s_f[sl][w], u2 = s_u[sl][w];
+      const int i2 = s_i[sl][w];
+      if (i2 >= 0 && (bi < 0 || f2 > bf || (f2 == bf && (u2 > bu || (u2 == bu && i2 > bi))))) bf = f2, bu = u2, bi = i2;
+    }
+    *fwin = bf;
+    if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;
+    // std::map rule (see fsel_pick_local): a live candidate with a higher id and the same key shadows the winner - scored or not
+    const bool hit = cl > bi && cu == bu;
+    const bool wh = __any(hit);
+    if ((t & 63) == 0) s_h[sl][wv] = wh ? 1 : 0;
+    __syncthreads();
+    int any = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) any |= s_h[sl][w];
+    if (!any) return bi;
+#pragma unroll
+    for (int qq = 0; qq < MAXSH; qq++)
+      if (qq == nsh) sh[qq] = bi;
+    nsh++;
+  }
+}
+
+template <int T, int BS, int NB>
+__global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_t* sync) {
+  FS_TABLES_GUARD(A);
+  constexpr int NW = FS_SOLO_NT / 64, MAXC = FS_FRAME_MAXC;
+  __shared__ double sC[T * T], sdpp[T];
+  __shared__ double s_f[MAXC], s_u[MAXC], s_bound[MAXC], s_pr[MAXC];
+  __shared__ int32_t s_alive[MAXC], s_scored[MAXC], s_mark[MAXC], s_list[MAXC];
+  __shared__ int s_n;
+  __shared__ double s_g0;
+  extern __shared__ double s_dd[];  // [MAXC][T]: every candidate's Delta diagonal (the bounds of every round read nothing else)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4;
+  const bool rec_lane = (lane & 15) == 0;
+  const avm_fsel_batch& b = A.b;
+  const int mc = b.max_cand;
+  // the candidates marked in s_mark -> s_list (ascending), s_n
+  auto build_list = [&]() {
+    __syncthreads();
+    if (wv == 0) {
+      int n = 0;
+      for (int base = 0; base < MAXC; base += 64) {
+        const bool m = s_mark[base + lane] != 0;
+        const unsigned long long bal = __ballot(m);
+        if (m) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = base + lane;
+        n += __popcll(bal);
+      }
+      if (lane == 0) s_n = n;
+    }
+    __syncthreads();
+    return s_n;
+  };
+  for (int p = blockIdx.x; p < b.n_problems; p += gridDim.x) {
+    __syncthreads();
+    const int nc = b.n_cand[p];
+    const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
+    const size_t pc = (size_t)p * mc;
+    const double* Dp = A.delta + pc * T * T;
+    for (int idx = t; idx < T * T; idx += FS_SOLO_NT) sC[idx] = A.C[(size_t)p * T * T + idx];
+    for (int idx = t; idx < T; idx += FS_SOLO_NT) sdpp[idx] = A.dpp[(size_t)p * T + idx];
+    {
+      const int c = t;
+      const bool ok = c < nc && A.valid[pc + min(c, mc - 1)] != 0;
+      s_alive[c] = ok ? 1 : 0, s_bound[c] = HUGE_VAL, s_scored[c] = 0, s_mark[c] = 0;
+      s_pr[c] = ok ? b.cand_prob[pc + c] : 0.0;
+    }
+    for (int idx = t; idx < nc * T; idx += FS_SOLO_NT) {  // (one strided pass over the frame's Deltas)
+      const int c = idx / T, d = idx % T;
+      s_dd[idx] = Dp[(size_t)c * T * T + d * T + d];
+    }
+    const double ld_nn = A.consts[(size_t)p * 4], ub_nn = A.consts[(size_t)p * 4 + 1];
+    __syncthreads();
+    if (wv == 0) {  // logdet of the frame's first C: the same evaluation with p = 0
+      double ld0, ub0;
+      const bool ok0 = fsel_logdet4<T, BS, NB, false, false>(sC, sdpp, Dp, 0.0, &ld0, &ub0);
+      if (lane == 0) s_g0 = ok0 ? (ld_nn + 2.0 * ld0) : __builtin_nan("");
+    }
+    __syncthreads();
+    double G = s_g0, gprev = HUGE_VAL;
+    // scores the candidates of s_list, four per wavefront
+    auto score_list = [&](int n) {
+      for (int i0 = 0; i0 < n; i0 += NW * 4) {
+        if (i0 + wv * 4 >= n) break;  // (uniform per wavefront)
+        const int i = i0 + wv * 4 + g;
+        const int c = s_list[min(i, n - 1)];  // (a row without a candidate scores the list's last one again and drops the result)
+        double ld, ubt;
+        const bool ok = fsel_logdet4<T, BS, NB, false, false>(sC, sdpp, Dp + (size_t)c * T * T, s_pr[c], &ld, &ubt);
+        if (i < n && rec_lane) {
+          const double f = ok ? (ld_nn + 2.0 * ld) : __builtin_nan("");
+          s_f[c] = f, s_scored[c] = 1;
+          s_bound[c] = ok ? f - G : HUGE_VAL;  // (a failed factorization: scored again every round)
+        }
+      }
+    };
+    int nsel = 0;
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, tkp = 0, n_scored = 0, n_second = 0;
+    const bool stats = A.lazy_stats != 0 && p == 0;
+#define FS_SOLO_SEG(i) if (stats) { const long long n__ = clock64(); tk[i] += n__ - tkp; tkp = n__; }
+    for (int k = 0; k < kappa; k++) {
+      if (stats) tkp = clock64();
+      // ---- 1. who is scored in the first pass; every live candidate's bound
+      const double th = A.lazy_tau * gprev;
+      {
+        const int c = t;
+        const bool live = c < nc && s_alive[c] != 0;
+        s_mark[c] = (live && !(s_bound[c] < th)) ? 1 : 0;
+        s_scored[c] = 0, s_f[c] = __builtin_nan("");
+      }
+      for (int c0 = 0; c0 < nc; c0 += NW * 4) {
+        const int c = c0 + wv * 4 + g, cc = min(c, nc - 1);
+        const bool live = c < nc && s_alive[cc] != 0;
+        if (__any(live)) {
+          const double ubt = fsel_ub4<T, BS, NB>(sdpp, s_dd + cc * T, s_pr[cc]);
+          if (live && rec_lane) s_u[c] = ub_nn + ubt;
+        }
+      }
+      FS_SOLO_SEG(0)
+      int n = build_list();
+      FS_SOLO_SEG(1)
+      n_scored += n;
+      // ---- 2. the scores
+      score_list(n);
+      FS_SOLO_SEG(2)
+      // ---- 3. the pick and its check
+      int win;
+      double fwin;
+      for (;;) {
+        __syncthreads();
+        const int c = t;
+        const bool live = c < nc && s_alive[c] != 0;
+        const bool scored = live && s_scored[c] != 0;
+        win = fsel_pick_solo(A, live ? c : -1, scored ? s_f[c] : __builtin_nan(""), s_u[c], &fwin);
+        const double V = win >= 0 ? fwin : -1.0;  // (the reference's fMax = -1.0 when nobody has won)
+        const double margin = 1e-8 * fmax(1.0, fabs(V));
+        s_mark[c] = (live && !scored && !(G + s_bound[c] + margin < V)) ? 1 : 0;
+        n = build_list();
+        FS_SOLO_SEG(3)
+        if (n == 0) break;
+        n_scored += n, n_second++;
+        score_list(n);
+        FS_SOLO_SEG(4)
+      }
+      if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
+      if (t == 0) {
+        A.out.selected_ids[(size_t)p * b.max_features + nsel] = b.cand_id[pc + win];
+        if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + nsel] = fwin;
+        A.out.n_selected[p] = nsel + 1;
+        A.black[pc + win] = 1;
+      }
+      nsel++;
+      gprev = fwin - G, G = fwin;  // the winner's value IS logdet of the next C
+      const double prw = s_pr[win];
+      const double* Dw = Dp + (size_t)win * T * T;
+      __syncthreads();
+      for (int idx = t; idx < T * T; idx += FS_SOLO_NT) {
+        const double dw = Dw[idx];
+        sC[idx] = sC[idx] + prw * dw;
+        if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dw;
+      }
+      if (t == 0) s_alive[win] = 0;
+      __syncthreads();
+      FS_SOLO_SEG(5)
+    }
+#undef FS_SOLO_SEG
+    if (stats && t == 0) {  // (cycles: bounds, list, first-pass scores, pick + check, second-pass scores, fold; then the counters)
+      long long* o = reinterpret_cast<long long*>(sync + 32);
+      for (int i = 0; i < 6; i++) o[i] = tk[i];
+      o[6] = n_scored, o[7] = n_second, o[8] = nsel;
+    }
+    if (t == 0) {
+      A.nsel[p] = nsel;
+      __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // frames finished
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void fsel_live_init_kernel(FselDev A) {
   FS_TABLES_GUARD(A);
   const avm_fsel_batch& b = A.b;
@@ -1412,6 +1655,38 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   if (!run_rounds) return hipSuccess;
   const int per_block = FS_CPWG;  // four candidates per wavefront
   const dim3 grid((b.max_cand + per_block - 1) / per_block, b.n_problems);
+  {
+    const char* lt = getenv("AVM_FSEL_LAZY_TAU");  // (development: any value gives the same result, see fsel_solo_kernel)
+    d.lazy_tau = lt ? atof(lt) : 0.95;
+    const char* ls = getenv("AVM_FSEL_LAZY_STATS");
+    d.lazy_stats = (ls && ls[0] == '1') ? 1 : 0;
+  }
+  if (frame_mode == 3) {  // one workgroup per frame, lazy evaluation (fsel_solo_kernel): batches of many frames, 3 H <= 30
+    if (b.max_cand > FS_FRAME_MAXC || T > 30) return hipErrorInvalidValue;
+    if ((e = hipMemsetAsync(w.sync, 0, sizeof(int32_t) * (FS_SYNC_HDR + 64), stream)) != hipSuccess) return e;
+    const size_t dl = sizeof(double) * (size_t)std::min(b.max_cand, FS_FRAME_MAXC) * T;
+    static int ncu = 0;  // (one device per process: include/avm.h)
+    if (ncu == 0) {
+      int dev = 0, v = 0;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    const int gridx = std::max(1, std::min(b.n_problems, ncu));
+#define AVM_SOLO(T_, BS_, NB_)                                                                                                \
+  {                                                                                                                           \
+    auto kf = fsel_solo_kernel<T_, BS_, NB_>;                                                                                 \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl)) != hipSuccess) return e; \
+    hipLaunchKernelGGL(kf, dim3(gridx), dim3(FS_SOLO_NT), dl, stream, d, w.sync);                                             \
+  }
+    switch (T) {
+      case 6: AVM_SOLO(6, 6, 1) break;
+      case 9: AVM_SOLO(9, 9, 1) break;
+      case 15: AVM_SOLO(15, 15, 1) break;
+      case 30: AVM_SOLO(30, 15, 2) break;
+      default: return hipErrorInvalidValue;
+    }
+#undef AVM_SOLO
+    return hipGetLastError();
+  }
   if (frame_mode != 0) {  // (every frame's rounds in one launch, see fsel_frame_kernel)
     if (b.max_cand > FS_FRAME_MAXC || b.max_features >= 4096 || (frame_mode == 1 && b.n_problems != 1)) return hipErrorInvalidValue;
     // teams per XCD: 0 = one team over the whole device (a single frame), 1, or 2 when there are frames for more than eight teams

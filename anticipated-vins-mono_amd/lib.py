@@ -67,6 +67,7 @@ def lib():
         L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
         L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
         L.avm_debug_last_solve_form.argtypes = [vp]
+        L.avm_debug_last_fsel_form.argtypes = [vp]
         L.avm_debug_counters.argtypes = [vp, C.POINTER(C.c_int64)]
         L.avm_debug_solve_tp_occupancy.argtypes = [C.POINTER(C.c_int)]
         L.avm_slide_window.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.c_int32, C.c_int32, C.c_double]
@@ -151,6 +152,11 @@ class Context:
         """Which form of the solve kernel the last optimization() took: 'throughput' (two 256-thread workgroups per CU,
         batches larger than the CU count) or 'latency' (one 512-thread workgroup per CU).  AVM_SOLVE_TP=0/1 forces it."""
         return "throughput" if self._L.avm_debug_last_solve_form(self.h) == 1 else "latency"
+
+    def last_fsel_form(self) -> str:
+        """Which form the last select_batch() started in: 'solo' (one workgroup per frame with lazy evaluation: batches of 24 frames and
+        more, HORIZON <= 10; AVM_FSEL_SOLO=0/1 forces it), 'teams' (a team of workgroups per frame) or 'rounds' (one launch per round)."""
+        return {3: "solo", 2: "teams", 1: "teams", 0: "rounds"}.get(self._L.avm_debug_last_fsel_form(self.h), "none")
 
     def counters(self) -> dict:
         """Debug counters of this ctx: device / pinned (re)allocations so far, and how the last marginalization's square roots were taken."""

@@ -539,8 +539,10 @@ def main():
             "kernel_rooflines": kernels,
             "furthest_below_roofline": furthest,
             # how far "parity" is pinned: the reference ships no tests / vectors and cannot be built here
-            "parity_pin": "unpinned at the Ceres / Eigen boundary (no reference vectors exist): the oracle is pinned by builder-written numpy "
-                          "restatements (tests/golden/), the marginalization prior by a binary128 arbiter (oracle/avm_truth.cpp, tests/test_prior_truth.py)",
+            "parity_pin": "unpinned at the Ceres / Eigen boundary (no reference vectors exist, the reference does not build here): the oracle is pinned by "
+                          "builder-written numpy restatements (tests/golden/) whose 50-digit run and the oracle's binary128 build agree to 1e-25 over whole solves "
+                          "(tests/test_solve_trace_mp.py), the marginalization prior by the binary128 arbiter (oracle/avm_truth.cpp), the 1-NN depth by the "
+                          "reference's own vendored nanoflann (tests/golden/nanoflann_nn.npz)",
         }
 
     # ---- sub-records the headline line does not carry: ragged tracks, one-window latency

@@ -15,7 +15,13 @@ o = abi.default_options()
 E = est_m.Estimator(ctx=ctx, options=o)
 o2 = abi.default_options(); o2.marginalization_flag = abi.MARGIN_NONE
 E2 = est_m.Estimator(ctx=ctx, options=o2)
-for tracks, nf, B, fid in (("sparse", 150, 2048, 20000), ("sparse", 70, 1024, 30000), ("dense", 150, 1024, 40000), ("sparse", 110, 1024, 50000)):
+# python tests/dev_sweep.py [rounds]: round r repeats the four shapes on window ids shifted by r * 100000 (round 4: ten rounds = 51 200 windows, all through
+# the throughput form of the solve, which batches of this size take on their own)
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+SHAPES = (("sparse", 150, 2048, 20000), ("sparse", 70, 1024, 30000), ("dense", 150, 1024, 40000), ("sparse", 110, 1024, 50000))
+tot_w = tot_mis = 0
+worst_pose = 0.0
+for tracks, nf, B, fid in [(t_, n_, b_, f_ + 100000 * r_) for r_ in range(ROUNDS) for (t_, n_, b_, f_) in SHAPES]:
     w = synth.make_windows_parallel(B, first_id=fid, procs=16, tracks=tracks, n_feat=nf, max_feat=150)
     wa, wb = w.copy(), w.copy()
     os.environ["AVM_PRIOR_NO_FAST"] = "1"
@@ -43,3 +49,7 @@ for tracks, nf, B, fid in (("sparse", 150, 2048, 20000), ("sparse", 70, 1024, 30
     dec = np.array_equal(sg["num_iterations"], so["num_iterations"]) and np.array_equal(sg["accept_mask"], so["accept_mask"]) and np.array_equal(sg["termination"], so["termination"])
     per = np.abs(wg.a["pose"] - wo.a["pose"]).reshape(B,-1).max(1) / np.abs(wo.a["pose"]).max()
     print("   solve vs oracle (", round(time.time()-t,1), "s ): decisions equal", dec, "mismatching windows", int((sg["accept_mask"] != so["accept_mask"]).sum()), "pose rel worst", per.max(), "sb", rel(wg.a["speedbias"], wo.a["speedbias"]), "lam", rel(wg.a["inv_depth"], wo.a["inv_depth"]), flush=True)
+    tot_w += B; tot_mis += int((sg["accept_mask"] != so["accept_mask"]).sum()) + int((sg["num_iterations"] != so["num_iterations"]).sum()) + int((sg["termination"] != so["termination"]).sum())
+    worst_pose = max(worst_pose, float(per.max()))
+    print("   form of the last solve:", ctx.last_solve_form(), flush=True)
+print(f"TOTAL: {tot_w} windows, decision mismatches against the oracle {tot_mis}, worst pose difference (relative) {worst_pose:.3e}")

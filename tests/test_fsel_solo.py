@@ -1,0 +1,89 @@
+"""GPU tier (-m gpu): the SOLO form of the selector (fsel_solo_kernel, csrc/fsel.hip: one workgroup per frame, lazy evaluation in the
+sense of Minoux' accelerated greedy).
+
+A batch takes it on its own from 24 frames on (HORIZON <= 10); the selector tests of the other files use smaller batches and therefore
+run the frame kernel's teams.  Here the same test bodies are collected once more with AVM_FSEL_SOLO=1, which forces the solo form
+wherever it is possible: ids bit-exact and in selection order against the FP64 oracle and against the binary128 selection, the
+std::map equal-key rule, non-finite inputs, the edge cases.  A candidate the lazy rounds never score is PROVEN to lose its round, so
+nothing may differ - not an id, not the order, and the fValues only by the rounding of the two evaluation forms.  Plus what is
+specific: the choice rule, the two forms against each other on a large batch, and that any lazy_tau gives the same result."""
+import numpy as np
+import pytest
+
+from helpers import buffers, rel, synth
+
+from test_gpu_parity import (  # noqa: F401
+    test_selector_bench_batch_matches_the_oracle,
+    test_selector_edge_cases,
+    test_selector_equal_upper_bounds_follow_the_std_map_rule,
+    test_selector_headline_500_to_150,
+    test_selector_ids_over_many_frames,
+    test_selector_information_and_ids,
+    test_selector_non_finite_inputs_match_the_oracle,
+)
+from test_fsel_truth import test_gpu_selects_what_the_binary128_selection_selects  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def solo_form(monkeypatch, selector):
+    monkeypatch.setenv("AVM_FSEL_SOLO", "1")
+    yield
+
+
+def test_every_re_collected_test_ran_the_solo_form_where_it_can(selector):
+    pr = synth.make_fsel(2, horizon=10, n_cand=60, n_used=0, max_features=20)
+    selector.select_batch(pr)
+    assert selector.ctx.last_fsel_form() == "solo"
+    pr = synth.make_fsel(1, horizon=13, n_cand=60, n_used=0, max_features=20)  # 3 H = 39: the diagonals of 512 candidates do not fit the LDS
+    selector.select_batch(pr)
+    assert selector.ctx.last_fsel_form() == "teams"
+
+
+def test_which_form_a_batch_takes(selector, monkeypatch):
+    monkeypatch.delenv("AVM_FSEL_SOLO", raising=False)
+    small = synth.make_fsel(8, horizon=5, n_cand=60, n_used=2, max_features=20)
+    selector.select_batch(small)
+    assert selector.ctx.last_fsel_form() == "teams"
+    big = synth.make_fsel(32, horizon=5, n_cand=60, n_used=2, max_features=20)
+    selector.select_batch(big)
+    assert selector.ctx.last_fsel_form() == "solo"
+    monkeypatch.setenv("AVM_FSEL_FRAME", "0")  # (a test that asks for the launch-per-round path gets it)
+    selector.select_batch(big)
+    assert selector.ctx.last_fsel_form() == "rounds"
+
+
+def test_the_two_forms_select_the_same_on_a_large_batch(selector, oracle, monkeypatch):
+    """96 bench-shaped frames (500 candidates -> 150, horizon 10): solo against the teams, ids and order identical in every frame, and 12 of
+    them against the oracle."""
+    pr = synth.make_fsel(96, first_id=1000)
+    dev = pr.to_device("cuda:0")
+    a = selector.select_batch(dev).to_host()
+    assert selector.ctx.last_fsel_form() == "solo"
+    monkeypatch.setenv("AVM_FSEL_SOLO", "0")
+    b = selector.select_batch(dev).to_host()
+    assert selector.ctx.last_fsel_form() == "teams"
+    assert (a.a["n_selected"] == 150).all()
+    assert np.array_equal(a.a["n_selected"], b.a["n_selected"]) and np.array_equal(a.a["selected_ids"], b.a["selected_ids"])
+    assert rel(a.a["fvalues"], b.a["fvalues"]) < 1e-10  # (the DPP elimination here, the matrix cores there)
+    sub = synth.make_fsel(12, first_id=1000)
+    oo = buffers.FselOutArrays.alloc(12, sub.dims["max_features"])
+    oracle.fsel_select(sub, oo, n_threads=8)
+    assert np.array_equal(a.a["selected_ids"][:12], oo.a["selected_ids"])
+
+
+@pytest.mark.parametrize("tau", ["0.0", "0.5", "0.95", "1.5", "1e9"])
+def test_lazy_tau_cannot_change_a_result(selector, oracle, monkeypatch, tau):
+    """tau = 0: every live candidate is scored in every round (the full evaluation); tau huge: the first pass scores nobody but the
+    never-scored, and the check of the pick finds everybody who matters.  Same ids, same order, same fValues bit for bit."""
+    pr = synth.make_fsel(3, horizon=10, n_cand=200, n_used=4, max_features=60)
+    monkeypatch.setenv("AVM_FSEL_LAZY_TAU", "0.0")
+    ref = selector.select_batch(pr)
+    monkeypatch.setenv("AVM_FSEL_LAZY_TAU", tau)
+    out = selector.select_batch(pr)
+    assert selector.ctx.last_fsel_form() == "solo"
+    assert np.array_equal(out.a["selected_ids"], ref.a["selected_ids"]) and np.array_equal(out.a["fvalues"], ref.a["fvalues"])
+    oo = buffers.FselOutArrays.alloc(3, 60)
+    oracle.fsel_select(pr, oo)
+    assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
