@@ -844,17 +844,17 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
 
 
 // The Hadamard bound alone, for the candidate of this lane's 16-lane row: the same expression, in the same order, as the bound
-// inside fsel_logdet4.  dd: the T diagonal entries of the candidate's Delta (fsel_solo_kernel takes every candidate's bound from
+// inside fsel_logdet4.  dd[d * stride]: the T diagonal entries of the candidate's Delta (fsel_solo_kernel takes every candidate's bound from
 // here, scored or not, so the equal-key rule and the (fValue, bound, id) order of the pick see one function).
 template <int T, int BS, int NB>
-AVM_DEV double fsel_ub4(const double* sdpp, const double* dd, double pr) {
+AVM_DEV double fsel_ub4(const double* sdpp, const double* dd, int stride, double pr) {
   const int lane = threadIdx.x & 63;
   const int r = min(lane & 15, BS - 1);
   double ubl = 0.0;
 #pragma unroll
   for (int bi = 0; bi < NB; bi++) {
     const int dgi = bi * BS + r;
-    ubl += fs_log(sdpp[dgi] + pr * dd[dgi]);
+    ubl += fs_log(sdpp[dgi] + pr * dd[dgi * stride]);
   }
   return fs_row_sum((lane & 15) < BS ? ubl : 0.0);
 }
@@ -1396,68 +1396,33 @@ __global__ __launch_bounds__(FS_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 constexpr int FS_SOLO_NT = 512;
 static_assert(FS_SOLO_NT == FS_FRAME_MAXC, "one candidate per thread");
 
-// the pick of fsel_pick_frame for a workgroup of FS_SOLO_NT threads with ONE candidate each (cl < 0: not in the race)
-AVM_DEV int fsel_pick_solo(const FselDev& A, int cl, double cf, double cu, double* fwin) {
-  constexpr int NW = FS_SOLO_NT / 64;
-  __shared__ double s_f[2][NW], s_u[2][NW];
-  __shared__ int s_i[2][NW], s_h[2][NW];
-  const int t = threadIdx.x, wv = t >> 6;
-  constexpr int MAXSH = 8;
-  int sh[MAXSH], nsh = 0;
-#pragma unroll
-  for (int qq = 0; qq < MAXSH; qq++) sh[qq] = -1;
-  for (int pass = 0;; pass++) {
-    const int sl = pass & 1;
-    bool out = cl < 0;
-#pragma unroll
-    for (int qq = 0; qq < MAXSH; qq++) out |= sh[qq] == cl;
-    const bool in = !out && cf > -1.0;  // (NaN never wins)
-    {  // the wavefront's best: three maxima in a row, each over the lanes that tie in the previous ones
-      const double wf = fs_wave_max(in ? cf : -1.0);
-      const bool tf = in && cf == wf;
-      const double wu = fs_wave_max(tf ? cu : -DBL_MAX);
-      const bool tu = tf && cu == wu;
-      const int wi = fs_wave_max(tu ? cl : -1);
-      if ((t & 63) == 0) s_f[sl][wv] = wf, s_u[sl][wv] = wu, s_i[sl][wv] = wi;
-    }
-    __syncthreads();
-    double bf = s_f[sl][0], bu = s_u[sl][0];
-    int bi = s_i[sl][0];
-#pragma unroll
-    for (int w = 1; w < NW; w++) {
-      const double f2 = s_f[sl][w], u2 = s_u[sl][w];
-      const int i2 = s_i[sl][w];
-      if (i2 >= 0 && (bi < 0 || f2 > bf || (f2 == bf && (u2 > bu || (u2 == bu && i2 > bi))))) bf = f2, bu = u2, bi = i2;
-    }
-    *fwin = bf;
-    if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;
-    // std::map rule (see fsel_pick_local): a live candidate with a higher id and the same key shadows the winner - scored or not
-    const bool hit = cl > bi && cu == bu;
-    const bool wh = __any(hit);
-    if ((t & 63) == 0) s_h[sl][wv] = wh ? 1 : 0;
-    __syncthreads();
-    int any = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) any |= s_h[sl][w];
-    if (!any) return bi;
-#pragma unroll
-    for (int qq = 0; qq < MAXSH; qq++)
-      if (qq == nsh) sh[qq] = bi;
-    nsh++;
-  }
-}
-
 template <int T, int BS, int NB>
 __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_t* sync) {
   FS_TABLES_GUARD(A);
   constexpr int NW = FS_SOLO_NT / 64, MAXC = FS_FRAME_MAXC;
   __shared__ double sC[T * T], sdpp[T];
-  __shared__ double s_f[MAXC], s_u[MAXC], s_bound[MAXC], s_pr[MAXC];
-  __shared__ int32_t s_alive[MAXC], s_scored[MAXC], s_mark[MAXC], s_list[MAXC];
+  __shared__ double s_f[MAXC], s_u[MAXC], s_ua[MAXC], s_ue[MAXC], s_bound[MAXC], s_pr[MAXC], s_inv[T];
+  __shared__ unsigned char s_alive[MAXC], s_scored[MAXC], s_mark[MAXC];
+  __shared__ short s_list[MAXC];
   __shared__ int s_n;
   __shared__ double s_g0;
-  extern __shared__ double s_dd[];  // [MAXC][T]: every candidate's Delta diagonal (the bounds of every round read nothing else)
+  __shared__ double s_wf[2][NW], s_wu[2][NW];
+  __shared__ int s_wi[2][NW];
+  extern __shared__ double s_dd[];  // [T][MAXC]: every candidate's Delta diagonal, candidates along the lanes (the bounds read nothing else)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4;
+  __shared__ int s_or[2][NW];
+  int orc = 0;
+  // "does any thread of the workgroup say yes": one barrier (two slots: a slot is written again only after the barrier of the call between)
+  auto wg_or = [&](bool v) {
+    const int sl = orc++ & 1;
+    const bool a = __any(v);
+    if (lane == 0) s_or[sl][wv] = a ? 1 : 0;
+    __syncthreads();
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) r |= s_or[sl][w];
+    return r != 0;
+  };
   const bool rec_lane = (lane & 15) == 0;
   const avm_fsel_batch& b = A.b;
   const int mc = b.max_cand;
@@ -1469,7 +1434,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       for (int base = 0; base < MAXC; base += 64) {
         const bool m = s_mark[base + lane] != 0;
         const unsigned long long bal = __ballot(m);
-        if (m) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = base + lane;
+        if (m) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = (short)(base + lane);
         n += __popcll(bal);
       }
       if (lane == 0) s_n = n;
@@ -1485,15 +1450,15 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     const double* Dp = A.delta + pc * T * T;
     for (int idx = t; idx < T * T; idx += FS_SOLO_NT) sC[idx] = A.C[(size_t)p * T * T + idx];
     for (int idx = t; idx < T; idx += FS_SOLO_NT) sdpp[idx] = A.dpp[(size_t)p * T + idx];
+    const int c = t;  // this thread's candidate
     {
-      const int c = t;
       const bool ok = c < nc && A.valid[pc + min(c, mc - 1)] != 0;
       s_alive[c] = ok ? 1 : 0, s_bound[c] = HUGE_VAL, s_scored[c] = 0, s_mark[c] = 0;
       s_pr[c] = ok ? b.cand_prob[pc + c] : 0.0;
     }
     for (int idx = t; idx < nc * T; idx += FS_SOLO_NT) {  // (one strided pass over the frame's Deltas)
-      const int c = idx / T, d = idx % T;
-      s_dd[idx] = Dp[(size_t)c * T * T + d * T + d];
+      const int cc = idx / T, d = idx % T;
+      s_dd[d * MAXC + cc] = Dp[(size_t)cc * T * T + d * T + d];
     }
     const double ld_nn = A.consts[(size_t)p * 4], ub_nn = A.consts[(size_t)p * 4 + 1];
     __syncthreads();
@@ -1504,48 +1469,123 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     }
     __syncthreads();
     double G = s_g0, gprev = HUGE_VAL;
-    // scores the candidates of s_list, four per wavefront
+    // the EXACT Hadamard bounds of the candidates of s_list (fsel_ub4: the one function every compared bound comes from)
+    auto bound_list = [&](int n) {
+      for (int i0 = 0; i0 < n; i0 += NW * 4) {
+        if (i0 + wv * 4 >= n) break;  // (uniform per wavefront)
+        const int i = i0 + wv * 4 + g;
+        const int cc = s_list[min(i, n - 1)];
+        const double ubt = fsel_ub4<T, BS, NB>(sdpp, s_dd + cc, MAXC, s_pr[cc]);
+        if (i < n && rec_lane) s_u[cc] = ub_nn + ubt;
+      }
+    };
+    // scores the candidates of s_list, four per wavefront, Delta straight from memory
     auto score_list = [&](int n) {
       for (int i0 = 0; i0 < n; i0 += NW * 4) {
         if (i0 + wv * 4 >= n) break;  // (uniform per wavefront)
         const int i = i0 + wv * 4 + g;
-        const int c = s_list[min(i, n - 1)];  // (a row without a candidate scores the list's last one again and drops the result)
+        const int cc = s_list[min(i, n - 1)];  // (a row without a candidate scores the list's last one again and drops the result)
         double ld, ubt;
-        const bool ok = fsel_logdet4<T, BS, NB, false, false>(sC, sdpp, Dp + (size_t)c * T * T, s_pr[c], &ld, &ubt);
+        const bool ok = fsel_logdet4<T, BS, NB, false, false>(sC, sdpp, Dp + (size_t)cc * T * T, s_pr[cc], &ld, &ubt);
         if (i < n && rec_lane) {
           const double f = ok ? (ld_nn + 2.0 * ld) : __builtin_nan("");
-          s_f[c] = f, s_scored[c] = 1;
-          s_bound[c] = ok ? f - G : HUGE_VAL;  // (a failed factorization: scored again every round)
+          s_f[cc] = f, s_scored[cc] = 1;
+          s_bound[cc] = ok ? f - G : HUGE_VAL;  // (a failed factorization: scored again every round)
         }
       }
+      bound_list(n);
     };
     int nsel = 0;
-    long long tk[6] = {0, 0, 0, 0, 0, 0}, tkp = 0, n_scored = 0, n_second = 0;
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, tkp = 0, n_scored = 0, n_second = 0, n_flag = 0, n_pass = 0;
     const bool stats = A.lazy_stats != 0 && p == 0;
+    // The round's winner among the scored candidates: the lexicographic maximum of (fValue, bound, id) - feature_selector.cpp:669-683 with
+    // the std::map equal-key rule of sortedlogDetUB (see fsel_pick_local): a live candidate with a higher id and a BIT-IDENTICAL bound
+    // shadows the winner, scored or not.  The bounds of the unscored candidates are not computed every round.  What is: an estimate ua of
+    // every live candidate's bound MINUS the part all candidates share, sum_d log1p(p Delta_dd / dpp_d), with a rigorous error bar ue
+    // (a term below 0.01 by its series, remainder < x^4 / 4; above, by the single-precision logarithm, 4e-7 of the term).  Two bounds can
+    // only be BIT-equal when the estimates are closer than the two error bars plus the rounding of the exact evaluation (1e-11 on values
+    // of a few hundred); only then the unscored candidate gets its exact bound, by the same function, to be compared.
+    auto pick = [&](bool live, bool scored, double* fwin) -> int {
+      constexpr int MAXSH = 8;
+      int sh[MAXSH], nsh = 0;
+#pragma unroll
+      for (int qq = 0; qq < MAXSH; qq++) sh[qq] = -1;
+      const double cf = scored ? s_f[c] : __builtin_nan("");
+      for (int pass = 0;; pass++) {
+        const int sl = pass & 1;
+        const double cu = s_u[c];  // (exact for the scored candidates and for those a previous pass has flagged)
+        bool out = !scored;
+#pragma unroll
+        for (int qq = 0; qq < MAXSH; qq++) out |= sh[qq] == c;
+        const bool in = !out && cf > -1.0;  // (NaN never wins)
+        {  // the wavefront's best: three maxima in a row, each over the lanes that tie in the previous ones
+          const double wf = fs_wave_max(in ? cf : -1.0);
+          const bool tf = in && cf == wf;
+          const double wu = fs_wave_max(tf ? cu : -DBL_MAX);
+          const bool tu = tf && cu == wu;
+          const int wi = fs_wave_max(tu ? c : -1);
+          if (lane == 0) s_wf[sl][wv] = wf, s_wu[sl][wv] = wu, s_wi[sl][wv] = wi;
+        }
+        __syncthreads();
+        double bf = s_wf[sl][0], bu = s_wu[sl][0];
+        int bi = s_wi[sl][0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+          const double f2 = s_wf[sl][w], u2 = s_wu[sl][w];
+          const int i2 = s_wi[sl][w];
+          if (i2 >= 0 && (bi < 0 || f2 > bf || (f2 == bf && (u2 > bu || (u2 == bu && i2 > bi))))) bf = f2, bu = u2, bi = i2;
+        }
+        *fwin = bf;
+        if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;  // (more than MAXSH chained collisions in one round: keep the last winner)
+        const bool flag = live && !scored && c > bi && !(fabs(s_ua[c] - s_ua[bi]) > s_ue[c] + s_ue[bi] + 1e-11);  // (an estimate that is not finite: compare the exact bounds)
+        s_mark[c] = flag ? 1 : 0;
+        n_pass++;
+        if (wg_or(flag)) {
+          n_flag++;
+          bound_list(build_list());
+          __syncthreads();
+        }
+        const bool hit = live && c > bi && (scored || flag) && s_u[c] == bu;
+        if (!wg_or(hit)) return bi;
+#pragma unroll
+        for (int qq = 0; qq < MAXSH; qq++)
+          if (qq == nsh) sh[qq] = bi;
+        nsh++;
+      }
+    };
 #define FS_SOLO_SEG(i) if (stats) { const long long n__ = clock64(); tk[i] += n__ - tkp; tkp = n__; }
     for (int k = 0; k < kappa; k++) {
       if (stats) tkp = clock64();
-      // ---- 1. who is scored in the first pass; every live candidate's bound
+      // ---- 1. who is scored in the first pass; the estimate of every live candidate's bound
       const double th = A.lazy_tau * gprev;
+      const bool live = c < nc && s_alive[c] != 0;
+      if (t < T) s_inv[t] = 1.0 / sdpp[t];
+      __syncthreads();
       {
-        const int c = t;
-        const bool live = c < nc && s_alive[c] != 0;
         s_mark[c] = (live && !(s_bound[c] < th)) ? 1 : 0;
-        s_scored[c] = 0, s_f[c] = __builtin_nan("");
-      }
-      for (int c0 = 0; c0 < nc; c0 += NW * 4) {
-        const int c = c0 + wv * 4 + g, cc = min(c, nc - 1);
-        const bool live = c < nc && s_alive[cc] != 0;
-        if (__any(live)) {
-          const double ubt = fsel_ub4<T, BS, NB>(sdpp, s_dd + cc * T, s_pr[cc]);
-          if (live && rec_lane) s_u[c] = ub_nn + ubt;
+        s_scored[c] = 0;
+        double ua = 0.0, ue = 0.0;
+        if (live) {
+          const double prc = s_pr[c];
+          const double* dd = s_dd + c;
+#pragma unroll
+          for (int d = 0; d < T; d++) {
+            const double x = (prc * dd[d * MAXC]) * s_inv[d];
+            const bool small = fabs(x) <= 0.01;  // (NaN: the other branch, and the estimate is NaN - compared exactly)
+            const double x2 = x * x, lg = (double)__log2f((float)(1.0 + x)) * 0.6931471805599453;
+            ua += small ? x * (1.0 + x * (-0.5 + x * (1.0 / 3.0))) : lg;
+            // the series' remainder is below x^4 / 4 / (1 - |x|); the other branch: 1 + x rounded to single precision (6e-8 of it) and a
+            // logarithm good to two units in its last place (2.4e-7 of the result)
+            ue += small ? 0.26 * x2 * x2 + 1e-15 * fabs(x) : 1e-7 + 3e-7 * fabs(lg);
+          }
         }
+        s_ua[c] = ua, s_ue[c] = ue;
       }
       FS_SOLO_SEG(0)
       int n = build_list();
       FS_SOLO_SEG(1)
       n_scored += n;
-      // ---- 2. the scores
+      // ---- 2. the scores (and the exact bounds of the scored)
       score_list(n);
       FS_SOLO_SEG(2)
       // ---- 3. the pick and its check
@@ -1553,20 +1593,20 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       double fwin;
       for (;;) {
         __syncthreads();
-        const int c = t;
-        const bool live = c < nc && s_alive[c] != 0;
         const bool scored = live && s_scored[c] != 0;
-        win = fsel_pick_solo(A, live ? c : -1, scored ? s_f[c] : __builtin_nan(""), s_u[c], &fwin);
+        win = pick(live, scored, &fwin);
         const double V = win >= 0 ? fwin : -1.0;  // (the reference's fMax = -1.0 when nobody has won)
         const double margin = 1e-8 * fmax(1.0, fabs(V));
-        s_mark[c] = (live && !scored && !(G + s_bound[c] + margin < V)) ? 1 : 0;
+        const bool need = live && !scored && !(G + s_bound[c] + margin < V);
+        s_mark[c] = need ? 1 : 0;
+        if (!wg_or(need)) break;
         n = build_list();
         FS_SOLO_SEG(3)
-        if (n == 0) break;
         n_scored += n, n_second++;
         score_list(n);
         FS_SOLO_SEG(4)
       }
+      FS_SOLO_SEG(3)
       if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
       if (t == 0) {
         A.out.selected_ids[(size_t)p * b.max_features + nsel] = b.cand_id[pc + win];
@@ -1578,7 +1618,6 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       gprev = fwin - G, G = fwin;  // the winner's value IS logdet of the next C
       const double prw = s_pr[win];
       const double* Dw = Dp + (size_t)win * T * T;
-      __syncthreads();
       for (int idx = t; idx < T * T; idx += FS_SOLO_NT) {
         const double dw = Dw[idx];
         sC[idx] = sC[idx] + prw * dw;
@@ -1589,10 +1628,10 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       FS_SOLO_SEG(5)
     }
 #undef FS_SOLO_SEG
-    if (stats && t == 0) {  // (cycles: bounds, list, first-pass scores, pick + check, second-pass scores, fold; then the counters)
+    if (stats && t == 0) {  // (cycles: marks + estimates, list, first-pass scores, pick + check, second-pass scores, fold; then the counters)
       long long* o = reinterpret_cast<long long*>(sync + 32);
       for (int i = 0; i < 6; i++) o[i] = tk[i];
-      o[6] = n_scored, o[7] = n_second, o[8] = nsel;
+      o[6] = n_scored, o[7] = n_second, o[8] = nsel, o[9] = n_flag, o[10] = n_pass;
     }
     if (t == 0) {
       A.nsel[p] = nsel;
@@ -1664,7 +1703,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   if (frame_mode == 3) {  // one workgroup per frame, lazy evaluation (fsel_solo_kernel): batches of many frames, 3 H <= 30
     if (b.max_cand > FS_FRAME_MAXC || T > 30) return hipErrorInvalidValue;
     if ((e = hipMemsetAsync(w.sync, 0, sizeof(int32_t) * (FS_SYNC_HDR + 64), stream)) != hipSuccess) return e;
-    const size_t dl = sizeof(double) * (size_t)std::min(b.max_cand, FS_FRAME_MAXC) * T;
+    const size_t dl = sizeof(double) * (size_t)FS_FRAME_MAXC * T;  // [T][512]
     static int ncu = 0;  // (one device per process: include/avm.h)
     if (ncu == 0) {
       int dev = 0, v = 0;

@@ -57,8 +57,11 @@ def projection_factor(pose_i, pose_j, ex, lam, pts_i, pts_j, s):
     pci = pts_i / lam
     pimu_i = ric @ pci + tic
     pw = Ri @ pimu_i + Pi
-    pimu_j = Rj.T @ (pw - Pj)
-    pcj = ric.T @ (pimu_j - tic)
+    qinv = lambda q: np.array([q[0], -q[1], -q[2], -q[3]]) / (q @ q)
+    # Qj.inverse() * (..), qic.inverse() * (..) (projection_factor.cpp:37-38): Eigen's conj / |q|^2, not R^T, for a quaternion that is
+    # unit only to FP64 rounding (see imu_residual_raw); the Jacobians below DO use the transposes, as the reference does (:52-81)
+    pimu_j = q2R(qinv(Qj)) @ (pw - Pj)
+    pcj = q2R(qinv(qic)) @ (pimu_j - tic)
     dep = pcj[2]
     r = s * (pcj[:2] / dep - pts_j[:2])
     red = s * np.array([[1 / dep, 0, -pcj[0] / dep**2], [0, 1 / dep, -pcj[1] / dep**2]])
@@ -141,12 +144,15 @@ def imu_residual_raw(pre, G, pose_i, sb_i, pose_j, sb_j, lba, lbg):
     cdq = qmul(dq, np.array([1.0, th[0] / 2, th[1] / 2, th[2] / 2]))
     cdv = dv + J[6:9, 9:12] @ dba + J[6:9, 12:15] @ dbg
     cdp = dp + J[0:3, 9:12] @ dba + J[0:3, 12:15] @ dbg
-    Ri = q2R(Qi)
     conj = lambda q: np.array([q[0], -q[1], -q[2], -q[3]]) / (q @ q)
+    # Qi.inverse() * v (integration_base.h:176,178): the rotation by conj(Qi) / |Qi|^2, which for a quaternion that is unit only to
+    # FP64 rounding is not R(Qi)^T but 1e-16 away from it (found by the 50-digit run, gen_solve_trace_mp.py: the two readings of
+    # the reference agreed to 1e-16 instead of 1e-30 until this line said what Eigen does)
+    RiT = q2R(conj(Qi))
     r = np.zeros(15)
-    r[0:3] = Ri.T @ (0.5 * G * sdt * sdt + Pj - Pi - Vi * sdt) - cdp
+    r[0:3] = RiT @ (0.5 * G * sdt * sdt + Pj - Pi - Vi * sdt) - cdp
     r[3:6] = 2 * qmul(conj(cdq), qmul(conj(Qi), Qj))[1:]
-    r[6:9] = Ri.T @ (G * sdt + Vj - Vi) - cdv
+    r[6:9] = RiT @ (G * sdt + Vj - Vi) - cdv
     r[9:12] = Baj - Bai
     r[12:15] = Bgj - Bgi
     return r

@@ -304,14 +304,23 @@ def trust_region_solve(P, x, opt):
     return x, dict(termination=termination, num_iterations=iteration, initial_cost=initial_cost, final_cost=x_cost, **{k: np.array(v) for k, v in trace.items()})
 
 
-CASES = [(5, 0.7, 1.0), (3, 0.6, 1.5), (7, 0.8, 1.0), (99, 0.35, 0.6)]  # (seed, attitude noise, position noise [m])
+# (seed, attitude noise, position noise [m]) of the first four: one window structure, four start points
+CASES = [(5, 0.7, 1.0), (3, 0.6, 1.5), (7, 0.8, 1.0), (99, 0.35, 0.6)]
+# round 4: eight more, over the window STRUCTURES the first four do not vary ("8 windows is thin") -
+# (seed, attitude noise, position noise, tracks, features, trajectory id, with the prior)
+CASES_R4 = [(11, 0.5, 0.8, "dense", 24, 100, True), (12, 0.3, 0.5, "sparse", 40, 200, True), (13, 0.6, 1.0, "sparse", 30, 300, False),
+            (14, 0.05, 0.1, "dense", 12, 400, True), (15, 0.9, 2.0, "sparse", 20, 500, True), (16, 0.02, 0.02, "sparse", 14, 600, False),
+            (17, 0.7, 1.0, "dense", 40, 700, True), (18, 0.4, 0.3, "sparse", 60, 800, True)]
 
 
-def make_case(seed, sq, sp):
-    """One 11-frame window with 14 ragged tracks and the synthetic 75-row prior; frames 1.. knocked far enough off for some
-    steps to be rejected (cases 0-2; case 3 is a clean run: every step accepted)."""
+def make_case(seed, sq, sp, tracks="sparse", n_feat=14, first_id=4242, with_prior=True):
+    """One 11-frame window (the first four cases: 14 ragged tracks and the synthetic 75-row prior); frames 1.. knocked far enough off
+    for some steps to be rejected (cases 0-2; case 3 is a clean run: every step accepted)."""
     synth = importlib.import_module(PKG + ".synth")
-    w = synth.make_windows(1, first_id=4242, tracks="sparse", n_feat=14, max_feat=16, max_obs=176)
+    if n_feat == 14 and first_id == 4242:
+        w = synth.make_windows(1, first_id=4242, tracks="sparse", n_feat=14, max_feat=16, max_obs=176)
+    else:
+        w = synth.make_windows(1, first_id=first_id, tracks=tracks, n_feat=n_feat, max_feat=64, max_obs=704, with_prior=with_prior)
     rng = np.random.default_rng(seed)
     q = w.a["pose"][0, 1:, 3:] + rng.normal(0, sq, w.a["pose"][0, 1:, 3:].shape)
     w.a["pose"][0, 1:, 3:] = q / np.linalg.norm(q, axis=-1, keepdims=True)
@@ -325,10 +334,11 @@ OPT = dict(initial_trust_region_radius=1e4, min_trust_region_radius=1e-32, max_n
 
 
 def main():
-    out = {"n_cases": np.int64(len(CASES))}
+    cases = [tuple(c) for c in CASES] + CASES_R4
+    out = {"n_cases": np.int64(len(cases))}
     out.update({"opt_" + k: np.float64(v) for k, v in OPT.items()})
-    for c, (seed, sq, sp) in enumerate(CASES):
-        w = make_case(seed, sq, sp)
+    for c, spec in enumerate(cases):
+        w = make_case(*spec)
         a = {k: v[0] for k, v in w.a.items()}
         P = Problem(a)
         x0 = dict(pose=a["pose"].copy(), sb=a["speedbias"].copy(), lam=a["inv_depth"][: P.nf].copy())

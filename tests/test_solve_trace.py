@@ -1,8 +1,15 @@
 """The oracle pin at the Ceres boundary: tests/golden/solve_trace.npz holds complete trust-region traces (cost, radius,
 accept / reject per iteration, final states) from an independent numpy statement of the Ceres 1.14 dogleg minimizer on the full
-dense Jacobian (tests/golden/gen_solve_trace.py).  Three of the four cases contain REJECTED steps.  The CPU oracle (CPU tier)
-and the HIP path (GPU tier) must reproduce them: identical decisions, costs and radii, states within the north-star
-tolerance."""
+dense Jacobian (tests/golden/gen_solve_trace.py).  Twelve windows: four start points of one structure (three of them with REJECTED
+steps) and, since round 4, eight more over the structures (dense / ragged tracks, 12 ... 60 features, with and without the prior,
+from almost converged to 2 m / 0.9 rad off).  The CPU oracle (CPU tier) and the HIP path (GPU tier) must reproduce them: identical
+decisions always; costs (1e-9), radii (1e-7) and states (1e-7, north star: 1e-6) on every trace FP64 arithmetic can reproduce at all.
+
+Which those are is not decided by the code under test: solve_trace_mp.npz holds the same numpy code's 50-digit run of every case
+(gen_solve_trace_mp.py) and how far ITS OWN FP64 run lands from that - 1e-13 ... 1e-9 on most, 1e-6 ... 1e-2 on the windows that start
+far off with many features (the cost still falls a hundred-fold per iteration when the limit of 12 stops it: rounding differences
+grow with it).  On those an FP64 implementation is graded on its decisions here; what it is graded on numerically is the
+50-digit run itself, through the binary128 arbiter (tests/test_solve_trace_mp.py: 1e-25) and tests/test_solve_truth.py."""
 import importlib
 import os
 
@@ -13,6 +20,13 @@ from helpers import abi, buffers, rel
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = np.load(os.path.join(HERE, "golden", "solve_trace.npz"))
+MP = np.load(os.path.join(HERE, "golden", "solve_trace_mp.npz"))
+
+
+def fp64_reproducible(c):
+    """A trace is graded at FP64 tolerances (costs 1e-9, states 1e-7) when the independent code's own FP64 run lands within a third of them
+    from its 50-digit run (same measures: gen_solve_trace_mp.py, merge step)."""
+    return float(MP[f"c{c}_fp64_cost_rel"]) < 3e-10 and float(MP[f"c{c}_fp64_state_rel"]) < 3e-8
 
 
 def _case(c):
@@ -28,12 +42,15 @@ def _case(c):
     return w, o, tr, sol
 
 
-def _check(s, w, tr, sol, tol_state):
+def _check(s, w, tr, sol, tol_state, c):
     n = int(tr["num_iterations"])
     assert int(s["num_iterations"][0]) == n and int(s["termination"][0]) == int(tr["termination"])
     acc = [(int(s["accept_mask"][0]) >> k) & 1 for k in range(n)]
     assert acc == tr["accepted"].astype(int).tolist(), (acc, tr["accepted"].astype(int).tolist())
-    assert rel(s["cost_trace"][0][:n], tr["cost"]) < 1e-9 and abs(s["initial_cost"][0] / tr["initial_cost"] - 1) < 1e-12
+    assert abs(s["initial_cost"][0] / tr["initial_cost"] - 1) < 1e-12
+    if not fp64_reproducible(c):
+        return
+    assert rel(s["cost_trace"][0][:n], tr["cost"]) < 1e-9
     assert np.abs(s["radius_trace"][0][:n] / tr["radius"] - 1).max() < 1e-7
     # the golden states are Ceres' solution BEFORE double2vector's gauge fix; the yaw / position of frame 0 are restored by it,
     # so compare gauge-invariant quantities: relative positions in frame 0's coordinates, biases, inverse depths
@@ -56,7 +73,7 @@ def test_oracle_reproduces_the_independent_numpy_trace(oracle, c):
     w, o, tr, sol = _case(c)
     s = buffers.summary_alloc(1)
     oracle.window_solve(o, w, None, s)
-    _check(s, w, tr, sol, 1e-7)
+    _check(s, w, tr, sol, 1e-7, c)
 
 
 def test_the_golden_traces_exercise_rejected_steps_and_all_three_dogleg_branches():
@@ -65,6 +82,9 @@ def test_the_golden_traces_exercise_rejected_steps_and_all_three_dogleg_branches
         kinds |= set(GOLD[f"c{c}_trace_kind"].tolist())
         rejected += int((~GOLD[f"c{c}_trace_accepted"].astype(bool)).sum())
     assert {0, 1, 2} <= kinds and rejected >= 5
+    graded = [c for c in range(int(GOLD["n_cases"])) if fp64_reproducible(c)]
+    print(f"\n[traces] graded at FP64 tolerances: cases {graded} of {int(GOLD['n_cases'])}")
+    assert len(graded) >= 8 and {0, 1, 2, 3} <= set(graded)
 
 
 @pytest.mark.gpu
@@ -73,4 +93,4 @@ def test_hip_path_reproduces_the_independent_numpy_trace(ctx, c):
     est_m = importlib.import_module("anticipated-vins-mono_amd.estimator")
     w, o, tr, sol = _case(c)
     s = buffers.summary_to_numpy(est_m.Estimator(ctx=ctx, options=o).optimization(w))
-    _check(s, w, tr, sol, 1e-7)
+    _check(s, w, tr, sol, 1e-7, c)
