@@ -1080,7 +1080,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   // 3 = one workgroup per frame with lazy evaluation (fsel_solo_kernel): what a batch of many frames takes - it has no waits between
   // workgroups, so it cannot time out and is never re-run.  AVM_FSEL_SOLO=0/1 overrides the batch-size rule (tests, measurements).
   {
-    constexpr size_t AVM_FSEL_SOLO_MIN = 24;  // (frames: below, the teams of fsel_frame_kernel are faster - DESIGN.md section 3)
+    constexpr size_t AVM_FSEL_SOLO_MIN = 48;  // (frames: a solo select takes 6 ms however few frames run side by side, the teams 0.13 ms per frame - DESIGN.md section 3)
     const bool can = d.max_cand <= 512 && 3 * d.horizon <= 30 && P >= 1;
     bool solo = can && P >= AVM_FSEL_SOLO_MIN && !getenv("AVM_FSEL_FRAME");
     if (const char* e = getenv("AVM_FSEL_SOLO")) solo = can && e[0] == '1';

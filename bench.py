@@ -704,22 +704,33 @@ def main():
                     FS.select_batch(f13_1)
                 torch.cuda.synchronize()
                 tl13 = (time.perf_counter() - t1) / reps
-                # larger batches (eight GPUs' worth of frames on one): where the issue rate, not the round's latency, is the limit
-                big_b = {}
-                for Pb in (64, 256):
+                # larger batches (eight GPUs' worth of frames on one): from 48 frames on a batch takes the SOLO form of the selector on its own (one
+                # workgroup per frame, lazy evaluation: csrc/fsel.hip, fsel_solo_kernel); the teams' time for the same batch is measured beside it
+                big_b, big_form, big_teams = {}, {}, {}
+                for Pb in (64, 128, 256):
                     fb = synth.make_fsel(min(Pb, 64), first_id=rank * P)
                     if Pb > 64:  # (tiled: the generator is the slow part)
                         fb = type(fb)(dict(fb.dims, n_problems=Pb), {k: np.ascontiguousarray(v[np.arange(Pb) % 64]) for k, v in fb.a.items()}, fb.scalars)
                     fbd = fb.to_device(dev)
-                    FS.select_batch(fbd)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(2):
+                    for forced, store in ((None, big_b), ("0", big_teams)):
+                        if forced is None:
+                            os.environ.pop("AVM_FSEL_SOLO", None)
+                        else:
+                            os.environ["AVM_FSEL_SOLO"] = forced
                         FS.select_batch(fbd)
-                    torch.cuda.synchronize()
-                    big_b[str(Pb)] = (time.perf_counter() - t1) / 2 / Pb * 1e3
+                        torch.cuda.synchronize()
+                        if forced is None:
+                            big_form[str(Pb)] = ctx.last_fsel_form()
+                        t1 = time.perf_counter()
+                        for _ in range(2):
+                            FS.select_batch(fbd)
+                        torch.cuda.synchronize()
+                        store[str(Pb)] = (time.perf_counter() - t1) / 2 / Pb * 1e3
+                    os.environ.pop("AVM_FSEL_SOLO", None)
                     del fbd
                 result["feature_select"]["ms_per_frame_by_batch"] = big_b
+                result["feature_select"]["form_by_batch"] = big_form
+                result["feature_select"]["ms_per_frame_by_batch_teams_forced"] = big_teams
                 # the pipelined deployment: single-frame selects while ANOTHER ctx runs the 4096-window solve on the same device
                 import threading
 
