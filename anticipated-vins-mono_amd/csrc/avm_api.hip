@@ -1112,8 +1112,8 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     }
     if (mode == 3 && getenv("AVM_FSEL_LAZY_STATS")) {  // (development: frame 0's workgroup of fsel_solo_kernel)
       const long long* q = reinterpret_cast<const long long*>(hsync + 32);
-      fprintf(stderr, "fsel solo kernel, frame 0 (cycles): bounds %lld list %lld scores %lld pick+check %lld second-pass scores %lld fold %lld | %lld candidates scored in %lld rounds, %lld second passes; %lld passes of the pick, %lld with exact bounds for unscored candidates\n",
-              q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[8], q[7], q[10], q[9]);
+      fprintf(stderr, "fsel solo kernel, frame 0 (cycles): bounds %lld list %lld scores %lld pick+check %lld second-pass scores %lld fold %lld | %lld candidates scored in %lld rounds, %lld second passes; %lld passes of the pick, %lld with exact bounds for unscored candidates | pick: maxima %lld flags %lld hits %lld check %lld\n",
+              q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[8], q[7], q[10], q[9], q[11], q[12], q[13], q[14]);
     }
     if (hsync[2] == 0 && hsync[4] == (int32_t)P) {
       // a fast-mode call that went through: the back-off starts from the beginning next time

@@ -1496,8 +1496,9 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       bound_list(n);
     };
     int nsel = 0;
-    long long tk[6] = {0, 0, 0, 0, 0, 0}, tkp = 0, n_scored = 0, n_second = 0, n_flag = 0, n_pass = 0;
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, tq[5] = {0, 0, 0, 0, 0}, tqp = 0, tkp = 0, n_scored = 0, n_second = 0, n_flag = 0, n_pass = 0;
     const bool stats = A.lazy_stats != 0 && p == 0;
+#define FS_SOLO_Q(i) if (stats) { const long long n__ = clock64(); tq[i] += n__ - tqp; tqp = n__; }
     // The round's winner among the scored candidates: the lexicographic maximum of (fValue, bound, id) - feature_selector.cpp:669-683 with
     // the std::map equal-key rule of sortedlogDetUB (see fsel_pick_local): a live candidate with a higher id and a BIT-IDENTICAL bound
     // shadows the winner, scored or not.  The bounds of the unscored candidates are not computed every round.  What is: an estimate ua of
@@ -1511,6 +1512,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
 #pragma unroll
       for (int qq = 0; qq < MAXSH; qq++) sh[qq] = -1;
       const double cf = scored ? s_f[c] : __builtin_nan("");
+      if (stats) tqp = clock64();
       for (int pass = 0;; pass++) {
         const int sl = pass & 1;
         const double cu = s_u[c];  // (exact for the scored candidates and for those a previous pass has flagged)
@@ -1536,6 +1538,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
           if (i2 >= 0 && (bi < 0 || f2 > bf || (f2 == bf && (u2 > bu || (u2 == bu && i2 > bi))))) bf = f2, bu = u2, bi = i2;
         }
         *fwin = bf;
+        FS_SOLO_Q(0)
         if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;  // (more than MAXSH chained collisions in one round: keep the last winner)
         const bool flag = live && !scored && c > bi && !(fabs(s_ua[c] - s_ua[bi]) > s_ue[c] + s_ue[bi] + 1e-11);  // (an estimate that is not finite: compare the exact bounds)
         s_mark[c] = flag ? 1 : 0;
@@ -1545,8 +1548,11 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
           bound_list(build_list());
           __syncthreads();
         }
+        FS_SOLO_Q(1)
         const bool hit = live && c > bi && (scored || flag) && s_u[c] == bu;
-        if (!wg_or(hit)) return bi;
+        const bool anyhit = wg_or(hit);
+        FS_SOLO_Q(2)
+        if (!anyhit) return bi;
 #pragma unroll
         for (int qq = 0; qq < MAXSH; qq++)
           if (qq == nsh) sh[qq] = bi;
@@ -1599,7 +1605,10 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         const double margin = 1e-8 * fmax(1.0, fabs(V));
         const bool need = live && !scored && !(G + s_bound[c] + margin < V);
         s_mark[c] = need ? 1 : 0;
-        if (!wg_or(need)) break;
+        if (stats) tqp = clock64();
+        const bool anyneed = wg_or(need);
+        FS_SOLO_Q(3)
+        if (!anyneed) break;
         n = build_list();
         FS_SOLO_SEG(3)
         n_scored += n, n_second++;
@@ -1628,10 +1637,12 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       FS_SOLO_SEG(5)
     }
 #undef FS_SOLO_SEG
+#undef FS_SOLO_Q
     if (stats && t == 0) {  // (cycles: marks + estimates, list, first-pass scores, pick + check, second-pass scores, fold; then the counters)
       long long* o = reinterpret_cast<long long*>(sync + 32);
       for (int i = 0; i < 6; i++) o[i] = tk[i];
       o[6] = n_scored, o[7] = n_second, o[8] = nsel, o[9] = n_flag, o[10] = n_pass;
+      for (int i = 0; i < 4; i++) o[11 + i] = tq[i];
     }
     if (t == 0) {
       A.nsel[p] = nsel;
