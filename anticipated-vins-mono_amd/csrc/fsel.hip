@@ -1402,9 +1402,8 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
   constexpr int NW = FS_SOLO_NT / 64, MAXC = FS_FRAME_MAXC;
   __shared__ double sC[T * T], sdpp[T];
   __shared__ double s_f[MAXC], s_u[MAXC], s_ua[MAXC], s_ue[MAXC], s_bound[MAXC], s_pr[MAXC], s_inv[T];
-  __shared__ unsigned char s_alive[MAXC], s_scored[MAXC], s_mark[MAXC];
+  __shared__ unsigned char s_alive[MAXC], s_scored[MAXC];
   __shared__ short s_list[MAXC];
-  __shared__ int s_n;
   __shared__ double s_g0;
   __shared__ double s_wf[2][NW], s_wu[2][NW];
   __shared__ int s_wi[2][NW];
@@ -1426,21 +1425,25 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
   const bool rec_lane = (lane & 15) == 0;
   const avm_fsel_batch& b = A.b;
   const int mc = b.max_cand;
-  // the candidates marked in s_mark -> s_list (ascending), s_n
-  auto build_list = [&]() {
+  // the candidates whose thread says `mark` -> s_list (ascending) with their gain bounds beside them in s_lb; returns how many
+  __shared__ int s_cnt[NW];
+  __shared__ double s_lb[MAXC];
+  auto build_list = [&](bool mark) {
+    const unsigned long long bal = __ballot(mark);
+    if (lane == 0) s_cnt[wv] = __popcll(bal);
     __syncthreads();
-    if (wv == 0) {
-      int n = 0;
-      for (int base = 0; base < MAXC; base += 64) {
-        const bool m = s_mark[base + lane] != 0;
-        const unsigned long long bal = __ballot(m);
-        if (m) s_list[n + __popcll(bal & ((1ull << lane) - 1ull))] = (short)(base + lane);
-        n += __popcll(bal);
-      }
-      if (lane == 0) s_n = n;
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const int cnt = s_cnt[w];
+      base += w < wv ? cnt : 0, tot += cnt;
+    }
+    if (mark) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      s_list[pos] = (short)t, s_lb[pos] = s_bound[t];
     }
     __syncthreads();
-    return s_n;
+    return tot;
   };
   for (int p = blockIdx.x; p < b.n_problems; p += gridDim.x) {
     __syncthreads();
@@ -1453,7 +1456,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     const int c = t;  // this thread's candidate
     {
       const bool ok = c < nc && A.valid[pc + min(c, mc - 1)] != 0;
-      s_alive[c] = ok ? 1 : 0, s_bound[c] = HUGE_VAL, s_scored[c] = 0, s_mark[c] = 0;
+      s_alive[c] = ok ? 1 : 0, s_bound[c] = HUGE_VAL, s_scored[c] = 0;
       s_pr[c] = ok ? b.cand_prob[pc + c] : 0.0;
     }
     for (int idx = t; idx < nc * T; idx += FS_SOLO_NT) {  // (one strided pass over the frame's Deltas)
@@ -1541,11 +1544,10 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         FS_SOLO_Q(0)
         if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;  // (more than MAXSH chained collisions in one round: keep the last winner)
         const bool flag = live && !scored && c > bi && !(fabs(s_ua[c] - s_ua[bi]) > s_ue[c] + s_ue[bi] + 1e-11);  // (an estimate that is not finite: compare the exact bounds)
-        s_mark[c] = flag ? 1 : 0;
         n_pass++;
         if (wg_or(flag)) {
           n_flag++;
-          bound_list(build_list());
+          bound_list(build_list(flag));
           __syncthreads();
         }
         FS_SOLO_Q(1)
@@ -1567,8 +1569,8 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       const bool live = c < nc && s_alive[c] != 0;
       if (t < T) s_inv[t] = 1.0 / sdpp[t];
       __syncthreads();
+      bool mark = live && !(s_bound[c] < th);
       {
-        s_mark[c] = (live && !(s_bound[c] < th)) ? 1 : 0;
         s_scored[c] = 0;
         double ua = 0.0, ue = 0.0;
         if (live) {
@@ -1588,7 +1590,27 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         s_ua[c] = ua, s_ue[c] = ue;
       }
       FS_SOLO_SEG(0)
-      int n = build_list();
+      int n = build_list(mark);
+      // A first pass holds NW * 4 = 32 candidates (two wavefronts per SIMD: the CU's FP64 pipe is full); a 33rd costs half a pass more.  When
+      // more are marked, only the 32 with the largest gain bounds are scored now - the others are exactly the ones the check of the pick
+      // looks at again, and it rarely needs them (their bounds are the lowest of the marked).  Like lazy_tau: a choice of WHEN a candidate
+      // is scored, never of the result.
+      constexpr int CAP = NW * 4;
+      if (n > CAP && gprev < HUGE_VAL) {
+        const double bc = s_bound[c];
+        int rank = 0;
+        if (mark) {
+#pragma unroll 4
+          for (int j = 0; j < n; j++) {
+            const int cj = s_list[j];
+            const double bj = s_lb[j];
+            rank += (bj > bc || (bj == bc && cj < c)) ? 1 : 0;
+          }
+        }
+        mark = mark && rank < CAP;
+        __syncthreads();  // (every reader of the first list is done)
+        n = build_list(mark);
+      }
       FS_SOLO_SEG(1)
       n_scored += n;
       // ---- 2. the scores (and the exact bounds of the scored)
@@ -1604,12 +1626,11 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         const double V = win >= 0 ? fwin : -1.0;  // (the reference's fMax = -1.0 when nobody has won)
         const double margin = 1e-8 * fmax(1.0, fabs(V));
         const bool need = live && !scored && !(G + s_bound[c] + margin < V);
-        s_mark[c] = need ? 1 : 0;
         if (stats) tqp = clock64();
         const bool anyneed = wg_or(need);
         FS_SOLO_Q(3)
         if (!anyneed) break;
-        n = build_list();
+        n = build_list(need);
         FS_SOLO_SEG(3)
         n_scored += n, n_second++;
         score_list(n);
