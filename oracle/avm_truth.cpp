@@ -114,7 +114,7 @@ int avmt_solve(const avm_options* opt, const avm_window_batch* batch, int w, dou
 }
 
 // The same solve with its result handed out BEYOND FP64: Ceres' own solution (before double2vector's gauge fix) as pose [11][7] |
-// speed-bias [11][9] | inverse depths [n_feat], and the cost at the start point and at the solution, each as a double-double pair
+// speed-bias [11][9] | inverse depths [n_feat] | ex_pose [7] | td [1] | relo_Pose [7], and the cost at the start point and at the solution, each as a double-double pair
 // hi + lo (the binary128 value to 32 digits), followed by the cost after every iteration.  For tests/test_solve_trace_mp.py: the 50-digit run of the independent numpy minimizer
 // (tests/golden/gen_solve_trace_mp.py) against this restatement.  cost_hi / cost_lo: [2 + AVM_MAX_ITER_TRACE]; returns the number of iterations.
 int avmt_solve_dd(const avm_options* opt, const avm_window_batch* batch, int w, double* x_hi, double* x_lo, double* cost_hi, double* cost_lo,
@@ -134,6 +134,9 @@ int avmt_solve_dd(const avm_options* opt, const avm_window_batch* batch, int w, 
   for (int f = 0; f < AVM_NFRAMES; f++)
     for (int k = 0; k < 9; k++, q++) put(R.x.sb[f][k], x_hi + q, x_lo + q);
   for (size_t e = 0; e < R.x.lam.size(); e++, q++) put(R.x.lam[e], x_hi + q, x_lo + q);
+  for (int k = 0; k < 7; k++, q++) put(R.x.ex[k], x_hi + q, x_lo + q);   // (the optional members: constants of the base problem)
+  put(R.x.td, x_hi + q, x_lo + q), q++;
+  for (int k = 0; k < 7; k++, q++) put(R.x.relo[k], x_hi + q, x_lo + q);
   put(P.evaluate(W.x, false), cost_hi, cost_lo);
   put(P.evaluate(R.x, false), cost_hi + 1, cost_lo + 1);
   for (size_t k = 0; k < R.cost_after.size(); k++) put(R.cost_after[k], cost_hi + 2 + k, cost_lo + 2 + k);

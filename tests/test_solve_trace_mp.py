@@ -45,14 +45,14 @@ def test_binary128_arbiter_agrees_with_the_50_digit_run_of_the_independent_minim
     w, o, tr, sol = _case(c)
     nf = sol["inv_depth"].shape[0]
     n = 77 + 99 + nf
-    x_hi, x_lo, c_hi, c_lo = np.zeros(n), np.zeros(n), np.zeros(2 + 16), np.zeros(2 + 16)  # costs: start, end, after every iteration
+    x_hi, x_lo, c_hi, c_lo = np.zeros(n + 15), np.zeros(n + 15), np.zeros(2 + 16), np.zeros(2 + 16)  # costs: start, end, after every iteration
     acc = C.c_int32()
     s = w.struct()
     L = truth_lib()
     it = L.avmt_solve_dd(C.byref(o), C.byref(s), 0, abi.dptr(x_hi), abi.dptr(x_lo), abi.dptr(c_hi), abi.dptr(c_lo), C.byref(acc))
     want_acc = GOLD[f"c{c}_accepted"].astype(bool).tolist()
     assert it == len(want_acc) and [(acc.value >> k) & 1 == 1 for k in range(it)] == want_acc
-    xa, xm = _dd(x_hi, x_lo), _dd(GOLD[f"c{c}_x_hi"], GOLD[f"c{c}_x_lo"])
+    xa, xm = _dd(x_hi[:n], x_lo[:n]), _dd(GOLD[f"c{c}_x_hi"], GOLD[f"c{c}_x_lo"])
     assert len(xm) == n
     scale = max(abs(v) for v in xm)
     worst = max(abs(a - b) for a, b in zip(xa, xm)) / scale
@@ -65,5 +65,41 @@ def test_binary128_arbiter_agrees_with_the_50_digit_run_of_the_independent_minim
     # 1e-25 - or, on a window that amplifies rounding errors so much that the FP64 run of the numpy code itself ends 1e-7 ... 6e-2 from its
     # 50-digit run, sixteen orders of magnitude below THAT distance: binary128 carries 18 digits more than FP64 and goes through the same
     # amplification (measured: 1.9e-25 where FP64 is 1.1e-7 off, 2.6e-24 at 2.9e-7, 3.6e-19 at 6e-2)
+    tol = max(mp.mpf("1e-25"), mp.mpf("1e-16") * fp64)
+    assert worst < tol and worst_c < tol
+
+
+# ---- the optional members of the problem (ex_pose as a variable, para_Td with ProjectionTdFactor, the relocalization frame) -----------
+XPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solve_trace_x_mp.npz")
+XGOLD = np.load(XPATH) if os.path.exists(XPATH) else None
+
+
+@pytest.mark.parametrize("c", [int(v) for v in XGOLD["cases"]] if XGOLD is not None else [])
+def test_binary128_arbiter_agrees_with_the_50_digit_run_on_the_extended_problem(c):
+    """tests/golden/gen_solve_trace_x_mp.py: the numpy minimizer of the extended problem (gen_solve_trace_x.py: estimator.cpp:672-688,
+    732-747, 760-792; projection_td_factor.cpp:34-141) in 50 digits against avmt_solve_dd with the same options - decisions, costs after
+    every iteration and every state including ex_pose, td and relo_Pose, at the tolerance of the base problem."""
+    from test_solve_trace_x import _case as _case_x
+
+    w, o, tr, sol, relo = _case_x(c)
+    nf = sol["inv_depth"].shape[0]
+    n = 77 + 99 + nf + 15
+    x_hi, x_lo, c_hi, c_lo = np.zeros(n), np.zeros(n), np.zeros(2 + 16), np.zeros(2 + 16)
+    acc = C.c_int32()
+    s = w.struct()
+    it = truth_lib().avmt_solve_dd(C.byref(o), C.byref(s), 0, abi.dptr(x_hi), abi.dptr(x_lo), abi.dptr(c_hi), abi.dptr(c_lo), C.byref(acc))
+    want_acc = XGOLD[f"c{c}_accepted"].astype(bool).tolist()
+    assert it == len(want_acc) and [(acc.value >> k) & 1 == 1 for k in range(it)] == want_acc
+    xa, xm = _dd(x_hi, x_lo), _dd(XGOLD[f"c{c}_x_hi"], XGOLD[f"c{c}_x_lo"])
+    assert len(xm) == n
+    scale = max(abs(v) for v in xm)
+    worst = max(abs(a - b) for a, b in zip(xa, xm)) / scale
+    worst_opt = max(abs(a - b) for a, b in zip(xa[-15:], xm[-15:])) / scale
+    ca, cm = _dd(c_hi[:2 + it], c_lo[:2 + it]), _dd(XGOLD[f"c{c}_cost_hi"], XGOLD[f"c{c}_cost_lo"])
+    assert len(cm) == 2 + it
+    worst_c = max(abs(a - b) / abs(b) for a, b in zip(ca, cm))
+    fp64 = mp.mpf(float(XGOLD[f"c{c}_fp64_state_rel"]))
+    print(f"\n[mp pin, extended] case {c} (ex {o.estimate_extrinsic} td {o.estimate_td} relo {relo}): binary128 arbiter vs 50-digit independent run: "
+          f"state {mp.nstr(worst, 3)} (ex_pose / td / relo_Pose {mp.nstr(worst_opt, 3)}), costs {mp.nstr(worst_c, 3)}  (FP64 run of the same code: {mp.nstr(fp64, 3)})")
     tol = max(mp.mpf("1e-25"), mp.mpf("1e-16") * fp64)
     assert worst < tol and worst_c < tol
