@@ -217,30 +217,36 @@ AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, do
 }
 
 // ---- setup: Omega, partial Cholesky of the non-position rows, Delta of every feature ------
-__global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
+// (round 4) Two launches: slice 0 of every frame with the whole carve (N x N doubles of Omega: 104 KB at H = 10, one workgroup per CU), and
+// the candidate slices (slice_base = 1, compact) with only what they touch - the camera frames, four wavefronts' C_h / W and Delta tiles,
+// 35 KB: four workgroups per CU.  In one launch the candidate slices of a 256-frame batch (8192 workgroups) went through the CUs one at a
+// time: 3.2 ms of its 10.4 (profiles/r04c_fsel.md).
+__global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A, int slice_base, int compact) {
   FS_TABLES_GUARD(A);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* lds = reinterpret_cast<double*>(smem_raw);
   const avm_fsel_batch& b = A.b;
   const int p = blockIdx.x, t = threadIdx.x;
-  const int slice = blockIdx.y;  // 0: Omega, its partial factorization, the used features; >= 1: candidates [256 (slice-1), 256 slice)
+  const int slice = blockIdx.y + slice_base;  // 0: Omega, its partial factorization, the used features; >= 1: candidates [16 (slice-1), 16 slice)
 #ifdef FS_TRACE_EVAL
   const long long ts0 = clock64();
 #endif
   const int H = b.horizon, N = 9 * (H + 1), T = 3 * H;
-  double* Om = lds;                 // N*N
-  double* Wh = Om + N * N;          // [H+1][81] Omega_h (h>=1)
+  double* Om = lds;                 // N*N (compact: the candidate slices' share of it, see fsel_setup_lds_bytes)
+  double* Wh = Om + (compact ? (FS_NT / 64) * (96 + T * T) : N * N);  // [H+1][81] Omega_h (h>=1)
   double* Ah = Wh + (H + 1) * 81;   // [H+1][81] Ablk_h
   double* Th = Ah + (H + 1) * 81;   // [H+1][81] At*Omega
-  double* cam = Th + (H + 1) * 81;  // [H+1][30]
+  double* cam = compact ? Wh : Th + (H + 1) * 81;  // [H+1][30]
   double* col = cam + (H + 1) * 30; // N
   double* red = col + N;            // 64
   int* isp = reinterpret_cast<int*>(red + 64);  // N: position-row flag
   const double* hp = b.hor_pos + (size_t)p * (H + 1) * 3;
   const double* hq = b.hor_quat + (size_t)p * (H + 1) * 4;
   const quat qic{b.q_ic[3], b.q_ic[0], b.q_ic[1], b.q_ic[2]};
-  for (int i = t; i < N * N; i += FS_NT) Om[i] = 0.0;
-  for (int i = t; i < N; i += FS_NT) isp[i] = (i >= 9 && (i % 9) < 3) ? 1 : 0;
+  if (!compact) {
+    for (int i = t; i < N * N; i += FS_NT) Om[i] = 0.0;
+    for (int i = t; i < N; i += FS_NT) isp[i] = (i >= 9 && (i % 9) < 3) ? 1 : 0;
+  }
   // per consecutive pair: createLinearImuMatrices (only slice 0 needs them).  The nr interpolated rotations of a pair are
   // independent: one thread each first (parked in Omega's storage, re-zeroed below), then thread h sums them in the
   // reference's order.  More rotations than fit there: thread h computes them in its loop as before.
@@ -328,11 +334,19 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         double* out = A.delta + ((size_t)p * b.max_cand + k) * T * T;
+        // (round 4) the block pairs are put together in this wavefront's LDS tile and go out as whole rows: written pair by pair
+        // - 24-byte pieces, ten to a row, from different lanes at different times - the batch's Deltas cost 6.8 x their size in
+        // write traffic (profiles/r04c_fsel.md: 3.2 ms of a 256-frame select)
+        double* tile = Om + (FS_NT / 64) * 96 + wv * T * T;  // (behind the four wavefronts' C_h / W; 384 + 36 H^2 <= 81 (H + 1)^2 doubles of Omega's storage)
         for (int q = lane; q < npair; q += 64) {
           int j = 1, rem = q;  // pairs in the order j = 1..H, i = j..H
           while (rem >= H - j + 1) rem -= H - j + 1, j++;
-          feature_pair(wl, wl + 80, j + rem, j, T, out);
+          feature_pair(wl, wl + 80, j + rem, j, T, tile);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int idx = lane; idx < T * T; idx += 64) out[idx] = tile[idx];
         __builtin_amdgcn_wave_barrier();
       }
       if (lane == 0) A.valid[(size_t)p * b.max_cand + k] = ok, A.black[(size_t)p * b.max_cand + k] = 0;
@@ -1701,6 +1715,10 @@ size_t fsel_setup_lds_bytes(int H) {
   const int N = 9 * (H + 1);
   return sizeof(double) * ((size_t)N * N + 3 * (H + 1) * 81 + (H + 1) * 30 + N + 64) + sizeof(int) * N + 16;
 }
+size_t fsel_setup_lds_bytes_compact(int H) {  // the candidate slices: C_h / W and the Delta tile of four wavefronts, the camera frames
+  const int T = 3 * H;
+  return sizeof(double) * ((size_t)(FS_NT / 64) * (96 + T * T) + (H + 1) * 30) + 16;
+}
 
 // Launches setup (+ optional rounds).  All pointers in `d` are device pointers.
 // frame_mode (single frames only): 0 = one launch per greedy round, 1 = fsel_frame_kernel on all XCDs, 2 = on one XCD
@@ -1721,7 +1739,13 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fsel_setup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int cand_per_wg = (FS_NT / 64) * FS_CPW;
-  hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems, 1 + (b.max_cand + cand_per_wg - 1) / cand_per_wg), dim3(FS_NT), lds, stream, d);
+  const int nslices = (b.max_cand + cand_per_wg - 1) / cand_per_wg;
+  if (b.n_problems < 16) {  // few frames: one launch, slice 0 beside the candidate slices (a single frame: 1.29 ms against 1.38 in two)
+    hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems, 1 + nslices), dim3(FS_NT), lds, stream, d, 0, 0);
+  } else {
+    hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems, 1), dim3(FS_NT), lds, stream, d, 0, 0);
+    if (nslices > 0) hipLaunchKernelGGL(fsel_setup_kernel, dim3(b.n_problems, nslices), dim3(FS_NT), fsel_setup_lds_bytes_compact(H), stream, d, 1, 1);
+  }
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (!run_rounds) return hipSuccess;
   const int per_block = FS_CPWG;  // four candidates per wavefront

@@ -83,7 +83,10 @@ def test_lazy_tau_cannot_change_a_result(selector, oracle, monkeypatch, tau):
     monkeypatch.setenv("AVM_FSEL_LAZY_TAU", tau)
     out = selector.select_batch(pr)
     assert selector.ctx.last_fsel_form() == "solo"
-    assert np.array_equal(out.a["selected_ids"], ref.a["selected_ids"]) and np.array_equal(out.a["fvalues"], ref.a["fvalues"])
+    assert np.array_equal(out.a["selected_ids"], ref.a["selected_ids"]) and np.array_equal(out.a["n_selected"], ref.a["n_selected"])
+    for q in range(3):  # (fvalues beyond n_selected are not written)
+        n = int(ref.a["n_selected"][q])
+        assert n > 0 and np.array_equal(out.a["fvalues"][q, :n], ref.a["fvalues"][q, :n])
     oo = buffers.FselOutArrays.alloc(3, 60)
     oracle.fsel_select(pr, oo)
     assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
