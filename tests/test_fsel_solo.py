@@ -90,3 +90,22 @@ def test_lazy_tau_cannot_change_a_result(selector, oracle, monkeypatch, tau):
     oo = buffers.FselOutArrays.alloc(3, 60)
     oracle.fsel_select(pr, oo)
     assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+
+
+def test_more_frames_than_compute_units_and_ragged_candidate_counts(selector, oracle):
+    """600 small frames in one call (the workgroups take frames p, p + grid, ...), candidate counts from 0 to the maximum, some frames with
+    every feature slot already used (kappa = 0): n_selected and ids identical to the oracle's in every frame."""
+    P = 600
+    pr = synth.make_fsel(P, first_id=5000, horizon=5, n_cand=48, n_used=12, n_cloud=20, max_features=12)
+    rng = np.random.default_rng(3)
+    pr.a["n_cand"][:] = rng.integers(0, 49, P)
+    pr.a["n_cand"][:5] = [0, 1, 2, 48, 47]
+    pr.a["n_used"][:] = 3
+    pr.a["n_used"][7:11] = [12, 12, 11, 0]   # (max_features 12: kappa = 0, 0, 1, 12)
+    out = selector.select_batch(pr)
+    assert selector.ctx.last_fsel_form() == "solo"
+    oo = buffers.FselOutArrays.alloc(P, 12)
+    oracle.fsel_select(pr, oo, n_threads=8)
+    assert np.array_equal(out.a["n_selected"], oo.a["n_selected"])
+    assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+    assert int(oo.a["n_selected"][0]) == 0 and int(oo.a["n_selected"][7]) == 0
