@@ -182,6 +182,102 @@ AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, do
   return true;
 }
 
+// feature_front for FOUR candidates per wavefront at once (round 4): candidate u on the 16-lane row u, horizon frame h = 1 + (lane & 15) on
+// its lanes.  The frames of a candidate are independent until E = sum_h C_h: every lane does ONE frame's projection, visibility test and C_h
+// (the one-candidate form did the H of them one after the other on 64 identical lanes), the nearest cloud point is searched by the row's 16
+// lanes, C_h goes to the row's LDS record wlu[6 h' + k] (h' = h - 1; zeros for a frame that does not see the feature, as before), and E is
+// summed from there IN THE SAME ORDER as feature_front sums it (frames 2 .. H, then frame 1) - the Deltas are bit-identical to the
+// one-candidate form's.  Returns (to every lane of the row) whether the candidate is visible from a second frame; W at wlu[6 H ..].
+AVM_DEV bool feature_front4(const avm_fsel_batch& b, int p, const double* cam, int k, bool have, int H, double* wlu) {
+  const int lane = threadIdx.x & 63, hl = lane & 15, h = hl + 1;
+  const double* xy = b.cand_xy + ((size_t)p * b.max_cand + (have ? k : 0)) * 2;
+  const double fx_ = xy[0], fy_ = xy[1];
+  // findNNDepth over the row's 16 lanes: the lexicographic minimum of (distance, index), as nn_depth<true>
+  double dep = 1.0;
+  const int ncl = b.n_cloud ? b.n_cloud[p] : 0;
+  if (ncl > 0) {
+    const double* cxy = b.cloud_xy + (size_t)p * b.max_cloud * 2;
+    int best = ncl;
+    double bd = DBL_MAX;
+    for (int i = hl; i < ncl; i += 16) {
+      const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
+      const double d = dx * dx + dy * dy;
+      if (d < bd) bd = d, best = i;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double od = __shfl_xor(bd, o, 64);
+      const int ob = __shfl_xor(best, o, 64);
+      if (od < bd || (od == bd && ob < best)) bd = od, best = ob;
+    }
+    if (best >= ncl) best = 0;
+    dep = b.cloud_depth[(size_t)p * b.max_cloud + best];
+  }
+  const double nrm = sqrt(fx_ * fx_ + fy_ * fy_ + 1.0);
+  const v3 fn = mk3(fx_ / nrm, fy_ / nrm, 1.0 / nrm);
+  const v3 feat = dep * fn;
+  const double* c1 = cam + 1 * 30;
+  const v3 pell = mk3(c1[0], c1[1], c1[2]) + Rmul(c1 + 21, feat);
+  double C[6] = {0, 0, 0, 0, 0, 0};
+  bool vis = false;
+  if (h <= H) {
+    const double* ch = cam + h * 30;
+    v3 ue = fn;
+    if (h >= 2) {
+      const v3 tw = mk3(ch[0], ch[1], ch[2]);
+      ue = Rmul(ch + 3, pell - tw);
+      const double n = sqrt(dot(ue, ue));
+      ue = mk3(ue.x / n, ue.y / n, ue.z / n);
+      const double xu = ue.x / ue.z, yu = ue.y / ue.z;
+      const double mx2 = xu * xu, my2 = yu * yu, mxy = xu * yu, rho2 = mx2 + my2;
+      const double rad = b.k1 * rho2 + b.k2 * rho2 * rho2;
+      const double dxx = xu * rad + 2.0 * b.p1 * mxy + b.p2 * (rho2 + 2.0 * mx2);
+      const double dyy = yu * rad + 2.0 * b.p2 * mxy + b.p1 * (rho2 + 2.0 * my2);
+      const double pu = b.fx * (xu + dxx) + b.cx, pv = b.fy * (yu + dyy) + b.cy;
+      const int iu = (int)round(pu), ivv = (int)round(pv);
+      vis = pu == pu && pv == pv && (0 <= iu && iu < b.image_width) && (0 <= ivv && ivv < b.image_height);
+    }
+    if (vis || h == 1) {
+      double S[9], Bm[9];
+      skew9(ue, S);
+      mat3mul(S, ch + 12, Bm);
+      C[0] = Bm[0] * Bm[0] + Bm[3] * Bm[3] + Bm[6] * Bm[6];
+      C[1] = Bm[0] * Bm[1] + Bm[3] * Bm[4] + Bm[6] * Bm[7];
+      C[2] = Bm[0] * Bm[2] + Bm[3] * Bm[5] + Bm[6] * Bm[8];
+      C[3] = Bm[1] * Bm[1] + Bm[4] * Bm[4] + Bm[7] * Bm[7];
+      C[4] = Bm[1] * Bm[2] + Bm[4] * Bm[5] + Bm[7] * Bm[8];
+      C[5] = Bm[2] * Bm[2] + Bm[5] * Bm[5] + Bm[8] * Bm[8];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) wlu[6 * (h - 1) + q] = C[q];
+  }
+  const unsigned long long bal = __ballot(vis);
+  const bool ok = have && ((bal >> (lane & 48)) & 0xffffull) != 0;  // numVisible > 1
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // E in feature_front's order: frames 2 .. H as the loop met them (an invisible frame adds an exact zero), then frame 1
+  double E[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    double e = 0.0;
+    for (int hh = 2; hh <= H; hh++) e += wlu[6 * (hh - 1) + q];
+    E[q] = e + wlu[q];
+  }
+  const double a00 = E[0], a01 = E[1], a02 = E[2], a11 = E[3], a12 = E[4], a22 = E[5];
+  const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+  const double c10 = a12 * a02 - a01 * a22, c11 = a00 * a22 - a02 * a02, c12 = a02 * a01 - a00 * a12;
+  const double c20 = a01 * a12 - a11 * a02, c21 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+  const double det = a00 * c00 + a01 * c10 + a02 * c20;
+  const double id = 1.0 / det;
+  if (hl == 0) {
+    double* Wm = wlu + 6 * H;
+    Wm[0] = id * c00, Wm[1] = id * c01, Wm[2] = id * c02, Wm[3] = id * c10, Wm[4] = id * c11, Wm[5] = id * c12, Wm[6] = id * c20,
+    Wm[7] = id * c21, Wm[8] = id * c22;
+  }
+  return ok;
+}
+
 // block (i, j), 1 <= j <= i <= H, of Delta_ell = blkdiag(C_h) - [C_i W C_j^T] (and its mirror image), dense T x T
 AVM_DEV void feature_pair(const double* Ch, const double* Wm, int i, int j, int T, double* out) {
   auto full = [&](int hidx, double* M) {
@@ -233,7 +329,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A, int slice_
 #endif
   const int H = b.horizon, N = 9 * (H + 1), T = 3 * H;
   double* Om = lds;                 // N*N (compact: the candidate slices' share of it, see fsel_setup_lds_bytes)
-  double* Wh = Om + (compact ? (FS_NT / 64) * (96 + T * T) : N * N);  // [H+1][81] Omega_h (h>=1)
+  double* Wh = Om + (compact ? (FS_NT / 64) * (FS_CPW * (6 * H + 9) + T * T) : N * N);  // [H+1][81] Omega_h (h>=1)
   double* Ah = Wh + (H + 1) * 81;   // [H+1][81] Ablk_h
   double* Th = Ah + (H + 1) * 81;   // [H+1][81] At*Omega
   double* cam = compact ? Wh : Th + (H + 1) * 81;  // [H+1][30]
@@ -317,31 +413,32 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A, int slice_
     // lane runs the short front part (uniform), lane 0 parks C_h and W in LDS, then the H (H + 1) / 2 block pairs go one
     // per lane - the T x T block is written by 64 lanes at once instead of 900 scattered stores from one thread.
     const int lane = t & 63, wv = t >> 6;
-    double* wl = Om + wv * 96;  // (Omega's storage is unused in these slices)
+    // (round 4: the four candidates' front parts run side by side, a frame per lane - feature_front4; then the block pairs and the
+    //  stores candidate by candidate through the wavefront's one tile)
+    const int WS = 6 * H + 9;                                   // a candidate's record: C_h (6 H) | W (9)
+    double* wl0 = Om + (wv * FS_CPW) * WS;                      // (Omega's storage is unused in these slices)
+    double* tile = Om + (FS_NT / 64) * FS_CPW * WS + wv * T * T;  // (16 (6 H + 9) + 36 H^2 <= 81 (H + 1)^2 doubles of Omega's storage)
     const int npair = H * (H + 1) / 2;
+    const int k0 = ((slice - 1) * (FS_NT / 64) + wv) * FS_CPW;
+    if (k0 >= b.n_cand[p]) return;  // (wave-uniform)
+    const int ku = k0 + (lane >> 4);
+    const bool oku = feature_front4(b, p, cam, ku, ku < b.n_cand[p], H, wl0 + (lane >> 4) * WS);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int u = 0; u < FS_CPW; u++) {
-      const int k = ((slice - 1) * (FS_NT / 64) + wv) * FS_CPW + u;
+      const int k = k0 + u;
       if (k >= b.n_cand[p]) break;  // (wave-uniform)
-      const double* xy = b.cand_xy + ((size_t)p * b.max_cand + k) * 2;
-      double Ch[13 * 6], Wm[9];
-      const bool ok = feature_front<true>(b, p, cam, xy[0], xy[1], H, Ch, Wm);
+      const bool ok = __shfl(oku ? 1 : 0, 16 * u, 64) != 0;
       if (ok) {
-        if (lane == 0) {
-          for (int i = 0; i < H * 6; i++) wl[i] = Ch[i];
-          for (int i = 0; i < 9; i++) wl[80 + i] = Wm[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double* wl = wl0 + u * WS;
         double* out = A.delta + ((size_t)p * b.max_cand + k) * T * T;
-        // (round 4) the block pairs are put together in this wavefront's LDS tile and go out as whole rows: written pair by pair
-        // - 24-byte pieces, ten to a row, from different lanes at different times - the batch's Deltas cost 6.8 x their size in
-        // write traffic (profiles/r04c_fsel.md: 3.2 ms of a 256-frame select)
-        double* tile = Om + (FS_NT / 64) * 96 + wv * T * T;  // (behind the four wavefronts' C_h / W; 384 + 36 H^2 <= 81 (H + 1)^2 doubles of Omega's storage)
+        // the block pairs are put together in this wavefront's LDS tile and go out as whole rows (written pair by pair - 24-byte
+        // pieces, ten to a row, from different lanes at different times - a batch's Deltas cost 6.8 x their size in write traffic)
         for (int q = lane; q < npair; q += 64) {
           int j = 1, rem = q;  // pairs in the order j = 1..H, i = j..H
           while (rem >= H - j + 1) rem -= H - j + 1, j++;
-          feature_pair(wl, wl + 80, j + rem, j, T, tile);
+          feature_pair(wl, wl + 6 * H, j + rem, j, T, tile);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1717,7 +1814,7 @@ size_t fsel_setup_lds_bytes(int H) {
 }
 size_t fsel_setup_lds_bytes_compact(int H) {  // the candidate slices: C_h / W and the Delta tile of four wavefronts, the camera frames
   const int T = 3 * H;
-  return sizeof(double) * ((size_t)(FS_NT / 64) * (96 + T * T) + (H + 1) * 30) + 16;
+  return sizeof(double) * ((size_t)(FS_NT / 64) * (FS_CPW * (6 * H + 9) + T * T) + (H + 1) * 30) + 16;
 }
 
 // Launches setup (+ optional rounds).  All pointers in `d` are device pointers.
