@@ -540,9 +540,9 @@ def main():
             "furthest_below_roofline": furthest,
             # how far "parity" is pinned: the reference ships no tests / vectors and cannot be built here
             "parity_pin": "unpinned at the Ceres / Eigen boundary (no reference vectors exist, the reference does not build here): the oracle is pinned by "
-                          "builder-written numpy restatements (tests/golden/) whose 50-digit run and the oracle's binary128 build agree to 1e-25 over whole solves "
-                          "(tests/test_solve_trace_mp.py), the marginalization prior by the binary128 arbiter (oracle/avm_truth.cpp), the 1-NN depth by the "
-                          "reference's own vendored nanoflann (tests/golden/nanoflann_nn.npz)",
+                          "builder-written numpy restatements (tests/golden/) whose 50-digit runs (mpmath) and the oracle's binary128 build agree to 1e-25 over whole solves "
+                          "(tests/test_solve_trace_mp.py) and to the rounding of the arbiter's FP64 output on the marginalization (test_marg_mp.py) and the selection "
+                          "(test_fsel_mp.py); the 1-NN depth by the reference's own vendored nanoflann (tests/golden/nanoflann_nn.npz)",
         }
 
     # ---- sub-records the headline line does not carry: ragged tracks, one-window latency
