@@ -1007,6 +1007,7 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   GET(dpp, double, 2 * P * T)  // (two buffers: csrc/fsel.hip, FselPar)
   GET(consts, double, P * 4)
   GET(delta, double, P * mc * T * T)
+  GET(delta_pk, double, (P >= 48 || getenv("AVM_FSEL_SOLO")) ? P * mc * (T * (T + 1) / 2) : 1)  // (the solo form's copy: csrc/fsel.hip, FselDev)
   GET(delta_u, double, P * mu * T * T)
   GET(fval, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)
   GET(ub, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)

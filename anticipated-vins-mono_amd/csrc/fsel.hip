@@ -43,6 +43,8 @@ struct FselDev {
   double* dpp;      // [P][T]   un-reduced diagonal of the position rows (for the Hadamard bound)
   double* consts;   // [P][4]   ld_nn, Kn
   double* delta;    // [P][max_cand][T*T]
+  double* delta_pk; // [P][max_cand][T(T+1)/2] the same, lower triangle by columns (entry (R, c), c <= R, at c T - c (c - 1) / 2 + R - c): what
+                    // fsel_solo_kernel scores from - half the bytes per evaluation; null unless the solo form runs
   double* delta_u;  // [P][max_used][T*T]
   int32_t* valid;   // [P][max_cand] 1 = triangulable (numVisible > 1)
   int32_t* valid_u; // [P][max_used]
@@ -444,6 +446,11 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A, int slice_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int idx = lane; idx < T * T; idx += 64) out[idx] = tile[idx];
+        if (A.delta_pk) {  // ... and the lower triangle by columns, for the solo form
+          double* opk = A.delta_pk + ((size_t)p * b.max_cand + k) * (T * (T + 1) / 2);
+          for (int cc = 0; cc < T; cc++)
+            if (cc + lane < T) opk[cc * T - cc * (cc - 1) / 2 + lane] = tile[cc * T + cc + lane];  // (row cc of the symmetric tile = column cc)
+        }
         __builtin_amdgcn_wave_barrier();
       }
       if (lane == 0) A.valid[(size_t)p * b.max_cand + k] = ok, A.black[(size_t)p * b.max_cand + k] = 0;
@@ -886,7 +893,8 @@ AVM_DEV double fs_log(double x) {
 //  per pair, the round trip hidden by look-ahead - made the evaluation 10-17 % slower.)
 // PACKED: D is the packed lower triangle (row R at R (R + 1) / 2, the single-frame kernel's LDS copy) instead of the full
 // T x T block; an entry past the diagonal of a diagonal block - never used, see above - then reads into the next row.
-template <int T, int BS, int NB, bool PHASED = false, bool PACKED = false>
+// PACKED == 2: D is the lower triangle BY COLUMNS (FselDev::delta_pk): the 15 lanes of a candidate still read consecutive doubles.
+template <int T, int BS, int NB, bool PHASED = false, int PACKED = 0>
 AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D, double pr, double* ld_out, double* ub_out, long long* tk = nullptr) {
 #ifdef FS_TRACE_EVAL
   long long tkp = clock64();
@@ -901,7 +909,8 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
 #pragma unroll
     for (int c = 0; c < (bi + 1) * BS; c++) {
       const int idx = c * T + bi * BS + r, R = bi * BS + r;
-      m[bi][c] = sC[idx] + pr * D[PACKED ? R * (R + 1) / 2 + c : idx];
+      const int pk2 = c <= R ? c * T - c * (c - 1) / 2 + (R - c) : R * T - R * (R - 1) / 2;  // (an entry past the diagonal is never used)
+      m[bi][c] = sC[idx] + pr * D[PACKED == 2 ? pk2 : (PACKED == 1 ? R * (R + 1) / 2 + c : idx)];
     }
   FS_TK(0)
   // Hadamard upper bound: sum over the rows, block row by block row, then across the 16 lanes in lane order
@@ -909,7 +918,7 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
 #pragma unroll
   for (int bi = 0; bi < NB; bi++) {
     const int dgi = bi * BS + r, idx = dgi * T + dgi;
-    ubl += fs_log(sdpp[dgi] + pr * D[PACKED ? dgi * (dgi + 1) / 2 + dgi : idx]);
+    ubl += fs_log(sdpp[dgi] + pr * D[PACKED == 2 ? dgi * T - dgi * (dgi - 1) / 2 : (PACKED == 1 ? dgi * (dgi + 1) / 2 + dgi : idx)]);
   }
   const double ubt = fs_row_sum((lane & 15) < BS ? ubl : 0.0);
   FS_TK(1)
@@ -1562,6 +1571,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     const int kappa = max(0, b.max_features - (b.n_used ? b.n_used[p] : 0));
     const size_t pc = (size_t)p * mc;
     const double* Dp = A.delta + pc * T * T;
+    const double* Dk = A.delta_pk + pc * (T * (T + 1) / 2);
     for (int idx = t; idx < T * T; idx += FS_SOLO_NT) sC[idx] = A.C[(size_t)p * T * T + idx];
     for (int idx = t; idx < T; idx += FS_SOLO_NT) sdpp[idx] = A.dpp[(size_t)p * T + idx];
     const int c = t;  // this thread's candidate
@@ -1578,7 +1588,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     __syncthreads();
     if (wv == 0) {  // logdet of the frame's first C: the same evaluation with p = 0
       double ld0, ub0;
-      const bool ok0 = fsel_logdet4<T, BS, NB, false, false>(sC, sdpp, Dp, 0.0, &ld0, &ub0);
+      const bool ok0 = fsel_logdet4<T, BS, NB, false, 2>(sC, sdpp, Dk, 0.0, &ld0, &ub0);
       if (lane == 0) s_g0 = ok0 ? (ld_nn + 2.0 * ld0) : __builtin_nan("");
     }
     __syncthreads();
@@ -1600,7 +1610,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         const int i = i0 + wv * 4 + g;
         const int cc = s_list[min(i, n - 1)];  // (a row without a candidate scores the list's last one again and drops the result)
         double ld, ubt;
-        const bool ok = fsel_logdet4<T, BS, NB, false, false>(sC, sdpp, Dp + (size_t)cc * T * T, s_pr[cc], &ld, &ubt);
+        const bool ok = fsel_logdet4<T, BS, NB, false, 2>(sC, sdpp, Dk + (size_t)cc * (T * (T + 1) / 2), s_pr[cc], &ld, &ubt);
         if (i < n && rec_lane) {
           const double f = ok ? (ld_nn + 2.0 * ld) : __builtin_nan("");
           s_f[cc] = f, s_scored[cc] = 1;
@@ -1828,6 +1838,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
     const char* nk = getenv("AVM_FSEL_NO_KEY_RULE");
     d.no_key_rule = (nk && nk[0] == '1') ? 1 : 0;
   }
+  d.delta_pk = frame_mode == 3 ? w.delta_pk : nullptr;
   d.C = w.C, d.dpp = w.dpp, d.consts = w.consts, d.delta = w.delta, d.delta_u = w.delta_u, d.valid = w.valid, d.valid_u = w.valid_u;
   d.black = w.black, d.fval = w.fval, d.ub = w.ub, d.nsel = w.nsel, d.done = w.done, d.omega_out = omega_out, d.out = out;
   d.live = w.live, d.pos = w.pos, d.nlive = w.nlive;
