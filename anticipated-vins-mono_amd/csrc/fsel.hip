@@ -1691,26 +1691,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       if (t < T) s_inv[t] = 1.0 / sdpp[t];
       __syncthreads();
       bool mark = live && !(s_bound[c] < th);
-      {
-        s_scored[c] = 0;
-        double ua = 0.0, ue = 0.0;
-        if (live) {
-          const double prc = s_pr[c];
-          const double* dd = s_dd + c;
-#pragma unroll
-          for (int d = 0; d < T; d++) {
-            const double x = (prc * dd[d * MAXC]) * s_inv[d];
-            const bool small = fabs(x) <= 0.01;  // (NaN: the other branch, and the estimate is NaN - compared exactly)
-            const double x2 = x * x, lg = (double)__log2f((float)(1.0 + x)) * 0.6931471805599453;
-            ua += small ? x * (1.0 + x * (-0.5 + x * (1.0 / 3.0))) : lg;
-            // the series' remainder is below x^4 / 4 / (1 - |x|); the other branch: 1 + x rounded to single precision (6e-8 of it) and a
-            // logarithm good to two units in its last place (2.4e-7 of the result)
-            ue += small ? 0.26 * x2 * x2 + 1e-15 * fabs(x) : 1e-7 + 3e-7 * fabs(lg);
-          }
-        }
-        s_ua[c] = ua, s_ue[c] = ue;
-      }
-      FS_SOLO_SEG(0)
+      s_scored[c] = 0;
       int n = build_list(mark);
       // A first pass holds NW * 4 = 32 candidates (two wavefronts per SIMD: the CU's FP64 pipe is full); a 33rd costs half a pass more.  When
       // more are marked, only the 32 with the largest gain bounds are scored now - the others are exactly the ones the check of the pick
@@ -1732,6 +1713,38 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         __syncthreads();  // (every reader of the first list is done)
         n = build_list(mark);
       }
+      // The listed candidates' Deltas are asked for NOW (one 8-byte read per 128-byte line, a candidate per instruction: 29 lanes) and the
+      // values are looked at only after the estimates below: the evaluations then find their operands in the L2 instead of waiting
+      // for memory with all eight wavefronts (a scoring pass: 31 K cycles, 19 K with the operands in cache).
+      constexpr int PKN = T * (T + 1) / 2, PFQ = (CAP + NW - 1) / NW, PFL = (PKN + 15) / 16;
+      double pf[PFQ];
+#pragma unroll
+      for (int q = 0; q < PFQ; q++) {
+        const int i = wv + q * NW;
+        pf[q] = 0.0;
+        if (n <= CAP && i < n && lane < PFL) pf[q] = Dk[(size_t)s_list[i] * PKN + min(lane * 16, PKN - 1)];
+      }
+      FS_SOLO_SEG(0)
+      {
+        double ua = 0.0, ue = 0.0;
+        if (live) {
+          const double prc = s_pr[c];
+          const double* dd = s_dd + c;
+#pragma unroll
+          for (int d = 0; d < T; d++) {
+            const double x = (prc * dd[d * MAXC]) * s_inv[d];
+            const bool small = fabs(x) <= 0.01;  // (NaN: the other branch, and the estimate is NaN - compared exactly)
+            const double x2 = x * x, lg = (double)__log2f((float)(1.0 + x)) * 0.6931471805599453;
+            ua += small ? x * (1.0 + x * (-0.5 + x * (1.0 / 3.0))) : lg;
+            // the series' remainder is below x^4 / 4 / (1 - |x|); the other branch: 1 + x rounded to single precision (6e-8 of it) and a
+            // logarithm good to two units in its last place (2.4e-7 of the result)
+            ue += small ? 0.26 * x2 * x2 + 1e-15 * fabs(x) : 1e-7 + 3e-7 * fabs(lg);
+          }
+        }
+        s_ua[c] = ua, s_ue[c] = ue;
+      }
+#pragma unroll
+      for (int q = 0; q < PFQ; q++) asm volatile("" ::"v"(pf[q]));
       FS_SOLO_SEG(1)
       n_scored += n;
       // ---- 2. the scores (and the exact bounds of the scored)
