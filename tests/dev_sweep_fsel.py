@@ -1,0 +1,24 @@
+"""TEST INFRASTRUCTURE (uses oracle/).  Development sweep (GPU box): the solo form of the selector (fsel_solo_kernel) against the FP64 oracle over many
+frames - ids and their order.  python tests/dev_sweep_fsel.py [frames of the bench shape] ; results: profiles/r04_sweep_fsel.txt"""
+import importlib, os, sys, time
+import numpy as np
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _root); sys.path.insert(0, os.path.join(_root, "tests"))
+from helpers import buffers, synth
+from oracle import oracle_py
+fs_m = importlib.import_module("anticipated-vins-mono_amd.feature_selector")
+FS = fs_m.FeatureSelector()
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+tot = bad = 0
+for name, kw, P in (("bench shape: 500 candidates -> 150, H 10", dict(), NB), ("H 5, 200 candidates -> 60, 4 tracked", dict(horizon=5, n_cand=200, n_used=4, max_features=60), 4 * NB),
+                    ("H 3, 60 candidates -> 25, no cloud", dict(horizon=3, n_cand=60, n_used=0, n_cloud=0, max_features=25), 8 * NB), ("H 10, 120 candidates -> 40, 10 tracked", dict(n_cand=120, n_used=10, max_features=40), 2 * NB)):
+    pr = synth.make_fsel(P, first_id=70000, **kw)
+    os.environ.pop("AVM_FSEL_SOLO", None)
+    t0 = time.time(); out = FS.select_batch(pr); tg = time.time() - t0
+    form = FS.ctx.last_fsel_form()
+    oo = buffers.FselOutArrays.alloc(P, pr.dims["max_features"])
+    t0 = time.time(); oracle_py.fsel_select(pr, oo, n_threads=16); to = time.time() - t0
+    same = [bool(np.array_equal(out.a["selected_ids"][q], oo.a["selected_ids"][q]) and out.a["n_selected"][q] == oo.a["n_selected"][q]) for q in range(P)]
+    tot += P; bad += P - sum(same)
+    print(f"{name}: {P} frames, form {form}, selected per frame {int(oo.a['n_selected'].min())}..{int(oo.a['n_selected'].max())}; frames whose ids or order differ from the oracle's: {P - sum(same)}   (GPU call {tg:.2f} s, oracle on 16 threads {to:.0f} s)", flush=True)
+print(f"TOTAL: {tot} frames, {bad} differ")
