@@ -998,6 +998,8 @@ int stage_fsel(avm_ctx* c, const avm_fsel_batch* h, avm_fsel_batch* d) {
   return AVM_OK;
 }
 
+constexpr size_t AVM_FSEL_SOLO_MIN = 48;  // frames per call from which a batch takes the solo form of the selector: a solo select takes 5 ms however few
+                                          // frames run side by side, the teams 0.12 ms per frame
 int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   const size_t P = b->n_problems, T = 3 * (size_t)b->horizon, mc = b->max_cand, mu = b->max_used > 0 ? b->max_used : 1;
 #define GET(field, type, count)                                                             \
@@ -1007,7 +1009,8 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   GET(dpp, double, 2 * P * T)  // (two buffers: csrc/fsel.hip, FselPar)
   GET(consts, double, P * 4)
   GET(delta, double, P * mc * T * T)
-  GET(delta_pk, double, (P >= 48 || getenv("AVM_FSEL_SOLO")) ? P * mc * (T * (T + 1) / 2) : 1)  // (the solo form's copy: csrc/fsel.hip, FselDev)
+  // (the solo form's packed copy - csrc/fsel.hip, FselDev::delta_pk - exists whenever avm_fsel_select_batch can choose that form: the rule is there)
+  GET(delta_pk, double, (T <= 30 && mc <= 512 && (P >= AVM_FSEL_SOLO_MIN || getenv("AVM_FSEL_SOLO"))) ? P * mc * (T * (T + 1) / 2) : 1)
   GET(delta_u, double, P * mu * T * T)
   GET(fval, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)
   GET(ub, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)
@@ -1081,7 +1084,6 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   // 3 = one workgroup per frame with lazy evaluation (fsel_solo_kernel): what a batch of many frames takes - it has no waits between
   // workgroups, so it cannot time out and is never re-run.  AVM_FSEL_SOLO=0/1 overrides the batch-size rule (tests, measurements).
   {
-    constexpr size_t AVM_FSEL_SOLO_MIN = 48;  // (frames: a solo select takes 6 ms however few frames run side by side, the teams 0.13 ms per frame - DESIGN.md section 3)
     const bool can = d.max_cand <= 512 && 3 * d.horizon <= 30 && P >= 1;
     bool solo = can && P >= AVM_FSEL_SOLO_MIN && !getenv("AVM_FSEL_FRAME");
     if (const char* e = getenv("AVM_FSEL_SOLO")) solo = can && e[0] == '1';
