@@ -1010,7 +1010,9 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   GET(consts, double, P * 4)
   GET(delta, double, P * mc * T * T)
   // (the solo form's packed copy - csrc/fsel.hip, FselDev::delta_pk - exists whenever avm_fsel_select_batch can choose that form: the rule is there)
-  GET(delta_pk, double, (T <= 30 && mc <= 512 && (P >= AVM_FSEL_SOLO_MIN || getenv("AVM_FSEL_SOLO"))) ? P * mc * (T * (T + 1) / 2) : 1)
+  const bool may_solo = T <= 39 && mc <= 512 && (P >= AVM_FSEL_SOLO_MIN || getenv("AVM_FSEL_SOLO"));
+  GET(delta_pk, double, may_solo ? P * mc * (T * (T + 1) / 2) : 1)
+  GET(ddiag, double, (may_solo && T > 30) ? P * mc * T : 1)
   GET(delta_u, double, P * mu * T * T)
   GET(fval, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)
   GET(ub, double, 2 * P * mc)  // (two buffers: csrc/fsel.hip, FselPar)
@@ -1084,7 +1086,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
   // 3 = one workgroup per frame with lazy evaluation (fsel_solo_kernel): what a batch of many frames takes - it has no waits between
   // workgroups, so it cannot time out and is never re-run.  AVM_FSEL_SOLO=0/1 overrides the batch-size rule (tests, measurements).
   {
-    const bool can = d.max_cand <= 512 && 3 * d.horizon <= 30 && P >= 1;
+    const bool can = d.max_cand <= 512 && 3 * d.horizon <= 39 && P >= 1;
     bool solo = can && P >= AVM_FSEL_SOLO_MIN && !getenv("AVM_FSEL_FRAME");
     if (const char* e = getenv("AVM_FSEL_SOLO")) solo = can && e[0] == '1';
     if (solo) mode = 3;

@@ -16,6 +16,7 @@
 // This is the same Cholesky with the constant leading pivots factored once — the same kind of
 // hoist as IMUFactor's sqrt_info.  All FP64; selection order is deterministic.
 #include <algorithm>
+#include <type_traits>
 #include <cfloat>
 #include <cstdlib>
 
@@ -46,6 +47,7 @@ struct FselDev {
   double* delta_pk; // [P][max_cand][T(T+1)/2] the same, lower triangle by columns (entry (R, c), c <= R, at c T - c (c - 1) / 2 + R - c): what
                     // fsel_solo_kernel scores from - half the bytes per evaluation; null unless the solo form runs
   double* delta_u;  // [P][max_used][T*T]
+  double* ddiag;    // [P][max_cand][T] every candidate's Delta diagonal (fsel_solo_kernel at 3 H = 39, where its LDS copy is single precision)
   int32_t* valid;   // [P][max_cand] 1 = triangulable (numVisible > 1)
   int32_t* valid_u; // [P][max_used]
   int32_t* black;   // [P][max_cand]
@@ -1527,7 +1529,12 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
   __shared__ double s_g0;
   __shared__ double s_wf[2][NW], s_wu[2][NW];
   __shared__ int s_wi[2][NW];
-  extern __shared__ double s_dd[];  // [T][MAXC]: every candidate's Delta diagonal, candidates along the lanes (the bounds read nothing else)
+  // [T][MAXC]: every candidate's Delta diagonal, candidates along the lanes - what the bound estimates of every round read.  3 H = 39: 160 KB in
+  // double precision, so the LDS copy is SINGLE precision there (the estimates' error bars account for it) and the exact bounds - rare - read
+  // the double-precision diagonals from A.ddiag.
+  using dd_t = std::conditional_t<(T > 30), float, double>;
+  extern __shared__ double s_dd_raw[];
+  dd_t* s_dd = reinterpret_cast<dd_t*>(s_dd_raw);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4;
   __shared__ int s_or[2][NW];
   int orc = 0;
@@ -1582,7 +1589,9 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     }
     for (int idx = t; idx < nc * T; idx += FS_SOLO_NT) {  // (one strided pass over the frame's Deltas)
       const int cc = idx / T, d = idx % T;
-      s_dd[d * MAXC + cc] = Dp[(size_t)cc * T * T + d * T + d];
+      const double dv = Dp[(size_t)cc * T * T + d * T + d];
+      s_dd[d * MAXC + cc] = (dd_t)dv;
+      if constexpr (T > 30) A.ddiag[pc * T + idx] = dv;
     }
     const double ld_nn = A.consts[(size_t)p * 4], ub_nn = A.consts[(size_t)p * 4 + 1];
     __syncthreads();
@@ -1599,7 +1608,9 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         if (i0 + wv * 4 >= n) break;  // (uniform per wavefront)
         const int i = i0 + wv * 4 + g;
         const int cc = s_list[min(i, n - 1)];
-        const double ubt = fsel_ub4<T, BS, NB>(sdpp, s_dd + cc, MAXC, s_pr[cc]);
+        double ubt;
+        if constexpr (T > 30) ubt = fsel_ub4<T, BS, NB>(sdpp, A.ddiag + (pc + cc) * T, 1, s_pr[cc]);
+        else ubt = fsel_ub4<T, BS, NB>(sdpp, reinterpret_cast<const double*>(s_dd) + cc, MAXC, s_pr[cc]);
         if (i < n && rec_lane) s_u[cc] = ub_nn + ubt;
       }
     };
@@ -1729,7 +1740,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         double ua = 0.0, ue = 0.0;
         if (live) {
           const double prc = s_pr[c];
-          const double* dd = s_dd + c;
+          const dd_t* dd = s_dd + c;
 #pragma unroll
           for (int d = 0; d < T; d++) {
             const double x = (prc * dd[d * MAXC]) * s_inv[d];
@@ -1738,7 +1749,7 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
             ua += small ? x * (1.0 + x * (-0.5 + x * (1.0 / 3.0))) : lg;
             // the series' remainder is below x^4 / 4 / (1 - |x|); the other branch: 1 + x rounded to single precision (6e-8 of it) and a
             // logarithm good to two units in its last place (2.4e-7 of the result)
-            ue += small ? 0.26 * x2 * x2 + 1e-15 * fabs(x) : 1e-7 + 3e-7 * fabs(lg);
+            ue += (small ? 0.26 * x2 * x2 + 1e-15 * fabs(x) : 1e-7 + 3e-7 * fabs(lg)) + (T > 30 ? 1.2e-7 * fabs(x) : 0.0);  // (a single-precision diagonal: 6e-8 of x)
           }
         }
         s_ua[c] = ua, s_ue[c] = ue;
@@ -1852,6 +1863,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
     d.no_key_rule = (nk && nk[0] == '1') ? 1 : 0;
   }
   d.delta_pk = frame_mode == 3 ? w.delta_pk : nullptr;
+  d.ddiag = w.ddiag;
   d.C = w.C, d.dpp = w.dpp, d.consts = w.consts, d.delta = w.delta, d.delta_u = w.delta_u, d.valid = w.valid, d.valid_u = w.valid_u;
   d.black = w.black, d.fval = w.fval, d.ub = w.ub, d.nsel = w.nsel, d.done = w.done, d.omega_out = omega_out, d.out = out;
   d.live = w.live, d.pos = w.pos, d.nlive = w.nlive;
@@ -1877,10 +1889,10 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
     const char* ls = getenv("AVM_FSEL_LAZY_STATS");
     d.lazy_stats = (ls && ls[0] == '1') ? 1 : 0;
   }
-  if (frame_mode == 3) {  // one workgroup per frame, lazy evaluation (fsel_solo_kernel): batches of many frames, 3 H <= 30
-    if (b.max_cand > FS_FRAME_MAXC || T > 30) return hipErrorInvalidValue;
+  if (frame_mode == 3) {  // one workgroup per frame, lazy evaluation (fsel_solo_kernel): batches of many frames
+    if (b.max_cand > FS_FRAME_MAXC || T > 39) return hipErrorInvalidValue;
     if ((e = hipMemsetAsync(w.sync, 0, sizeof(int32_t) * (FS_SYNC_HDR + 64), stream)) != hipSuccess) return e;
-    const size_t dl = sizeof(double) * (size_t)FS_FRAME_MAXC * T;  // [T][512]
+    const size_t dl = (T > 30 ? sizeof(float) : sizeof(double)) * (size_t)FS_FRAME_MAXC * T;  // [T][512]
     static int ncu = 0;  // (one device per process: include/avm.h)
     if (ncu == 0) {
       int dev = 0, v = 0;
@@ -1898,6 +1910,7 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
       case 9: AVM_SOLO(9, 9, 1) break;
       case 15: AVM_SOLO(15, 15, 1) break;
       case 30: AVM_SOLO(30, 15, 2) break;
+      case 39: AVM_SOLO(39, 13, 3) break;
       default: return hipErrorInvalidValue;
     }
 #undef AVM_SOLO

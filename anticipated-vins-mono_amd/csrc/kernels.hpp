@@ -77,7 +77,7 @@ struct EvalArgs {
 // device work buffers of the feature selector (owned by the ctx)
 constexpr int FS_SYNC_INTS = 64 + 16 * 32 + 16 * 2 * 2 * 512 * 4;  // header, 16 team headers, per team (fValue, ub) x two parities x 512 16-byte records
 struct FselBuffers {
-  double *C, *dpp, *consts, *delta, *delta_pk, *delta_u, *fval, *ub;
+  double *C, *dpp, *consts, *delta, *delta_pk, *ddiag, *delta_u, *fval, *ub;
   int32_t *valid, *valid_u, *black, *nsel, *done, *live, *pos, *nlive;
   int32_t* sync;  // [FS_SYNC_INTS] slot counter / failure flag / cycle trace / per-slot records of the single-frame kernel (csrc/fsel.hip)
 };

@@ -764,6 +764,24 @@ def main():
                             "the select queues behind the solve's kernels (they fill every CU)", "fallback_stats": ctx.fsel_fallback_stats()}
                 result["feature_select"]["horizon_13"] = {"workload": "500 candidates -> 150 selected, HORIZON 13 (the reference's compiled value, utility/state_defs.h:8)",
                                                           "ms_per_frame_batched": tb13 / P * 1e3, "batch": P, "ms_per_frame_single": tl13 * 1e3}
+                # ... and a large batch of it (the solo form; the teams' time for the same batch beside it)
+                f13b = synth.make_fsel(64, first_id=rank * P, horizon=13)
+                f13b = type(f13b)(dict(f13b.dims, n_problems=256), {k: np.ascontiguousarray(v[np.arange(256) % 64]) for k, v in f13b.a.items()}, f13b.scalars).to_device(dev)
+                for forced, key in ((None, "ms_per_frame_batch_256"), ("0", "ms_per_frame_batch_256_teams_forced")):
+                    if forced is None:
+                        os.environ.pop("AVM_FSEL_SOLO", None)
+                    else:
+                        os.environ["AVM_FSEL_SOLO"] = forced
+                    FS.select_batch(f13b)
+                    torch.cuda.synchronize()
+                    if forced is None:
+                        result["feature_select"]["horizon_13"]["form_batch_256"] = ctx.last_fsel_form()
+                    t1 = time.perf_counter()
+                    FS.select_batch(f13b)
+                    torch.cuda.synchronize()
+                    result["feature_select"]["horizon_13"][key] = (time.perf_counter() - t1) / 256 * 1e3
+                os.environ.pop("AVM_FSEL_SOLO", None)
+                del f13b
 
     # ---- CPU baseline (oracle = port of the reference algorithm), rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

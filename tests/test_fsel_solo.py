@@ -36,9 +36,12 @@ def test_every_re_collected_test_ran_the_solo_form_where_it_can(selector):
     pr = synth.make_fsel(2, horizon=10, n_cand=60, n_used=0, max_features=20)
     selector.select_batch(pr)
     assert selector.ctx.last_fsel_form() == "solo"
-    pr = synth.make_fsel(1, horizon=13, n_cand=60, n_used=0, max_features=20)  # 3 H = 39: the diagonals of 512 candidates do not fit the LDS
+    pr = synth.make_fsel(1, horizon=13, n_cand=60, n_used=0, max_features=20)  # 3 H = 39: single-precision diagonals in LDS, exact bounds from memory
     selector.select_batch(pr)
-    assert selector.ctx.last_fsel_form() == "teams"
+    assert selector.ctx.last_fsel_form() == "solo"
+    pr = synth.make_fsel(1, horizon=5, n_cand=600, n_used=0, max_features=20)   # more than 512 candidates: one launch per round
+    selector.select_batch(pr)
+    assert selector.ctx.last_fsel_form() == "rounds"
 
 
 def test_which_form_a_batch_takes(selector, monkeypatch):
@@ -109,3 +112,23 @@ def test_more_frames_than_compute_units_and_ragged_candidate_counts(selector, or
     assert np.array_equal(out.a["n_selected"], oo.a["n_selected"])
     assert np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
     assert int(oo.a["n_selected"][0]) == 0 and int(oo.a["n_selected"][7]) == 0
+
+
+def test_reference_horizon_batch_on_the_solo_form(selector, oracle, monkeypatch):
+    """HORIZON = 13 (utility/state_defs.h:8, what the reference is compiled with): 64 frames, 300 candidates -> 100, on the solo form
+    (39 x 39 position blocks; the LDS copy of the candidates' diagonals is single precision there): ids and order identical to the teams' in
+    every frame and to the oracle's in eight of them."""
+    monkeypatch.delenv("AVM_FSEL_SOLO", raising=False)
+    pr = synth.make_fsel(64, first_id=3000, horizon=13, n_cand=300, n_used=10, n_cloud=100, max_features=110)
+    dev = pr.to_device("cuda:0")
+    a = selector.select_batch(dev).to_host()
+    assert selector.ctx.last_fsel_form() == "solo"
+    monkeypatch.setenv("AVM_FSEL_SOLO", "0")
+    b = selector.select_batch(dev).to_host()
+    assert selector.ctx.last_fsel_form() == "teams"
+    assert (a.a["n_selected"] == 100).all()
+    assert np.array_equal(a.a["n_selected"], b.a["n_selected"]) and np.array_equal(a.a["selected_ids"], b.a["selected_ids"])
+    sub = synth.make_fsel(8, first_id=3000, horizon=13, n_cand=300, n_used=10, n_cloud=100, max_features=110)
+    oo = buffers.FselOutArrays.alloc(8, 110)
+    oracle.fsel_select(sub, oo, n_threads=8)
+    assert np.array_equal(a.a["selected_ids"][:8], oo.a["selected_ids"])
