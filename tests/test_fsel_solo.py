@@ -132,3 +132,21 @@ def test_reference_horizon_batch_on_the_solo_form(selector, oracle, monkeypatch)
     oo = buffers.FselOutArrays.alloc(8, 110)
     oracle.fsel_select(sub, oo, n_threads=8)
     assert np.array_equal(a.a["selected_ids"][:8], oo.a["selected_ids"])
+
+
+def test_equal_key_rule_at_the_reference_horizon(selector, oracle):
+    """The mirror-pair frames of test_selector_equal_upper_bounds_follow_the_std_map_rule at HORIZON 13: there the solo form keeps the
+    candidates' diagonals in single precision for its estimates - mirror candidates still get equal estimates, are compared by their exact
+    bounds from memory, and the std::map rule is applied as the oracle applies it."""
+    from test_gpu_parity import _mirror_frame
+
+    for seed in (0, 1, 2):
+        pr = _mirror_frame(H=13, seed=seed)
+        oo = buffers.FselOutArrays.alloc(1, pr.dims["max_features"])
+        oracle.fsel_select(pr, oo)
+        out = selector.select_batch(pr)
+        assert selector.ctx.last_fsel_form() == "solo"
+        assert np.array_equal(out.a["n_selected"], oo.a["n_selected"]) and np.array_equal(out.a["selected_ids"], oo.a["selected_ids"])
+        ids = pr.a["cand_id"][0].tolist()
+        order = [ids.index(s) for s in oo.a["selected_ids"][0, : oo.a["n_selected"][0]]]
+        assert any(k + 1 in order and k in order and order.index(k + 1) < order.index(k) for k in range(0, 40, 2))  # (the rule was exercised)
