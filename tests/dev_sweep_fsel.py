@@ -11,7 +11,8 @@ FS = fs_m.FeatureSelector()
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 tot = bad = 0
 for name, kw, P in (("bench shape: 500 candidates -> 150, H 10", dict(), NB), ("H 5, 200 candidates -> 60, 4 tracked", dict(horizon=5, n_cand=200, n_used=4, max_features=60), 4 * NB),
-                    ("H 3, 60 candidates -> 25, no cloud", dict(horizon=3, n_cand=60, n_used=0, n_cloud=0, max_features=25), 8 * NB), ("H 10, 120 candidates -> 40, 10 tracked", dict(n_cand=120, n_used=10, max_features=40), 2 * NB)):
+                    ("H 3, 60 candidates -> 25, no cloud", dict(horizon=3, n_cand=60, n_used=0, n_cloud=0, max_features=25), 8 * NB), ("H 10, 120 candidates -> 40, 10 tracked", dict(n_cand=120, n_used=10, max_features=40), 2 * NB),
+                    ("H 13, 200 candidates -> 60, 5 tracked", dict(horizon=13, n_cand=200, n_used=5, max_features=65), NB)):
     pr = synth.make_fsel(P, first_id=70000, **kw)
     os.environ.pop("AVM_FSEL_SOLO", None)
     t0 = time.time(); out = FS.select_batch(pr); tg = time.time() - t0
