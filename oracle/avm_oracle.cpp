@@ -277,7 +277,8 @@ int avmo_fsel_nn_depth(const avm_fsel_batch* batch, double* depth_out) {
   for (int p = 0; p < batch->n_problems; p++) {
     FselProblem P;
     load_fsel(*batch, p, P);
-    for (size_t c = 0; c < P.cand_id.size(); c++) depth_out[(size_t)p * batch->max_cand + c] = findNNDepth(P, P.cand_x[c], P.cand_y[c]);
+    const KdIndex kd(P.cloud_x, P.cloud_y);  // initKDTree, feature_selector.cpp:424-429
+    for (size_t c = 0; c < P.cand_id.size(); c++) depth_out[(size_t)p * batch->max_cand + c] = findNNDepth(P, kd, P.cand_x[c], P.cand_y[c]);
   }
   return 0;
 }

@@ -3,7 +3,7 @@
 // CPU restatement of FeatureSelector::select() (vins_estimator/src/feature_selector.cpp:74-202)
 // for the initialized (NON_LINEAR) branch, with HORIZON a runtime parameter:
 //   calcInfoFromRobotMotion :463-527, createLinearImuMatrices :531-598, addOmegaPrior :602-609,
-//   calcInfoFromFeatures :239-365, inFOV :369-376, findNNDepth :437-459 (exact 1-NN, brute force),
+//   calcInfoFromFeatures :239-365, inFOV :369-376, findNNDepth :437-459 (the reference's kd-tree, nanoflann, restated: KdIndex),
 //   selectInformativeFeatures :613-686, sortedlogDetUB :690-728, Utility::logdet utility.h:144-167,
 //   PinholeCamera::spaceToPlane / distortion camera_model/src/camera_models/PinholeCamera.cc:520-542,646-662.
 // Bug-compatibility kept on purpose: q_IC applied twice in Bh, no z>0
@@ -110,17 +110,200 @@ inline Mat calcInfoFromRobotMotion(const FselProblem& p) {
   return Om;
 }
 
-// findNNDepth, feature_selector.cpp:437-459 (nanoflann exact 1-NN, L2_Simple; first strictly smaller wins)
-inline double findNNDepth(const FselProblem& p, double x, double y) {
-  if (p.cloud_d.empty()) return 1.0;
-  size_t best = 0;
-  double bd = AVMO_NUM_MAX;
-  for (size_t i = 0; i < p.cloud_d.size(); i++) {
-    double dx = x - p.cloud_x[i], dy = y - p.cloud_y[i];
-    double d = dx * dx + dy * dy;
-    if (d < bd) bd = d, best = i;
+// The kd-tree behind findNNDepth: nanoflann::KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<double, PointCloud>, PointCloud, 2>
+// with leaf_max_size 10, as initKDTree builds it (feature_selector.cpp:424-429; vendored header
+// vins_estimator/lib/nanoflann/nanoflann.hpp).  Restated because WHICH of several equidistant cloud points a query gets
+// is decided by the order in which the tree's traversal meets them:
+//   buildIndex :1189-1201, computeBoundingBox :1309-1337, divideTree :857-907, middleSplit_ :909-958, planeSplit :969-1005,
+//   computeMinMax :835-848, findNeighbors :1222-1243, computeInitialDistances :1007-1026, searchLevel :1346-1405,
+//   L2_Simple_Adaptor::evalMetric / accum_dist :432-445, KNNResultSet<double>(1)::addPoint :175-202 (strict compare).
+// Pinned by the outputs of that header itself: tests/golden/nanoflann_nn.npz (tests/test_nanoflann_nn.py).
+struct KdIndex {
+  struct Interval { double low, high; };
+  struct Node {
+    int child1 = -1, child2 = -1;  // both -1: a leaf over vind[left, right)
+    size_t left = 0, right = 0;
+    int divfeat = 0;
+    double divlow = 0, divhigh = 0;
+  };
+  const std::vector<double>&X, &Y;
+  std::vector<size_t> vind;
+  std::vector<Node> nodes;
+  Interval root_bbox[2];
+  int root = -1;
+  static constexpr size_t LEAF_MAX = 10;  // KDTreeSingleIndexAdaptorParams(10), feature_selector.cpp:428
+
+  double pt(size_t idx, int dim) const { return dim == 0 ? X[idx] : Y[idx]; }  // PointCloud::kdtree_get_pt, feature_selector.h:130-134
+
+  KdIndex(const std::vector<double>& x, const std::vector<double>& y) : X(x), Y(y) {
+    const size_t N = X.size();
+    vind.resize(N);
+    for (size_t i = 0; i < N; i++) vind[i] = i;  // init_vind
+    if (N == 0) return;
+    for (int i = 0; i < 2; i++) root_bbox[i].low = root_bbox[i].high = pt(0, i);  // computeBoundingBox
+    for (size_t k = 1; k < N; k++)
+      for (int i = 0; i < 2; i++) {
+        if (pt(k, i) < root_bbox[i].low) root_bbox[i].low = pt(k, i);
+        if (pt(k, i) > root_bbox[i].high) root_bbox[i].high = pt(k, i);
+      }
+    root = divideTree(0, N, root_bbox);
   }
-  return p.cloud_d[best];
+
+  void computeMinMax(const size_t* ind, size_t count, int element, double& min_elem, double& max_elem) const {
+    min_elem = max_elem = pt(ind[0], element);
+    for (size_t i = 1; i < count; i++) {
+      const double val = pt(ind[i], element);
+      if (val < min_elem) min_elem = val;
+      if (val > max_elem) max_elem = val;
+    }
+  }
+
+  // on return: [0, lim1) < cutval, [lim1, lim2) == cutval, [lim2, count) > cutval
+  void planeSplit(size_t* ind, size_t count, int cutfeat, double cutval, size_t& lim1, size_t& lim2) const {
+    size_t left = 0, right = count - 1;
+    for (;;) {
+      while (left <= right && pt(ind[left], cutfeat) < cutval) ++left;
+      while (right && left <= right && pt(ind[right], cutfeat) >= cutval) --right;
+      if (left > right || !right) break;
+      std::swap(ind[left], ind[right]);
+      ++left, --right;
+    }
+    lim1 = left;
+    right = count - 1;
+    for (;;) {
+      while (left <= right && pt(ind[left], cutfeat) <= cutval) ++left;
+      while (right && left <= right && pt(ind[right], cutfeat) > cutval) --right;
+      if (left > right || !right) break;
+      std::swap(ind[left], ind[right]);
+      ++left, --right;
+    }
+    lim2 = left;
+  }
+
+  void middleSplit(size_t* ind, size_t count, size_t& index, int& cutfeat, double& cutval, const Interval* bbox) const {
+    const double EPS = 0.00001;
+    double max_span = bbox[0].high - bbox[0].low;
+    for (int i = 1; i < 2; i++) {
+      const double span = bbox[i].high - bbox[i].low;
+      if (span > max_span) max_span = span;
+    }
+    double max_spread = -1;
+    cutfeat = 0;
+    for (int i = 0; i < 2; i++) {
+      const double span = bbox[i].high - bbox[i].low;
+      if (span > (1 - EPS) * max_span) {
+        double mn, mx;
+        computeMinMax(ind, count, i, mn, mx);
+        const double spread = mx - mn;
+        if (spread > max_spread) cutfeat = i, max_spread = spread;
+      }
+    }
+    const double split_val = (bbox[cutfeat].low + bbox[cutfeat].high) / 2;
+    double mn, mx;
+    computeMinMax(ind, count, cutfeat, mn, mx);
+    cutval = split_val < mn ? mn : (split_val > mx ? mx : split_val);
+    size_t lim1, lim2;
+    planeSplit(ind, count, cutfeat, cutval, lim1, lim2);
+    index = lim1 > count / 2 ? lim1 : (lim2 < count / 2 ? lim2 : count / 2);
+  }
+
+  int divideTree(size_t left, size_t right, Interval* bbox) {
+    const int me = (int)nodes.size();
+    nodes.emplace_back();
+    if (right - left <= LEAF_MAX) {
+      nodes[me].left = left, nodes[me].right = right;
+      for (int i = 0; i < 2; i++) bbox[i].low = bbox[i].high = pt(vind[left], i);
+      for (size_t k = left + 1; k < right; k++)
+        for (int i = 0; i < 2; i++) {
+          if (bbox[i].low > pt(vind[k], i)) bbox[i].low = pt(vind[k], i);
+          if (bbox[i].high < pt(vind[k], i)) bbox[i].high = pt(vind[k], i);
+        }
+    } else {
+      size_t idx;
+      int cutfeat;
+      double cutval;
+      middleSplit(&vind[0] + left, right - left, idx, cutfeat, cutval, bbox);
+      Interval lb[2] = {bbox[0], bbox[1]}, rb[2] = {bbox[0], bbox[1]};
+      lb[cutfeat].high = cutval;
+      const int c1 = divideTree(left, left + idx, lb);
+      rb[cutfeat].low = cutval;
+      const int c2 = divideTree(left + idx, right, rb);
+      Node& n = nodes[me];
+      n.child1 = c1, n.child2 = c2, n.divfeat = cutfeat;
+      n.divlow = lb[cutfeat].high, n.divhigh = rb[cutfeat].low;
+      for (int i = 0; i < 2; i++) {
+        bbox[i].low = std::min(lb[i].low, rb[i].low);
+        bbox[i].high = std::max(lb[i].high, rb[i].high);
+      }
+    }
+    return me;
+  }
+
+  // KNNResultSet<double>(1): one slot, replaced only by a strictly smaller distance
+  struct Result {
+    size_t index = 0;
+    double dist = AVMO_NUM_MAX;
+    size_t count = 0;
+    void addPoint(double d, size_t i) {
+      if (count == 0 || dist > d) dist = d, index = i;
+      count = 1;
+    }
+  };
+
+  void searchLevel(Result& res, const double* vec, int ni, double mindistsq, double* dists) const {
+    const Node& node = nodes[ni];
+    if (node.child1 < 0 && node.child2 < 0) {
+      const double worst_dist = res.dist;  // (read once per leaf)
+      for (size_t i = node.left; i < node.right; i++) {
+        const size_t index = vind[i];
+        double dist = 0;
+        for (int d = 0; d < 2; d++) {
+          const double diff = vec[d] - pt(index, d);
+          dist += diff * diff;
+        }
+        if (dist < worst_dist) res.addPoint(dist, index);
+      }
+      return;
+    }
+    const int idx = node.divfeat;
+    const double val = vec[idx];
+    const double diff1 = val - node.divlow, diff2 = val - node.divhigh;
+    int best, other;
+    double cut_dist;
+    if (diff1 + diff2 < 0)
+      best = node.child1, other = node.child2, cut_dist = (val - node.divhigh) * (val - node.divhigh);
+    else
+      best = node.child2, other = node.child1, cut_dist = (val - node.divlow) * (val - node.divlow);
+    searchLevel(res, vec, best, mindistsq, dists);
+    const double dst = dists[idx];
+    mindistsq = mindistsq + cut_dist - dst;
+    dists[idx] = cut_dist;
+    if (mindistsq * 1.0f <= res.dist) searchLevel(res, vec, other, mindistsq, dists);  // epsError = 1 + SearchParams(10).eps (0)
+    dists[idx] = dst;
+  }
+
+  size_t nearest(double x, double y) const {  // findNeighbors
+    const double vec[2] = {x, y};
+    double dists[2] = {0, 0}, distsq = 0;
+    for (int i = 0; i < 2; i++) {  // computeInitialDistances
+      if (vec[i] < root_bbox[i].low) dists[i] = (vec[i] - root_bbox[i].low) * (vec[i] - root_bbox[i].low), distsq += dists[i];
+      if (vec[i] > root_bbox[i].high) dists[i] = (vec[i] - root_bbox[i].high) * (vec[i] - root_bbox[i].high), distsq += dists[i];
+    }
+    Result res;
+    searchLevel(res, vec, root, distsq, dists);
+    return res.index;
+  }
+};
+
+// findNNDepth, feature_selector.cpp:437-459: the depth of the cloud point nanoflann's exact 1-NN search returns
+// (ret_index starts at 0 and stays there when nothing beats the initial worst distance, e.g. NaN coordinates)
+inline double findNNDepth(const FselProblem& p, const KdIndex& kd, double x, double y) {
+  if (p.cloud_d.empty()) return 1.0;
+  return p.cloud_d[kd.nearest(x, y)];
+}
+inline double findNNDepth(const FselProblem& p, double x, double y) {
+  KdIndex kd(p.cloud_x, p.cloud_y);
+  return findNNDepth(p, kd, x, y);
 }
 
 // calcInfoFromFeatures, feature_selector.cpp:239-365. Returns dense Delta_ell per id (only for
@@ -131,9 +314,10 @@ inline std::map<int, Mat> calcInfoFromFeatures(const FselProblem& p, const std::
   const int H = p.H, N = 9 * (H + 1);
   V3 t_WC_k1 = p.pos[1] + rot(p.quat[1], p.t_IC);
   Q q_WC_k1 = p.quat[1] * p.q_IC;
+  const KdIndex kd(p.cloud_x, p.cloud_y);  // initKDTree (feature_selector.cpp:380-432): built once per frame
   for (size_t f = 0; f < ids.size(); f++) {
     V3 feature(xs[f], ys[f], 1.0);
-    double d = findNNDepth(p, feature.x, feature.y);
+    double d = findNNDepth(p, kd, feature.x, feature.y);
     feature = normalized(feature) * d;
     V3 pell = t_WC_k1 + rot(q_WC_k1, feature);
     int numVisible = 1;

@@ -21,7 +21,11 @@ def main():
         sys.exit("needs the reference tree (build container only)")
     exe = os.path.join(tempfile.gettempdir(), "gen_nanoflann_nn")
     subprocess.check_call(["g++", "-O2", "-std=c++11", "-I", INC, os.path.join(HERE, "gen_nanoflann_nn.cpp"), "-o", exe])
-    tok = subprocess.check_output([exe], text=True).split()
+    for arg, name in (("1", "nanoflann_nn.npz"), ("2", "nanoflann_nn2.npz")):   # 2: the degenerate clouds (see the .cpp)
+        write(subprocess.check_output([exe, arg], text=True).split(), name)
+
+
+def write(tok, name):
     it = iter(tok)
     n_clouds = int(next(it))
     out = {"n_clouds": np.int64(n_clouds)}
@@ -32,9 +36,9 @@ def main():
         out[f"cloud_xy_{c}"], out[f"cloud_depth_{c}"] = cl[:, :2].copy(), cl[:, 2].copy()
         out[f"query_xy_{c}"], out[f"nn_index_{c}"] = qs[:, :2].copy(), qs[:, 2].astype(np.int64)
         out[f"nn_dist2_{c}"], out[f"nn_depth_{c}"] = qs[:, 3].copy(), qs[:, 4].copy()
-    np.savez_compressed(os.path.join(HERE, "nanoflann_nn.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, name), **out)
     tot = sum(len(out[f"query_xy_{c}"]) for c in range(n_clouds))
-    print("wrote nanoflann_nn.npz:", n_clouds, "clouds,", tot, "queries")
+    print("wrote", name + ":", n_clouds, "clouds,", tot, "queries")
 
 
 if __name__ == "__main__":

@@ -5,11 +5,11 @@ seeded clouds; tests/golden/nanoflann_nn.npz holds, for 10 500 queries, the inde
 findNNDepth hands back.  Empty clouds (the "return 1.0" branch), clouds around the leaf size, queries ON cloud points, and
 EXACT TIES (dyadic grid points, queries at midpoints and cell centres: two resp. four points at bit-identical distances).
 
-What is asserted: on every query without a tie the oracle's and the GPU's 1-NN return nanoflann's depth bit for bit (10 422
-queries); the squared distance of the winner is bit-identical always; on the 78 exact ties the depth returned belongs to one of
-the tied points - the lowest index, where nanoflann takes the point its kd-tree traversal meets first (40 of the 78 differ).  That
-deviation is documented (include/avm.h): ties have measure zero in real data, and restating the tree's traversal order
-would be restating nanoflann."""
+What is asserted: on EVERY query - the 78 exact ties included - the oracle's and the GPU's search return nanoflann's depth bit for
+bit, and the squared distance of the winner is bit-identical.  Which of several equidistant points wins is decided by the order in
+which the tree's traversal meets them, so both restate the tree: oracle/fsel.hpp `KdIndex` (divideTree / middleSplit_ / planeSplit /
+searchLevel as written in the header), csrc/fsel.hip `fsel_kdtree_kernel` + `kd_nearest` (the same tree built by one wavefront per
+frame, searched with an explicit stack).  Depths in the fixture are distinct per cloud, so equal depth = equal index."""
 import os
 
 import numpy as np
@@ -19,12 +19,15 @@ from helpers import synth
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "nanoflann_nn.npz"))
 NC = int(GOLD["n_clouds"])
+# the degenerate clouds (second set of the generator): duplicated points, clouds of one repeated point, collinear clouds, a complete
+# dyadic grid, 300 points, queries far outside the bounding box and with NaN / infinite coordinates
+GOLD2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "nanoflann_nn2.npz"))
 
 
-def _problems():
+def _problems(GOLD=GOLD):
     """The fixture's clouds and queries as avm_fsel_batch frames: one frame per cloud, the queries as its candidates."""
     out = []
-    for c in range(NC):
+    for c in range(int(GOLD["n_clouds"])):
         xy, dep, q = GOLD[f"cloud_xy_{c}"], GOLD[f"cloud_depth_{c}"], GOLD[f"query_xy_{c}"]
         p = synth.make_fsel(1, horizon=3, n_cand=len(q), n_used=0, n_cloud=max(len(xy), 1), max_features=4)
         p.a["n_cloud"][0] = len(xy)
@@ -36,7 +39,7 @@ def _problems():
 
 
 def _check(depths_of):
-    n_plain = n_tie = n_tie_other = 0
+    n_plain = n_tie = n_tie_other = n_tie_not_lowest = 0
     for c, p in enumerate(_problems()):
         xy, dep, q = GOLD[f"cloud_xy_{c}"], GOLD[f"cloud_depth_{c}"], GOLD[f"query_xy_{c}"]
         want, d2 = GOLD[f"nn_depth_{c}"], GOLD[f"nn_dist2_{c}"]
@@ -48,14 +51,39 @@ def _check(depths_of):
         D = (q[:, None, 0] - xy[None, :, 0]) ** 2 + (q[:, None, 1] - xy[None, :, 1]) ** 2
         assert np.array_equal(D.min(1), d2)                         # nanoflann's L2_Simple distance, bit for bit
         tied = (D == d2[:, None]).sum(1) > 1
+        assert len(np.unique(dep)) == len(dep)                      # (a depth identifies its point)
+        assert np.array_equal(dep[GOLD[f"nn_index_{c}"]], want)
         assert np.array_equal(got[~tied], want[~tied]), c           # no tie: the reference's answer exactly
         for i in np.nonzero(tied)[0]:
-            assert got[i] in dep[D[i] == d2[i]], (c, i)            # a tie: one of the tied points (the lowest index)
-            assert got[i] == dep[np.argmin(D[i])]
+            assert got[i] in dep[D[i] == d2[i]], (c, i)            # a tie: one of the tied points ...
         n_plain += int((~tied).sum())
         n_tie += int(tied.sum())
         n_tie_other += int((got[tied] != want[tied]).sum())
-    return n_plain, n_tie, n_tie_other
+        n_tie_not_lowest += int((want[tied] != dep[np.argmin(D[tied], axis=1)]).sum()) if tied.any() else 0
+    assert n_tie_other == 0                                         # ... and the one nanoflann's traversal meets first
+    return n_plain, n_tie, n_tie_not_lowest
+
+
+def _check2(depths_of):
+    """Second set: every answer bit for bit; how many of them a lowest-index rule would have got wrong is reported."""
+    n = n_tie = n_not_lowest = 0
+    for c, p in enumerate(_problems(GOLD2)):
+        xy, dep, q = GOLD2[f"cloud_xy_{c}"], GOLD2[f"cloud_depth_{c}"], GOLD2[f"query_xy_{c}"]
+        want, d2, idx = GOLD2[f"nn_depth_{c}"], GOLD2[f"nn_dist2_{c}"], GOLD2[f"nn_index_{c}"]
+        got = depths_of(p)[0, :len(q)]
+        assert len(np.unique(dep)) == len(dep) and np.array_equal(dep[idx], want)
+        fin = np.isfinite(q).all(1)
+        with np.errstate(invalid="ignore", over="ignore"):
+            D = (q[:, None, 0] - xy[None, :, 0]) ** 2 + (q[:, None, 1] - xy[None, :, 1]) ** 2
+        assert np.array_equal(D[fin].min(1), d2[fin])
+        assert (idx[~fin] == 0).all()                               # NaN / inf: nothing is "closer", ret_index stays 0
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (c, len(xy), bad[:8], q[bad[:8]])
+        tied = fin & ((D == d2[:, None]).sum(1) > 1)
+        n += len(q)
+        n_tie += int(tied.sum())
+        n_not_lowest += int((idx[tied] != np.argmin(D[tied], axis=1)).sum()) if tied.any() else 0
+    return n, n_tie, n_not_lowest
 
 
 def test_the_fixture_is_what_the_docstring_says():
@@ -66,12 +94,25 @@ def test_the_fixture_is_what_the_docstring_says():
 
 def test_oracle_find_nn_depth_against_the_reference_nanoflann(oracle):
     n_plain, n_tie, n_other = _check(oracle.fsel_nn_depth)
-    print(f"\n[nanoflann] oracle: {n_plain} queries without a tie identical; {n_tie} exact ties, {n_other} of them answered with another tied point")
+    print(f"\n[nanoflann] oracle: {n_plain} queries without a tie identical; {n_tie} exact ties identical as well ({n_other} of them are not the lowest index)")
     assert n_plain >= 10000 and n_tie >= 50
 
 
 @pytest.mark.gpu
 def test_gpu_find_nn_depth_against_the_reference_nanoflann(selector):
     n_plain, n_tie, n_other = _check(selector.nn_depth)
-    print(f"\n[nanoflann] gpu: {n_plain} queries without a tie identical; {n_tie} exact ties, {n_other} of them answered with another tied point")
+    print(f"\n[nanoflann] gpu: {n_plain} queries without a tie identical; {n_tie} exact ties identical as well ({n_other} of them are not the lowest index)")
     assert n_plain >= 10000 and n_tie >= 50
+
+
+def test_oracle_on_the_degenerate_clouds(oracle):
+    n, n_tie, n_nl = _check2(oracle.fsel_nn_depth)
+    print(f"\n[nanoflann] oracle, degenerate clouds: {n} queries identical, {n_tie} of them exact ties ({n_nl} not the lowest index)")
+    assert n >= 6000 and n_tie >= 1000
+
+
+@pytest.mark.gpu
+def test_gpu_on_the_degenerate_clouds(selector):
+    n, n_tie, n_nl = _check2(selector.nn_depth)
+    print(f"\n[nanoflann] gpu, degenerate clouds: {n} queries identical, {n_tie} of them exact ties ({n_nl} not the lowest index)")
+    assert n >= 6000 and n_tie >= 1000
