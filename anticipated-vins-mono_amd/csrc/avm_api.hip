@@ -956,6 +956,7 @@ int check_fsel(avm_ctx* c, const avm_fsel_batch* b) {
   if (!b || b->n_problems < 0) return fail(c, AVM_ERR_INVALID, "null/negative argument");
   if (!fsel_horizon_supported(b->horizon)) return fail(c, AVM_ERR_UNSUPPORTED, "horizon must be one of 2,3,5,10,13");
   if (b->max_cand <= 0 || b->max_features < 0) return fail(c, AVM_ERR_INVALID, "bad max_cand / max_features");
+  if (b->n_cloud && b->max_cloud > FS_MAX_CLOUD) return fail(c, AVM_ERR_UNSUPPORTED, "max_cloud above 4096 (the kd-tree of the depth cloud is built in LDS)");
   return AVM_OK;
 }
 
@@ -1000,7 +1001,17 @@ int stage_fsel(avm_ctx* c, const avm_fsel_batch* h, avm_fsel_batch* d) {
 
 constexpr size_t AVM_FSEL_SOLO_MIN = 48;  // frames per call from which a batch takes the solo form of the selector: a solo select takes 5 ms however few
                                           // frames run side by side, the teams 0.12 ms per frame
-int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
+// Does a select of this batch take the solo form (one workgroup per frame, lazy evaluation: fsel_solo_kernel)?  ONE rule for the mode
+// choice in avm_fsel_select_batch and for the solo form's packed Delta copy in fsel_buffers (0.8 GB at 256 frames x 512 candidates,
+// H = 13: not to be held by a ctx that never runs the form).  AVM_FSEL_SOLO=0/1 overrides the batch-size rule, AVM_FSEL_FRAME vetoes it.
+bool fsel_takes_solo(const avm_fsel_batch* b) {
+  const bool can = b->max_cand <= 512 && 3 * b->horizon <= 39 && b->n_problems >= 1;
+  bool solo = can && (size_t)b->n_problems >= AVM_FSEL_SOLO_MIN && !getenv("AVM_FSEL_FRAME");
+  if (const char* e = getenv("AVM_FSEL_SOLO")) solo = can && e[0] == '1';
+  return solo;
+}
+
+int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w, bool may_solo) {
   const size_t P = b->n_problems, T = 3 * (size_t)b->horizon, mc = b->max_cand, mu = b->max_used > 0 ? b->max_used : 1;
 #define GET(field, type, count)                                                             \
   w->field = static_cast<type*>(pool_get(c, "fw_" #field, sizeof(type) * (count)));          \
@@ -1010,7 +1021,6 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   GET(consts, double, P * 4)
   GET(delta, double, P * mc * T * T)
   // (the solo form's packed copy - csrc/fsel.hip, FselDev::delta_pk - exists whenever avm_fsel_select_batch can choose that form: the rule is there)
-  const bool may_solo = T <= 39 && mc <= 512 && (P >= AVM_FSEL_SOLO_MIN || getenv("AVM_FSEL_SOLO"));
   GET(delta_pk, double, may_solo ? P * mc * (T * (T + 1) / 2) : 1)
   GET(ddiag, double, (may_solo && T > 30) ? P * mc * T : 1)
   GET(delta_u, double, P * mu * T * T)
@@ -1025,6 +1035,7 @@ int fsel_buffers(avm_ctx* c, const avm_fsel_batch* b, FselBuffers* w) {
   GET(pos, int32_t, 2 * P * mc)
   GET(nlive, int32_t, 2 * P)
   GET(sync, int32_t, FS_SYNC_INTS)
+  GET(kd, double, fsel_kd_doubles(*b))
 #undef GET
   return AVM_OK;
 }
@@ -1067,7 +1078,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     dout = *out;
   }
   FselBuffers w;
-  if ((rc = fsel_buffers(c, &d, &w)) != AVM_OK) return rc;
+  if ((rc = fsel_buffers(c, &d, &w, fsel_takes_solo(&d))) != AVM_OK) return rc;
   // Every frame's greedy rounds in ONE launch (csrc/fsel.hip, fsel_frame_kernel): 2 = a team of workgroups per XCD, the teams
   // take frames from a queue; 1 = one team over all XCDs (a single frame only); 0 = one launch per round.  A kernel that reports
   // a timed-out wait, or that did not finish every frame, is re-run one mode down, and the ctx stays there.
@@ -1085,12 +1096,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     if (e[0] >= '0' && e[0] <= '2') mode = std::min(mode, e[0] - '0');
   // 3 = one workgroup per frame with lazy evaluation (fsel_solo_kernel): what a batch of many frames takes - it has no waits between
   // workgroups, so it cannot time out and is never re-run.  AVM_FSEL_SOLO=0/1 overrides the batch-size rule (tests, measurements).
-  {
-    const bool can = d.max_cand <= 512 && 3 * d.horizon <= 39 && P >= 1;
-    bool solo = can && P >= AVM_FSEL_SOLO_MIN && !getenv("AVM_FSEL_FRAME");
-    if (const char* e = getenv("AVM_FSEL_SOLO")) solo = can && e[0] == '1';
-    if (solo) mode = 3;
-  }
+  if (fsel_takes_solo(&d)) mode = 3;
   c->last_fsel_mode = mode;
   int32_t* hsync = mode ? static_cast<int32_t*>(pinned_get(c, "f_sync", sizeof(int32_t) * 64)) : nullptr;
   if (mode && !hsync) mode = 0;
@@ -1256,7 +1262,9 @@ int avm_fsel_nn_depth(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, doub
   double* dd = mem == AVM_MEM_HOST ? static_cast<double*>(pool_get(c, "fi_nn", sizeof(double) * n)) : depth;
   if (!dd) return fail(c, AVM_ERR_HIP, "hipMalloc failed (nn depth)");
   HIPCHK(c, hipMemsetAsync(dd, 0, sizeof(double) * n, c->stream));
-  HIPCHK(c, launch_fsel_nn_depth(d, dd, c->stream));
+  double* kd = static_cast<double*>(pool_get(c, "fw_kd", sizeof(double) * fsel_kd_doubles(d)));
+  if (!kd) return fail(c, AVM_ERR_HIP, "hipMalloc failed (kd-tree)");
+  HIPCHK(c, launch_fsel_nn_depth(d, kd, dd, c->stream));
   if (mem == AVM_MEM_HOST) HIPCHK(c, hipMemcpyAsync(depth, dd, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return AVM_OK;
@@ -1276,7 +1284,7 @@ int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, d
     d = *batch;
   }
   FselBuffers w;
-  if ((rc = fsel_buffers(c, &d, &w)) != AVM_OK) return rc;
+  if ((rc = fsel_buffers(c, &d, &w, false)) != AVM_OK) return rc;
   const size_t P = batch->n_problems, N = 9 * ((size_t)batch->horizon + 1), T = 3 * (size_t)batch->horizon, mc = batch->max_cand;
   double* d_om = nullptr;
   if (omega) {

@@ -60,6 +60,7 @@ struct FselDev {
   int32_t* nlive;   // [P]
   double* omega_out;  // optional [P][N*N] (tests)
   avm_fsel_out out;
+  double* kd;         // [P][kd_stride(max_cloud)] the frame's kd-tree over its depth cloud (fsel_kdtree_kernel; searched by kd_depth)
 };
 
 AVM_DEV quat slerp_eigen(quat a, double t, quat b) {
@@ -82,50 +83,333 @@ AVM_DEV quat slerp_eigen(quat a, double t, quat b) {
 // Delta_ell position blocks of one feature (calcInfoFromFeatures), written as dense T x T.
 // cam[h] (h = 1..H): t_WC (3), R of q_WC^-1 (9), R of (q_WC * q_IC)^-1 (9)  => 21 doubles per h
 // front part: per-frame blocks C_h (Ch, 6 per h), W = (sum C_h)^-1 (Wm); false if the feature is seen in no future frame
-// WAVE: called by all 64 lanes of a wavefront for the same feature - the nearest-neighbour search is split over the lanes
-// findNNDepth (feature_selector.cpp:437-459): the depth of the cloud point nearest to (fx_, fy_) - exact 1-NN, first strictly
-// smaller distance wins (the lowest index among points at bit-identical distances; the reference's kd-tree takes whichever of those
-// its traversal meets first: tests/test_nanoflann_nn.py), 1.0 for an empty cloud.
-template <bool WAVE>
-AVM_DEV double nn_depth(const avm_fsel_batch& b, int p, double fx_, double fy_) {
-  double dep = 1.0;
-  const int ncl = b.n_cloud ? b.n_cloud[p] : 0;
-  if (ncl > 0) {
-    const double* cxy = b.cloud_xy + (size_t)p * b.max_cloud * 2;
-    int best = 0;
-    double bd = DBL_MAX;
-    if (WAVE) {
-      // lane l takes points l, l + 64, ...; then the lexicographic minimum of (distance, index) = the sequential loop's
-      // "first strictly smaller distance wins"
-      const int lane = threadIdx.x & 63;
-      best = ncl;
-      for (int i = lane; i < ncl; i += 64) {
-        const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
-        const double d = dx * dx + dy * dy;
-        if (d < bd) bd = d, best = i;
-      }
+// WAVE: called by all 64 lanes of a wavefront for the same feature - the leaves of the nearest-neighbour search are split over the lanes
+//
+// ---- findNNDepth (feature_selector.cpp:437-459): the reference's kd-tree, bit for bit -------------------------------------------
+// The reference asks nanoflann (vendored, vins_estimator/lib/nanoflann/nanoflann.hpp; KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<double>, ., 2>,
+// leaf_max_size 10, feature_selector.cpp:424-429) for the 1-NN of the candidate among the window's landmarks and uses that landmark's depth.
+// The search is exact, so WHICH point it returns only depends on the tree when several points are at bit-identical distances - and
+// then it is the one the traversal meets first (KNNResultSet::addPoint :175-202 replaces on a strictly smaller distance only).  That
+// order is part of the reference's behaviour (selected ids are compared bit-exact), so the tree is built here as nanoflann builds it:
+//   divideTree :857-907 - a range of <= 10 indices is a leaf; else middleSplit_ :909-958 picks the dimension of largest spread among
+//   those whose bounding-box span is within 1e-5 of the largest, cuts at the box's middle clamped to the points' range, planeSplit
+//   :969-1005 partitions the index range Hoare-style (< cut | == cut | > cut) and the split position is lim1 / lim2 / count / 2;
+//   divlow / divhigh of a node are the children's tightened boxes = max of the left points / min of the right points in the cut dimension;
+//   searchLevel :1346-1405 - nearer child first ((val - divlow) + (val - divhigh) < 0), the other one if mindistsq <= worst, a leaf's
+//   points in index-array order against the worst distance read at the leaf's entry; computeInitialDistances :1007-1026 from the root box.
+// fsel_kdtree_kernel builds it with one wavefront per frame (the partitions as ballot / prefix-count permutations: Hoare's swaps pair
+// the i-th misplaced index from the left with the i-th from the right, which is what the sequential loop does), kd_depth walks it
+// without a stack: the state of searchLevel's recursion along the current root-to-leaf path is a bit per level (near or far child),
+// and (mindistsq, dists[]) are functions of that path, recomputed on the way down - the same additions in the same order.
+// Arithmetic that decides comparisons is kept un-contracted (no FMA: the reference's x86 build has none).
+// Known-answer tests: tests/test_nanoflann_nn.py (16 928 queries answered by the reference's own header, 4 237 of them exact ties).
+struct KdNode {   // 32 bytes
+  int a, b;       // inner node: children; leaf: the range [a, b) of the permuted point arrays
+  int feat, pad;  // cut dimension (0 / 1); -1: leaf
+  double lo, hi;  // divlow, divhigh
+};
+constexpr int KD_HDR = 8;  // doubles: root box low0 high0 low1 high1 | n_nodes, max_depth (two ints) | -
+__host__ __device__ constexpr size_t kd_stride(int max_cloud) { return KD_HDR + (size_t)11 * max_cloud; }  // header | 2 mc nodes (4 doubles each) | xy[mc][2] | depth[mc], in tree order
+constexpr int KD_MAXW = 64;  // path words of 64 levels each beyond the first (a tree of n points is at most n - 10 deep)
+
+AVM_DEV double kd_wave_min(double v) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double od = __shfl_xor(bd, o, 64);
-        const int ob = __shfl_xor(best, o, 64);
-        if (od < bd || (od == bd && ob < best)) bd = od, best = ob;
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+AVM_DEV double kd_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// initKDTree (feature_selector.cpp:380-432, the buildIndex part): one wavefront per frame.  LDS: x[mc] y[mc] (doubles), vind[mc], two
+// work lists [mc] (ints), a stack of pending ranges.  A node's work depends on its own index range and the box handed down only, so
+// the larger child is parked and the smaller one taken first: the stack stays below log2(n) entries whatever the tree's shape.
+struct KdPending {
+  int l, r, slot, depth;
+  double bb[4];
+};
+constexpr int KD_STACK = 40;
+__global__ __launch_bounds__(64) void fsel_kdtree_kernel(FselDev A) {
+#pragma clang fp contract(off)
+  FS_TABLES_GUARD(A);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const avm_fsel_batch& b = A.b;
+  const int p = blockIdx.x, lane = threadIdx.x, mc = b.max_cloud;
+  const int n = b.n_cloud ? b.n_cloud[p] : 0;
+  if (n <= 0) return;  // (findNNDepth answers 1.0 without a tree)
+  double* X = reinterpret_cast<double*>(smem_raw);
+  double* Y = X + mc;
+  KdPending* stk = reinterpret_cast<KdPending*>(Y + mc);
+  int* vi = reinterpret_cast<int*>(stk + KD_STACK);
+  int* lml = vi + mc;   // positions of the misplaced indices of the left part, ascending
+  int* lmr = lml + mc;  // ... of the right part, ascending
+  double* kd = A.kd + (size_t)p * kd_stride(mc);
+  KdNode* nodes = reinterpret_cast<KdNode*>(kd + KD_HDR);
+  const double* cxy = b.cloud_xy + (size_t)p * mc * 2;
+  double lo0 = DBL_MAX, hi0 = -DBL_MAX, lo1 = DBL_MAX, hi1 = -DBL_MAX;
+  for (int i = lane; i < n; i += 64) {
+    const double x = cxy[2 * i], y = cxy[2 * i + 1];
+    X[i] = x, Y[i] = y, vi[i] = i;
+    lo0 = fmin(lo0, x), hi0 = fmax(hi0, x), lo1 = fmin(lo1, y), hi1 = fmax(hi1, y);
+  }
+  lo0 = kd_wave_min(lo0), hi0 = kd_wave_max(hi0), lo1 = kd_wave_min(lo1), hi1 = kd_wave_max(hi1);  // computeBoundingBox
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto coord = [&](int pos, int dim) { return dim == 0 ? X[vi[pos]] : Y[vi[pos]]; };
+  // min / max of one coordinate over the index range [l, r)
+  auto minmax = [&](int l, int r, int dim, double& mn, double& mx) {
+    double a = DBL_MAX, c = -DBL_MAX;
+    for (int q = l + lane; q < r; q += 64) {
+      const double v = coord(q, dim);
+      a = fmin(a, v), c = fmax(c, v);
+    }
+    mn = kd_wave_min(a), mx = kd_wave_max(c);
+  };
+  // one pass of planeSplit over [l, l + cnt): indices whose coordinate is < cut (strict) or <= cut to the front; returns how many
+  auto partition = [&](int l, int cnt, int dim, double cut, bool strict) {
+    int nl = 0;
+    for (int base = 0; base < cnt; base += 64) {
+      const int q = base + lane;
+      const double v = q < cnt ? coord(l + q, dim) : 0.0;
+      nl += __popcll(__ballot(q < cnt && (strict ? v < cut : v <= cut)));
+    }
+    int nml = 0, nmr = 0;
+    for (int base = 0; base < cnt; base += 64) {
+      const int q = base + lane;
+      const double v = q < cnt ? coord(l + q, dim) : 0.0;
+      const bool f = q < cnt && (strict ? v < cut : v <= cut);
+      const bool ml = q < cnt && !f && q < nl, mr = f && q >= nl;
+      const unsigned long long bl = __ballot(ml), br = __ballot(mr), lt = (1ull << lane) - 1ull;
+      if (ml) lml[nml + __popcll(bl & lt)] = q;
+      if (mr) lmr[nmr + __popcll(br & lt)] = q;
+      nml += __popcll(bl), nmr += __popcll(br);
+    }
+    sync();
+    // Hoare's swaps: the i-th misplaced index from the left with the i-th from the right (nml == nmr)
+    for (int i = lane; i < nml; i += 64) {
+      const int qa = l + lml[i], qb = l + lmr[nml - 1 - i];
+      const int t = vi[qa];
+      vi[qa] = vi[qb], vi[qb] = t;
+    }
+    sync();
+    return nl;
+  };
+  int nn = 1, sp = 0, maxdepth = 0;
+  int l = 0, r = n, slot = 0, depth = 0;
+  double bb[4] = {lo0, hi0, lo1, hi1};
+  for (;;) {
+    const int cnt = r - l;
+    maxdepth = max(maxdepth, depth);
+    if (cnt <= 10) {  // a leaf
+      if (lane == 0) nodes[slot] = KdNode{l, r, -1, 0, 0.0, 0.0};
+      if (sp == 0) break;
+      sp--;
+      l = stk[sp].l, r = stk[sp].r, slot = stk[sp].slot, depth = stk[sp].depth;
+#pragma unroll
+      for (int k = 0; k < 4; k++) bb[k] = stk[sp].bb[k];
+      continue;
+    }
+    // middleSplit_
+    const double EPS = 0.00001;
+    const double span0 = bb[1] - bb[0], span1 = bb[3] - bb[2];
+    double max_span = span0;
+    if (span1 > max_span) max_span = span1;
+    double max_spread = -1.0, mn = 0, mx = 0;
+    int cutfeat = 0;
+    if (span0 > (1 - EPS) * max_span) {
+      double a, c;
+      minmax(l, r, 0, a, c);
+      const double spread = c - a;
+      if (spread > max_spread) cutfeat = 0, max_spread = spread;
+      mn = a, mx = c;
+    }
+    if (span1 > (1 - EPS) * max_span) {
+      double a, c;
+      minmax(l, r, 1, a, c);
+      const double spread = c - a;
+      if (spread > max_spread) cutfeat = 1, max_spread = spread, mn = a, mx = c;
+    }
+    if (max_spread < 0) minmax(l, r, 0, mn, mx);  // (no dimension passed the test: NaN boxes; cutfeat stays 0 like the reference's)
+    const double split_val = (bb[2 * cutfeat] + bb[2 * cutfeat + 1]) / 2;
+    const double cutval = split_val < mn ? mn : (split_val > mx ? mx : split_val);
+    const int lim1 = partition(l, cnt, cutfeat, cutval, true);
+    const int lim2 = lim1 + partition(l + lim1, cnt - lim1, cutfeat, cutval, false);
+    int idx = lim1 > cnt / 2 ? lim1 : (lim2 < cnt / 2 ? lim2 : cnt / 2);
+    idx = min(max(idx, 1), cnt - 1);  // (both children non-empty: holds for every finite cloud, keeps the loop finite for any other)
+    double dl, dh, tmp;
+    minmax(l, l + idx, cutfeat, tmp, dl);  // divlow: the left child's tightened box, high side
+    minmax(l + idx, r, cutfeat, dh, tmp);  // divhigh: the right child's, low side
+    const int c1 = nn, c2 = nn + 1;
+    nn += 2;
+    if (lane == 0) nodes[slot] = KdNode{c1, c2, cutfeat, 0, dl, dh};
+    // children: (l, l + idx) with the box cut at high = cutval, (l + idx, r) with low = cutval; the smaller one now, the other parked
+    const bool left_now = idx <= cnt - idx;
+    if (lane == 0 && sp < KD_STACK) {
+      KdPending& e = stk[sp];
+      e.l = left_now ? l + idx : l, e.r = left_now ? r : l + idx, e.slot = left_now ? c2 : c1, e.depth = depth + 1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) e.bb[k] = bb[k];
+      e.bb[left_now ? 2 * cutfeat : 2 * cutfeat + 1] = cutval;
+    }
+    sp++;
+    sync();
+    if (left_now) r = l + idx, bb[2 * cutfeat + 1] = cutval, slot = c1;
+    else l = l + idx, bb[2 * cutfeat] = cutval, slot = c2;
+    depth++;
+  }
+  // header + the points and their depths in tree order (a leaf reads consecutive entries)
+  if (lane == 0) {
+    kd[0] = lo0, kd[1] = hi0, kd[2] = lo1, kd[3] = hi1;
+    int* hi = reinterpret_cast<int*>(kd + 4);
+    hi[0] = nn, hi[1] = maxdepth;
+  }
+  double* pxy = kd + KD_HDR + 8 * (size_t)mc;
+  double* pdep = pxy + 2 * (size_t)mc;
+  const double* cdep = b.cloud_depth + (size_t)p * mc;
+  for (int i = lane; i < n; i += 64) {
+    const int o = vi[i];
+    pxy[2 * i] = X[o], pxy[2 * i + 1] = Y[o], pdep[i] = cdep[o];
+  }
+}
+size_t fsel_kdtree_lds_bytes(int max_cloud) { return (size_t)max_cloud * (2 * sizeof(double) + 3 * sizeof(int)) + KD_STACK * sizeof(KdPending) + 16; }
+// the kd-tree of every frame's depth cloud -> kd[P][kd_stride(max_cloud)] (what the setup kernel and fsel_nn_depth_kernel search)
+hipError_t launch_fsel_kdtree(const FselDev& d, hipStream_t stream) {
+  const avm_fsel_batch& b = d.b;
+  if (b.n_problems == 0 || !b.n_cloud || b.max_cloud <= 0) return hipSuccess;
+  if (b.max_cloud > FS_MAX_CLOUD) return hipErrorInvalidValue;
+  const size_t lds = fsel_kdtree_lds_bytes(b.max_cloud);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fsel_kdtree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fsel_kdtree_kernel, dim3(b.n_problems), dim3(64), lds, stream, d);
+  return hipGetLastError();
+}
+
+
+// findNeighbors + searchLevel for ONE query by W cooperating lanes (1, 16 or 64 consecutive lanes that enter together with the same
+// query): everything is uniform over the group except the leaf scan, where lane i of the group takes the leaf's i-th point.
+// Returns findNNDepth's value: the depth of the point the reference's search returns (ret_index stays 0 if nothing is ever closer
+// than the initial worst distance, e.g. for a NaN query: then the depth of cloud point 0), 1.0 for an empty cloud.
+template <int W>
+AVM_DEV double kd_depth(const avm_fsel_batch& b, const double* kdall, int p, double qx, double qy) {
+#pragma clang fp contract(off)
+  const int n = b.n_cloud ? b.n_cloud[p] : 0;
+  if (n <= 0) return 1.0;
+  const int mc = b.max_cloud, gl = threadIdx.x & (W - 1);
+  const double* kd = kdall + (size_t)p * kd_stride(mc);
+  const KdNode* nodes = reinterpret_cast<const KdNode*>(kd + KD_HDR);
+  const double* pxy = kd + KD_HDR + 8 * (size_t)mc;
+  const double* pdep = pxy + 2 * (size_t)mc;
+  // computeInitialDistances
+  double di0 = 0.0, di1 = 0.0, dsq = 0.0;
+  if (qx < kd[0]) di0 = (qx - kd[0]) * (qx - kd[0]), dsq += di0;
+  if (qx > kd[1]) di0 = (qx - kd[1]) * (qx - kd[1]), dsq += di0;
+  if (qy < kd[2]) di1 = (qy - kd[2]) * (qy - kd[2]), dsq += di1;
+  if (qy > kd[3]) di1 = (qy - kd[3]) * (qy - kd[3]), dsq += di1;
+  double worst = DBL_MAX, ans = b.cloud_depth[(size_t)p * mc];
+  // the current root-to-leaf path: bit l set = the FAR child was taken at level l (its near child is done); levels >= plen: near
+  unsigned long long path0 = 0;
+  unsigned long long pathx[KD_MAXW];  // levels 64 .. (touched only by trees deeper than 64: private memory); words [0, nx) are in use
+  int plen = 0, nx = 0;
+  auto bit = [&](int l) -> bool { return l < 64 ? (path0 >> l) & 1ull : (pathx[min(l >> 6, KD_MAXW) - 1] >> (l & 63)) & 1ull; };
+  for (;;) {
+    // down: along the recorded path, then near children to a leaf
+    int node = 0, lvl = 0;
+    double mind = dsq, d0 = di0, d1 = di1;
+    KdNode nd = nodes[0];
+    while (nd.feat >= 0) {
+      const double val = nd.feat ? qy : qx;
+      const bool near1 = (val - nd.lo) + (val - nd.hi) < 0.0;
+      if (lvl < plen && bit(lvl)) {
+        const double cut = near1 ? (val - nd.hi) * (val - nd.hi) : (val - nd.lo) * (val - nd.lo);
+        const double dst = nd.feat ? d1 : d0;
+        mind = mind + cut - dst;
+        if (nd.feat) d1 = cut; else d0 = cut;
+        node = near1 ? nd.b : nd.a;
+      } else {
+        node = near1 ? nd.a : nd.b;
       }
-      if (best >= ncl) best = 0;  // (every distance was NaN / DBL_MAX: the sequential loop keeps index 0)
-    } else {
-      for (int i = 0; i < ncl; i++) {
-        const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
+      lvl++;
+      nd = nodes[node];
+    }
+    // the leaf: points in index-array order against the worst distance at entry; a strictly smaller distance replaces
+    {
+      const int cnt = nd.b - nd.a;
+      if (W == 1) {
+        const double wl = worst;
+        for (int i = 0; i < cnt; i++) {
+          const double dx = qx - pxy[2 * (nd.a + i)], dy = qy - pxy[2 * (nd.a + i) + 1];
+          const double d = dx * dx + dy * dy;
+          if (d < wl && d < worst) worst = d, ans = pdep[nd.a + i];
+        }
+      } else {
+        const bool in = gl < cnt;
+        const int q = nd.a + min(gl, max(cnt - 1, 0));
+        const double dx = qx - pxy[2 * q], dy = qy - pxy[2 * q + 1];
         const double d = dx * dx + dy * dy;
-        if (d < bd) bd = d, best = i;
+        double bd = (in && d < worst) ? d : DBL_MAX;
+        int bi = (in && d < worst) ? gl : 1 << 20;
+#pragma unroll
+        for (int o = W / 2; o > 0; o >>= 1) {
+          const double od = __shfl_xor(bd, o, 64);
+          const int ob = __shfl_xor(bi, o, 64);
+          if (ob < (1 << 20) && (bi >= (1 << 20) || od < bd || (od == bd && ob < bi))) bd = od, bi = ob;
+        }
+        if (bi < (1 << 20)) worst = bd, ans = pdep[nd.a + bi];
       }
     }
-    dep = b.cloud_depth[(size_t)p * b.max_cloud + best];
+    // up: the deepest level of the path whose far child is still pending and passes mindistsq <= worst (the others below it fail
+    // now, which is when the recursion would test them)
+    int take = -1;
+    {
+      int node2 = 0;
+      double mind2 = dsq, e0 = di0, e1 = di1;
+      for (int l2 = 0; l2 < lvl; l2++) {
+        const KdNode m = nodes[node2];
+        const double val = m.feat ? qy : qx;
+        const bool near1 = (val - m.lo) + (val - m.hi) < 0.0;
+        const double cut = near1 ? (val - m.hi) * (val - m.hi) : (val - m.lo) * (val - m.lo);
+        const double mo = mind2 + cut - (m.feat ? e1 : e0);
+        if (l2 < plen && bit(l2)) {
+          mind2 = mo;
+          if (m.feat) e1 = cut; else e0 = cut;
+          node2 = near1 ? m.b : m.a;
+        } else {
+          if (mo <= worst) take = l2;
+          node2 = near1 ? m.a : m.b;
+        }
+      }
+    }
+    if (take < 0) break;
+    if (take < 64) {
+      path0 = (path0 & ((1ull << take) - 1ull)) | (1ull << take);
+      nx = 0;
+    } else {
+      const int w = min(take >> 6, KD_MAXW) - 1;
+      while (nx <= w) pathx[nx++] = 0ull;
+      pathx[w] = (pathx[w] & ((1ull << (take & 63)) - 1ull)) | (1ull << (take & 63));
+      nx = w + 1;
+    }
+    plen = take + 1;
   }
-  return dep;
+  return ans;
 }
 
 template <bool WAVE>
-AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* Ch /*13*6*/, double* Wm /*9*/) {
-  const double dep = nn_depth<WAVE>(b, p, fx_, fy_);
+AVM_DEV double nn_depth(const avm_fsel_batch& b, const double* kd, int p, double fx_, double fy_) {
+  return kd_depth<WAVE ? 64 : 1>(b, kd, p, fx_, fy_);
+}
+
+template <bool WAVE>
+AVM_DEV bool feature_front(const avm_fsel_batch& b, const double* kd, int p, const double* cam, double fx_, double fy_, int H, double* Ch /*13*6*/, double* Wm /*9*/) {
+  const double dep = nn_depth<WAVE>(b, kd, p, fx_, fy_);
   const double nrm = sqrt(fx_ * fx_ + fy_ * fy_ + 1.0);
   const v3 fn = mk3(fx_ / nrm, fy_ / nrm, 1.0 / nrm);  // feature.normalized()
   const v3 feat = dep * fn;
@@ -189,34 +473,15 @@ AVM_DEV bool feature_front(const avm_fsel_batch& b, int p, const double* cam, do
 // feature_front for FOUR candidates per wavefront at once (round 4): candidate u on the 16-lane row u, horizon frame h = 1 + (lane & 15) on
 // its lanes.  The frames of a candidate are independent until E = sum_h C_h: every lane does ONE frame's projection, visibility test and C_h
 // (the one-candidate form did the H of them one after the other on 64 identical lanes), the nearest cloud point is searched by the row's 16
-// lanes, C_h goes to the row's LDS record wlu[6 h' + k] (h' = h - 1; zeros for a frame that does not see the feature, as before), and E is
+// lanes (kd_depth<16>), C_h goes to the row's LDS record wlu[6 h' + k] (h' = h - 1; zeros for a frame that does not see the feature, as before), and E is
 // summed from there IN THE SAME ORDER as feature_front sums it (frames 2 .. H, then frame 1) - the Deltas are bit-identical to the
 // one-candidate form's.  Returns (to every lane of the row) whether the candidate is visible from a second frame; W at wlu[6 H ..].
-AVM_DEV bool feature_front4(const avm_fsel_batch& b, int p, const double* cam, int k, bool have, int H, double* wlu) {
+AVM_DEV bool feature_front4(const avm_fsel_batch& b, const double* kd, int p, const double* cam, int k, bool have, int H, double* wlu) {
   const int lane = threadIdx.x & 63, hl = lane & 15, h = hl + 1;
   const double* xy = b.cand_xy + ((size_t)p * b.max_cand + (have ? k : 0)) * 2;
   const double fx_ = xy[0], fy_ = xy[1];
-  // findNNDepth over the row's 16 lanes: the lexicographic minimum of (distance, index), as nn_depth<true>
-  double dep = 1.0;
-  const int ncl = b.n_cloud ? b.n_cloud[p] : 0;
-  if (ncl > 0) {
-    const double* cxy = b.cloud_xy + (size_t)p * b.max_cloud * 2;
-    int best = ncl;
-    double bd = DBL_MAX;
-    for (int i = hl; i < ncl; i += 16) {
-      const double dx = fx_ - cxy[2 * i], dy = fy_ - cxy[2 * i + 1];
-      const double d = dx * dx + dy * dy;
-      if (d < bd) bd = d, best = i;
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const double od = __shfl_xor(bd, o, 64);
-      const int ob = __shfl_xor(best, o, 64);
-      if (od < bd || (od == bd && ob < best)) bd = od, best = ob;
-    }
-    if (best >= ncl) best = 0;
-    dep = b.cloud_depth[(size_t)p * b.max_cloud + best];
-  }
+  // findNNDepth by the row's 16 lanes (kd_depth<16>: the reference's kd-tree search, a leaf's points across the lanes)
+  const double dep = kd_depth<16>(b, kd, p, fx_, fy_);
   const double nrm = sqrt(fx_ * fx_ + fy_ * fy_ + 1.0);
   const v3 fn = mk3(fx_ / nrm, fy_ / nrm, 1.0 / nrm);
   const v3 feat = dep * fn;
@@ -308,9 +573,9 @@ AVM_DEV void feature_pair(const double* Ch, const double* Wm, int i, int j, int 
 }
 
 // Delta_ell of one feature by one thread (the used subset; the candidates go one per wavefront, see fsel_setup_kernel)
-AVM_DEV bool feature_delta(const avm_fsel_batch& b, int p, const double* cam, double fx_, double fy_, int H, double* out /*T*T*/) {
+AVM_DEV bool feature_delta(const avm_fsel_batch& b, const double* kd, int p, const double* cam, double fx_, double fy_, int H, double* out /*T*T*/) {
   double Ch[13 * 6], Wm[9];
-  if (!feature_front<false>(b, p, cam, fx_, fy_, H, Ch, Wm)) return false;
+  if (!feature_front<false>(b, kd, p, cam, fx_, fy_, H, Ch, Wm)) return false;
   for (int j = 1; j <= H; ++j)
     for (int i = j; i <= H; ++i) feature_pair(Ch, Wm, i, j, 3 * H, out);
   return true;
@@ -426,7 +691,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A, int slice_
     const int k0 = ((slice - 1) * (FS_NT / 64) + wv) * FS_CPW;
     if (k0 >= b.n_cand[p]) return;  // (wave-uniform)
     const int ku = k0 + (lane >> 4);
-    const bool oku = feature_front4(b, p, cam, ku, ku < b.n_cand[p], H, wl0 + (lane >> 4) * WS);
+    const bool oku = feature_front4(b, A.kd, p, cam, ku, ku < b.n_cand[p], H, wl0 + (lane >> 4) * WS);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -569,7 +834,7 @@ __global__ __launch_bounds__(FS_NT) void fsel_setup_kernel(FselDev A, int slice_
   const int nu = b.n_used ? b.n_used[p] : 0;
   for (int k = t; k < nu; k += FS_NT) {
     const double* xy = b.used_xy + ((size_t)p * b.max_used + k) * 2;
-    A.valid_u[(size_t)p * b.max_used + k] = feature_delta(b, p, cam, xy[0], xy[1], H, A.delta_u + ((size_t)p * b.max_used + k) * T * T);
+    A.valid_u[(size_t)p * b.max_used + k] = feature_delta(b, A.kd, p, cam, xy[0], xy[1], H, A.delta_u + ((size_t)p * b.max_used + k) * T * T);
   }
   __syncthreads();
   // Omega += sum of Delta_used (ascending id order = input order)
@@ -1595,9 +1860,15 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     }
     const double ld_nn = A.consts[(size_t)p * 4], ub_nn = A.consts[(size_t)p * 4 + 1];
     __syncthreads();
-    if (wv == 0) {  // logdet of the frame's first C: the same evaluation with p = 0
+    if (wv == 0) {  // logdet of the frame's first C: the same evaluation with p = 0 - on the Delta of the first VALID candidate (the setup
+                    // kernel writes delta_pk for those only: 0 x stale memory could be 0 x NaN)
+      int first = -1;
+      for (int c0 = 0; c0 < MAXC && first < 0; c0 += 64) {
+        const unsigned long long m = __ballot(s_alive[c0 + lane] != 0);
+        if (m) first = c0 + __ffsll((long long)m) - 1;
+      }
       double ld0, ub0;
-      const bool ok0 = fsel_logdet4<T, BS, NB, false, 2>(sC, sdpp, Dk, 0.0, &ld0, &ub0);
+      const bool ok0 = fsel_logdet4<T, BS, NB, false, 2>(sC, sdpp, Dk + (size_t)max(first, 0) * (T * (T + 1) / 2), 0.0, &ld0, &ub0);
       if (lane == 0) s_g0 = ok0 ? (ld_nn + 2.0 * ld0) : __builtin_nan("");
     }
     __syncthreads();
@@ -1639,8 +1910,8 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     // shadows the winner, scored or not.  The bounds of the unscored candidates are not computed every round.  What is: an estimate ua of
     // every live candidate's bound MINUS the part all candidates share, sum_d log1p(p Delta_dd / dpp_d), with a rigorous error bar ue
     // (a term below 0.01 by its series, remainder < x^4 / 4; above, by the single-precision logarithm, 4e-7 of the term).  Two bounds can
-    // only be BIT-equal when the estimates are closer than the two error bars plus the rounding of the exact evaluation (1e-11 on values
-    // of a few hundred); only then the unscored candidate gets its exact bound, by the same function, to be compared.
+    // only be BIT-equal when the estimates are closer than the two error bars plus the rounding of the exact evaluation (64 T ulps of
+    // the bound: 1.3e-10 on values of a few hundred at T = 30); only then the unscored candidate gets its exact bound, by the same function, to be compared.
     auto pick = [&](bool live, bool scored, double* fwin) -> int {
       constexpr int MAXSH = 8;
       int sh[MAXSH], nsh = 0;
@@ -1675,7 +1946,8 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
         *fwin = bf;
         FS_SOLO_Q(0)
         if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;  // (more than MAXSH chained collisions in one round: keep the last winner)
-        const bool flag = live && !scored && c > bi && !(fabs(s_ua[c] - s_ua[bi]) > s_ue[c] + s_ue[bi] + 1e-11);  // (an estimate that is not finite: compare the exact bounds)
+        const double slack = 64.0 * DBL_EPSILON * T * fmax(fabs(s_u[bi]), 1.0);  // (rounding of the two exact bounds: it grows with their size)
+        const bool flag = live && !scored && c > bi && !(fabs(s_ua[c] - s_ua[bi]) > s_ue[c] + s_ue[bi] + slack);  // (an estimate that is not finite: compare the exact bounds)
         n_pass++;
         if (wg_or(flag)) {
           n_flag++;
@@ -1867,9 +2139,12 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
   d.C = w.C, d.dpp = w.dpp, d.consts = w.consts, d.delta = w.delta, d.delta_u = w.delta_u, d.valid = w.valid, d.valid_u = w.valid_u;
   d.black = w.black, d.fval = w.fval, d.ub = w.ub, d.nsel = w.nsel, d.done = w.done, d.omega_out = omega_out, d.out = out;
   d.live = w.live, d.pos = w.pos, d.nlive = w.nlive;
+  d.kd = w.kd;
+  hipError_t e = launch_fsel_kdtree(d, stream);  // initKDTree: the setup kernel's findNNDepth walks it
+  if (e != hipSuccess) return e;
   const int H = b.horizon, T = 3 * H;
   const size_t lds = fsel_setup_lds_bytes(H);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fsel_setup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(fsel_setup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int cand_per_wg = (FS_NT / 64) * FS_CPW;
   const int nslices = (b.max_cand + cand_per_wg - 1) / cand_per_wg;
@@ -2030,20 +2305,28 @@ __global__ __launch_bounds__(64) void fsel_build_cloud_kernel(avm_window_batch B
 }
 
 // B8, second half as a parity surface: findNNDepth of every candidate, one wavefront per (frame, candidate) - the search the setup
-// kernel runs inside calcInfoFromFeatures (nn_depth<true>)
-__global__ __launch_bounds__(256) void fsel_nn_depth_kernel(avm_fsel_batch b, double* depth_out) {
+// kernel runs inside calcInfoFromFeatures - in all three of its forms: by a whole wavefront, by a 16-lane row (the candidates' slices:
+// feature_front4) and by one thread (the used features: feature_delta).  They must agree bit for bit; a disagreement is reported as NaN.
+__global__ __launch_bounds__(256) void fsel_nn_depth_kernel(avm_fsel_batch b, const double* kd, double* depth_out) {
   const int p = blockIdx.y, cnd = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cnd >= b.n_cand[p]) return;  // (wave-uniform)
   const double* xy = b.cand_xy + ((size_t)p * b.max_cand + cnd) * 2;
-  const double d = nn_depth<true>(b, p, xy[0], xy[1]);
-  if ((threadIdx.x & 63) == 0) depth_out[(size_t)p * b.max_cand + cnd] = d;
+  const double d = kd_depth<64>(b, kd, p, xy[0], xy[1]);
+  const double d16 = kd_depth<16>(b, kd, p, xy[0], xy[1]), d1 = kd_depth<1>(b, kd, p, xy[0], xy[1]);
+  const bool same = __double_as_longlong(d16) == __double_as_longlong(d) && __double_as_longlong(d1) == __double_as_longlong(d);
+  if ((threadIdx.x & 63) == 0) depth_out[(size_t)p * b.max_cand + cnd] = __all(same) ? d : __longlong_as_double(0x7ff8000000000000ll);
 }
 
-hipError_t launch_fsel_nn_depth(const avm_fsel_batch& b, double* depth_out, hipStream_t stream) {
+hipError_t launch_fsel_nn_depth(const avm_fsel_batch& b, double* kd, double* depth_out, hipStream_t stream) {
   if (b.n_problems == 0 || b.max_cand == 0) return hipSuccess;
-  hipLaunchKernelGGL(fsel_nn_depth_kernel, dim3((b.max_cand + 3) / 4, b.n_problems), dim3(256), 0, stream, b, depth_out);
+  FselDev d{};
+  d.b = b, d.kd = kd, d.vflag = nullptr;
+  hipError_t e = launch_fsel_kdtree(d, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fsel_nn_depth_kernel, dim3((b.max_cand + 3) / 4, b.n_problems), dim3(256), 0, stream, b, kd, depth_out);
   return hipGetLastError();
 }
+size_t fsel_kd_doubles(const avm_fsel_batch& b) { return (size_t)b.n_problems * kd_stride(b.max_cloud > 0 ? b.max_cloud : 0) + 8; }
 
 hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,
                                    double* cloud_xy, double* cloud_depth, hipStream_t stream) {

@@ -76,8 +76,10 @@ struct EvalArgs {
 
 // device work buffers of the feature selector (owned by the ctx)
 constexpr int FS_SYNC_INTS = 64 + 16 * 32 + 16 * 2 * 2 * 512 * 4;  // header, 16 team headers, per team (fValue, ub) x two parities x 512 16-byte records
+constexpr int FS_MAX_CLOUD = 4096;  // depth-cloud points per frame the kd-tree builder has LDS for (28 bytes each; the reference's cloud is the window's <= 150 landmarks)
 struct FselBuffers {
   double *C, *dpp, *consts, *delta, *delta_pk, *ddiag, *delta_u, *fval, *ub;
+  double* kd;  // [P][8 + 11 max_cloud] the frames' kd-trees over their depth clouds (csrc/fsel.hip, fsel_kdtree_kernel)
   int32_t *valid, *valid_u, *black, *nsel, *done, *live, *pos, *nlive;
   int32_t* sync;  // [FS_SYNC_INTS] slot counter / failure flag / cycle trace / per-slot records of the single-frame kernel (csrc/fsel.hip)
 };
@@ -161,7 +163,8 @@ hipError_t launch_fsel(const avm_fsel_batch& b, const FselBuffers& w, const avm_
 bool fsel_horizon_supported(int H);
 hipError_t launch_fsel_build_cloud(const avm_window_batch& b, const double* k1_pos, const double* k1_quat, int max_cloud, int32_t* n_cloud,
                                    double* cloud_xy, double* cloud_depth, hipStream_t stream);
-hipError_t launch_fsel_nn_depth(const avm_fsel_batch& b, double* depth_out, hipStream_t stream);
+hipError_t launch_fsel_nn_depth(const avm_fsel_batch& b, double* kd, double* depth_out, hipStream_t stream);
+size_t fsel_kd_doubles(const avm_fsel_batch& b);  // doubles of FselBuffers::kd / the kd argument above for this batch
 hipError_t launch_fsel_horizon_imu(const avm_fsel_horizon_in& in, double* hor_pos, double* hor_quat, hipStream_t stream);
 hipError_t launch_triangulate(const avm_window_batch& b, double init_depth, hipStream_t stream);
 hipError_t launch_imu_propagate(const avm_window_batch& b, const double* g, hipStream_t stream);

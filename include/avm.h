@@ -446,11 +446,13 @@ int avm_fsel_select(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* frame, int3
 int avm_fsel_fallback_stats(const avm_ctx* ctx, int64_t out[4]);
 
 /* B8, second half as a parity surface: FeatureSelector::findNNDepth (feature_selector.cpp:437-459) for every candidate of every
- * frame - the depth of the cloud point nearest to the candidate on the normalized plane (exact 1-NN, squared Euclidean distance
- * as nanoflann's L2_Simple_Adaptor, feature_selector.h:143; 1.0 for an empty cloud, feature_selector.cpp:444).  depth
- * [P][max_cand] (entries beyond n_cand: 0).  The same search runs inside avm_fsel_select_batch / avm_fsel_information; this
- * entry exists so that it can be checked against the reference's own nanoflann (tests/golden/nanoflann_nn.npz).  Among cloud
- * points at bit-identical distances the lowest index wins here; nanoflann takes the one its kd-tree traversal meets first. */
+ * frame - the depth of the cloud point the reference's kd-tree search returns for the candidate on the normalized plane (exact
+ * 1-NN, squared Euclidean distance as nanoflann's L2_Simple_Adaptor, feature_selector.h:143; 1.0 for an empty cloud,
+ * feature_selector.cpp:444).  depth [P][max_cand] (entries beyond n_cand: 0).  The same search runs inside
+ * avm_fsel_select_batch / avm_fsel_information; this entry exists so that it can be checked against the reference's own nanoflann
+ * (tests/golden/nanoflann_nn.npz, nanoflann_nn2.npz).  Round 5: the tree is built and walked as nanoflann builds and walks it
+ * (csrc/fsel.hip: fsel_kdtree_kernel, kd_depth), so among cloud points at bit-identical distances the answer is nanoflann's too - the
+ * point its traversal meets first; every query of the two fixtures is answered bit for bit.  max_cloud <= 4096 (the tree is built in LDS). */
 int avm_fsel_nn_depth(avm_ctx* ctx, avm_mem mem, const avm_fsel_batch* batch, double* depth);
 
 /* B5/B6 only: Omega_kkH (+prior) [P][N][N] and compact Delta_ell position blocks

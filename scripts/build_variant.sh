@@ -9,12 +9,13 @@ which=${@:-base x tp}
 out=../../build/variants; mkdir -p $out/$name
 make -s -j4 >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -mllvm -sink-insts-to-avoid-spills"
+IPRA=${IPRA--mllvm -enable-ipra -fno-optimize-sibling-calls}   # (as csrc/Makefile: base and tp builds; IPRA= switches it off)
 cp window_solve.o window_solve_x.o window_solve_tp.o $out/$name/
 for w in $which; do
   case $w in
-    base) /opt/rocm/bin/hipcc $FLAGS $extra -c window_solve.hip -o $out/$name/window_solve.o & ;;
+    base) /opt/rocm/bin/hipcc $FLAGS $IPRA $extra -c window_solve.hip -o $out/$name/window_solve.o & ;;
     x) /opt/rocm/bin/hipcc $FLAGS $extra -DAVM_X=1 -c window_solve.hip -o $out/$name/window_solve_x.o & ;;
-    tp) /opt/rocm/bin/hipcc $FLAGS $extra -DAVM_TP=1 -c window_solve.hip -o $out/$name/window_solve_tp.o & ;;
+    tp) /opt/rocm/bin/hipcc $FLAGS $IPRA $extra -DAVM_TP=1 -c window_solve.hip -o $out/$name/window_solve_tp.o & ;;
   esac
 done
 wait
