@@ -271,7 +271,7 @@ def default_options() -> Options:
     o.marg_eps = 1e-8
     o.tr, o.row = 0.0, 480.0  # global shutter (euroc_config.yaml:66), image_height 480
     o.max_solver_time_s = 0.0  # no wall-clock cap (estimator.cpp:803-806 sets SOLVER_TIME; off for parity and the bench)
-    o.marg_noise_rel = 1e-16   # the eigenvalue clamp also tests against the rounding noise of the eigenvector's variables (0: reference-literal)
+    o.marg_noise_rel = 1e-18   # the eigenvalue clamp also tests against the rounding noise of the eigenvector's variables (0: reference-literal)
     return o
 
 

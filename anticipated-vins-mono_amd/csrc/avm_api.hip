@@ -80,6 +80,7 @@ struct avm_ctx {
   hipEvent_t ev[8];
   std::map<std::string, float> last_ms;
   int last_fsel_mode = -1;  // the form the last avm_fsel_select_batch took (3: fsel_solo_kernel)
+  int64_t last_fsel_evals = -1;  // candidate evaluations the last select executed on the device (solo form: counted by the kernel; else -1)
   int fsel_frame_mode = 2;  // how a single-frame select runs (avm_fsel_select_batch); AVM_FSEL_FRAME=0/1/2 caps it
   ncclComm_t comm = nullptr;  // avm_comm_init
   int comm_ranks = 0, comm_rank = 0;
@@ -390,7 +391,8 @@ int avm_default_options(avm_options* o) {
   o->marg_eps = 1e-8;
   o->tr = 0.0, o->row = 480.0;  // global shutter (config/euroc/euroc_config.yaml:66), image_height
   o->max_solver_time_s = 0.0;   // no wall-clock cap (the host sets SOLVER_TIME, estimator.cpp:803-806; avm_host.hpp does)
-  o->marg_noise_rel = 1e-16;    // the eigenvalue clamp also tests against the rounding noise of the eigenvector's variables (0: literal)
+  o->marg_noise_rel = 1e-18;    // the eigenvalue clamp also tests against the rounding noise of the eigenvector's variables (0: literal).  Round 5: 1e-18
+                                // (was 1e-16, which dropped GENUINE weak directions on 11 of 160 stream frames: profiles/r05_noise_rel.md)
   return AVM_OK;
 }
 
@@ -618,7 +620,9 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     int* pe_done = static_cast<int*>(pool_get(c, "pe_done", sizeof(int) * B));
     if (!pe_done) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior flags)");
-    const double noise_rel = (opt->marg_noise_rel > 0.0 && opt->marg_noise_rel < 1.0) ? opt->marg_noise_rel : 0.0;
+    double noise_rel = (opt->marg_noise_rel > 0.0 && opt->marg_noise_rel < 1.0) ? opt->marg_noise_rel : 0.0;
+    if (const char* e = getenv("AVM_MARG_NOISE_REL"))  // (development: another value for callers that pass the default, tests/tools/dev_noise_rel.sh)
+      if (opt->marg_noise_rel == 1e-18) noise_rel = atof(e);
     HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, noise_rel, marg_scale, c->prof, pe_done, c->stream));
     c->last_marg_windows = (int)B;
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
@@ -742,6 +746,14 @@ int avm_debug_counters(avm_ctx* c, int64_t* out) {
     HIPCHK(c, hipMemcpy(h.data(), it->second.first, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
     for (int v : h) out[1] += v != 0;
   }
+  return AVM_OK;
+}
+
+// bench hook (not in avm.h): candidate evaluations the last avm_fsel_select_batch executed on the device - counted by fsel_solo_kernel
+// (the lazy form scores a fraction of the live candidates per round); -1 for the forms that score every live candidate every round
+int avm_debug_fsel_evaluations(avm_ctx* c, int64_t* out) {
+  if (!c || !out) return AVM_ERR_INVALID;
+  *out = c->last_fsel_evals;
   return AVM_OK;
 }
 
@@ -1126,6 +1138,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
       fprintf(stderr, "fsel solo kernel, frame 0 (cycles): bounds %lld list %lld scores %lld pick+check %lld second-pass scores %lld fold %lld | %lld candidates scored in %lld rounds, %lld second passes; %lld passes of the pick, %lld with exact bounds for unscored candidates | pick: maxima %lld flags %lld hits %lld check %lld\n",
               q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[8], q[7], q[10], q[9], q[11], q[12], q[13], q[14]);
     }
+    c->last_fsel_evals = mode == 3 ? *reinterpret_cast<const int64_t*>(hsync + 16) : -1;
     if (hsync[2] == 0 && hsync[4] == (int32_t)P) {
       // a fast-mode call that went through: the back-off starts from the beginning next time
       if (mode == 2 || (mode == c->fsel_frame_mode && !rerun)) c->fsel_backoff = AVM_FSEL_REPROBE_CALLS;

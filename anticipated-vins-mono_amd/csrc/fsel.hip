@@ -1534,7 +1534,7 @@ AVM_DEV void fsel_rec_store(FselRec* p, double v, int tag) {
 // !TEAMS: one team over the whole device (blockIdx.x = slot, records written through to memory), one frame: the first fallback.
 constexpr long long FS_TEAM_TICKS = 2 * 100000;  // 2 ms
 constexpr int FS_TEAM_HDR = 32;                   // ints per team header: [0] members [1] done [4..7] the frame assignment record
-constexpr int FS_SYNC_HDR = 64;                   // ints: [2] failure [3] frame queue [4] frames finished [8..15] arrivals per XCD [32..] trace
+constexpr int FS_SYNC_HDR = 64;                   // ints: [2] failure [3] frame queue [4] frames finished [8..15] arrivals per XCD [16..17] evaluations executed (solo form, 64-bit) [32..] trace
 constexpr int FS_MAX_TEAMS = 16;
 // TPX = 2 (batches of more than eight frames, 3H <= 30): TWO teams per XCD, i.e. two wavefronts per SIMD - the second one fills the
 // latency gaps of the first (a team alone is bound by dependent latencies, not by issue).  Two workgroups then share a compute
@@ -2085,6 +2085,8 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
     if (t == 0) {
       A.nsel[p] = nsel;
       __hip_atomic_fetch_add(&sync[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // frames finished
+      // candidate evaluations this frame executed (what bench.py prices the solo form's roofline on): a 64-bit count at sync[16..17]
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(sync + 16), (unsigned long long)n_scored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -161,7 +161,8 @@ __device__ __forceinline__ void pc_sync() {
 // sqrt(s_i s_j) - plain formation noise - or, for the small magnitudes, 1e-7 (s_i s_j)^1/4: the level the eigen path's own noise test
 // works at (it drops S when S^2 <= 1e-16 g^T diag(s) g, i.e. S <= 1e-8 sqrt(s) for a coordinate direction; a factor 10 on top because
 // the noise of a pivot that follows a small genuine pivot is amplified by their ratio - measured: 5e-6 at s = 3e4 behind a pivot of 0.05)
-// (noise_rel = avm_options::marg_noise_rel: the constants belong to its default 1e-16 and scale with its square root; 0 switches the test off)
+// (noise_rel = avm_options::marg_noise_rel: the constants were measured at 1e-16 and scale with its square root - a tenth of them at the
+//  default of round 5, 1e-18; 0 switches the test off)
 __device__ __forceinline__ double pc_zero(double si, double sj, double noise_rel) {
   const double g = sqrt(si * sj), f = sqrt(noise_rel * 1e16);
   return f * fmax(1e-12 * g, 1e-7 * sqrt(g));
@@ -694,7 +695,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // or two of the 16 .. 30 zeros in half of those windows and leaves the streams at 3.9e-7 / 1.1e-4, the values they have
     // without any noise test.  1e-16: 2.5e-4 for a pure gyroscope-bias direction (information worth sigma = 60 rad/s), 6e-7 for
     // an accelerometer-bias direction, 1e-9 for directions in the poses.
-    // (avm_options::marg_noise_rel, default 1e-16; 0 - also under AVM_PRIOR_LITERAL=1 - leaves the reference's S > eps alone)
+    // Round 5, eight 20-frame streams (tests/test_prior_truth.py, profiles/r05_noise_rel.md): at 1e-16 the prior drops MORE directions than the
+    // exact one on 11 of 160 frames - genuine weak ones - and the states are within 1e-6 of the exact-prior stream on 54 frames; at
+    // 1e-18 on 3 frames (as with no noise test at all) and 120.  Keeping a noise direction costs the states nothing, dropping a genuine
+    // one does: the default is 1e-18.
+    // (avm_options::marg_noise_rel, default 1e-18; 0 - also under AVM_PRIOR_LITERAL=1 - leaves the reference's S > eps alone)
     const bool kx = lX > eps && lX * lX > noise_rel * wX, ky = lY > eps && lY * lY > noise_rel * wY;
 #pragma unroll
     for (int r = 0; r < RW; r++) {

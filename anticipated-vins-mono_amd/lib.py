@@ -69,6 +69,7 @@ def lib():
         L.avm_debug_last_solve_form.argtypes = [vp]
         L.avm_debug_last_fsel_form.argtypes = [vp]
         L.avm_debug_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.avm_debug_fsel_evaluations.argtypes = [vp, C.POINTER(C.c_int64)]
         L.avm_debug_solve_tp_occupancy.argtypes = [C.POINTER(C.c_int)]
         L.avm_slide_window.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), C.c_int32, C.c_int32, C.c_double]
         L.avm_comm_unique_id.argtypes = [vp, C.c_void_p]
@@ -157,6 +158,13 @@ class Context:
         """Which form the last select_batch() started in: 'solo' (one workgroup per frame with lazy evaluation: batches of 48 frames and
         more; AVM_FSEL_SOLO=0/1 forces it), 'teams' (a team of workgroups per frame) or 'rounds' (one launch per round)."""
         return {3: "solo", 2: "teams", 1: "teams", 0: "rounds"}.get(self._L.avm_debug_last_fsel_form(self.h), "none")
+
+    def last_fsel_evaluations(self) -> int:
+        """Candidate evaluations the last select_batch() executed on the device: counted by the solo form's kernel (lazy evaluation);
+        -1 for the forms that score every live candidate in every round (their count follows from the frame: bench.py)."""
+        out = C.c_int64(0)
+        self.check(self._L.avm_debug_fsel_evaluations(self.h, C.byref(out)), "avm_debug_fsel_evaluations")
+        return int(out.value)
 
     def counters(self) -> dict:
         """Debug counters of this ctx: device / pinned (re)allocations so far, and how the last marginalization's square roots were taken."""

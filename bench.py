@@ -83,7 +83,7 @@ def kernel_source_sha256():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("window_solve.hip", "prior_eig.hip", "preint.hip", "kernels.hpp", "devmath.hpp", "Makefile"):
+    for f in ("window_solve.hip", "prior_eig.hip", "preint.hip", "fsel.hip", "kernels.hpp", "devmath.hpp", "Makefile"):
         h.update(open(os.path.join(ROOT, PKG, "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -706,7 +706,7 @@ def main():
                 tl13 = (time.perf_counter() - t1) / reps
                 # larger batches (eight GPUs' worth of frames on one): from 48 frames on a batch takes the SOLO form of the selector on its own (one
                 # workgroup per frame, lazy evaluation: csrc/fsel.hip, fsel_solo_kernel); the teams' time for the same batch is measured beside it
-                big_b, big_form, big_teams = {}, {}, {}
+                big_b, big_form, big_teams, big_evals, big_kms = {}, {}, {}, {}, {}
                 for Pb in (64, 128, 256):
                     fb = synth.make_fsel(min(Pb, 64), first_id=rank * P)
                     if Pb > 64:  # (tiled: the generator is the slow part)
@@ -726,9 +726,24 @@ def main():
                             FS.select_batch(fbd)
                         torch.cuda.synchronize()
                         store[str(Pb)] = (time.perf_counter() - t1) / 2 / Pb * 1e3
+                        if forced is None:
+                            big_evals[str(Pb)], big_kms[str(Pb)] = ctx.last_fsel_evaluations(), ctx.kernel_ms("fsel_select")
                     os.environ.pop("AVM_FSEL_SOLO", None)
                     del fbd
                 result["feature_select"]["ms_per_frame_by_batch"] = big_b
+                if big_form.get("256") == "solo" and big_evals.get("256", -1) > 0:
+                    # the solo form (one workgroup per frame, lazy evaluation) priced on the evaluations it EXECUTES - counted on the device
+                    # (fsel_solo_kernel adds every frame's scored candidates to a counter) - not on the hoisted full evaluation it
+                    # proves unnecessary: T^3/3 + 2 T^2 FLOP each, HIP events around the whole select (setup + tree + solo kernel)
+                    ev_s, k_s = float(big_evals["256"]), float(big_kms["256"])
+                    result["feature_select"]["roofline_solo"] = {
+                        "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "batch": 256, "kernel": "fsel_kdtree + fsel_setup + fsel_solo_kernel, HIP events around the whole select",
+                        "kernel_ms": k_s, "candidate_evaluations_executed": ev_s, "candidate_evaluations_full_greedy": evals / P * 256,
+                        "executed_fraction": ev_s / (evals / P * 256), "flops_per_launch": ev_s * (T**3 / 3.0 + 2.0 * T * T),
+                        "achieved": ev_s * (T**3 / 3.0 + 2.0 * T * T) / (k_s * 1e-3) / 1e12,
+                        "frac": ev_s * (T**3 / 3.0 + 2.0 * T * T) / (k_s * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                        "frac_if_priced_on_the_full_greedy": (evals / P * 256) * (T**3 / 3.0 + 2.0 * T * T) / (k_s * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    }
                 result["feature_select"]["form_by_batch"] = big_form
                 result["feature_select"]["ms_per_frame_by_batch_teams_forced"] = big_teams
                 # the pipelined deployment: single-frame selects while ANOTHER ctx runs the 4096-window solve on the same device
@@ -857,6 +872,27 @@ def main():
             result["feature_select"]["gpu_over_cpu_1_core_batched"] = (1e3 / rf1) / result["feature_select"]["ms_per_frame_batched"]
 
     if rank == 0:
+        # The numbers a reader of a truncated line needs, once more, compact and LAST (a log that keeps the tail of stdout keeps this):
+        def _g(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+                if d is None:
+                    return None
+            return round(d, 4) if isinstance(d, float) else d
+        fsr = result.get("feature_select", {})
+        result["summary"] = {
+            "value": _g(result, "value"), "ms_per_step": _g(result, "ms_per_step"), "kernel_ms": {k: round(v, 3) for k, v in result.get("kernel_ms", {}).items()},
+            "frac": {k: _g(v, "frac") for k, v in result.get("kernel_rooflines", {}).items()},
+            "sparse_tracks": _g(result, "sparse_tracks", "value"), "margin_second_new": _g(result, "margin_second_new", "value"),
+            "extended_problem": _g(result, "extended_problem", "value"), "latency_single_window_ms": _g(result, "latency_single_window_ms", "value"),
+            "fsel_ms_per_frame": {"batch16": _g(fsr, "ms_per_frame_batched"), "single": _g(fsr, "ms_per_frame_single"), "by_batch": fsr.get("ms_per_frame_by_batch"),
+                                  "h13_batch16": _g(fsr, "horizon_13", "ms_per_frame_batched"), "h13_single": _g(fsr, "horizon_13", "ms_per_frame_single"),
+                                  "h13_batch256": _g(fsr, "horizon_13", "ms_per_frame_batch_256")},
+            "fsel_frac": {"teams16": _g(fsr, "roofline", "frac"), "solo256_executed": _g(fsr, "roofline_solo", "frac"),
+                          "solo256_executed_fraction_of_full_greedy": _g(fsr, "roofline_solo", "executed_fraction")},
+            "cpu": {"solves_per_s": _g(result, "cpu_baseline", "value"), "cores": _g(result, "cpu_baseline", "cores"), "one_core": _g(result, "cpu_baseline", "value_1_core"),
+                    "fsel_ms_per_frame_1_core": _g(fsr, "cpu_baseline", "value")},
+        }
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

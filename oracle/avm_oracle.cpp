@@ -104,7 +104,7 @@ int avmo_default_options(avm_options* o) {
   o->jacobi_scaling = 1;
   o->marg_eps = 1e-8;
   o->max_solver_time_s = 0.0;
-  o->marg_noise_rel = 1e-16;  // (the oracle's own clamp is always the reference-literal one: this field only steers the product)
+  o->marg_noise_rel = 1e-18;  // (the oracle's own clamp is always the reference-literal one: this field only steers the product)
   o->tr = 0.0, o->row = 480.0;  // global shutter (config/euroc/euroc_config.yaml:66), image_height
   return 0;
 }
