@@ -229,7 +229,7 @@ class FselBatch(C.Structure):
 
 
 class FselOut(C.Structure):
-    _fields_ = [("n_selected", c_ip), ("selected_ids", c_ip), ("fvalues", c_dp)]
+    _fields_ = [("n_selected", c_ip), ("selected_ids", c_ip), ("fvalues", c_dp), ("min_gap", c_dp)]
 
 
 class Config(C.Structure):

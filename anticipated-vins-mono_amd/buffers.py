@@ -148,15 +148,17 @@ class FselArrays(_Arrays):
 
 
 class FselOutArrays(_Arrays):
-    F64, I32 = ["fvalues"], ["n_selected", "selected_ids"]
+    F64, I32 = ["fvalues", "min_gap"], ["n_selected", "selected_ids"]
 
     @staticmethod
-    def alloc(n_problems: int, max_features: int, device=None) -> "FselOutArrays":
+    def alloc(n_problems: int, max_features: int, device=None, want_min_gap: bool = False) -> "FselOutArrays":
         a = {
             "n_selected": np.zeros(n_problems, np.int32),
             "selected_ids": np.full((n_problems, max_features), -1, np.int32),
             "fvalues": np.zeros((n_problems, max_features)),
         }
+        if want_min_gap:  # avm_fsel_out::min_gap (nullable: an absent key is a NULL pointer)
+            a["min_gap"] = np.zeros((n_problems, max_features))
         o = FselOutArrays({}, a)
         return o.to_device(device) if device else o
 

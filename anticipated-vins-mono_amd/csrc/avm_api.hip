@@ -1084,6 +1084,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
     dout.n_selected = static_cast<int32_t*>(pool_get(c, "fo_n", sizeof(int32_t) * P));
     dout.selected_ids = static_cast<int32_t*>(pool_get(c, "fo_ids", sizeof(int32_t) * P * (mf ? mf : 1)));
     dout.fvalues = out->fvalues ? static_cast<double*>(pool_get(c, "fo_fv", sizeof(double) * P * (mf ? mf : 1))) : nullptr;
+    dout.min_gap = out->min_gap ? static_cast<double*>(pool_get(c, "fo_gap", sizeof(double) * P * (mf ? mf : 1))) : nullptr;
     if (!dout.n_selected || !dout.selected_ids) return fail(c, AVM_ERR_HIP, "hipMalloc failed (selector out)");
   } else {
     d = *batch;
@@ -1123,6 +1124,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
       HIPCHK(c, hipMemcpyAsync(out->n_selected, dout.n_selected, sizeof(int32_t) * P, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync(out->selected_ids, dout.selected_ids, sizeof(int32_t) * P * mf, hipMemcpyDeviceToHost, c->stream));
       if (out->fvalues) HIPCHK(c, hipMemcpyAsync(out->fvalues, dout.fvalues, sizeof(double) * P * mf, hipMemcpyDeviceToHost, c->stream));
+      if (out->min_gap) HIPCHK(c, hipMemcpyAsync(out->min_gap, dout.min_gap, sizeof(double) * P * mf, hipMemcpyDeviceToHost, c->stream));
     }
     if (vflag) HIPCHK(c, hipMemcpyAsync(hflag, vflag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (the one synchronization of the call)
@@ -1164,7 +1166,7 @@ int avm_fsel_select_batch(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, 
 int avm_fsel_select(avm_ctx* c, avm_mem mem, const avm_fsel_batch* frame, int32_t* selected_ids, int32_t* n_selected, double* fvalues_opt) {
   if (!c) return AVM_ERR_INVALID;
   if (!frame || frame->n_problems != 1) return fail(c, AVM_ERR_INVALID, "avm_fsel_select takes exactly one frame (n_problems == 1)");
-  avm_fsel_out out{n_selected, selected_ids, fvalues_opt};
+  avm_fsel_out out{n_selected, selected_ids, fvalues_opt, nullptr};
   return avm_fsel_select_batch(c, mem, frame, &out);
 }
 
@@ -1304,7 +1306,7 @@ int avm_fsel_information(avm_ctx* c, avm_mem mem, const avm_fsel_batch* batch, d
     d_om = mem == AVM_MEM_HOST ? static_cast<double*>(pool_get(c, "fi_om", sizeof(double) * P * N * N)) : omega;
     if (!d_om) return fail(c, AVM_ERR_HIP, "hipMalloc failed (omega)");
   }
-  avm_fsel_out none{nullptr, nullptr, nullptr};
+  avm_fsel_out none{nullptr, nullptr, nullptr, nullptr};
   HIPCHK(c, launch_fsel(d, w, none, d_om, false, 0, nullptr, c->stream));
   const hipMemcpyKind kind = mem == AVM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (omega && mem == AVM_MEM_HOST) HIPCHK(c, hipMemcpyAsync(omega, d_om, sizeof(double) * P * N * N, kind, c->stream));

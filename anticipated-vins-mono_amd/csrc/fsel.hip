@@ -966,8 +966,9 @@ AVM_DEV int fs_wave_max(int v) {
 }
 
 // ---- the round's winner (feature_selector.cpp:669-683), computed by every workgroup of the problem for itself ---------------
-// returns the winner's candidate index (-1: none) to all threads; *fwin its value
-AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
+// returns the winner's candidate index (-1: none) to all threads; *fwin its value; *frun (when the caller asked for avm_fsel_out::min_gap)
+// the largest value among the OTHER candidates of the round (-HUGE_VAL: nobody else took part)
+AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin, double* frun) {
   __shared__ double s_f[FS_NT / 64], s_u[FS_NT / 64];
   __shared__ int s_i[FS_NT / 64];
   __shared__ int s_win;
@@ -1058,13 +1059,39 @@ AVM_DEV int fsel_pick_local(const FselDev& A, const FselPar& S, double* fwin) {
     __syncthreads();
   }
   *fwin = s_f[0];
+  if (A.out.min_gap) {  // the runner-up: the best value among the others that took part (the candidates the std::map rule ruled out above did not)
+    const int wl = s_win, nsh = s_nsh;
+    double r2 = -HUGE_VAL;
+#pragma unroll
+    for (int q = 0; q < FS_PC; q++) {
+      const int l = cl[q];
+      bool sh = l < 0 || l == wl;
+      for (int qq = 0; qq < nsh; qq++) sh |= s_shadow[qq] == l;
+      if (!sh && cf[q] > -1.0) r2 = fmax(r2, cf[q]);
+    }
+    for (int sq = t + FS_PC * FS_NT; sq < nl; sq += FS_NT) {
+      const int l = live[sq];
+      bool sh = l == wl;
+      for (int qq = 0; qq < nsh; qq++) sh |= s_shadow[qq] == l;
+      const double f = S.fval[sq];
+      if (!sh && f > -1.0) r2 = fmax(r2, f);
+    }
+    r2 = fs_wave_max(r2);
+    __syncthreads();  // (s_u is free: every thread has read the winner's bound)
+    if ((t & 63) == 0) s_u[t >> 6] = r2;
+    __syncthreads();
+    double rr = s_u[0];
+#pragma unroll
+    for (int w = 1; w < FS_NT / 64; w++) rr = fmax(rr, s_u[w]);
+    *frun = rr;
+  }
   return s_win;
 }
 
 // The same pick for the single-frame kernel (slot s IS candidate s; the caller hands in this thread's two candidates - index -1 =
 // not in the race - with the values it has read): two workgroup barriers per pass, the shadow list in registers, and the
 // lexicographic maximum of (fValue, ub, id) as three maxima in a row, each over the lanes that tie in the previous ones.
-AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, const double* cu, double* fwin) {
+AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, const double* cu, double* fwin, double* frun) {
   __shared__ double s_f[2][FS_NT / 64], s_u[2][FS_NT / 64];
   __shared__ int s_i[2][FS_NT / 64], s_h[2][FS_NT / 64];
   const int t = threadIdx.x, wv = t >> 6;
@@ -1103,7 +1130,31 @@ AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, c
       if (i2 >= 0 && (bi < 0 || f2 > bf || (f2 == bf && (u2 > bu || (u2 == bu && i2 > bi))))) bf = f2, bu = u2, bi = i2;
     }
     *fwin = bf;
-    if (bi < 0 || A.no_key_rule || nsh >= MAXSH) return bi;  // (more than MAXSH chained collisions in one round: keep the last winner)
+    // the runner-up for avm_fsel_out::min_gap (see fsel_pick_local): one more maximum, only when it was asked for
+    auto runner_up = [&](int wl) {
+      if (!A.out.min_gap) return;
+      double r2 = -HUGE_VAL;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int l = cl[q];
+        bool out = l < 0 || l == wl;
+#pragma unroll
+        for (int qq = 0; qq < MAXSH; qq++) out |= sh[qq] == l;
+        if (!out && cf[q] > -1.0) r2 = fmax(r2, cf[q]);
+      }
+      r2 = fs_wave_max(r2);
+      __syncthreads();  // (every thread has read slot sl of s_u)
+      if ((t & 63) == 0) s_u[sl][wv] = r2;
+      __syncthreads();
+      double rr = s_u[sl][0];
+#pragma unroll
+      for (int w = 1; w < FS_NT / 64; w++) rr = fmax(rr, s_u[sl][w]);
+      *frun = rr;
+    };
+    if (bi < 0 || A.no_key_rule || nsh >= MAXSH) {  // (more than MAXSH chained collisions in one round: keep the last winner)
+      runner_up(bi);
+      return bi;
+    }
     // std::map rule (see fsel_pick_local): a live candidate with a higher id and the same key shadows the winner
     const bool hit = (cl[0] > bi && cu[0] == bu) || (cl[1] > bi && cu[1] == bu);
     const bool wh = __any(hit);
@@ -1112,7 +1163,10 @@ AVM_DEV int fsel_pick_frame(const FselDev& A, const int* cl, const double* cf, c
     int any = 0;
 #pragma unroll
     for (int w = 0; w < FS_NT / 64; w++) any |= s_h[sl][w];
-    if (!any) return bi;
+    if (!any) {
+      runner_up(bi);
+      return bi;
+    }
 #pragma unroll
     for (int qq = 0; qq < MAXSH; qq++)
       if (qq == nsh) sh[qq] = bi;
@@ -1406,9 +1460,9 @@ AVM_DEV bool fsel_round_body(const FselDev& A, int p, int k, int bx) {
   const FselPar S = fsel_par(A, p, k);
   // ---- 1. the previous round's winner
   int win = -1;
-  double fwin = 0.0;
+  double fwin = 0.0, frun = -HUGE_VAL;
   if (has_pick) {
-    win = fsel_pick_local(A, S, &fwin);
+    win = fsel_pick_local(A, S, &fwin, &frun);
     if (win < 0) {
       if (bx == 0 && t == 0) A.done[p] = 1;  // lMax == -1: nothing is added; later rounds would repeat the same state
       return true;
@@ -1425,6 +1479,7 @@ AVM_DEV bool fsel_round_body(const FselDev& A, int p, int k, int bx) {
       const int ks = A.nsel[p];
       A.out.selected_ids[(size_t)p * b.max_features + ks] = b.cand_id[(size_t)p * b.max_cand + win];
       if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + ks] = fwin;
+      if (A.out.min_gap) A.out.min_gap[(size_t)p * b.max_features + ks] = fwin - frun;
       A.nsel[p] = ks + 1;
       A.out.n_selected[p] = ks + 1;
       A.black[(size_t)p * b.max_cand + win] = 1;
@@ -1686,14 +1741,15 @@ AVM_DEV void fsel_frame_body(const FselDev& A, int32_t* sync, int nslots, int te
           cf[q] = rf.v, cu[q] = ru.v;
         }
         FS_SEG(tk_wait)
-        double fwin;
-        const int win = fsel_pick_frame(A, cl, cf, cu, &fwin);  // (a workgroup barrier inside: s_fail is settled after it)
+        double fwin, frun = -HUGE_VAL;
+        const int win = fsel_pick_frame(A, cl, cf, cu, &fwin, &frun);  // (a workgroup barrier inside: s_fail is settled after it)
         FS_SEG(tk_pick)
         if (s_fail) return;
         if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
         if (bx == 0 && t == 0) {  // this frame's recorder
           A.out.selected_ids[(size_t)p * b.max_features + nsel] = b.cand_id[pc + win];
           if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + nsel] = fwin;
+          if (A.out.min_gap) A.out.min_gap[(size_t)p * b.max_features + nsel] = fwin - frun;
           A.out.n_selected[p] = nsel + 1;
           A.black[pc + win] = 1;
         }
@@ -2055,9 +2111,27 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       }
       FS_SOLO_SEG(3)
       if (win < 0) break;  // lMax == -1: nothing is added; later rounds would repeat the same state
+      double frun = -HUGE_VAL;
+      if (A.out.min_gap) {
+        // avm_fsel_out::min_gap: the winner's value minus the largest value any OTHER live candidate can have this round - its score if it
+        // was scored, else its bound G + g_l, which the check above has put more than 1e-8 (relative) below the winner: exact whenever
+        // the gap is smaller than that, a lower bound otherwise
+        const bool scd = live && s_scored[c] != 0;
+        double r2 = (live && c != win) ? (scd ? s_f[c] : G + s_bound[c]) : -HUGE_VAL;
+        if (!(r2 > -1.0)) r2 = -HUGE_VAL;  // (NaN / a failed factorization never wins)
+        r2 = fs_wave_max(r2);
+        __syncthreads();
+        if (lane == 0) s_wf[0][wv] = r2;
+        __syncthreads();
+        frun = s_wf[0][0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) frun = fmax(frun, s_wf[0][w]);
+        __syncthreads();
+      }
       if (t == 0) {
         A.out.selected_ids[(size_t)p * b.max_features + nsel] = b.cand_id[pc + win];
         if (A.out.fvalues) A.out.fvalues[(size_t)p * b.max_features + nsel] = fwin;
+        if (A.out.min_gap) A.out.min_gap[(size_t)p * b.max_features + nsel] = fwin - frun;
         A.out.n_selected[p] = nsel + 1;
         A.black[pc + win] = 1;
       }

@@ -20,11 +20,12 @@ class FeatureSelector:
         self.trackedFeatures_ = []  # feature_selector.h:93
         self.lastFeatureId_ = 0
 
-    def select_batch(self, problems: buffers.FselArrays, want_fvalues: bool = True):
-        """Greedy selection for P independent frames. Returns (n_selected[P], ids[P, max_features], fvalues)."""
+    def select_batch(self, problems: buffers.FselArrays, want_fvalues: bool = True, want_min_gap: bool = False):
+        """Greedy selection for P independent frames. Returns (n_selected[P], ids[P, max_features], fvalues[, min_gap: how firmly every
+        round was decided, avm_fsel_out::min_gap])."""
         P, mf = problems.n_problems, problems.dims["max_features"]
         dev = "cuda:%d" % self.ctx.device if problems.on_device else None
-        out = buffers.FselOutArrays.alloc(P, mf, dev)
+        out = buffers.FselOutArrays.alloc(P, mf, dev, want_min_gap=want_min_gap)
         if not want_fvalues:
             out.a["fvalues"] = None
         s, o = problems.struct(), out.struct()

@@ -260,6 +260,13 @@ typedef struct avm_fsel_out {
   int32_t* n_selected;   /* [P] */
   int32_t* selected_ids; /* [P][max_features] in selection order (blacklist order) */
   double* fvalues;       /* [P][max_features] fMax of each round (nullable) */
+  double* min_gap;       /* [P][max_features] (nullable; round 5) fMax of the round minus the largest fValue among the OTHER candidates that
+                            took part in it (+inf when there was no other): how firmly the round was decided.  Every round compares FP64
+                            log-determinants, so a pick whose gap is of the order of their rounding errors (1e-12 of the value) is decided by
+                            rounding - a host can see that here and need not expect another FP64 implementation (the reference's own run
+                            included) to make the same pick.  Exact in the forms that score every candidate every round; in the lazy form of
+                            large batches exact whenever it is below 1e-8 of the value and a lower bound otherwise.  Candidates the
+                            std::map equal-key rule of sortedlogDetUB keeps out of the round are not counted as far as the pick meets them. */
 } avm_fsel_out;
 
 /* B4: FeatureSelector::generateFutureHorizon in IMU mode = HorizonGenerator::imu

@@ -747,7 +747,7 @@ class FeatureSelector {
     int32_t n_sel = 0;
     std::vector<int32_t> ids(std::max(1, maxFeatures_), 0);
     lastF_.assign(std::max(1, maxFeatures_), 0.0);
-    avm_fsel_out out{&n_sel, ids.data(), lastF_.data()};
+    avm_fsel_out out{&n_sel, ids.data(), lastF_.data(), nullptr};
     c.check(avm_fsel_select_batch(c.get(), AVM_MEM_HOST, &p, &out), "avm_fsel_select_batch");
     lastF_.resize(n_sel);
     return std::vector<int>(ids.begin(), ids.begin() + n_sel);

@@ -231,11 +231,12 @@ int avmo_fsel_select_batch(const avm_fsel_batch* batch, avm_fsel_out* out, int n
   parallel_for(batch->n_problems, n_threads, [&](int p) {
     FselProblem P;
     load_fsel(*batch, p, P);
-    FselResult R = fsel_select(P);
+    FselResult R = fsel_select(P, out->min_gap != nullptr);
     out->n_selected[p] = (int)R.selected.size();
     for (size_t i = 0; i < R.selected.size(); i++) {
       out->selected_ids[(size_t)p * batch->max_features + i] = R.selected[i];
       if (out->fvalues) out->fvalues[(size_t)p * batch->max_features + i] = R.fvalues[i];
+      if (out->min_gap) out->min_gap[(size_t)p * batch->max_features + i] = R.min_gap[i];
     }
     total += R.n_logdet;
   });

@@ -368,11 +368,14 @@ inline double logdet_chol(const Mat& M) {
 struct FselResult {
   std::vector<int> selected;
   std::vector<double> fvalues;
+  std::vector<double> min_gap;  // (want_gap only) fMax of the round minus the best fValue among the other candidates of the round's std::map
   long n_logdet = 0;
 };
 
-// selectInformativeFeatures + sortedlogDetUB, feature_selector.cpp:613-728
-inline FselResult fsel_select(const FselProblem& p) {
+// selectInformativeFeatures + sortedlogDetUB, feature_selector.cpp:613-728.
+// want_gap (not in the reference; the checker of avm_fsel_out::min_gap): after the round's own loop, every candidate of the round's map that
+// the lazy `ub < fMax` break left unscored is scored as well, and the runner-up's value is recorded.  Selection and fValues are untouched.
+inline FselResult fsel_select(const FselProblem& p, bool want_gap = false) {
   FselResult R;
   const int N = 9 * (p.H + 1);
   Mat Omega = calcInfoFromRobotMotion(p);
@@ -411,6 +414,19 @@ inline FselResult fsel_select(const FselProblem& p) {
       double fValue = logdet_chol(A);
       R.n_logdet++;
       if (fValue > fMax) fMax = fValue, lMax = id;
+    }
+    if (want_gap && lMax > -1) {
+      double runner = -AVMO_NUM_INF;
+      for (auto& up : UBs) {
+        if (up.second == lMax) continue;
+        const Mat& D = Delta_ells.at(up.second);
+        double pr = prob.at(up.second);
+        Mat A(N, N);
+        for (size_t i = 0; i < A.a.size(); i++) A.a[i] = Omega.a[i] + OmegaS.a[i] + pr * D.a[i];
+        double fValue = logdet_chol(A);
+        if (fValue > -1.0 && fValue > runner) runner = fValue;
+      }
+      R.min_gap.push_back(fMax - runner);
     }
     if (lMax > -1) {
       double pr = prob.at(lMax);
