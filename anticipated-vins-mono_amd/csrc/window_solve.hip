@@ -86,8 +86,10 @@ constexpr int XRS = 132;           // column stride of the frame tasks' column-m
 #ifdef AVM_X
 constexpr int WCH = 8;             // rows of the scratch tile at L_WCH (x 80 columns): diag-block temporaries, back-substitution vector
 constexpr int XCOLS = 20;          // staged factor row: Jj(6) | Ji(6) | r | Jex(6) | Jtd
-constexpr int XSTG = XCOLS * XRS;
-constexpr int ASM_WAVES = 5;       // wavefronts assembling projection factors
+constexpr int XRS_X = 68;          // column stride of the HALF-chunk staging tile (round 5): 32 factors x 2 residual rows + 4 (bank spread)
+constexpr int XSTG = XCOLS * XRS_X;
+constexpr int ASM_WAVES = 7;       // wavefronts assembling projection factors (round 5: seven half-chunk tiles fit where five whole ones did; eleven
+                                   // frames deal 2 2 2 2 1 1 1 instead of 3 2 2 2 2, and wavefront 7 takes the raw IMU Jacobians AND the prior)
 #elif defined(AVM_TP)
 constexpr int XRS_H = 68;          // column stride of the HALF-chunk staging tile: 32 factors x 2 residual rows + 4 (bank spread)
 constexpr int XSTG = 13 * XRS_H;   // 884
@@ -1228,56 +1230,62 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
       PF[(7 * NFRP + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
       PF[(14 * NFRP + b) * WLE + e] = Jt[0] * Je[0] + Jt[1] * Je[1];
     }
-    {
-      dv2* st = reinterpret_cast<dv2*>(stage) + lane;
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        st[k * (XRS / 2)] = dv2{Jj[k], Jj[6 + k]};
-        st[(6 + k) * (XRS / 2)] = dv2{Ji[k], Ji[6 + k]};
-        st[(13 + k) * (XRS / 2)] = dv2{Jx[k], Jx[6 + k]};
-      }
-      st[12 * (XRS / 2)] = dv2{r[0], r[1]};
-      st[19 * (XRS / 2)] = dv2{Jt[0], Jt[1]};
-    }
-    wave_lds_sync();
+    // The staging tile holds HALF a chunk (lanes 0-31 stage and the wavefront multiplies, then lanes 32-63: the scheme of the throughput build
+    // and of marg_frame_task).  A run that straddles the two halves simply continues: the switch below only acts on a new start frame.
     const int nact = min(64, ncov - chunk0);
     const int fav = act ? fa : -1;
-    int l = 0;
-    while (l < nact) {
-      const int a_cur = __shfl(fav, l, 64);
-      const int cnt = __popcll(__ballot(act && fa == a_cur));
-      const int l_end = l + cnt;
-      if (a_cur != a_run) {
-        flush();
-        a_run = a_cur;
-      }
-      const int j_end = (l_end + 3) >> 2;
 #pragma unroll 1
-      for (int j0 = l >> 2; j0 < j_end; j0 += 4) {
-        dv2 u0[4], u1[4];
+    for (int half = 0; half < 2; half++) {
+      const int h0 = 32 * half, lim = min(nact, h0 + 32);
+      if (h0 >= nact) break;  // (uniform)
+      if ((lane >> 5) == half) {
+        dv2* st = reinterpret_cast<dv2*>(stage) + (lane & 31);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int ro = 8 * min(j0 + u, 15) + 2 * drow;
-          u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS + ro);
-          u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * XRS + ro);
+        for (int k = 0; k < 6; k++) {
+          st[k * (XRS_X / 2)] = dv2{Jj[k], Jj[6 + k]};
+          st[(6 + k) * (XRS_X / 2)] = dv2{Ji[k], Ji[6 + k]};
+          st[(13 + k) * (XRS_X / 2)] = dv2{Jx[k], Jx[6 + k]};
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int f = 4 * (j0 + u) + drow;
-          const bool in = f >= l && f < l_end;
-          const double a0 = (in && dcol < 13) ? u0[u][0] : 0.0, a1 = (in && dcol < 13) ? u0[u][1] : 0.0;
-          const double x0 = (in && dcol < 7) ? u1[u][0] : 0.0, x1 = (in && dcol < 7) ? u1[u][1] : 0.0;
-          D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
-          D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
-          D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
-          E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
-          E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
-          E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
-        }
+        st[12 * (XRS_X / 2)] = dv2{r[0], r[1]};
+        st[19 * (XRS_X / 2)] = dv2{Jt[0], Jt[1]};
       }
-      l = l_end;
+      wave_lds_sync();
+      int l = h0;
+      while (l < lim) {
+        const int a_cur = __shfl(fav, l, 64);
+        const int l_end = min(l + __popcll(__ballot(act && fa == a_cur && lane >= l)), lim);
+        if (a_cur != a_run) {
+          flush();
+          a_run = a_cur;
+        }
+        const int j_end = (l_end - h0 + 3) >> 2;
+#pragma unroll 1
+        for (int j0 = (l - h0) >> 2; j0 < j_end; j0 += 4) {
+          dv2 u0[4], u1[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int ro = 8 * min(j0 + u, 7) + 2 * drow;
+            u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS_X + ro);
+            u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * XRS_X + ro);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int f = h0 + 4 * (j0 + u) + drow;
+            const bool in = f >= l && f < l_end;
+            const double a0 = (in && dcol < 13) ? u0[u][0] : 0.0, a1 = (in && dcol < 13) ? u0[u][1] : 0.0;
+            const double x0 = (in && dcol < 7) ? u1[u][0] : 0.0, x1 = (in && dcol < 7) ? u1[u][1] : 0.0;
+            D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
+            D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
+            D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
+            E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
+            E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
+            E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+          }
+        }
+        l = l_end;
+      }
+      wave_lds_sync();
     }
-    wave_lds_sync();
   }
   flush();
   D11 += E11;
