@@ -116,3 +116,69 @@ def test_gpu_on_the_degenerate_clouds(selector):
     n, n_tie, n_nl = _check2(selector.nn_depth)
     print(f"\n[nanoflann] gpu, degenerate clouds: {n} queries identical, {n_tie} of them exact ties ({n_nl} not the lowest index)")
     assert n >= 6000 and n_tie >= 1000
+
+
+def _cloud_problem(xy, dep, q):
+    p = synth.make_fsel(1, horizon=3, n_cand=len(q), n_used=0, n_cloud=len(xy), max_features=4)
+    p.a["n_cloud"][0] = len(xy)
+    p.a["cloud_xy"][0, :len(xy)] = xy
+    p.a["cloud_depth"][0, :len(xy)] = dep
+    p.a["cand_xy"][0, :len(q)] = q
+    return p
+
+
+def _shapes():
+    """Clouds beyond the fixtures, answered by the oracle's restatement (which the fixtures pin): a tree deeper than 64 levels - the device
+    search keeps the recursion's state as one bit per level, 64 to a word - a window-sized cloud searched with 2000 queries, and the largest
+    cloud the tree builder takes (4096 points: 115 KB of LDS)."""
+    rng = np.random.default_rng(20240905)
+    out = []
+    n = 300                                            # geometric: every split cuts ONE point off -> depth ~ n - 10
+    xy = np.stack([0.75 * 0.5 ** np.arange(n), np.zeros(n)], 1)[rng.permutation(n)]
+    q = np.concatenate([rng.uniform(-0.1, 0.8, (400, 2)) * [1, 0.02], 10.0 ** rng.uniform(-89, 0, (300, 1)) * [1, 0], xy[:100], (xy[:100] + xy[100:200]) / 2])
+    out.append(("deep tree (geometric cloud, 300 points)", xy, q))
+    xy = rng.uniform(-0.8, 0.8, (150, 2)) * [1, 0.6]
+    out.append(("window-sized cloud, 2000 queries", xy, rng.uniform(-1, 1, (2000, 2))))
+    xy = np.round(rng.uniform(-0.8, 0.8, (4096, 2)) * 64) / 64       # 4096 points on a lattice of 103 x 103: hundreds of duplicates and ties
+    out.append(("4096 points on a coarse lattice", xy, np.round(rng.uniform(-0.9, 0.9, (1500, 2)) * 128) / 128))
+    return out
+
+
+def test_oracle_tree_depth_of_the_geometric_cloud(oracle):
+    """(what the GPU test below relies on: the geometric cloud really gives a tree deeper than 64 levels - checked on a Python statement of
+    middleSplit_'s cut, not on the oracle's internals)"""
+    name, xy, q = _shapes()[0]
+    idx, depth = np.arange(len(xy)), 0
+    lo, hi = xy.min(0), xy.max(0)
+    while len(idx) > 10:                               # follow the larger child
+        span = hi - lo
+        d = int(np.argmax([np.ptp(xy[idx, k]) if span[k] > (1 - 1e-5) * span.max() else -1 for k in (0, 1)]))
+        cut = min(max((lo[d] + hi[d]) / 2, xy[idx, d].min()), xy[idx, d].max())
+        left, right = idx[xy[idx, d] < cut], idx[xy[idx, d] >= cut]
+        if len(left) >= len(right):
+            idx, hi = left, np.where(np.arange(2) == d, cut, hi)
+        else:
+            idx, lo = right, np.where(np.arange(2) == d, cut, lo)
+        depth += 1
+    assert depth > 64, depth
+
+
+@pytest.mark.gpu
+def test_gpu_against_the_oracle_on_deep_and_large_trees(selector, oracle):
+    for name, xy, q in _shapes():
+        dep = np.random.default_rng(len(xy)).permutation(len(xy)) + 2.0
+        p = _cloud_problem(xy, dep, q)
+        want = oracle.fsel_nn_depth(p)[0, :len(q)]
+        got = selector.nn_depth(p)[0, :len(q)]
+        assert not np.isnan(got).any(), name           # (NaN: the three widths of the device search disagreed)
+        assert np.array_equal(got, want), (name, int((got != want).sum()))
+        D = ((q[:, None, :] - xy[None, :, :]) ** 2).sum(2)
+        print(f"\n[kd-tree] {name}: {len(q)} queries identical to the oracle's; {int(((D == D.min(1)[:, None]).sum(1) > 1).sum())} exact ties")
+
+
+@pytest.mark.gpu
+def test_a_cloud_above_the_tree_builder_s_limit_is_refused(selector):
+    p = synth.make_fsel(1, horizon=3, n_cand=4, n_used=0, n_cloud=4097, max_features=2)
+    with pytest.raises(Exception) as e:
+        selector.nn_depth(p)
+    assert "4096" in str(e.value)
