@@ -112,15 +112,25 @@ constexpr int KD_HDR = 8;  // doubles: root box low0 high0 low1 high1 | n_nodes,
 __host__ __device__ constexpr size_t kd_stride(int max_cloud) { return KD_HDR + (size_t)11 * max_cloud; }  // header | 2 mc nodes (4 doubles each) | xy[mc][2] | depth[mc], in tree order
 constexpr int KD_MAXW = 64;  // path words of 64 levels each beyond the first (a tree of n points is at most n - 10 deep)
 
+// minimum / maximum over the wavefront, the result in every lane: four DPP exchange steps inside the 16-lane rows (two 32-bit moves each),
+// then the four row results through SGPRs - a __shfl_xor ladder is twelve dependent ds_bpermute per double (1.5 K cycles; the tree of a
+// 150-point cloud takes ~90 of these reductions)
+template <int CTRL>
+AVM_DEV double kd_dpp(double v) {
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+AVM_DEV double kd_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 AVM_DEV double kd_wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmin(v, kd_dpp<0xB1>(v)), v = fmin(v, kd_dpp<0x4E>(v)), v = fmin(v, kd_dpp<0x141>(v)), v = fmin(v, kd_dpp<0x140>(v));
+  return fmin(fmin(kd_lane(v, 0), kd_lane(v, 16)), fmin(kd_lane(v, 32), kd_lane(v, 48)));
 }
 AVM_DEV double kd_wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, kd_dpp<0xB1>(v)), v = fmax(v, kd_dpp<0x4E>(v)), v = fmax(v, kd_dpp<0x141>(v)), v = fmax(v, kd_dpp<0x140>(v));
+  return fmax(fmax(kd_lane(v, 0), kd_lane(v, 16)), fmax(kd_lane(v, 32), kd_lane(v, 48)));
 }
 
 // initKDTree (feature_selector.cpp:380-432, the buildIndex part): one wavefront per frame.  LDS: x[mc] y[mc] (doubles), vind[mc], two
