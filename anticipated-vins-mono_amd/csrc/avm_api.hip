@@ -539,12 +539,15 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR, &tp_fits)) != AVM_OK) return rc;
   // Which form of the solve kernel: the throughput form (two 256-thread workgroups per CU, window_solve_tp.o) for batches that give
   // every CU more than one window, the latency form (one 512-thread workgroup per CU) otherwise - and always for the extended
-  // problem, a wall-clock cap (its clock is per window), or a prior the structural form cannot hold.
+  // problem or a prior the structural form cannot hold.  (Round 5: a wall-clock cap no longer forces the latency form - both kernels
+  // check options.max_solver_time_in_seconds against a clock that starts with the window's own solve, and a batch that is larger than
+  // the CU count is not a real-time call.  A window shares its CU there and runs 1.6 ms instead of 0.9: a cap between those two
+  // durations ends it an iteration earlier than the latency form would - wall-clock semantics.)
   // AVM_SOLVE_TP=0 / 1 forces the choice where both are possible (tests, A/B runs).
   const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || batch->relo_n != nullptr;
   bool use_tp = batch->n_windows > c->n_slots;
   if (const char* e = getenv("AVM_SOLVE_TP")) use_tp = e[0] == '1' ? true : (e[0] == '0' ? false : use_tp);
-  use_tp = use_tp && !extended && tp_fits && !(opt->max_solver_time_s > 0.0 && opt->max_solver_time_s <= 1.0e9);
+  use_tp = use_tp && !extended && tp_fits;
   if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp)) != AVM_OK) return rc;
   avm_window_batch d;
   avm_solve_summary* d_sum = nullptr;

@@ -117,7 +117,8 @@ typedef struct avm_options {
                                                 every iteration, before the iteration limit, against a device wall clock that starts when the
                                                 window's solve starts on the GPU (staging and pre-integration are not counted); the
                                                 minimizer then stops at the current point with AVM_TERM_NO_CONVERGENCE.  Non-finite values
-                                                and anything above 1e9 s mean "no cap" */
+                                                and anything above 1e9 s mean "no cap".  Both forms of the solve kernel check it (round 5:
+                                                a batch larger than the CU count keeps the throughput form under a cap) */
   double marg_noise_rel;                     /* The eigenvalue clamp of marginalization_factor.cpp:284-285 keeps S > marg_eps.  With
                                                 marg_noise_rel > 0 (default 1e-18) an eigenvalue is kept only if it ALSO exceeds the
                                                 rounding noise of the variables its eigenvector lives on,
