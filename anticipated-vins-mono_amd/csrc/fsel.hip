@@ -1235,21 +1235,47 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
   // m[bi][c] = (C + p Delta)[bi BS + r][c], c < (bi + 1) BS.  Both matrices are symmetric, so the entry is fetched as
   // [c][bi BS + r]: the 15 lanes of a candidate then read 15 consecutive doubles instead of 15 different cache lines
   double m[NB][T];
+  double ddg[NB];  // the candidate's diagonal entries of this lane's rows (the Hadamard bound)
+  if constexpr (PACKED == 2) {
+    // D comes from MEMORY here (fsel_solo_kernel): a block row's entries are all requested before the first one is used.  Left to itself the
+    // compiler pairs each load with its multiply-add and keeps one or two in flight - 45 dependent trips to the L2, 15.3 K of an
+    // evaluation's 23.2 K cycles (round 5, profiles/r05_fsel_single_frame_floor.md).  One block row at a time (15 + 30 entries at 3 H = 30,
+    // 13 + 26 + 39 at 39): every entry of the candidate at once costs registers the elimination needs (49 spilled at 30, 6 % slower at 39).
 #pragma unroll
-  for (int bi = 0; bi < NB; bi++)
+    for (int bi = 0; bi < NB; bi++) {
 #pragma unroll
-    for (int c = 0; c < (bi + 1) * BS; c++) {
-      const int idx = c * T + bi * BS + r, R = bi * BS + r;
-      const int pk2 = c <= R ? c * T - c * (c - 1) / 2 + (R - c) : R * T - R * (R - 1) / 2;  // (an entry past the diagonal is never used)
-      m[bi][c] = sC[idx] + pr * D[PACKED == 2 ? pk2 : (PACKED == 1 ? R * (R + 1) / 2 + c : idx)];
+      for (int c = 0; c < (bi + 1) * BS; c++) {
+        const int R = bi * BS + r;
+        m[bi][c] = D[c <= R ? c * T - c * (c - 1) / 2 + (R - c) : R * T - R * (R - 1) / 2];  // (an entry past the diagonal is never used)
+      }
+      const int dgi = bi * BS + r;
+      ddg[bi] = D[dgi * T - dgi * (dgi - 1) / 2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < (bi + 1) * BS; c++) m[bi][c] = sC[c * T + bi * BS + r] + pr * m[bi][c];
+      __builtin_amdgcn_sched_barrier(0);
     }
+  } else {
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+      for (int c = 0; c < (bi + 1) * BS; c++) {
+        const int idx = c * T + bi * BS + r, R = bi * BS + r;
+        m[bi][c] = sC[idx] + pr * D[PACKED == 1 ? R * (R + 1) / 2 + c : idx];
+      }
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+      const int dgi = bi * BS + r;
+      ddg[bi] = D[PACKED == 1 ? dgi * (dgi + 1) / 2 + dgi : dgi * T + dgi];
+    }
+  }
   FS_TK(0)
   // Hadamard upper bound: sum over the rows, block row by block row, then across the 16 lanes in lane order
   double ubl = 0.0;
 #pragma unroll
   for (int bi = 0; bi < NB; bi++) {
-    const int dgi = bi * BS + r, idx = dgi * T + dgi;
-    ubl += fs_log(sdpp[dgi] + pr * D[PACKED == 2 ? dgi * T - dgi * (dgi - 1) / 2 : (PACKED == 1 ? dgi * (dgi + 1) / 2 + dgi : idx)]);
+    const int dgi = bi * BS + r;
+    ubl += fs_log(sdpp[dgi] + pr * ddg[bi]);
   }
   const double ubt = fs_row_sum((lane & 15) < BS ? ubl : 0.0);
   FS_TK(1)
@@ -1764,12 +1790,22 @@ AVM_DEV void fsel_frame_body(const FselDev& A, int32_t* sync, int nslots, int te
           A.black[pc + win] = 1;
         }
         nsel++;
-        const double prw = b.cand_prob[pc + win];
         const double* Dw = A.delta + (pc + win) * T * T;
-        for (int idx = t; idx < T * T; idx += FS_NT) {
-          const double dw = Dw[idx];
-          sC[idx] = sC[idx] + prw * dw;
-          if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dw;
+        // (all of the thread's entries of the winner's Delta - and its probability - requested before the first is used: one trip to memory,
+        //  not one per entry; round 5)
+        constexpr int NFOLD = (T * T + FS_NT - 1) / FS_NT;
+        double dwv[NFOLD];
+#pragma unroll
+        for (int q = 0; q < NFOLD; q++) dwv[q] = Dw[min(t + q * FS_NT, T * T - 1)];
+        const double prw = b.cand_prob[pc + win];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NFOLD; q++) {
+          const int idx = t + q * FS_NT;
+          if (idx < T * T) {
+            sC[idx] = sC[idx] + prw * dwv[q];
+            if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dwv[q];
+          }
         }
         if (t == 0) s_alive[win] = 0;
         __syncthreads();
@@ -2149,10 +2185,18 @@ __global__ __launch_bounds__(FS_SOLO_NT) void fsel_solo_kernel(FselDev A, int32_
       gprev = fwin - G, G = fwin;  // the winner's value IS logdet of the next C
       const double prw = s_pr[win];
       const double* Dw = Dp + (size_t)win * T * T;
-      for (int idx = t; idx < T * T; idx += FS_SOLO_NT) {
-        const double dw = Dw[idx];
-        sC[idx] = sC[idx] + prw * dw;
-        if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dw;
+      constexpr int NFOLD = (T * T + FS_SOLO_NT - 1) / FS_SOLO_NT;  // (the thread's entries of the winner's Delta in one trip to memory)
+      double dwv[NFOLD];
+#pragma unroll
+      for (int q = 0; q < NFOLD; q++) dwv[q] = Dw[min(t + q * FS_SOLO_NT, T * T - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NFOLD; q++) {
+        const int idx = t + q * FS_SOLO_NT;
+        if (idx < T * T) {
+          sC[idx] = sC[idx] + prw * dwv[q];
+          if (idx / T == idx % T) sdpp[idx / T] = sdpp[idx / T] + prw * dwv[q];
+        }
       }
       if (t == 0) s_alive[win] = 0;
       __syncthreads();
