@@ -4166,30 +4166,42 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     const WinCtx& c = lds_ctx();
     __syncthreads();
     PROF_T0();
-    // ---- load the post-solve state and tables
-    for (int i = t; i < 77; i += NT) lds[L_X + i] = B.pose[(size_t)w * 77 + i];
-    for (int i = t; i < 99; i += NT) lds[L_X + XSB + i] = B.speedbias[(size_t)w * 99 + i];
-    for (int i = t; i < MAXE; i += NT) lds[L_X + XLAM + i] = i < c.nf ? B.inv_depth[(size_t)w * B.max_feat + i] : 1.0;
-    for (int i = t; i < MAXPRIOR; i += NT) lds[L_DXP + i] = 0.0, lds[L_RP + i] = 0.0;
-    for (int i = t; i < MROWS + 176 + 152; i += NT) lds[i] = 0.0;  // S, b, g_e
-    for (int i = t; i < 152; i += NT) lds[L_HEE + i] = 0.0;
-    if (t < c.nf) {
-      ids[I_FSTART + t] = B.feat_start[(size_t)w * B.max_feat + t];
-      ids[I_FNOBS + t] = B.feat_nobs[(size_t)w * B.max_feat + t];
-      ids[I_FOBS + t] = B.feat_obs_begin[(size_t)w * B.max_feat + t];
-    }
-    if (t < 7) lds[L_RIC + 12 + t] = B.ex_pose[(size_t)w * 7 + t];
-    if (t == 7) lds[L_RIC + 19] = c.est_td ? B.td[w] : 0.0;  // para_Td
-    if (t >= 256 && t < 256 + c.pnblk) {  // the prior's block table (one round trip instead of one per block, as in the solve)
-      const int k = t - 256;
-      ids[I_PBLK + k * 3] = B.prior_blk_kind[(size_t)w * B.max_pblk + k], ids[I_PBLK + k * 3 + 1] = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
-    }
-    if (t == 0) {
-      const double* ex = B.ex_pose + (size_t)w * 7;
-      double R[9];
-      q2R(quat{ex[6], ex[3], ex[4], ex[5]}, R);
-      for (int k = 0; k < 9; k++) lds[L_RIC + k] = R[k];
-      for (int k = 0; k < 3; k++) lds[L_RIC + 9 + k] = ex[k];
+    // ---- load the post-solve state and tables.  Every table entry of this thread is requested before the first one is stored (round 5:
+    // written as one loop per table, each load waited for its own store - eight dependent trips to memory per window, half of this phase)
+    static_assert(NT >= 160 && 99 <= NT && MAXE <= NT, "one entry of every table per thread");
+    {
+      const int nfl = c.nf, npb = c.pnblk;
+      const bool in_f = t < nfl, in_pb = t >= 256 && t < 256 + npb;
+      const int kpb = in_pb ? t - 256 : 0;
+      const double v_pose = B.pose[(size_t)w * 77 + min(t, 76)], v_sb = B.speedbias[(size_t)w * 99 + min(t, 98)];
+      const double v_lam = in_f ? B.inv_depth[(size_t)w * B.max_feat + t] : 1.0;
+      const size_t kf = (size_t)w * B.max_feat + (in_f ? t : 0);
+      const int v_fs = B.feat_start[kf], v_fn = B.feat_nobs[kf], v_fo = B.feat_obs_begin[kf];
+      const double v_ex = B.ex_pose[(size_t)w * 7 + min(t, 6)];
+      const double v_td = (t == 7 && c.est_td) ? B.td[w] : 0.0;
+      const int v_pk = in_pb ? B.prior_blk_kind[(size_t)w * B.max_pblk + kpb] : 0, v_pf = in_pb ? B.prior_blk_frame[(size_t)w * B.max_pblk + kpb] : 0;
+      double ex[7] = {0, 0, 0, 0, 0, 0, 1};
+      if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) ex[k] = B.ex_pose[(size_t)w * 7 + k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      for (int i = t; i < MAXPRIOR; i += NT) lds[L_DXP + i] = 0.0, lds[L_RP + i] = 0.0;
+      for (int i = t; i < MROWS + 176 + 152; i += NT) lds[i] = 0.0;  // S, b, g_e
+      for (int i = t; i < 152; i += NT) lds[L_HEE + i] = 0.0;
+      if (t < 77) lds[L_X + t] = v_pose;
+      if (t < 99) lds[L_X + XSB + t] = v_sb;
+      if (t < MAXE) lds[L_X + XLAM + t] = v_lam;
+      if (in_f) ids[I_FSTART + t] = v_fs, ids[I_FNOBS + t] = v_fn, ids[I_FOBS + t] = v_fo;
+      if (t < 7) lds[L_RIC + 12 + t] = v_ex;
+      if (t == 7) lds[L_RIC + 19] = v_td;  // para_Td
+      if (in_pb) ids[I_PBLK + kpb * 3] = v_pk, ids[I_PBLK + kpb * 3 + 1] = v_pf;  // the prior's block table
+      if (t == 0) {
+        double R[9];
+        q2R(quat{ex[6], ex[3], ex[4], ex[5]}, R);
+        for (int k = 0; k < 9; k++) lds[L_RIC + k] = R[k];
+        for (int k = 0; k < 3; k++) lds[L_RIC + 9 + k] = ex[k];
+      }
     }
     __syncthreads();
     if (t == 0) {  // offsets and state columns of the prior's blocks (read after the barrier that precedes phase A)
