@@ -1014,8 +1014,9 @@ int stage_fsel(avm_ctx* c, const avm_fsel_batch* h, avm_fsel_batch* d) {
   return AVM_OK;
 }
 
-constexpr size_t AVM_FSEL_SOLO_MIN = 48;  // frames per call from which a batch takes the solo form of the selector: a solo select takes 5 ms however few
-                                          // frames run side by side, the teams 0.12 ms per frame
+constexpr size_t AVM_FSEL_SOLO_MIN = 33;  // frames per call from which a batch takes the solo form of the selector.  A solo select takes 4.3 ms (H = 10; 7.2 ms at
+                                          // H = 13) however few frames run side by side; the sixteen teams take 2.0 ms (3.7 ms) per sixteen frames: up to 32 frames
+                                          // two passes of the teams are ahead, from the third pass on the solo form is (measured: profiles/r05_solo_crossover.txt)
 // Does a select of this batch take the solo form (one workgroup per frame, lazy evaluation: fsel_solo_kernel)?  ONE rule for the mode
 // choice in avm_fsel_select_batch and for the solo form's packed Delta copy in fsel_buffers (0.8 GB at 256 frames x 512 candidates,
 // H = 13: not to be held by a ctx that never runs the form).  AVM_FSEL_SOLO=0/1 overrides the batch-size rule, AVM_FSEL_FRAME vetoes it.

@@ -145,7 +145,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // that is not noise, a bound that does not clear the thresholds - is left untouched (done[w] = 0) and taken by prior_eig_kernel.
 constexpr int PC_T = 5;                                 // tiles per dimension: n <= 80
 constexpr int PC_NT = PC_T * (PC_T + 1) / 2;            // 15 upper tiles
-constexpr int PC_LDS = 256 + PC_T * 256 + 5 * 80;       // doubles: the diagonal patch | L_kk^-1 of every block | b', y, s, a 16-vector, a column of J
+constexpr int PC_LDS = 256 + PC_T * 256 + 6 * 80 + 256; // doubles: the diagonal patch | L_kk^-1 of every block | b', y, s, a 16-vector, a column of J, the pivots' thresholds | a 16 x 16 identity
 constexpr int PC_MAXDEL = 8;                            // deleted pivots per window
 typedef double pd4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ constexpr int pc_ti(int k, int i) { return k * PC_T - k * (k - 1) / 2 + (i - k); }
@@ -167,7 +167,10 @@ __device__ __forceinline__ double pc_zero(double si, double sj, double noise_rel
   const double g = sqrt(si * sj), f = sqrt(noise_rel * 1e16);
   return f * fmax(1e-12 * g, 1e-7 * sqrt(g));
 }
-__global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_windows, double eps, double noise_rel, const double* scale, int* done) {
+#ifndef AVM_PC_WAVES
+#define AVM_PC_WAVES 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES, AVM_PC_WAVES))) void prior_chol_kernel(avm_prior_out PO, int n_windows, double eps, double noise_rel, const double* scale, int* done) {
   __shared__ double pc_lds[PC_LDS];
   const int w = blockIdx.x, lane = threadIdx.x, lk = lane >> 4, lr = lane & 15;
   if (w >= n_windows) return;
@@ -184,22 +187,62 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
   double* vs = vy + 80;                 // s: the magnitude every diagonal entry was formed at (marginalize_kernel), 0 on the pad
   double* vt = vs + 80;                 // a 16-vector in transit
   double* vc = vt + 80;                 // column j of J (the check of a deleted pivot)
+  double* vthr = vc + 80;               // pc_zero(s_j, s_j): what counts as a zero pivot (three square roots each: once per window, not once per block)
+  double* ident = vthr + 80;            // [16][16] identity: the rows the lanes 16..31 of the pivot chain start from
   // ---- load: upper tiles (A' is symmetric and stored as its lower triangle), identity on the pad
   pd4 U[PC_NT];
+  {
+    // (entry (row, col) of an upper tile lies at [col][row] of the stored lower triangle; off the diagonal tiles row < col also after
+    //  the clamp to n - 1, so one product per tile column and one add per entry address it: written with max / min of the two clamped
+    //  indices the 60 loads cost 800 instructions)
+    size_t cb[PC_T];
+    bool cin[PC_T];
 #pragma unroll
-  for (int k = 0; k < PC_T; k++)
+    for (int i = 0; i < PC_T; i++) cb[i] = (size_t)min(16 * i + lr, n - 1) * ldj, cin[i] = 16 * i + lr < n;
 #pragma unroll
-    for (int i = k; i < PC_T; i++)
+    for (int k = 0; k < PC_T; k++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int row = 16 * k + lk + 4 * r, col = 16 * i + lr;
-        const int rc = min(row, n - 1), cc = min(col, n - 1);
-        const double v = gJ[(size_t)max(rc, cc) * ldj + min(rc, cc)];
-        U[pc_ti(k, i)][r] = (row < n && col < n) ? v : (row == col ? 1.0 : 0.0);
+        const int rc = min(16 * k + lk + 4 * r, n - 1);
+#pragma unroll
+        for (int i = k; i < PC_T; i++) {
+          if (i == k) {
+            const int cc = min(16 * i + lr, n - 1);
+            U[pc_ti(k, i)][r] = gJ[(size_t)max(rc, cc) * ldj + min(rc, cc)];
+          } else {
+            U[pc_ti(k, i)][r] = gJ[cb[i] + rc];
+          }
+        }
       }
-  for (int c = lane; c < 80; c += 64) {
-    vb[c] = c < n ? gr[c] : 0.0;
-    vs[c] = c < n ? scale[(size_t)w * ldj + c] : 0.0;
+    // all sixty loads are out before the first is looked at.  (Left as `in ? load : pad` the selects became branches around the loads -
+    // CodeGenPrepare sinks a load that only a select uses -, each with its own wait: sixty trips to memory one after the other.)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < PC_T; k++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * k + lk + 4 * r;
+        const bool rin = row < n;
+#pragma unroll
+        for (int i = k; i < PC_T; i++) {
+          double v = U[pc_ti(k, i)][r];
+          asm volatile("" : "+v"(v));
+          U[pc_ti(k, i)][r] = (rin && cin[i]) ? v : (row == 16 * i + lr ? 1.0 : 0.0);
+        }
+      }
+  }
+  {
+    // (b' and s: loads first, selects afterwards, as above)
+    const int c0 = lane, c1 = lane + 64;
+    double b0 = gr[min(c0, n - 1)], s0 = scale[(size_t)w * ldj + min(c0, n - 1)];
+    double b1 = gr[min(c1, n - 1)], s1 = scale[(size_t)w * ldj + min(c1, n - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(b0), "+v"(s0), "+v"(b1), "+v"(s1));
+    s0 = c0 < n ? s0 : 0.0, s1 = c1 < n ? s1 : 0.0;
+    vb[c0] = c0 < n ? b0 : 0.0, vs[c0] = s0, vthr[c0] = pc_zero(s0, s0, noise_rel);
+    if (c1 < 80) vb[c1] = c1 < n ? b1 : 0.0, vs[c1] = s1, vthr[c1] = pc_zero(s1, s1, noise_rel);
+#pragma unroll
+    for (int q = 0; q < 4; q++) ident[lane + 64 * q] = ((lane + 64 * q) >> 4) == ((lane + 64 * q) & 15) ? 1.0 : 0.0;
   }
   pc_sync();
   bool bad = false;
@@ -212,35 +255,44 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
     pc_sync();
     {
       // lane = row (lanes 0..15), lanes 16..31: the rows of the identity (they end as the rows of L_kk^-T); the others carry junk
+      // (lanes 32..63 repeat lanes 0..31 - same loads, same arithmetic, same stores -, so that no store below is conditional)
       double a[16];
-      const bool idl = (lane & 48) == 16;
+      const bool idl = (lane & 16) != 0;
+      const double* src = idl ? ident + lr * 16 : blk + lr * 16;  // (the diagonal tile is symmetric: its row lr)
 #pragma unroll
-      for (int c = 0; c < 16; c++) a[c] = idl ? (lr == c ? 1.0 : 0.0) : blk[lr * 16 + c];
-      const double thr_l = pc_zero(vs[16 * k + lr], vs[16 * k + lr], noise_rel);  // (off the pivot chain: lane j holds pivot j's threshold)
+      for (int c = 0; c < 16; c++) a[c] = src[c];
+      const double thr_l = vthr[16 * k + lr];  // (off the pivot chain: lane j holds pivot j's threshold)
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const double pj = pc_readlane(a[j], j);
         const double thr = pc_readlane(thr_l, j);
         const bool del = fabs(pj) <= thr;  // zero up to formation noise: the direction is dropped (pads: s = 0, pivot 1)
-        bad |= !(del || pj > 0.0) || !(pj < 1e300);
-        if (16 * k + j < 64) dm0 |= del ? 1ull << ((16 * k + j) & 63) : 0ull;
-        else dm1 |= del ? 1ull << ((16 * k + j) & 63) : 0ull;
         a[j] *= del ? 0.0 : nrm_rsqrt(pj);
 #pragma unroll
         for (int c = j + 1; c < 16; c++) a[c] = fma(-a[j], pc_readlane(a[j], c), a[c]);
       }
       pc_sync();  // (every lane has read its row of the patch)
-      // L_kk (lower) back into the patch; L_kk^-1[c][i] = (L_kk^-T)[i][c] = a[c] of lane 16 + i
+      // Row lr of L_kk goes back into the patch as COLUMN lr (the patch then holds L_kk^T = J_kk), row i of L_kk^-T (lane 16 + i) as column
+      // i of L_kk^-1: both with stride 16, sixteen unconditional stores at constant offsets.  The entries c > lr of a matrix lane are
+      // leftovers of the elimination, masked where the patch is read; those c < i of an identity lane are exact zeros already.
+      double* dst = idl ? Linv + k * 256 + lr : blk + lr;
 #pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (lane < 16) blk[lr * 16 + c] = c <= lr ? a[c] : 0.0;
-        if (idl) Linv[k * 256 + c * 16 + lr] = c >= lr ? a[c] : 0.0;
-      }
+      for (int c = 0; c < 16; c++) dst[c * 16] = a[c];
     }
     pc_sync();
-    // J_kk = L_kk^T in the tile layout: entry (row, col) = L[col][row]
+    {
+      // What became of the sixteen pivots, read off L_kk's diagonal (in the chain this bookkeeping was twelve scalar instructions per pivot
+      // on values the compiler then kept in spilled SGPRs: 2 K of the kernel's 12.8 K instructions): a deleted pivot left an exact zero
+      // (a[j] *= 0), a negative or non-finite one a NaN (rsqrt), one beyond 1e300 a diagonal beyond 1e150
+      const double dj = blk[lr * 17];  // L_kk[lr][lr]
+      bad |= !(dj == 0.0 || (dj > 0.0 && dj < 1e150));
+      const unsigned long long delm = __ballot(dj == 0.0) & 0xffffull;
+      if (k < 4) dm0 |= delm << (16 * k);
+      else dm1 |= delm;
+    }
+    // J_kk = L_kk^T in the tile layout: entry (row, col) = L[col][row], zero below the diagonal
 #pragma unroll
-    for (int r = 0; r < 4; r++) U[pc_ti(k, k)][r] = blk[lr * 16 + lk + 4 * r];
+    for (int r = 0; r < 4; r++) U[pc_ti(k, k)][r] = lk + 4 * r <= lr ? blk[(lk + 4 * r) * 16 + lr] : 0.0;
     if (k + 1 < PC_T) {
       double ao[4];  // A operand L_kk^-1[i' = lr][k' = lk + 4 r]
 #pragma unroll
@@ -358,15 +410,25 @@ __global__ __launch_bounds__(64) void prior_chol_kernel(avm_prior_out PO, int n_
   }
   if (!ok) return;
   // ---- the prior: linearized_jacobians = J = L^T (upper triangular), linearized_residuals = y
+  // (one row base per register row; the tiles a window of n >= 64 variables covers entirely - sixteen of the twenty-five - are stored without
+  //  a bounds test: a predicated store is a branch of its own)
+  {
+    const bool full4 = n >= 64;  // (uniform)
 #pragma unroll
-  for (int k = 0; k < PC_T; k++)
-#pragma unroll
-    for (int i = 0; i < PC_T; i++)
+    for (int k = 0; k < PC_T; k++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int row = 16 * k + lk + 4 * r, col = 16 * i + lr;
-        if (row < n && col < n) gJ[(size_t)row * ldj + col] = i >= k ? U[pc_ti(min(k, i), max(k, i))][r] : 0.0;
+        const int row = 16 * k + lk + 4 * r;
+        double* rb = gJ + (size_t)min(row, n - 1) * ldj + lr;
+        const bool rin = row < n;
+#pragma unroll
+        for (int i = 0; i < PC_T; i++) {
+          const double v = i >= k ? U[pc_ti(min(k, i), max(k, i))][r] : 0.0;
+          if (k < 4 && i < 4 && full4) rb[16 * i] = v;
+          else if (rin && 16 * i + lr < n) rb[16 * i] = v;
+        }
       }
+  }
   for (int c = lane; c < n; c += 64) gr[c] = vy[c];
   if (lane == 0) done[w] = 1;
 }

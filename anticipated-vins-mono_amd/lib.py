@@ -155,7 +155,7 @@ class Context:
         return "throughput" if self._L.avm_debug_last_solve_form(self.h) == 1 else "latency"
 
     def last_fsel_form(self) -> str:
-        """Which form the last select_batch() started in: 'solo' (one workgroup per frame with lazy evaluation: batches of 48 frames and
+        """Which form the last select_batch() started in: 'solo' (one workgroup per frame with lazy evaluation: batches of 33 frames and
         more; AVM_FSEL_SOLO=0/1 forces it), 'teams' (a team of workgroups per frame) or 'rounds' (one launch per round)."""
         return {3: "solo", 2: "teams", 1: "teams", 0: "rounds"}.get(self._L.avm_debug_last_fsel_form(self.h), "none")
 

@@ -704,7 +704,7 @@ def main():
                     FS.select_batch(f13_1)
                 torch.cuda.synchronize()
                 tl13 = (time.perf_counter() - t1) / reps
-                # larger batches (eight GPUs' worth of frames on one): from 48 frames on a batch takes the SOLO form of the selector on its own (one
+                # larger batches (eight GPUs' worth of frames on one): from 33 frames on a batch takes the SOLO form of the selector on its own (one
                 # workgroup per frame, lazy evaluation: csrc/fsel.hip, fsel_solo_kernel); the teams' time for the same batch is measured beside it
                 big_b, big_form, big_teams, big_evals, big_kms = {}, {}, {}, {}, {}
                 for Pb in (64, 128, 256):

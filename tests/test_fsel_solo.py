@@ -1,7 +1,7 @@
 """GPU tier (-m gpu): the SOLO form of the selector (fsel_solo_kernel, csrc/fsel.hip: one workgroup per frame, lazy evaluation in the
 sense of Minoux' accelerated greedy).
 
-A batch takes it on its own from 48 frames on (HORIZON <= 10); the selector tests of the other files use smaller batches and therefore
+A batch takes it on its own from 33 frames on (HORIZON <= 10); the selector tests of the other files use smaller batches and therefore
 run the frame kernel's teams.  Here the same test bodies are collected once more with AVM_FSEL_SOLO=1, which forces the solo form
 wherever it is possible: ids bit-exact and in selection order against the FP64 oracle and against the binary128 selection, the
 std::map equal-key rule, non-finite inputs, the edge cases.  A candidate the lazy rounds never score is PROVEN to lose its round, so
