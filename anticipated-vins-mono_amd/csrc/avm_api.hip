@@ -66,6 +66,7 @@ struct avm_ctx {
   int64_t n_allocs = 0;       // device / pinned (re)allocations since avm_create (avm_debug_counters: a timed region should see none)
   int last_marg_windows = 0;  // batch size of the last marginalization (its per-window "the one-wavefront kernel finished it" flags: pool "pe_done")
   bool last_solve_tp = false;  // which form of the solve kernel the last avm_window_solve_batch took (avm_debug_last_solve_form)
+  bool last_marg_tp = false;   // ... and which form of the marginalization kernel (avm_debug_last_marg_form)
   int scratch_slots = 0;  // slots allocated (n_slots, or 2 n_slots once a batch has taken the throughput form of the solve)
   double *pre_delta = nullptr, *pre_jac = nullptr, *pre_cov = nullptr, *pre_sqrt = nullptr, *pre_sum = nullptr;
   size_t pre_cap = 0;  // windows
@@ -78,6 +79,7 @@ struct avm_ctx {
   std::map<std::string, std::pair<void*, size_t>> pinned;
   bool packed_in = false;  // the last stage_window_batch took the packed path (states are contiguous on the device)
   hipEvent_t ev[8];
+  hipEvent_t ev_flag = nullptr;  // recorded behind the copy of a table check's verdict (validate_windows_begin)
   std::map<std::string, float> last_ms;
   int last_fsel_mode = -1;  // the form the last avm_fsel_select_batch took (3: fsel_solo_kernel)
   int64_t last_fsel_evals = -1;  // candidate evaluations the last select executed on the device (solo form: counted by the kernel; else -1)
@@ -151,9 +153,10 @@ int report_bad(avm_ctx* c, int first_bad, const char* unit) {
 
 // Runs before any kernel indexes with the caller's tables: host tables are checked on the host, device-resident ones by a
 // one-thread-per-window kernel whose 4-byte verdict is read back (the only extra synchronization of a device-mode call).
-// tp_fits (optional, with CHK_PRIOR): false when some window's prior does not fit the throughput form of the solve (kernels.hpp)
-int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int what, bool* tp_fits = nullptr) {
-  if (tp_fits) *tp_fits = true;
+// tp_misfit (optional, with CHK_PRIOR): bit 0 set when some window's prior does not fit the throughput form of the solve, bit 1 when one
+// does not fit the throughput form of the marginalization (kernels.hpp, window_prior_tp_misfit)
+int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int what, int* tp_misfit = nullptr) {
+  if (tp_misfit) *tp_misfit = 0;
   if ((what & CHK_TRACKS) && (!b->n_feat || !b->feat_start || !b->feat_nobs || !b->feat_obs_begin)) return fail(c, AVM_ERR_INVALID, "null feature table");
   if ((what & CHK_IMU) && !b->imu_n) return fail(c, AVM_ERR_INVALID, "null imu_n");
   if ((what & CHK_PRIOR) && b->prior_n && (!b->prior_nblk || !b->prior_blk_kind || !b->prior_blk_frame)) return fail(c, AVM_ERR_INVALID, "null prior table");
@@ -161,7 +164,7 @@ int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int wha
     for (int w = 0; w < b->n_windows; w++) {
       const int rule = check_window_tables(*b, w, what);
       if (rule) return report_bad(c, w * 8 + rule, "window");
-      if (tp_fits && (what & CHK_PRIOR) && !window_prior_fits_tp(*b, w)) *tp_fits = false;
+      if (tp_misfit && (what & CHK_PRIOR)) *tp_misfit |= window_prior_tp_misfit(*b, w);
     }
     return AVM_OK;
   }
@@ -173,8 +176,36 @@ int validate_windows(avm_ctx* c, avm_mem mem, const avm_window_batch* b, int wha
   int h[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(h, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (tp_fits) *tp_fits = h[1] == 0;
+  if (tp_misfit) *tp_misfit = h[1];
   return h[0] == 0x7f7f7f7f ? AVM_OK : report_bad(c, h[0], "window");
+}
+
+// The same check for a device-resident batch of avm_window_solve_batch, in two halves: _begin enqueues the check, the copy of its
+// verdict into pinned memory and an event; _end waits for that event only.  What the caller enqueues in between (the pre-integration,
+// which clamps the one table entry it indexes with) runs while the host reads the verdict and prepares the next launches, instead of
+// the device idling through a blocking round trip at the top of every call.  On a failed check _end drains the stream before it
+// reports, so the caller's buffers are no longer being read when the error returns.
+int validate_windows_begin(avm_ctx* c, const avm_window_batch* b, int what, int** host_flag) {
+  if ((what & CHK_TRACKS) && (!b->n_feat || !b->feat_start || !b->feat_nobs || !b->feat_obs_begin)) return fail(c, AVM_ERR_INVALID, "null feature table");
+  if ((what & CHK_IMU) && !b->imu_n) return fail(c, AVM_ERR_INVALID, "null imu_n");
+  if ((what & CHK_PRIOR) && b->prior_n && (!b->prior_nblk || !b->prior_blk_kind || !b->prior_blk_frame)) return fail(c, AVM_ERR_INVALID, "null prior table");
+  int* flag = static_cast<int*>(pool_get(c, "v_flag", 2 * sizeof(int)));
+  int* h = static_cast<int*>(pinned_get(c, "v_flag_h", 2 * sizeof(int)));
+  if (!flag || !h) return fail(c, AVM_ERR_HIP, "allocation failed (validation flag)");
+  HIPCHK(c, hipMemsetAsync(flag, 0x7f, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(flag + 1, 0, sizeof(int), c->stream));
+  HIPCHK(c, launch_validate_windows(*b, what, flag, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_flag, c->stream));
+  *host_flag = h;
+  return AVM_OK;
+}
+int validate_windows_end(avm_ctx* c, const int* host_flag, int* tp_misfit) {
+  HIPCHK(c, hipEventSynchronize(c->ev_flag));
+  if (tp_misfit) *tp_misfit = host_flag[1];
+  if (host_flag[0] == 0x7f7f7f7f) return AVM_OK;
+  (void)hipStreamSynchronize(c->stream);
+  return report_bad(c, host_flag[0], "window");
 }
 
 int validate_fsel(avm_ctx* c, avm_mem mem, const avm_fsel_batch* b) {
@@ -426,6 +457,7 @@ int avm_create(const avm_config* cfg, avm_ctx** out) {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) c->wall_clock_hz = 1.0e3 * khz;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  (void)hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming);
   if (const char* pe = getenv("AVM_PROFILE"))
     if (pe[0] == '1') (void)hipMalloc(&c->prof, sizeof(long long) * PROF_SLOTS * 2 * c->n_slots);  // (two workgroups per CU in the throughput form)
   *out = c;
@@ -535,8 +567,14 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     if (prior_out->max_prior > MAXPRIOR || prior_out->max_prior < 1 || prior_out->max_pblk < 1) return fail(c, AVM_ERR_CAPACITY, "prior_out dims");
   }
   if (batch->n_windows == 0) return AVM_OK;
-  bool tp_fits = true;
-  if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR, &tp_fits)) != AVM_OK) return rc;
+  // table check: host tables on the host, now; device-resident ones by a kernel whose verdict is read while the pre-integration runs
+  int tp_misfit = 0;
+  int* vflag_host = nullptr;
+  if (mem == AVM_MEM_HOST) {
+    if ((rc = validate_windows(c, mem, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR, &tp_misfit)) != AVM_OK) return rc;
+  } else {
+    if ((rc = validate_windows_begin(c, batch, CHK_TRACKS | CHK_IMU | CHK_PRIOR, &vflag_host)) != AVM_OK) return rc;
+  }
   // Which form of the solve kernel: the throughput form (two 256-thread workgroups per CU, window_solve_tp.o) for batches that give
   // every CU more than one window, the latency form (one 512-thread workgroup per CU) otherwise - and always for the extended
   // problem or a prior the structural form cannot hold.  (Round 5: a wall-clock cap no longer forces the latency form - both kernels
@@ -547,8 +585,12 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   const bool extended = opt->estimate_extrinsic != 0 || opt->estimate_td != 0 || batch->relo_n != nullptr;
   bool use_tp = batch->n_windows > c->n_slots;
   if (const char* e = getenv("AVM_SOLVE_TP")) use_tp = e[0] == '1' ? true : (e[0] == '0' ? false : use_tp);
-  use_tp = use_tp && !extended && tp_fits;
-  if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp)) != AVM_OK) return rc;
+  use_tp = use_tp && !extended;
+  // (the slots for the throughput forms are sized before the priors' verdict is in: a batch that then takes the latency forms uses half of them)
+  if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp)) != AVM_OK) {
+    if (vflag_host) (void)hipStreamSynchronize(c->stream);
+    return rc;
+  }
   avm_window_batch d;
   avm_solve_summary* d_sum = nullptr;
   if (mem == AVM_MEM_HOST) {
@@ -564,6 +606,12 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if ((rc = run_preint(c, opt, &d)) != AVM_OK) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (vflag_host && (rc = validate_windows_end(c, vflag_host, &tp_misfit)) != AVM_OK) return rc;
+  use_tp = use_tp && (tp_misfit & 1) == 0;
+  // ... and the marginalization follows the solve: its throughput form (two 256-thread workgroups per CU on the solve's 2 x CUs slots)
+  // for the batches that took the throughput solve, unless a prior keeps a speed-bias block beyond frame 1 (AVM_MARG_TP=0: never)
+  bool use_marg_tp = use_tp && (tp_misfit & 2) == 0;
+  if (const char* e = getenv("AVM_MARG_TP")) use_marg_tp = use_marg_tp && e[0] != '0';
   SolveArgs sa;
   sa.b = d, sa.opt = *opt;
   sa.pre_delta = c->pre_delta, sa.pre_jac = c->pre_jac, sa.pre_sqrt = c->pre_sqrt, sa.pre_sum_dt = c->pre_sum;
@@ -581,11 +629,12 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     sa.n_slots = 2 * c->n_slots;
     if (const char* e = getenv("AVM_TP_GRID")) sa.n_slots = std::max(1, std::min(atoi(e), 2 * c->n_slots));  // (experiments: fewer resident workgroups)
     HIPCHK(c, launch_window_solve_tp(sa, c->stream));
-    sa.n_slots = c->n_slots;  // (the marginalization below runs one workgroup per CU)
+    sa.n_slots = use_marg_tp ? 2 * c->n_slots : c->n_slots;  // (the marginalization below: two workgroups per CU in its throughput form, else one)
   } else {
     HIPCHK(c, extended ? launch_window_solve_x(sa, c->stream) : launch_window_solve(sa, c->stream));
   }
   c->last_solve_tp = use_tp;
+  c->last_marg_tp = false;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   avm_prior_out dpo;
   int* marg_err = nullptr;
@@ -619,7 +668,8 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     double* marg_scale = static_cast<double*>(pool_get(c, "marg_scale", sizeof(double) * B * mp));
     if (!marg_scale) return fail(c, AVM_ERR_HIP, "hipMalloc failed (marginalization scales)");
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    HIPCHK(c, launch_marginalize(sa, dpo, marg_err, marg_scale, c->stream));
+    HIPCHK(c, use_marg_tp ? launch_marginalize_tp(sa, dpo, marg_err, marg_scale, c->stream) : launch_marginalize(sa, dpo, marg_err, marg_scale, c->stream));
+    c->last_marg_tp = use_marg_tp;
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     int* pe_done = static_cast<int*>(pool_get(c, "pe_done", sizeof(int) * B));
     if (!pe_done) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior flags)");
@@ -727,6 +777,8 @@ int avm_debug_copy_profile(avm_ctx* c, long long* host_out) {
 
 // test / bench hook (not in avm.h): 1 when the last avm_window_solve_batch ran the throughput form of the solve kernel
 int avm_debug_last_solve_form(const avm_ctx* c) { return c ? (c->last_solve_tp ? 1 : 0) : -1; }
+// ... 1 when its marginalization ran the throughput form (marginalize_tp_kernel: two 256-thread workgroups per CU)
+int avm_debug_last_marg_form(const avm_ctx* c) { return c ? (c->last_marg_tp ? 1 : 0) : -1; }
 // ... and which form the last avm_fsel_select_batch STARTED in: 3 = one workgroup per frame with lazy evaluation (fsel_solo_kernel), 2 / 1 = the
 // frame kernel's teams, 0 = one launch per greedy round
 int avm_debug_last_fsel_form(const avm_ctx* c) { return c ? c->last_fsel_mode : -1; }

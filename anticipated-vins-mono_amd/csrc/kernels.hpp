@@ -144,16 +144,20 @@ __host__ __device__ inline int check_fsel_tables(const avm_fsel_batch& b, int p)
 // The throughput form of the solve (window_solve_tp.o) keeps the speed-bias rows of the system in their structural form plus ONE strip
 // "the prior's speed-bias block x every pose" (window_solve.hip, s_off): a prior with more than one speed-bias block does not fit it.
 // The reference never builds one (estimator.cpp:904-916 keeps para_SpeedBias[1] only); such a batch simply takes the other kernel.
-__host__ __device__ inline bool window_prior_fits_tp(const avm_window_batch& B, int w) {
-  if (!B.prior_n || B.prior_n[w] <= 0) return true;
-  int nsb = 0;
+// The throughput form of the marginalization (marginalize_tp_kernel, round 5) holds the joint system over poses | speed-biases 0, 1 |
+// ex_pose | td only: a prior with a speed-bias block of a later frame does not fit it (the reference keeps frame 1's, as frame 0).
+// Returns a bit mask of what window w's prior does NOT fit: bit 0 the throughput solve, bit 1 the throughput marginalization.
+__host__ __device__ inline int window_prior_tp_misfit(const avm_window_batch& B, int w) {
+  if (!B.prior_n || B.prior_n[w] <= 0) return 0;
+  int nsb = 0, late = 0;
   const int nb = B.prior_nblk[w];
-  for (int k = 0; k < nb && k < B.max_pblk; k++) nsb += B.prior_blk_kind[(size_t)w * B.max_pblk + k] == AVM_BLK_SPEEDBIAS;
-  return nsb <= 1;
+  for (int k = 0; k < nb && k < B.max_pblk; k++)
+    if (B.prior_blk_kind[(size_t)w * B.max_pblk + k] == AVM_BLK_SPEEDBIAS) nsb++, late |= B.prior_blk_frame[(size_t)w * B.max_pblk + k] > 1;
+  return (nsb > 1 ? 1 : 0) | (late ? 2 : 0);
 }
 
 // first_bad: TWO ints.  [0]: INT_MAX when every window / problem passes, else (index * 8 + rule) of the lowest failing index;
-// [1] (windows, with CHK_PRIOR): set to 1 when some window's prior does not fit the throughput kernel (left alone otherwise)
+// [1] (windows, with CHK_PRIOR): the OR of window_prior_tp_misfit() over the windows (left alone when every prior fits)
 hipError_t launch_validate_windows(const avm_window_batch& b, int what, int* first_bad, hipStream_t stream);
 hipError_t launch_validate_fsel(const avm_fsel_batch& b, int* first_bad, hipStream_t stream);
 
@@ -179,6 +183,8 @@ int window_solve_tp_occupancy();
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 // scale: [n_windows][po.max_prior] device array: the magnitude every diagonal entry of A' was formed at (for launch_prior_eig's noise test)
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, double* scale, hipStream_t stream);
+// window_solve_tp.o: the same marginalization as two 256-thread workgroups per CU (a.n_slots = the throughput solve's 2 x CUs slots)
+hipError_t launch_marginalize_tp(const SolveArgs& a, const avm_prior_out& po, int* err, double* scale, hipStream_t stream);
 // second half of the marginalization: eigen-decomposition of A' (left in po.J / po.r by launch_marginalize) -> sqrt prior
 // noise_rel: avm_options::marg_noise_rel (0 = the reference-literal clamp S > eps and nothing else)
 hipError_t launch_prior_eig(const avm_prior_out& po, int n_windows, double eps, double noise_rel, const double* scale, long long* prof,

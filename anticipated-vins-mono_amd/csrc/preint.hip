@@ -71,7 +71,9 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
   const bool gv = iv0 + lk < n_iv;
   const long iv = gv ? iv0 + lk : n_iv - 1;
   PreLds& L = Lw[lk];
-  const int ns = gv ? a.imu_n[iv] : 0;
+  // (clamped to the table's stride: the pre-integration may be enqueued behind the table check whose verdict the host reads while it
+  //  runs - avm_api.hip, validate_windows_begin / _end; a batch with a bad imu_n is refused either way, it must only not be read out of bounds)
+  const int ns = gv ? min(max(a.imu_n[iv], 0), a.max_samp) : 0;
   int nsg[PG], ns_max = 0;
 #pragma unroll
   for (int g = 0; g < PG; g++) nsg[g] = __builtin_amdgcn_readlane(ns, 16 * g), ns_max = max(ns_max, nsg[g]);

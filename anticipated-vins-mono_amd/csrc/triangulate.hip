@@ -286,7 +286,10 @@ __global__ __launch_bounds__(64) void validate_windows_kernel(avm_window_batch B
   for (int o = 32; o > 0; o >>= 1) rule = min(rule, __shfl_xor(rule, o, 64));
   if (lane == 0 && rule != 1 << 30) atomicMin(first_bad, w * 8 + rule);
   // (only for a window whose prior tables passed: the count below indexes with them)
-  if (lane == 0 && rule == 1 << 30 && (what & CHK_PRIOR) && !window_prior_fits_tp(B, w)) first_bad[1] = 1;
+  if (lane == 0 && rule == 1 << 30 && (what & CHK_PRIOR)) {
+    const int m = window_prior_tp_misfit(B, w);
+    if (m) atomicOr(first_bad + 1, m);
+  }
 }
 
 __global__ __launch_bounds__(64) void validate_fsel_kernel(avm_fsel_batch b, int* first_bad) {

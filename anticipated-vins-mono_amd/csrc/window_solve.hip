@@ -186,6 +186,50 @@ constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 54
 static_assert(I_END <= 720, "int carve");
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Issue priority of the calling wavefront (throughput build only).  Two windows share every SIMD there, one wavefront each: while one
+// of them streams MFMAs / factor arithmetic (the frame tasks, the Schur tiles, the trailing updates of the factorization: AVM_PRIO_BULK)
+// and the other walks a dependent chain or one of the short barrier-separated vector phases of the trust-region loop (AVM_PRIO_LIGHT),
+// the arbiter should hand the next free issue slot to the latter - its instructions are the window's critical path, the bulk work
+// fills whatever is left.  (The pivot chains have run at priority 3 since round 4.)
+#ifdef AVM_TP
+#ifndef AVM_PRIO_L
+#define AVM_PRIO_L 2
+#endif
+#ifndef AVM_PRIO_CHOL
+#define AVM_PRIO_CHOL 1
+#endif
+#ifndef AVM_PRIO_SCHUR
+#define AVM_PRIO_SCHUR 1
+#endif
+#define AVM_PRIO_BULK() __builtin_amdgcn_s_setprio(0)
+#define AVM_PRIO_BULK_CHOL() __builtin_amdgcn_s_setprio(AVM_PRIO_CHOL)
+#define AVM_PRIO_BULK_SCHUR() __builtin_amdgcn_s_setprio(AVM_PRIO_SCHUR)
+#define AVM_PRIO_LIGHT() __builtin_amdgcn_s_setprio(AVM_PRIO_L)
+#ifdef AVM_PRIO_IMUF
+#define AVM_PRIO_X_IMUF() __builtin_amdgcn_s_setprio(AVM_PRIO_IMUF)
+#else
+#define AVM_PRIO_X_IMUF() ((void)0)
+#endif
+#ifdef AVM_PRIO_BSUB
+#define AVM_PRIO_X_BSUB() __builtin_amdgcn_s_setprio(AVM_PRIO_BSUB)
+#else
+#define AVM_PRIO_X_BSUB() ((void)0)
+#endif
+#ifdef AVM_PRIO_PB
+#define AVM_PRIO_X_PB() __builtin_amdgcn_s_setprio(AVM_PRIO_PB)
+#else
+#define AVM_PRIO_X_PB() ((void)0)
+#endif
+#else
+#define AVM_PRIO_X_IMUF() ((void)0)
+#define AVM_PRIO_X_BSUB() ((void)0)
+#define AVM_PRIO_X_PB() ((void)0)
+#define AVM_PRIO_BULK() ((void)0)
+#define AVM_PRIO_BULK_CHOL() ((void)0)
+#define AVM_PRIO_BULK_SCHUR() ((void)0)
+#define AVM_PRIO_LIGHT() ((void)0)
+#endif
+
 AVM_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -268,6 +312,15 @@ AVM_DEV double fast_rcp(double x) {
   e = fma(-x, y, 1.0);
   return fma(y, e, y);
 }
+// raw v_rsq_f64 + two Newton steps (the library rsqrt spends ~3x as long in range handling we do not need:
+// pivots of an SPD matrix are normal positive numbers)
+AVM_DEV double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  return y;
+}
+
 AVM_DEV double fast_rsqrt_pe(double x) {
   double y = __builtin_amdgcn_rsq(x);
   y = y * (1.5 - (0.5 * x) * y * y);
@@ -797,7 +850,6 @@ AVM_NOINL double eval_cost(const WinCtx&, const avm_options&, int xs_off, int wh
   return block_sum1(acc);
 }
 
-#ifndef AVM_TP
 // Prior J0^T J0 on the matrix cores (16x16 tiles, K = prior rows), marginalization-kernel variant: the tiles are
 // added straight into the packed system in LDS at the
 // columns pidx[] maps the prior's columns to (every lower entry is produced exactly once, so the wavefronts never
@@ -834,8 +886,6 @@ AVM_NOINL void prior_jtj_add_lds(gcdouble* pJ, int ldp, int pn, int s_off) {
     }
   }
 }
-
-#endif  // !AVM_TP
 
 // Solve-kernel variant: lower triangle packed by idx = p (p + 1) / 2 + q into HPk, plus the destination of every
 // entry inside the packed S (or -1 if the prior column is not a state of the solve) - the per-iteration add is then
@@ -1427,7 +1477,9 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     for (int b = 1; b < NFRP; b++)
       if (ids[I_FRW + b] == wv) acc += frame_task(c, o, b, L_S + SPP + wv * XSTG);
 #else
+    AVM_PRIO_BULK();
     acc += frame_task(c, o, wv, L_S + SPP + wv * XSTG);  // all the frames of this wavefront as one list
+    AVM_PRIO_LIGHT();
 #endif
   }
 #ifdef AVM_TP
@@ -1458,6 +1510,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   __syncthreads();
   PROF(c, 0);
   // ---- phase B: per-feature sums over the start pose, diagonal blocks, pose gradient
+  AVM_PRIO_X_PB();
   {
     double* W = c.sc + Scratch::W;
     const double* PF = c.sc + Scratch::PF;
@@ -1619,6 +1672,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
 #endif
   }
   PROF(c, 1);
+  AVM_PRIO_LIGHT();
   // phase D's operands (sqrt_info, the raw Jacobians wave ASM_WAVES left in the slot during phase A) and phase E's packed
   // prior are fetched now: their trip to the slot's memory overlaps the zeroing and the barriers in between
 #ifdef AVM_TP
@@ -1658,12 +1712,14 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   // ---- phase D: IMU factors on MFMA, one wavefront per factor; even factors then odd ones (neighbours share a frame)
   {
 #ifdef AVM_TP
+    AVM_PRIO_X_IMUF();
 #pragma unroll
     for (int rd = 0; rd < NIMR; rd++) {
       const int i = imu_of(rd);
       if (i >= 0 && c.psum[max(i, 0)] <= o.max_sum_dt) acc += imu_factor_mfma(c, i, io[rd]);
       __syncthreads();
     }
+    AVM_PRIO_LIGHT();
 #else
 #pragma unroll
     for (int par = 0; par < 2; par++) {
@@ -1939,7 +1995,7 @@ AVM_DEV void tp_diag_chain(int nb, int buf) {
 #pragma unroll
     for (int k = 0; k < NB; k++) *(k <= kmax ? dst + k : dump) = a[k];
   }
-  __builtin_amdgcn_s_setprio(0);
+  AVM_PRIO_BULK_CHOL();
 }
 
 // sum over the 16 lanes of a DPP row; the result is valid in lane 15 of every row (row_shr with bound_ctrl: a lane without a source adds 0)
@@ -2173,15 +2229,6 @@ struct CholTile {
   double d[4];
   int o[4];  // destination offsets (doubles from lds[0]); masked-out entries point at the dump slot
 };
-
-// raw v_rsq_f64 + two Newton steps (the library rsqrt spends ~3x as long in range handling we do not need:
-// pivots of an SPD matrix are normal positive numbers)
-AVM_DEV double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - (0.5 * x) * y * y);
-  y = y * (1.5 - (0.5 * x) * y * y);
-  return y;
-}
 
 // Factor the nb x nb diagonal block at c0 in the registers of the calling wavefront (lane = row, register = column).
 //  * Select-free: lanes / columns outside the block (and the upper triangle) just carry finite junk that is never stored.
@@ -2609,12 +2656,14 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
   }
   __syncthreads();
 #ifdef AVM_TP
+  AVM_PRIO_BULK_SCHUR();
   switch (t >> 6) {  // four wavefronts, one per SIMD: 4 | 3 + 1 | 3 + 1... tiles (the 15 lower tiles of the 5 x 5 grid)
     case 0: schur_macro_tile<2, 3, 0, 1>(c); break;                                       // 4 tiles
     case 1: schur_macro_tile<0, 1, 0, 1>(c); schur_macro_tile<4, -1, 4, -1>(c); break;    // 3 + 1
     case 2: schur_macro_tile<2, 3, 2, 3>(c); break;                                       // 3
     default: schur_macro_tile<4, -1, 0, 1>(c); schur_macro_tile<4, -1, 2, 3>(c); break;   // 2 + 2
   }
+  AVM_PRIO_LIGHT();
   __syncthreads();
   return;
 #endif
@@ -2643,6 +2692,7 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
   if (t < NPOSE) ys[t] = scl[t] * lds[L_Y + t];
   if (t >= NPOSE && t < 4 * NQ4 + 4) ys[t] = 0.0;
   __syncthreads();
+  AVM_PRIO_X_BSUB();
   const int part = t & 3;
 #pragma unroll
   for (int pass = 0; pass < (MAXE + NT / 4 - 1) / (NT / 4); pass++) {
@@ -2663,6 +2713,7 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
       lds[L_Y + NF + e] = (lds[L_G + NF + e] - scl[NF + e] * sacc) / he;
     }
   }
+  AVM_PRIO_LIGHT();
   __syncthreads();
   double bad = 0;
   for (int i = t; i < NF + c.nf; i += NT)
@@ -2818,6 +2869,7 @@ AVM_DEV void state_plus() {
 __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A) {
   lds_base_check();
   red_init();
+  AVM_PRIO_LIGHT();
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
   const int t = threadIdx.x;
@@ -3297,12 +3349,14 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
 #ifdef AVM_TP
           // factorization + both triangular solves on the register tiles of the four wavefronts (y -> lds[L_Y])
           bool ok;
+          AVM_PRIO_BULK_CHOL();  // (its pivot chains raise themselves to 3)
           switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
             case 0: ok = chol_regs<0>(); break;
             case 1: ok = chol_regs<1>(); break;
             case 2: ok = chol_regs<2>(); break;
             default: ok = chol_regs<3>(); break;
           }
+          AVM_PRIO_LIGHT();
           PROF(c, 12);
           if (!ok) {
             mu *= mu_inc;
@@ -3597,7 +3651,7 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
   }
 }
 
-#if !defined(AVM_X) && !defined(AVM_TP)
+#if !defined(AVM_X)
 // =====================================================================================
 // Post-solve marginalization: MarginalizationInfo::addResidualBlockInfo / preMarginalize /
 // marginalize / getParameterBlocks (vins_estimator/src/factor/marginalization_factor.cpp:89-319)
@@ -3614,16 +3668,42 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
 // Deterministic block order (the reference's is address-hash order): kept = poses by frame,
 // speed-bias by frame, ex_pose.
 namespace mg {
-constexpr int MEX0 = 165, MTD = 171, MROWS = croff(172);  // 172 variables: poses | speed-biases | ex_pose | td
 constexpr int MXRS = 68;                              // rows per staged column: HALF a chunk (32 factors x 2 residual rows) + 4 (bank spread)
 constexpr int MXSTG = 20 * MXRS;                      // column-major staging tile: Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18 | Jtd 19
+#ifdef AVM_TP
+// THROUGHPUT form of the marginalization (marginalize_tp_kernel in window_solve_tp.o, round 5): the same phases as a 256-thread
+// workgroup inside the throughput build's 80 KB of LDS, so that TWO windows are resident per CU - the kernel is a sequence of short
+// latency-bound phases (62 % of its wavefront cycles waiting), and a second window fills them.  What makes it fit: the joint system
+// only holds the variables a marginalization can touch - poses | speed-bias 0, 1 | ex_pose | td = 91 instead of 172 (packed 33 KB
+// instead of 117): IMU factor 0 reaches speed-biases 0 and 1, the projection factors the poses and ex_pose / td, and the old prior
+// whatever it kept last time, which for a prior the reference can build is a subset of these (estimator.cpp:904-916 keeps
+// para_SpeedBias[1], shifted to frame 0).  A prior with a speed-bias block of a later frame takes the other kernel (the host checks:
+// window_prior_fits_marg_tp).  Speed-biases 0 and 1 keep their indices (66 .. 83), so imu_col() and SB0 + 9 fr hold unchanged.
+constexpr int MEX0 = 84, MTD = 90, MVARS = 91;
+constexpr int MASM = 4;                               // every wavefront assembles (frames 1 8 9 | 2 7 10 | 3 6 + raw IMU, prior | 4 5 + prior)
+#else
+constexpr int MEX0 = 165, MTD = 171, MVARS = 172;     // 172 variables: poses | speed-biases | ex_pose | td
 constexpr int MASM = 7;                               // assembling wavefronts (staging must stay below row 165: half tiles let seven fit)
+#endif
+constexpr int MROWS = croff(MVARS);
+#ifdef AVM_TP
+// LDS of the throughput form: S (4232) | EA EV EB / IMU factor rows (2048) | T (1536) | g_e (152) ... b in the scaling vector's place;
+// the staging tiles of phase A lie over everything from row 66 of S to 7684, all of it written after phase A only
+constexpr int M_WCH = MROWS;                          // Amm, its eigenvectors / inverse factor, Arm (n x 16); before: the IMU factor's rows
+constexpr int M_GT = M_WCH + 2048;                    // T = Arm Amm^+ (n x 16)
+constexpr int M_GE = M_GT + 96 * 16;                  // g_e (152)
+constexpr int M_G = L_SC;                             // b over the 91 variables (the Jacobi scaling is the solve's)
+static_assert(M_GE + 152 <= M_G && MVARS <= VEC && M_G + VEC <= L_X, "marg layout (throughput form)");
+static_assert(L_S + SPP + MASM * MXSTG <= M_G, "marg staging must not reach b");
+#else
 constexpr int M_G = MROWS;                            // b over the 171 variables (176)
 constexpr int M_GE = M_G + 176;                       // g_e (152)
 constexpr int M_WCH = M_GE + 152;                     // [24][80] Schur staging / IMU factor rows
+constexpr int M_GT = L_G;                             // T = Arm Amm^+ in the range of the solve's gradient / scaling vectors (unused here)
 constexpr int MWCH = 24;
 static_assert(M_WCH + MWCH * WLD <= L_G, "marg layout");
 static_assert(SPP + MASM * MXSTG <= 13778, "marg staging must not reach the ex_pose rows (roff(165))");
+#endif
 constexpr int PARTW = 146;  // aa 21 | g_a 6 | [ex td].pose0 42 | [ex td]^2 28 | g_[ex td] 7 | [ex td].pose_b 42
 constexpr int MNW = 73;     // columns of W = E^T F here: 66 pose | 6 ex_pose | 1 td
 constexpr int MWS = 80;     // row stride of W[e][.]
@@ -3794,19 +3874,30 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
     }
     D00 = D10 = D11 = E00 = E10 = E11 = d4{0, 0, 0, 0};
   };
+  // inputs of a chunk (feature id, its two observations) are fetched one chunk ahead, as in the solve's frame task (round 5: the
+  // id and then the observations were two dependent trips to memory at the top of every chunk)
+  int e_nx = 0, b_nx = b0, s0_nx = 0;
+  double ob_nx[4] = {0, 0, 0, 0};
+  auto fetch = [&](int chunk0) {
+    const int ic = min(chunk0 + lane, max(ntot - 1, 0));
+    b_nx = ic < n0 ? b0 : b1;
+    e_nx = c.cov[b_nx * MAXE + (ic < n0 ? ic : ic - n0)];  // (inactive lanes repeat the last factor: valid, never stored)
+    s0_nx = ids[I_FOBS + e_nx];
+    const int s = s0_nx + b_nx;
+    ob_nx[0] = c.obs[2 * s0_nx], ob_nx[1] = c.obs[2 * s0_nx + 1], ob_nx[2] = c.obs[2 * s], ob_nx[3] = c.obs[2 * s + 1];
+  };
+  if (ntot > 0) fetch(0);
   for (int chunk0 = 0; chunk0 < ntot; chunk0 += 64) {
     const int idx = chunk0 + lane;
     const bool act = idx < ntot;
-    const int ic = min(idx, max(ntot - 1, 0));
-    const int b = ic < n0 ? b0 : b1;
-    const int e = c.cov[b * MAXE + (ic < n0 ? ic : ic - n0)];  // (inactive lanes repeat the last factor: valid, never stored)
-    const int s0 = ids[I_FOBS + e];
-    const int s = s0 + b;
+    const int b = b_nx, e = e_nx, s0 = s0_nx, s = s0 + b;
+    const double ob0 = ob_nx[0], ob1 = ob_nx[1], ob2 = ob_nx[2], ob3 = ob_nx[3];
+    if (chunk0 + 64 < ntot) fetch(chunk0 + 64);
     double r[2] = {0, 0}, Ji[12], Jj[12], Je[2] = {0, 0}, Jx[12], Jt[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < 12; k++) Ji[k] = 0, Jj[k] = 0, Jx[k] = 0;
     if (act) {
-      double ob[4] = {c.obs[2 * s0], c.obs[2 * s0 + 1], c.obs[2 * s], c.obs[2 * s + 1]}, ai[4] = {0, 0, 0, 0}, aj[4] = {0, 0, 0, 0};
+      double ob[4] = {ob0, ob1, ob2, ob3}, ai[4] = {0, 0, 0, 0}, aj[4] = {0, 0, 0, 0};
       if (c.est_td) {  // ProjectionTdFactor (estimator.cpp:874-885)
 #pragma unroll
         for (int k = 0; k < 4; k++) ai[k] = c.aux[4 * s0 + k], aj[k] = c.aux[4 * s + k];
@@ -4130,8 +4221,16 @@ AVM_DEV bool pinv16_cholesky(double* EA, double* EV, int m, double eps) {
   return fast;
 }
 
-__global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_out PO, int* err, double* scale_out) {
+#ifdef AVM_TP
+#define AVM_MARG_KERNEL marginalize_tp_kernel
+#define AVM_MARG_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))  // two four-wavefront workgroups per CU, like the solve beside it
+#else
+#define AVM_MARG_KERNEL marginalize_kernel
+#define AVM_MARG_OCC
+#endif
+__global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, avm_prior_out PO, int* err, double* scale_out) {
   lds_base_check();
+  AVM_PRIO_LIGHT();
   using namespace mg;
   double* lds = LDS();
   int* ids = reinterpret_cast<int*>(lds + L_INT);
@@ -4171,8 +4270,9 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     static_assert(NT >= 160 && 99 <= NT && MAXE <= NT, "one entry of every table per thread");
     {
       const int nfl = c.nf, npb = c.pnblk;
-      const bool in_f = t < nfl, in_pb = t >= 256 && t < 256 + npb;
-      const int kpb = in_pb ? t - 256 : 0;
+      constexpr int PBT0 = NT >= 512 ? 256 : 160;
+      const bool in_f = t < nfl, in_pb = t >= PBT0 && t < PBT0 + npb;
+      const int kpb = in_pb ? t - PBT0 : 0;
       const double v_pose = B.pose[(size_t)w * 77 + min(t, 76)], v_sb = B.speedbias[(size_t)w * 99 + min(t, 98)];
       const double v_lam = in_f ? B.inv_depth[(size_t)w * B.max_feat + t] : 1.0;
       const size_t kf = (size_t)w * B.max_feat + (in_f ? t : 0);
@@ -4187,7 +4287,13 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       }
       __builtin_amdgcn_sched_barrier(0);
       for (int i = t; i < MAXPRIOR; i += NT) lds[L_DXP + i] = 0.0, lds[L_RP + i] = 0.0;
+#ifdef AVM_TP
+      for (int i = t; i < MROWS; i += NT) lds[L_S + i] = 0.0;
+      for (int i = t; i < VEC; i += NT) lds[M_G + i] = 0.0;
+      for (int i = t; i < 152; i += NT) lds[M_GE + i] = 0.0;
+#else
       for (int i = t; i < MROWS + 176 + 152; i += NT) lds[i] = 0.0;  // S, b, g_e
+#endif
       for (int i = t; i < 152; i += NT) lds[L_HEE + i] = 0.0;
       if (t < 77) lds[L_X + t] = v_pose;
       if (t < 99) lds[L_X + XSB + t] = v_sb;
@@ -4249,6 +4355,32 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     for (int e0 = 0; e0 < c.nf; e0 += 64) nf0 += __popcll(__ballot(e0 + lane < c.nf && ids[I_FSTART + min(e0 + lane, MAXE - 1)] == 0));
     PROF(c, 16);
     // ---- phase A: projection factors of the start-0 features || IMU factor 0
+#ifdef AVM_TP
+    {
+      // four wavefronts, one per SIMD: frames {1 8 9} {2 7 10} {3 6} {4 5} (a start-0 feature's track ends early or late: the factor
+      // counts fall with the frame, and this deal keeps the sums level), a pair as one list of factors, the third frame after it;
+      // wavefront 2 then takes IMU factor 0 and two fifths of the old prior's rows, wavefront 3 the other three fifths (each reads J0
+      // along its own rows only; the partial gradients are added in phase E, as in the solve)
+      static_assert(NFR == 11 && MASM == 4, "the deal below");
+      const int stage = L_S + SPP + wv * MXSTG;
+      AVM_PRIO_BULK();
+      switch (wv) {
+        case 0: marg_frame_task(c, o, 1, 8, stage), marg_frame_task(c, o, 9, NFR, stage); break;
+        case 1: marg_frame_task(c, o, 2, 7, stage), marg_frame_task(c, o, 10, NFR, stage); break;
+        case 2: marg_frame_task(c, o, 3, 6, stage); break;
+        default: marg_frame_task(c, o, 4, 5, stage); break;
+      }
+      AVM_PRIO_LIGHT();
+      if (wv == 2 && lane == 0 && imu0) imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
+      if (wv >= 2 && use_prior) {
+        const int h = (3 * c.pn + 2) / 5;
+        if (wv == 2)
+          prior_wave<true>(L_X, h, c.pn, L_DX2);
+        else
+          prior_wave<true>(L_X, 0, h, L_DXP);
+      }
+    }
+#else
     if (wv < MASM) {
       marg_frame_task(c, o, 1 + wv, 1 + wv + MASM, L_S + SPP + wv * MXSTG);  // this wavefront's (at most two) frames
       static_assert(1 + 2 * MASM >= NFR, "two frames per wavefront cover all frames");
@@ -4257,6 +4389,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
       // ... and the old prior's residual and gradient (MarginalizationFactor at the current state): dx, r_p, J0^T r_p
       if (use_prior) prior_wave<true>(L_X, 0, c.pn, L_DXP);
     }
+#endif
     __syncthreads();
     PROF(c, 17);
     // ---- phase B: per-feature sums, PART gather
@@ -4389,7 +4522,11 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     if (use_prior) {
       const int* pidx = ids + I_PIDX;
       prior_jtj_add_lds(c.pJ, c.ldp, c.pn, L_S);
+#ifdef AVM_TP
+      if (t < c.pn) lds[M_G + pidx[t]] += lds[L_DXP + t] + lds[L_DX2 + t];  // g += J0^T r_p (the two shares of phase A)
+#else
       if (t < c.pn) lds[M_G + pidx[t]] += lds[L_DXP + t];  // g += J0^T r_p (left in lds[L_DXP] by phase A)
+#endif
     }
     __syncthreads();
     PROF(c, 20);
@@ -4397,6 +4534,16 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     if (flag == AVM_MARGIN_OLD && nf0 > 0) {
       if (t < MAXE) lds[L_HEE + t] = (t < nf0 && lds[L_HEE + t] > o.marg_eps) ? 1.0 / lds[L_HEE + t] : 0.0;  // 1 / E^T E in place
       __syncthreads();
+#ifdef AVM_TP
+      AVM_PRIO_BULK();
+      switch (t >> 6) {  // four wavefronts, one per SIMD: 4 | 3 + 1 | 3 | 2 + 2 tiles (as schur_reduce)
+        case 0: marg_schur_macro_tile<2, 3, 0, 1>(nf0); break;
+        case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0), marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
+        case 2: marg_schur_macro_tile<2, 3, 2, 3>(nf0); break;
+        default: marg_schur_macro_tile<4, -1, 0, 1>(nf0), marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
+      }
+      AVM_PRIO_LIGHT();
+#else
       switch (t >> 6) {
         case 0: marg_schur_macro_tile<2, 3, 0, 1>(nf0); break;
         case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0); break;
@@ -4406,6 +4553,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
         case 5: marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
         default: break;
       }
+#endif
     }
     __syncthreads();
     PROF(c, 21);
@@ -4495,8 +4643,11 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
     }
     // T = Arm Amm^+ : n x 16, in the LDS range of the solve's gradient / scaling vectors (unused here; it was in the scratch slot:
     // every entry of A' then waited for 16 trips to its memory)
+#ifndef AVM_TP
     static_assert(MAXKEEP * 16 <= L_X - L_G, "T fits the dead vectors");
-    double* GT = lds + L_G;
+#endif
+    static_assert(MAXKEEP <= 96, "T / Arm: 96 rows");
+    double* GT = lds + M_GT;
     for (int idx = t; idx < n * 16; idx += NT) {
       const int i = idx / 16, j = idx % 16;
       double sacc = 0;
@@ -4568,6 +4719,7 @@ __global__ __launch_bounds__(NT) void marginalize_kernel(SolveArgs A, avm_prior_
   }
 }
 
+#ifndef AVM_TP
 // Per-factor evaluation at the input state (no solve): parity-test surface for A5/A6/A8.
 __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
   lds_base_check();
@@ -4663,8 +4815,9 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
   const double cost = block_sum<NT>(acc, lds + L_RED);
   if (t == 0 && A.cost) A.cost[w] = cost;
 }
+#endif  // !AVM_TP
 
-#endif  // !AVM_X (marginalization + per-factor evaluation kernels: base build only)
+#endif  // !AVM_X (marginalization: base and throughput build; per-factor evaluation kernel: base build only)
 
 #ifdef AVM_TP
 int window_solve_tp_lds_bytes() { return L_END * 8; }
@@ -4686,6 +4839,19 @@ hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream) {
   }
   const int grid = a.b.n_windows < a.n_slots ? a.b.n_windows : a.n_slots;
   hipLaunchKernelGGL(window_solve_tp_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a);
+  return hipGetLastError();
+}
+
+// Throughput form of the marginalization: two 256-thread workgroups per CU, a.n_slots = 2 x CUs scratch slots (the solve's)
+hipError_t launch_marginalize_tp(const SolveArgs& a, const avm_prior_out& po, int* err, double* scale, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(marginalize_tp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_END * 8);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = a.b.n_windows < a.n_slots ? a.b.n_windows : a.n_slots;
+  hipLaunchKernelGGL(marginalize_tp_kernel, dim3(grid), dim3(NT), L_END * 8, stream, a, po, err, scale);
   return hipGetLastError();
 }
 #elif !defined(AVM_X)

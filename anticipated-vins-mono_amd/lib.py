@@ -67,6 +67,7 @@ def lib():
         L.avm_fsel_build_cloud.argtypes = [vp, C.c_int, C.POINTER(abi.WindowBatch), abi.c_dp, abi.c_dp, C.c_int32, abi.c_ip, abi.c_dp, abi.c_dp]
         L.avm_debug_copy_sqrt_info.argtypes = [vp, C.c_int, abi.c_dp]
         L.avm_debug_last_solve_form.argtypes = [vp]
+        L.avm_debug_last_marg_form.argtypes = [vp]
         L.avm_debug_last_fsel_form.argtypes = [vp]
         L.avm_debug_counters.argtypes = [vp, C.POINTER(C.c_int64)]
         L.avm_debug_fsel_evaluations.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -153,6 +154,11 @@ class Context:
         """Which form of the solve kernel the last optimization() took: 'throughput' (two 256-thread workgroups per CU,
         batches larger than the CU count) or 'latency' (one 512-thread workgroup per CU).  AVM_SOLVE_TP=0/1 forces it."""
         return "throughput" if self._L.avm_debug_last_solve_form(self.h) == 1 else "latency"
+
+    def last_marg_form(self) -> str:
+        """Which form of the marginalization kernel the last optimization() took: 'throughput' (two 256-thread workgroups per CU; it
+        follows the solve's form unless a prior keeps a speed-bias block beyond frame 1, AVM_MARG_TP=0 switches it off) or 'latency'."""
+        return "throughput" if self._L.avm_debug_last_marg_form(self.h) == 1 else "latency"
 
     def last_fsel_form(self) -> str:
         """Which form the last select_batch() started in: 'solo' (one workgroup per frame with lazy evaluation: batches of 33 frames and
