@@ -205,25 +205,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define AVM_PRIO_BULK_CHOL() __builtin_amdgcn_s_setprio(AVM_PRIO_CHOL)
 #define AVM_PRIO_BULK_SCHUR() __builtin_amdgcn_s_setprio(AVM_PRIO_SCHUR)
 #define AVM_PRIO_LIGHT() __builtin_amdgcn_s_setprio(AVM_PRIO_L)
-#ifdef AVM_PRIO_IMUF
-#define AVM_PRIO_X_IMUF() __builtin_amdgcn_s_setprio(AVM_PRIO_IMUF)
 #else
-#define AVM_PRIO_X_IMUF() ((void)0)
-#endif
-#ifdef AVM_PRIO_BSUB
-#define AVM_PRIO_X_BSUB() __builtin_amdgcn_s_setprio(AVM_PRIO_BSUB)
-#else
-#define AVM_PRIO_X_BSUB() ((void)0)
-#endif
-#ifdef AVM_PRIO_PB
-#define AVM_PRIO_X_PB() __builtin_amdgcn_s_setprio(AVM_PRIO_PB)
-#else
-#define AVM_PRIO_X_PB() ((void)0)
-#endif
-#else
-#define AVM_PRIO_X_IMUF() ((void)0)
-#define AVM_PRIO_X_BSUB() ((void)0)
-#define AVM_PRIO_X_PB() ((void)0)
 #define AVM_PRIO_BULK() ((void)0)
 #define AVM_PRIO_BULK_CHOL() ((void)0)
 #define AVM_PRIO_BULK_SCHUR() ((void)0)
@@ -1510,7 +1492,6 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   __syncthreads();
   PROF(c, 0);
   // ---- phase B: per-feature sums over the start pose, diagonal blocks, pose gradient
-  AVM_PRIO_X_PB();
   {
     double* W = c.sc + Scratch::W;
     const double* PF = c.sc + Scratch::PF;
@@ -1672,7 +1653,6 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
 #endif
   }
   PROF(c, 1);
-  AVM_PRIO_LIGHT();
   // phase D's operands (sqrt_info, the raw Jacobians wave ASM_WAVES left in the slot during phase A) and phase E's packed
   // prior are fetched now: their trip to the slot's memory overlaps the zeroing and the barriers in between
 #ifdef AVM_TP
@@ -1712,14 +1692,12 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   // ---- phase D: IMU factors on MFMA, one wavefront per factor; even factors then odd ones (neighbours share a frame)
   {
 #ifdef AVM_TP
-    AVM_PRIO_X_IMUF();
 #pragma unroll
     for (int rd = 0; rd < NIMR; rd++) {
       const int i = imu_of(rd);
       if (i >= 0 && c.psum[max(i, 0)] <= o.max_sum_dt) acc += imu_factor_mfma(c, i, io[rd]);
       __syncthreads();
     }
-    AVM_PRIO_LIGHT();
 #else
 #pragma unroll
     for (int par = 0; par < 2; par++) {
@@ -2692,7 +2670,7 @@ AVM_NOINL double back_substitute(const WinCtx&, double mu) {
   if (t < NPOSE) ys[t] = scl[t] * lds[L_Y + t];
   if (t >= NPOSE && t < 4 * NQ4 + 4) ys[t] = 0.0;
   __syncthreads();
-  AVM_PRIO_X_BSUB();
+  AVM_PRIO_BULK();  // (150 independent dot products from the slot: bulk work; measured 12.54 -> 12.46 ms against leaving it at the light level)
   const int part = t & 3;
 #pragma unroll
   for (int pass = 0; pass < (MAXE + NT / 4 - 1) / (NT / 4); pass++) {
@@ -3051,11 +3029,13 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
       // Longest-processing-time assignment of the frames to the four wavefronts (lane q keeps the load of wavefront q, in factors).
       // Every wavefront has a SIMD to itself within the workgroup; wavefront 2 also evaluates the raw IMU Jacobians (about two
       // chunks' worth) and two fifths of the prior's rows, wavefront 3 the other three fifths: they start with that load.
+      // (Round 5: with the issue priorities those two run at the light level and weigh less than they did: 60 / 300 factors' worth,
+      //  re-measured - were 88 / 380: ragged tracks 11.82 -> 11.74 ms, dense 12.54 -> 12.49.)
 #ifndef AVM_TP_WIMU
-#define AVM_TP_WIMU 88
+#define AVM_TP_WIMU 60
 #endif
 #ifndef AVM_TP_WPRI
-#define AVM_TP_WPRI 380
+#define AVM_TP_WPRI 300
 #endif
       int fc = t == 2 ? AVM_TP_WIMU + (c.pn > 0 ? 2 * AVM_TP_WPRI / 5 : 0) : (t == 3 && c.pn > 0 ? 3 * AVM_TP_WPRI / 5 : 0), done = 0;
       if (t == 0) ids[I_FRW] = -1;

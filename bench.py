@@ -427,6 +427,8 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         solve_form = ctx.last_solve_form() if hasattr(ctx, "last_solve_form") else "latency"
         solve_kernel = "window_solve_tp_kernel" if solve_form == "throughput" else "window_solve_kernel"
+        marg_form = ctx.last_marg_form() if hasattr(ctx, "last_marg_form") else "latency"
+        marg_kernel = "marginalize_tp_kernel" if marg_form == "throughput" else "marginalize_kernel"
         achieved = flops / (k_ms * 1e-3) / 1e12
         traffic, traffic_src, mfma_util, fabric_gbs, wait_any = None, None, None, None, None
         prof_j, prof_name, prof_err = committed_profile()  # newest committed rocprofv3 --pmc summary, if it belongs to these kernel sources
@@ -465,7 +467,7 @@ def main():
         # ---- the kernels around the solve: the same roofline entry each (FLOP models: flop_models_other; counters: the committed profile)
         other = flop_models_other(host, W)
         kernels = {}
-        for key, names in (("preint", ("preint_kernel", "sqrt_info_kernel")), ("marginalize", ("marginalize_kernel",)),
+        for key, names in (("preint", ("preint_kernel", "sqrt_info_kernel")), ("marginalize", (marg_kernel,)),
                            ("prior_eig", ("prior_chol_kernel", "prior_eig_kernel"))):
             ms_k = float(np.mean(all_ms[key])) if all_ms[key] else 0.0
             if ms_k <= 0.0:
@@ -515,6 +517,8 @@ def main():
                 "input_generation_s": t_gen,
                 "solve_form": solve_form + (" (two 256-thread workgroups per CU, window_solve_tp.o)" if solve_form == "throughput" else
                                             " (one 512-thread workgroup per CU)"),
+                "marginalize_form": marg_form + (" (marginalize_tp_kernel: two 256-thread workgroups per CU)" if marg_form == "throughput" else
+                                                 " (marginalize_kernel: one 512-thread workgroup per CU)"),
             },
             "roofline": {
                 "bound": "mfma",
