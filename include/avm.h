@@ -19,7 +19,10 @@
  *     tables, the selector's counts) are validated before any kernel indexes with
  *     them - host tables on the host, device-resident ones by a one-thread-per-window
  *     kernel: AVM_ERR_INVALID, avm_last_error() names the first bad window and the
- *     rule, nothing has been modified.
+ *     rule, nothing has been modified.  (avm_window_solve_batch on device-resident
+ *     tables reads that kernel's verdict while the pre-integration - which writes
+ *     library-owned buffers only and clamps the one entry it indexes with - is already
+ *     running; nothing else is launched before the verdict is in.)
  *   - all buffers are caller owned.  `mem` says whether the pointers are host
  *     pointers (the library stages them over PCIe) or device pointers already
  *     resident in HBM (what bench.py times).
