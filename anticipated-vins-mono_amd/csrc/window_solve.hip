@@ -1052,10 +1052,13 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int wvi, int stage_
     if (act) {
       cost += proj_eval<true>(xs, fr, lds + L_RIC, lds + L_RIC + 9, ob0, ob1, ob2, ob3,
                               xs[XLAM + e], fa, b, sqi, o.cauchy_a, true, r, Ji, Jj, Je);
+      // (round 5: Ji's translation columns are minus Jj's - set so in proj_eval -, so Ji_t^T Je is exactly -W[6 b + k][e], k < 3: those three products
+      //  are not stored a second time, the per-feature sums read them out of W.  Every 8 bytes per factor written here cost 0.1 ms per 4096 windows:
+      //  profiles/r05e_experiments.md section 10.)
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         W[(6 * b + k) * WLE + e] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
-        PF[(k * NFR + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+        if (k >= 3) PF[(k * NFR + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
       }
       PF[(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
       PF[(7 * NFR + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
@@ -1255,7 +1258,7 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         W[(6 * b + k) * WLE + e] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
-        PF[(k * NFRP + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+        if (k >= 3) PF[(k * NFRP + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];  // (k < 3: minus W's entry, see the base build's frame task)
         PF[((8 + k) * NFRP + b) * WLE + e] = Jx[k] * Je[0] + Jx[6 + k] * Je[1];
       }
       PF[(6 * NFRP + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
@@ -1509,13 +1512,15 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       const int q = idx / max(c.nf, 1), e = idx - q * c.nf;
       // (a window without features has no table entry to read: the clamped loads then stay at the start of the region)
       const int a = c.nf > 0 ? ids[I_FSTART + e] : 0, no = c.nf > 0 ? ids[I_FNOBS + e] : 0;
-      const double* P = PF + (q * NFRP + a) * WLE + e;  // + k * WLE : the factor observed in frame a + k
+      // + k * stride : the factor observed in frame a + k.  q < 3 (Ji_t^T Je): minus the observing frame's E^T F entry, read out of W (frame_task)
+      const double* P = q < 3 ? W + (6 * a + q) * WLE + e : PF + (q * NFRP + a) * WLE + e;
+      const int pst = q < 3 ? 6 * WLE : WLE;
       // all (<= 10) loads in flight, clamped to the feature's last observation and masked; same pairing of the
       // partial sums as a sequential two-accumulator loop
 #pragma unroll
-      for (int k = 1; k < NFR; k++) pv[u][k - 1] = P[min(k, max(no - 1, 0)) * WLE];
+      for (int k = 1; k < NFR; k++) pv[u][k - 1] = P[min(k, max(no - 1, 0)) * pst];
 #ifdef AVM_X
-      prl[u] = PF[(q * NFRP + (NFRP - 1)) * WLE + e];
+      prl[u] = q < 3 ? W[(6 * (NFRP - 1) + q) * WLE + e] : PF[(q * NFRP + (NFRP - 1)) * WLE + e];
 #endif
     }
 #ifndef AVM_X
@@ -1553,7 +1558,8 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       }
 #ifdef AVM_X
       // + the feature's relocalization factor (frame 11; its slots were zeroed at window load for unmatched features)
-      const double sacc = (s0a + s1a) + (c.relo_n > 0 ? prl[u] : 0.0);
+      const double sraw = (s0a + s1a) + (c.relo_n > 0 ? prl[u] : 0.0);
+      const double sacc = q < 3 ? -sraw : sraw;  // (the W entries are minus the products summed here: exact)
       if (q < 6)
         W[(6 * a + q) * WLE + e] = sacc;
       else if (q == 6)
@@ -1563,7 +1569,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
       else
         W[(XC_EX + (q - 8)) * WLE + e] = sacc;  // E^T F of the ex_pose (6) and td (1) columns
 #else
-      const double sacc = s0a + s1a;
+      const double sacc = q < 3 ? -(s0a + s1a) : s0a + s1a;  // (the W entries are minus the products summed here: exact)
       if (q < 6)
         W[(6 * a + q) * WLE + e] = sacc;
       else if (q == 6)
@@ -3889,7 +3895,7 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         W[(size_t)(6 * b + k) * WLE + e] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
-        PF[(size_t)(k * NFR + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
+        if (k >= 3) PF[(size_t)(k * NFR + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];  // (k < 3: minus W's entry, as in the solve's frame task)
         PF2[(size_t)(k * NFR + b) * WLE + e] = Jx[k] * Je[0] + Jx[6 + k] * Je[1];
       }
       PF[(size_t)(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
@@ -4391,14 +4397,17 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
 #pragma unroll
           for (int k = 1; k < NFR; k++)
 #pragma unroll
-            for (int q = 0; q < 7; q++) pv[q][k - 1] = P[(size_t)(min(q, f == 0 ? 5 : 6) * NFR + min(k, max(no - 1, 0))) * WLE + e];
+            for (int q = 0; q < 7; q++) {  // (f == 0, q < 3: Ji_t^T Je is minus the observing frame's W entry - marg_frame_task does not store it twice)
+              const int kk = min(k, max(no - 1, 0));
+              pv[q][k - 1] = (f == 0 && q < 3) ? W[(size_t)(6 * kk + q) * WLE + e] : P[(size_t)(min(q, f == 0 ? 5 : 6) * NFR + kk) * WLE + e];
+            }
           double sacc[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int k = 1; k < NFR; k++)
 #pragma unroll
             for (int q = 0; q < 7; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
 #pragma unroll
-          for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = sacc[q];
+          for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = (f == 0 && q < 3) ? -sacc[q] : sacc[q];
           if (f == 11) W[(size_t)72 * WLE + e] = sacc[6];
           if (f == 0) {
             double hv[2][NFR - 1];
