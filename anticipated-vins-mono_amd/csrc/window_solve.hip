@@ -131,6 +131,13 @@ constexpr int L_WCH = L_XC + XN;
 constexpr int L_DUMP = L_WCH + 160;
 constexpr int L_G = L_WCH + WCH_TP;
 constexpr int L_DD = L_G + VEC;               // (g / D is recomputed where it is needed, as in the extended build)
+// Per-wavefront accumulators of the two per-feature sums that end in LDS anyway (E^T E -> lds[L_HEE], E^T r -> lds[L_G + NF]), over the range the
+// Gauss-Newton step, the dogleg step and the candidate state occupy between evaluations (all three are dead or parked while eval_jac runs: the
+// minimizer recomputes them, and a speculative evaluation parks y in the slot).  Wavefront 0 accumulates in the destinations themselves, wavefronts
+// 1..3 in [3][2][152] here; the per-feature sums add the four in a fixed order.  Round 5: every 8 bytes per factor the frame tasks write to the slot
+// cost 0.1 ms per 4096 windows (profiles/r05e_experiments.md section 10); these two were sixteen of them.
+constexpr int L_ACC = L_Y, ACCW = 152;
+static_assert(L_ACC + 6 * ACCW <= L_WCH, "the accumulators stay inside y | step | candidate state");
 #else
 constexpr int L_Y = L_S + SROWS;   // Gauss-Newton solution y of (H + mu D^2) y = g
 constexpr int L_ST = L_Y + VEC;    // trust region step (scaled space)
@@ -1060,10 +1067,28 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int wvi, int stage_
         W[(6 * b + k) * WLE + e] = Jj[k] * Je[0] + Jj[6 + k] * Je[1];
         if (k >= 3) PF[(k * NFR + b) * WLE + e] = Ji[k] * Je[0] + Ji[6 + k] * Je[1];
       }
+#ifndef AVM_TP
       PF[(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
       PF[(7 * NFR + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
+#endif
     }
 #ifdef AVM_TP
+    {
+      // E^T E and E^T r of the chunk's factors into this wavefront's accumulators (L_ACC above), frame by frame: the frames of a list are in ascending
+      // order along the lanes, and a feature occurs once per frame - so the lanes of one frame never meet in an address, and a feature's terms are
+      // added in the order of this wavefront's frames, always the same
+      const double he = Je[0] * Je[0] + Je[1] * Je[1], ge = Je[0] * r[0] + Je[1] * r[1];
+      double* a0 = wvi == 0 ? lds + L_HEE : lds + L_ACC + (2 * (wvi - 1)) * ACCW;
+      double* a1 = wvi == 0 ? lds + L_G + NF : lds + L_ACC + (2 * (wvi - 1) + 1) * ACCW;
+      int bb = __builtin_amdgcn_readfirstlane(b);
+      for (;;) {
+        if (act && b == bb) a0[e] += he, a1[e] += ge;
+        wave_lds_sync();
+        const unsigned long long rest = __ballot(act && b > bb);
+        if (!rest) break;
+        bb = __builtin_amdgcn_readlane(b, (int)__ffsll((long long)rest) - 1);
+      }
+    }
     // Throughput build: the staging tile holds HALF a chunk (lanes 0-31 stage and the wavefront multiplies, then lanes 32-63; the
     // scheme of marg_frame_task).  A run that straddles the two halves simply continues: the switches below only act on a new key.
     const int nact = min(64, ntot - chunk0);
@@ -1445,6 +1470,10 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
   build_frames(L_X, 0);
   for (int i = t; i < SPP; i += NT) lds[L_S + i] = 0.0;
   for (int i = t; i < VEC; i += NT) lds[L_G + i] = 0.0;
+#ifdef AVM_TP
+  for (int i = t; i < 6 * ACCW; i += NT) lds[L_ACC + i] = 0.0;  // the frame tasks' E^T E / E^T r accumulators (wavefront 0's are lds[L_HEE], lds[L_G + NF])
+  for (int i = t; i < 152; i += NT) lds[L_HEE + i] = 0.0;
+#endif
   if (t < NFRP) ids[I_PMASK + t] = 0;
   double* IJR = c.sc + Scratch::IJRAW;  // (zeroed once per window: imu_raw rewrites the same entries every time)
   __syncthreads();
@@ -1501,14 +1530,19 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     // sums over the feature's own factors: one thread per (quantity, feature), features along the lanes
     // (the W blocks of frames that do not observe a feature were zeroed once, at window load)
     // (every round's loads are requested before the first sum: one trip to the slot's memory instead of one per round)
-    constexpr int NRND = (MAXE * NQ + NT - 1) / NT;
+#ifdef AVM_TP
+    constexpr int NQB = 6;  // (E^T E and E^T r come out of the frame tasks' accumulators in LDS: below)
+#else
+    constexpr int NQB = NQ;
+#endif
+    constexpr int NRND = (MAXE * NQB + NT - 1) / NT;
     double pv[NRND][NFR - 1];
 #ifdef AVM_X
     double prl[NRND];
 #endif
 #pragma unroll
     for (int u = 0; u < NRND; u++) {
-      const int idx = min(t + u * NT, max(c.nf * NQ - 1, 0));
+      const int idx = min(t + u * NT, max(c.nf * NQB - 1, 0));
       const int q = idx / max(c.nf, 1), e = idx - q * c.nf;
       // (a window without features has no table entry to read: the clamped loads then stay at the start of the region)
       const int a = c.nf > 0 ? ids[I_FSTART + e] : 0, no = c.nf > 0 ? ids[I_FNOBS + e] : 0;
@@ -1547,7 +1581,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
 #pragma unroll
     for (int u = 0; u < NRND; u++) {
       const int idx = t + u * NT;
-      if (idx >= c.nf * NQ) break;
+      if (idx >= c.nf * NQB) break;
       const int q = idx / c.nf, e = idx - q * c.nf;
       const int a = ids[I_FSTART + e], no = ids[I_FNOBS + e];
       double s0a = 0, s1a = 0;
@@ -1578,6 +1612,13 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
         lds[L_G + NF + e] = sacc;
 #endif
     }
+#ifdef AVM_TP
+    for (int e = t; e < c.nf; e += NT) {  // the four wavefronts' accumulators, in a fixed order
+      const double* ac = lds + L_ACC + e;
+      lds[L_HEE + e] = (lds[L_HEE + e] + ac[0]) + (ac[2 * ACCW] + ac[4 * ACCW]);
+      lds[L_G + NF + e] = (lds[L_G + NF + e] + ac[ACCW]) + (ac[3 * ACCW] + ac[5 * ACCW]);
+    }
+#endif
     const double* PART = c.sc + Scratch::PART;
 #ifdef AVM_X
     __syncthreads();  // (the sums below add to blocks other frames' tasks have written: all of phase A is behind the barrier above)
@@ -3900,7 +3941,7 @@ AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1
       }
       PF[(size_t)(6 * NFR + b) * WLE + e] = Je[0] * Je[0] + Je[1] * Je[1];
       PF[(size_t)(7 * NFR + b) * WLE + e] = Je[0] * r[0] + Je[1] * r[1];
-      PF2[(size_t)(6 * NFR + b) * WLE + e] = Jt[0] * Je[0] + Jt[1] * Je[1];
+      if (c.est_td) PF2[(size_t)(6 * NFR + b) * WLE + e] = Jt[0] * Je[0] + Jt[1] * Je[1];  // (without a time offset the per-feature sums take a zero instead)
     }
     // staged column-major like the solve kernel's frame tasks (Jj 0-5 | Ji 6-11 | r 12 | Jex 13-18): one 16-byte store
     // per column, contiguous across the lanes; inactive lanes stage zeros, so no row needs masking.  The tile holds half
@@ -4399,7 +4440,7 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
 #pragma unroll
             for (int q = 0; q < 7; q++) {  // (f == 0, q < 3: Ji_t^T Je is minus the observing frame's W entry - marg_frame_task does not store it twice)
               const int kk = min(k, max(no - 1, 0));
-              pv[q][k - 1] = (f == 0 && q < 3) ? W[(size_t)(6 * kk + q) * WLE + e] : P[(size_t)(min(q, f == 0 ? 5 : 6) * NFR + kk) * WLE + e];
+              pv[q][k - 1] = (f == 0 && q < 3) ? W[(size_t)(6 * kk + q) * WLE + e] : P[(size_t)(min(q, (f == 0 || !c.est_td) ? 5 : 6) * NFR + kk) * WLE + e];
             }
           double sacc[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -4408,7 +4449,7 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
             for (int q = 0; q < 7; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
 #pragma unroll
           for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = (f == 0 && q < 3) ? -sacc[q] : sacc[q];
-          if (f == 11) W[(size_t)72 * WLE + e] = sacc[6];
+          if (f == 11) W[(size_t)72 * WLE + e] = c.est_td ? sacc[6] : 0.0;
           if (f == 0) {
             double hv[2][NFR - 1];
 #pragma unroll
