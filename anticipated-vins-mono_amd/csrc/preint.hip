@@ -37,8 +37,8 @@ AVM_DEV void wsync() {
 // the nine rows of a half wavefront hit 18 distinct bank pairs.
 constexpr int FS = 17, VS = 22;
 struct PreLds {
-  double Fi[9 * FS];  // rows 0..8 of F, 16 columns (column 15 = 0) + 1 pad; rows 9..14 are rows of the identity
-  double Vi[9 * VS];  // rows 0..8 of V, 20 columns (18-19 = 0) + 2 pad; rows 9..14 hold I dt in the columns row + 3
+  double Fi[9 * FS];  // rows p, theta, v of F (the reference's rows 0..8); COLUMNS in the new order theta 0 | v 3 | ba 6 | bg 9 (| p 12: never read)
+  double Vi[9 * VS];  // rows p, theta, v of V, noise columns 0..11 (the reference's order); the rows ba, bg are zero there
   double m[72];       // Rd, Rr, Ra0, Ra1, IRw (I - Rw*dt), T1=Rd*Ra0, T2=Rr*Ra1, T3=T2*IRw
 };
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -53,10 +53,17 @@ AVM_DEV double readlane_f64(double v, int srclane) {  // srclane must be wave-un
 
 // The 15 x 15 state matrices never leave registers: with v_mfma_f64_16x16x4 the accumulator layout
 // (lane l, register r) = M[(l >> 4) + 4 r][l & 15] is also the layout of a B operand (k = (l >> 4) + 4 m), so
-//   jacobian   <- F * jacobian                      4 MFMAs, the result is the next B operand
-//   covariance <- F * (P * F^T) + V * (Q V^T)       4 + 4 + 5 MFMAs; P is symmetric, so its accumulator registers
+//   jacobian   <- F * jacobian                      3 MFMAs, the result is the next B operand
+//   covariance <- F * (P * F^T) + V * (Q V^T)       3 + 3 + 3 MFMAs; P is symmetric, so its accumulator registers
 //                                                   double as the A operand P[l & 15][(l >> 4) + 4 m], and the
 //                                                   A-layout registers of F (of V) double as the B operand F^T (V^T)
+// Twelve instead of seventeen (round 5) by the order the state is held in: theta | v | ba | bg | p instead of the reference's
+// p | theta | v | ba | bg (NEW index n <-> reference index n < 12 ? n + 3 : n - 12; undone by the final store).  F's p COLUMNS are
+// columns of the identity (nothing depends on delta_p, integration_base.h:90-105), and they now fill the fourth k-step of a product
+// together with the padding: that k-step is "add rows / columns p of the other operand", i.e. the accumulator's initial value.
+// V's noise columns 12..17 (the bias random walks) only reach the rows ba, bg, as I dt (:119-120): V Q V^T is the product over
+// the first twelve noise columns (three k-steps; the ba, bg rows of V are zero there) plus dt^2 sigma_w^2 on six diagonal entries.
+// Every term left out is an exact zero or a product with 1.0: the results differ from the seventeen-MFMA form by the order of the sums.
 __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   PreLds* all = reinterpret_cast<PreLds*>(smem_raw);
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
   const v3 lbg = mk3(a.imu_lin_bg[iv * 3], a.imu_lin_bg[iv * 3 + 1], a.imu_lin_bg[iv * 3 + 2]);
 
   // static part of the images: zeros, the identity blocks of F's rows 0..8 (16 lanes per image)
-  for (int i = li; i < 9 * FS; i += 16) L.Fi[i] = (i / FS == i % FS) ? 1.0 : 0.0;
+  for (int i = li; i < 9 * FS; i += 16) L.Fi[i] = (i / FS >= 6 && i % FS == i / FS - 3) ? 1.0 : 0.0;  // F[v][v] = I; everything else is written per sample or zero
   for (int i = li; i < 9 * VS; i += 16) L.Vi[i] = 0.0;
   d4 Jb[PG], Pb[PG];
 #pragma unroll
@@ -94,12 +101,18 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) Jb[g][r] = (lk + 4 * r == li && li < 15) ? 1.0 : 0.0;
   }
-  // noise variance of V's column k = lk + 4 m (integration_base.h:21-27)
-  double qn[5];
+  // noise variance of V's column k = lk + 4 m < 12 (integration_base.h:21-27), and of the random walks on this lane's diagonal entries
+  // (register r holds row lk + 4 r, column li; new rows 6..8 = ba, 9..11 = bg)
+  double qn[3], qw[4];
 #pragma unroll
-  for (int m = 0; m < 5; m++) {
+  for (int m = 0; m < 3; m++) {
     const int k = lk + 4 * m;
-    qn[m] = k >= 18 ? 0.0 : (k < 3 || (k >= 6 && k < 9)) ? a.acc_n * a.acc_n : (k < 12 ? a.gyr_n * a.gyr_n : (k < 15 ? a.acc_w * a.acc_w : a.gyr_w * a.gyr_w));
+    qn[m] = (k < 3 || (k >= 6 && k < 9)) ? a.acc_n * a.acc_n : a.gyr_n * a.gyr_n;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = lk + 4 * r;
+    qw[r] = (row != li || row < 6 || row >= 12) ? 0.0 : (row < 9 ? a.acc_w * a.acc_w : a.gyr_w * a.gyr_w);
   }
   // running state of the lane's interval (the 16 lanes of a group hold copies)
   v3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
@@ -162,15 +175,16 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
       const double I = (r == c) ? 1.0 : 0.0;
       const double dt2 = dt * dt;
       // F (integration_base.h:90-105)
-      L.Fi[(0 + r) * FS + 3 + c] = -0.25 * T1 * dt2 + -0.25 * T3 * dt2;
-      L.Fi[(0 + r) * FS + 6 + c] = I * dt;
-      L.Fi[(0 + r) * FS + 9 + c] = -0.25 * (Rd + Rr) * dt2;
-      L.Fi[(0 + r) * FS + 12 + c] = -0.25 * T2 * dt2 * -dt;
-      L.Fi[(3 + r) * FS + 3 + c] = L.m[36 + li];
-      L.Fi[(3 + r) * FS + 12 + c] = -1.0 * I * dt;
-      L.Fi[(6 + r) * FS + 3 + c] = -0.5 * T1 * dt + -0.5 * T3 * dt;
-      L.Fi[(6 + r) * FS + 9 + c] = -0.5 * (Rd + Rr) * dt;
-      L.Fi[(6 + r) * FS + 12 + c] = -0.5 * T2 * dt * -dt;
+      // (image rows: the reference's 0..8 = p, theta, v; image columns: theta 0 | v 3 | ba 6 | bg 9)
+      L.Fi[(0 + r) * FS + 0 + c] = -0.25 * T1 * dt2 + -0.25 * T3 * dt2;
+      L.Fi[(0 + r) * FS + 3 + c] = I * dt;
+      L.Fi[(0 + r) * FS + 6 + c] = -0.25 * (Rd + Rr) * dt2;
+      L.Fi[(0 + r) * FS + 9 + c] = -0.25 * T2 * dt2 * -dt;
+      L.Fi[(3 + r) * FS + 0 + c] = L.m[36 + li];
+      L.Fi[(3 + r) * FS + 9 + c] = -1.0 * I * dt;
+      L.Fi[(6 + r) * FS + 0 + c] = -0.5 * T1 * dt + -0.5 * T3 * dt;
+      L.Fi[(6 + r) * FS + 6 + c] = -0.5 * (Rd + Rr) * dt;
+      L.Fi[(6 + r) * FS + 9 + c] = -0.5 * T2 * dt * -dt;
       // V (integration_base.h:108-120)
       const double v03 = 0.25 * -T2 * dt2 * 0.5 * dt;
       const double v63 = 0.5 * -T2 * dt * 0.5 * dt;
@@ -186,34 +200,42 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
       L.Vi[(6 + r) * VS + 9 + c] = v63;
     }
     wsync();
-    // ---- matrix side: the four intervals in turn, all 64 lanes each.  Rows 9..14 of the operands do not depend on the
-    //      rotations: F's are rows of the identity, V's hold I dt in column row + 3 (integration_base.h:102-104, 119-120)
-    const int lic = min(li, 8);
+    // ---- matrix side: the four intervals in turn, all 64 lanes each.  Lane li is row li of the NEW order: rows 0..5 (theta, v) are
+    //      image rows 3..8, rows 12..14 (p) image rows 0..2; rows 6..11 (ba, bg) do not depend on the rotations: F's are rows of the
+    //      identity, V's are zero in the first twelve noise columns (integration_base.h:102-104, 119-120)
+    const bool dat = li < 6 || (li >= 12 && li < 15);
+    const int lic = li < 6 ? li + 3 : (dat ? li - 12 : 0);
 #pragma unroll
     for (int g = 0; g < PG; g++) {
       if (s >= nsg[g]) continue;  // (wave-uniform)
       const PreLds& G = Lw[g];
       const double dtg = readlane_f64(dt, 16 * g);
-      double fa[4], va[5];
+      double fa[3], va[3];
 #pragma unroll
-      for (int m = 0; m < 4; m++) fa[m] = G.Fi[lic * FS + lk + 4 * m];
+      for (int m = 0; m < 3; m++) fa[m] = G.Fi[lic * FS + lk + 4 * m];
 #pragma unroll
-      for (int m = 0; m < 5; m++) va[m] = G.Vi[lic * VS + lk + 4 * m];
+      for (int m = 0; m < 3; m++) va[m] = G.Vi[lic * VS + lk + 4 * m];
 #pragma unroll
-      for (int m = 0; m < 4; m++) fa[m] = li < 9 ? fa[m] : ((li < 15 && lk + 4 * m == li) ? 1.0 : 0.0);
+      for (int m = 0; m < 3; m++) fa[m] = dat ? fa[m] : ((li < 12 && lk + 4 * m == li) ? 1.0 : 0.0);
 #pragma unroll
-      for (int m = 0; m < 5; m++) va[m] = li < 9 ? va[m] : ((li < 15 && lk + 4 * m == li + 3) ? dtg : 0.0);
-      // jacobian = F * jacobian
-      d4 Jn = {0, 0, 0, 0}, Z = {0, 0, 0, 0}, Pn = {0, 0, 0, 0};
+      for (int m = 0; m < 3; m++) va[m] = dat ? va[m] : 0.0;
+      // jacobian = F * jacobian: the k-step over the p columns of F (columns of the identity) is "+ rows p of the jacobian" (register 3 of
+      // the lane groups 0..2; group 3 holds the padding row)
+      d4 Jn = {0, 0, 0, lk < 3 ? Jb[g][3] : 0.0};
 #pragma unroll
-      for (int m = 0; m < 4; m++) Jn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Jb[g][m], Jn, 0, 0, 0);
-      // Z = P * F^T ; covariance = F * Z + V * (Q V^T)
+      for (int m = 0; m < 3; m++) Jn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Jb[g][m], Jn, 0, 0, 0);
+      // Z = P * F^T (its columns p start as P's columns p); covariance = F * Z (rows p start as Z's rows p) + V * (Q V^T)
+      const bool pc = li >= 12 && li < 15;
+      d4 Z = {pc ? Pb[g][0] : 0.0, pc ? Pb[g][1] : 0.0, pc ? Pb[g][2] : 0.0, pc ? Pb[g][3] : 0.0};
 #pragma unroll
-      for (int m = 0; m < 4; m++) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(Pb[g][m], fa[m], Z, 0, 0, 0);
+      for (int m = 0; m < 3; m++) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(Pb[g][m], fa[m], Z, 0, 0, 0);
+      d4 Pn = {0, 0, 0, lk < 3 ? Z[3] : 0.0};
 #pragma unroll
-      for (int m = 0; m < 4; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Z[m], Pn, 0, 0, 0);
+      for (int m = 0; m < 3; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], Z[m], Pn, 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 5; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(va[m], va[m] * qn[m], Pn, 0, 0, 0);
+      for (int m = 0; m < 3; m++) Pn = __builtin_amdgcn_mfma_f64_16x16x4f64(va[m], va[m] * qn[m], Pn, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) Pn[r] = fma(dtg, dtg * qw[r], Pn[r]);  // the random walks: (I dt) sigma_w^2 (I dt) on the diagonals of ba, bg
       Jb[g] = Jn;
       Pb[g] = Pn;
     }
@@ -233,9 +255,10 @@ __global__ __launch_bounds__(64 * PW) void preint_kernel(PreintArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = lk + 4 * r;
-      if (row < 15 && li < 15) {
-        a.out_jacobian[(iv0 + g) * 225 + row * 15 + li] = Jb[g][r];
-        a.out_covariance[(iv0 + g) * 225 + row * 15 + li] = Pb[g][r];
+      if (row < 15 && li < 15) {  // back to the reference's order p | theta | v | ba | bg
+        const int ro = row < 12 ? row + 3 : row - 12, co = li < 12 ? li + 3 : li - 12;
+        a.out_jacobian[(iv0 + g) * 225 + ro * 15 + co] = Jb[g][r];
+        a.out_covariance[(iv0 + g) * 225 + ro * 15 + co] = Pb[g][r];
       }
     }
   }

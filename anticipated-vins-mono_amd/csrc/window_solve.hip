@@ -2648,6 +2648,75 @@ AVM_DEV void schur_macro_tile(const WinCtx&) {
     }
 }
 
+#ifdef AVM_TP
+// Tile row 4 of the 5 x 5 grid holds three rows: pose columns 64, 65 and the right-hand side.  As 16 x 16 tiles that is a third of the
+// update's matrix instructions for 3 / 80 of its rows; v_mfma_f64_4x4x4 - four independent 4 x 4 x 4 products per instruction, a
+// quarter of the FP64 pipe time (scripts/ubench/pair.hip: 18 cycles against 64) - does the same strip with the SAME B operand a
+// 16 x 16 tile takes (lane 16 k + c holds W[column c][feature k]: block b = c / 4 is the quad column, fsel.hip's layout note) when all
+// four blocks get the three rows (+ one of zeros) as their A: lane 16 k + c holds row c % 4.  D[i][c] comes out at lane 16 i + c.
+// The strip over the column blocks C0, C1, C2 (-1 = absent), round 5.
+AVM_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+template <int C0, int C1, int C2>
+AVM_DEV void schur_strip4(const WinCtx&) {
+  const WinCtx& c = lds_ctx();
+  double* lds = LDS();
+  const double* scl = lds + L_SC;
+  gcdouble* W = c.sc + Scratch::W;  // Wt[c][e]
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ai = li & 3;
+  constexpr int NC = C2 >= 0 ? 3 : (C1 >= 0 ? 2 : 1);
+  constexpr int CB[3] = {C0, C1, C2};
+  constexpr int KB = 8;
+  static_assert(NPOSE == 66, "rows 64, 65 | right-hand side | zeros");
+  double D[3] = {0, 0, 0};
+  for (int e0 = 0; e0 < c.nf; e0 += 4 * KB) {
+    double va[KB], vc[3][KB], fe[KB], xe[KB];
+    {
+      gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)min(64 + ai, NPOSE - 1) * WLE + e0 + 8 * lk);
+#pragma unroll
+      for (int m2 = 0; m2 < KB / 2; m2++) {
+        const dv2 v = src[m2];
+        va[2 * m2] = v.x, va[2 * m2 + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NC; b++) {
+      if (CB[b] == 4) continue;  // (the diagonal block's columns 64, 65 are the A rows of the lanes li < 2)
+      gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)(16 * CB[b] + li) * WLE + e0 + 8 * lk);
+#pragma unroll
+      for (int m2 = 0; m2 < KB / 2; m2++) {
+        const dv2 v = src[m2];
+        vc[b][2 * m2] = v.x, vc[b][2 * m2 + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      const int el = min(e0 + 8 * lk + m, MAXE + 1);
+      fe[m] = lds[L_ST + el], xe[m] = lds[L_ST + 152 + el];
+    }
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      const bool on = e0 + 8 * lk + m < c.nf;
+      const double w = (on && ai < 2) ? va[m] : 0.0;
+      const double aop = ai == 2 ? xe[m] : w * fe[m];  // (x_e = 0 beyond the window's features: schur_reduce)
+#pragma unroll
+      for (int b = 0; b < NC; b++) {
+        const double bop = CB[b] == 4 ? (li < 2 ? w : 0.0) : (on ? vc[b][m] : 0.0);
+        D[b] = mfma4(aop, bop, D[b]);
+      }
+    }
+  }
+  // lane (lk, li): row 64 + lk (lk = 2: the right-hand side, 3: nothing), column 16 C + li
+#pragma unroll
+  for (int b = 0; b < NC; b++) {
+    const int gi = 64 + lk, gj = 16 * CB[b] + li;
+    const bool body = gi < NPOSE && gj <= gi, rhs = gi == NPOSE && gj < NPOSE;
+    const int off = body ? L_S + roff(gi) + gj : (rhs ? L_RHS + gj : L_DUMP + lane);
+    const double sc = (body ? scl[min(gi, NPOSE - 1)] : 1.0) * scl[min(gj, NPOSE - 1)];
+    lds[off] = lds[off] - sc * D[b];
+  }
+}
+#endif
+
 // Schur complement on the inverse depths, then the right-hand side into the augmented row:
 //   S_pp -= W'^T (hee' + mu D_e^2)^-1 W' ,  rhs = g'_f - W'^T (hee' + mu D_e^2)^-1 g'_e      (' = Jacobi-scaled)
 // W = E^T F stays UNSCALED in the scratch slot (W'[e][c] = s_e s_c W[e][c]); the scaling is folded in here:
@@ -2682,11 +2751,11 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
   __syncthreads();
 #ifdef AVM_TP
   AVM_PRIO_BULK_SCHUR();
-  switch (t >> 6) {  // four wavefronts, one per SIMD: 4 | 3 + 1 | 3 + 1... tiles (the 15 lower tiles of the 5 x 5 grid)
-    case 0: schur_macro_tile<2, 3, 0, 1>(c); break;                                       // 4 tiles
-    case 1: schur_macro_tile<0, 1, 0, 1>(c); schur_macro_tile<4, -1, 4, -1>(c); break;    // 3 + 1
-    case 2: schur_macro_tile<2, 3, 2, 3>(c); break;                                       // 3
-    default: schur_macro_tile<4, -1, 0, 1>(c); schur_macro_tile<4, -1, 2, 3>(c); break;   // 2 + 2
+  switch (t >> 6) {  // four wavefronts, one per SIMD: the 10 lower tiles of the 4 x 4 grid 2 | 3 | 3 | 2, the three-row strip below them with the pairs
+    case 0: schur_macro_tile<2, -1, 0, 1>(c); schur_strip4<0, 1, -1>(c); break;
+    case 1: schur_macro_tile<0, 1, 0, 1>(c); break;
+    case 2: schur_macro_tile<2, 3, 2, 3>(c); break;
+    default: schur_macro_tile<3, -1, 0, 1>(c); schur_strip4<2, 3, 4>(c); break;
   }
   AVM_PRIO_LIGHT();
   __syncthreads();
