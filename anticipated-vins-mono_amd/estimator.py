@@ -23,14 +23,16 @@ class Estimator:
         self.last_marginalization_info = None  # PriorOutArrays after a MARGIN_OLD / SECOND_NEW solve
 
     # the reference's name
-    def optimization(self, windows: buffers.WindowArrays, want_summary: bool = True, prior_out: buffers.PriorOutArrays = None):
+    def optimization(self, windows: buffers.WindowArrays, want_summary: bool = True, prior_out: buffers.PriorOutArrays = None,
+                     summary_out=None):
         """Solve all windows in place.  `prior_out` lets a caller that solves batch after batch hand the same
-        output slots back in (the reference allocates a new MarginalizationInfo per call; the slots are plain data)."""
+        output slots back in (the reference allocates a new MarginalizationInfo per call; the slots are plain data);
+        `summary_out` (buffers.summary_alloc) likewise for the per-window summaries: every record is rewritten by a call."""
         L = self.ctx._L
         B = windows.n_windows
         s = windows.struct()
         dev = "cuda:%d" % self.ctx.device if windows.on_device else None
-        summ = buffers.summary_alloc(B, dev) if want_summary else None
+        summ = (summary_out if summary_out is not None else buffers.summary_alloc(B, dev)) if want_summary else None
         prior = None
         if self.options.marginalization_flag != abi.MARGIN_NONE:
             prior = prior_out or buffers.PriorOutArrays.alloc(B, windows.dims["max_prior"], windows.dims["max_pblk"], dev)

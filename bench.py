@@ -370,12 +370,19 @@ def main():
     marg = opt.marginalization_flag != abi.MARGIN_NONE
     prior_slots = buffers.PriorOutArrays.alloc(W, win.dims["max_prior"], win.dims["max_pblk"], dev) if marg else None
 
+    summ_slots = buffers.summary_alloc(W, dev)  # (handed back in like the prior's slots: no allocation or fill inside a step)
+    restore_dst, restore_src = [win.a[k] for k in pristine], list(pristine.values())
+
     def step():
         # (torch's copies run on the legacy default stream; the ctx stream is a blocking stream, so the solve is ordered
         #  after them and the next step's copies after the solve: include/avm.h "stream ordering")
-        for k, v in pristine.items():
-            win.a[k].copy_(v)
-        summ = E.optimization(win, want_summary=True, prior_out=prior_slots)
+        # the batch's states back to the unsolved ones (the stand-in for the next batch arriving): one launch for the four arrays
+        if hasattr(torch, "_foreach_copy_"):
+            torch._foreach_copy_(restore_dst, restore_src)
+        else:
+            for k, v in pristine.items():
+                win.a[k].copy_(v)
+        summ = E.optimization(win, want_summary=True, prior_out=prior_slots, summary_out=summ_slots)
         if world > 1:
             if use_lib_gather:
                 ctx.gather_states(win.a["pose"], gathered, W * 77)
