@@ -2559,7 +2559,11 @@ AVM_NOINL void chol_solve_lds(int vec) {
 
 // One wavefront's share of the Schur update: the tiles (R, C), R in {R0, R1}, C in {C0, C1}, C <= R, of the 5x5
 // grid (-1 = absent).  Every 16-column block of W is loaded once per k-step and feeds all the tiles that use it.
-template <int R0, int R1, int C0, int C1>
+// SM (throughput build): the wavefront also does its share of the three-row strip under the grid (schur_strip4 below: rows 64, 65 and
+// the right-hand side on v_mfma_f64_4x4x4) over column blocks whose operands it holds anyway - SM = 1: C0, C1 and R0; SM = 2: R0 and the
+// strip's own diagonal block 4 - so that the strip costs two more rows of loads and no block a second time.
+AVM_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+template <int R0, int R1, int C0, int C1, int SM = 0>
 AVM_DEV void schur_macro_tile(const WinCtx&) {
   const WinCtx& c = lds_ctx();
   double* lds = LDS();
@@ -2567,22 +2571,37 @@ AVM_DEV void schur_macro_tile(const WinCtx&) {
   gcdouble* W = c.sc + Scratch::W;  // Wt[c][e]
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
   constexpr int NR = R1 >= 0 ? 2 : 1, NC = C1 >= 0 ? 2 : 1;
+  static_assert(SM == 0 || (R1 < 0 && C1 >= 0 && R0 != C0), "strip modes: one row block against two column blocks");
+  constexpr int NS = SM == 1 ? 3 : (SM == 2 ? 2 : 0);
+  constexpr int SB[3] = {SM == 1 ? C0 : R0, SM == 1 ? C1 : 4, SM == 1 ? R0 : -1};  // the strip's column blocks
+  const int ai = li & 3;
+  double D4[3] = {0, 0, 0};
   constexpr int RB[2] = {R0, R1}, CB[2] = {C0, C1};
   constexpr bool SAME = R0 == C0 && R1 == C1;  // diagonal macro tile: the row blocks are the column blocks
   constexpr int KB = 8;                        // k-steps (of 4 features) per batch
   d4 D[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-  for (int e0 = 0; e0 < c.nf; e0 += 4 * KB) {
-    double vr[2][KB], vc[2][KB], fe[KB], xe[KB];
-    // The k index of the products is a summation index, so features may be dealt to (k-step m, lane group lk) in any
-    // order: e = e0 + 8 lk + m gives every lane 8 consecutive features = 64 contiguous bytes per block of Wt.
-    // Unconditional loads from clamped rows, masked afterwards (a predicated load is a branch + wait).
+  // The k index of the products is a summation index, so features may be dealt to (k-step m, lane group lk) in any
+  // order: e = e0 + 8 lk + m gives every lane 8 consecutive features = 64 contiguous bytes per block of Wt.
+  // Unconditional loads from clamped rows, masked afterwards (a predicated load is a branch + wait).
+  struct Batch {
+    double vr[2][KB], vc[2][KB], va[KB];
+  };
+  auto load = [&](int e0, Batch& q) {
+    if (SM) {
+      gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)min(64 + ai, NPOSE - 1) * WLE + e0 + 8 * lk);
+#pragma unroll
+      for (int m2 = 0; m2 < KB / 2; m2++) {
+        const dv2 v = src[m2];
+        q.va[2 * m2] = v.x, q.va[2 * m2 + 1] = v.y;
+      }
+    }
 #pragma unroll
     for (int a = 0; a < NR; a++) {
       gcdv2* src = reinterpret_cast<gcdv2*>(W + (size_t)min(16 * RB[a] + li, NPOSE - 1) * WLE + e0 + 8 * lk);
 #pragma unroll
       for (int m2 = 0; m2 < KB / 2; m2++) {
         const dv2 v = src[m2];
-        vr[a][2 * m2] = v.x, vr[a][2 * m2 + 1] = v.y;
+        q.vr[a][2 * m2] = v.x, q.vr[a][2 * m2 + 1] = v.y;
       }
     }
     if (!SAME) {
@@ -2592,10 +2611,13 @@ AVM_DEV void schur_macro_tile(const WinCtx&) {
 #pragma unroll
         for (int m2 = 0; m2 < KB / 2; m2++) {
           const dv2 v = src[m2];
-          vc[b][2 * m2] = v.x, vc[b][2 * m2 + 1] = v.y;
+          q.vc[b][2 * m2] = v.x, q.vc[b][2 * m2 + 1] = v.y;
         }
       }
     }
+  };
+  auto multiply = [&](int e0, const Batch& q) {
+    double fe[KB], xe[KB];
 #pragma unroll
     for (int m = 0; m < KB; m++) {
       const int el = min(e0 + 8 * lk + m, MAXE + 1);
@@ -2604,24 +2626,52 @@ AVM_DEV void schur_macro_tile(const WinCtx&) {
 #pragma unroll
     for (int m = 0; m < KB; m++) {
       const bool on = e0 + 8 * lk + m < c.nf;
-      double aop[2], bop[2];
+      double aop[2], bop[2], wr0 = 0;
 #pragma unroll
       for (int a = 0; a < NR; a++) {
         const int col = 16 * RB[a] + li;
-        const double w = (on && col < NPOSE) ? vr[a][m] : 0.0;
+        const double w = (on && col < NPOSE) ? q.vr[a][m] : 0.0;
         aop[a] = col == NPOSE ? xe[m] : w * fe[m];  // padded row 66: the right-hand side
         if (SAME) bop[a] = w;
+        if (a == 0) wr0 = w;
       }
       if (!SAME) {
 #pragma unroll
-        for (int b = 0; b < NC; b++) bop[b] = (on && 16 * CB[b] + li < NPOSE) ? vc[b][m] : 0.0;
+        for (int b = 0; b < NC; b++) bop[b] = (on && 16 * CB[b] + li < NPOSE) ? q.vc[b][m] : 0.0;
       }
 #pragma unroll
       for (int a = 0; a < NR; a++)
 #pragma unroll
         for (int b = 0; b < NC; b++)
           if (CB[b] <= RB[a]) D[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a], bop[b], D[a][b], 0, 0, 0);
+      if (SM) {  // the strip: A = rows 64, 65 (scaled by f_e), x_e, zeros in lane li % 4 of every quad; B = the blocks as the tiles take them
+        const double w4 = (on && ai < 2) ? q.va[m] : 0.0;
+        const double a4 = ai == 2 ? xe[m] : w4 * fe[m];
+        if (SM == 1) {
+          D4[0] = mfma4(a4, bop[0], D4[0]), D4[1] = mfma4(a4, bop[1], D4[1]), D4[2] = mfma4(a4, wr0, D4[2]);
+        } else {
+          D4[0] = mfma4(a4, wr0, D4[0]), D4[1] = mfma4(a4, li < 2 ? w4 : 0.0, D4[1]);
+        }
+      }
     }
+  };
+  // (requesting batch n + 1 while batch n is multiplied was measured: nothing in the throughput build, slower in the other two - registers)
+  for (int e0 = 0; e0 < c.nf; e0 += 4 * KB) {
+    Batch q;
+    load(e0, q);
+    multiply(e0, q);
+  }
+#pragma unroll
+  for (int b = 0; b < NS; b++) {  // lane (lk, li) of a strip: row 64 + lk (lk = 2: the right-hand side, 3: nothing), column 16 SB + li
+    const int gi = 64 + lk, gj = 16 * SB[b] + li;
+    const bool body = gi < NPOSE && gj <= gi, rhs = gi == NPOSE && gj < NPOSE;
+#ifdef AVM_TP
+    const int off = body ? L_S + roff(gi) + gj : (rhs ? L_RHS + gj : L_DUMP + lane);
+#else
+    const int off = body ? L_S + roff(gi) + gj : (rhs ? L_S + roff(NF) + gj : L_DUMP + lane);
+#endif
+    const double sc = (body ? scl[min(gi, NPOSE - 1)] : 1.0) * scl[min(gj, NPOSE - 1)];
+    lds[off] = lds[off] - sc * D4[b];
   }
 #pragma unroll
   for (int a = 0; a < NR; a++)
@@ -2648,14 +2698,13 @@ AVM_DEV void schur_macro_tile(const WinCtx&) {
     }
 }
 
-#ifdef AVM_TP
+#ifndef AVM_X
 // Tile row 4 of the 5 x 5 grid holds three rows: pose columns 64, 65 and the right-hand side.  As 16 x 16 tiles that is a third of the
 // update's matrix instructions for 3 / 80 of its rows; v_mfma_f64_4x4x4 - four independent 4 x 4 x 4 products per instruction, a
 // quarter of the FP64 pipe time (scripts/ubench/pair.hip: 18 cycles against 64) - does the same strip with the SAME B operand a
 // 16 x 16 tile takes (lane 16 k + c holds W[column c][feature k]: block b = c / 4 is the quad column, fsel.hip's layout note) when all
 // four blocks get the three rows (+ one of zeros) as their A: lane 16 k + c holds row c % 4.  D[i][c] comes out at lane 16 i + c.
 // The strip over the column blocks C0, C1, C2 (-1 = absent), round 5.
-AVM_DEV double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 template <int C0, int C1, int C2>
 AVM_DEV void schur_strip4(const WinCtx&) {
   const WinCtx& c = lds_ctx();
@@ -2710,7 +2759,11 @@ AVM_DEV void schur_strip4(const WinCtx&) {
   for (int b = 0; b < NC; b++) {
     const int gi = 64 + lk, gj = 16 * CB[b] + li;
     const bool body = gi < NPOSE && gj <= gi, rhs = gi == NPOSE && gj < NPOSE;
+#ifdef AVM_TP
     const int off = body ? L_S + roff(gi) + gj : (rhs ? L_RHS + gj : L_DUMP + lane);
+#else
+    const int off = body ? L_S + roff(gi) + gj : (rhs ? L_S + roff(NF) + gj : L_DUMP + lane);
+#endif
     const double sc = (body ? scl[min(gi, NPOSE - 1)] : 1.0) * scl[min(gj, NPOSE - 1)];
     lds[off] = lds[off] - sc * D[b];
   }
@@ -2752,15 +2805,16 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
 #ifdef AVM_TP
   AVM_PRIO_BULK_SCHUR();
   switch (t >> 6) {  // four wavefronts, one per SIMD: the 10 lower tiles of the 4 x 4 grid 2 | 3 | 3 | 2, the three-row strip below them with the pairs
-    case 0: schur_macro_tile<2, -1, 0, 1>(c); schur_strip4<0, 1, -1>(c); break;
+    case 0: schur_macro_tile<2, -1, 0, 1, 1>(c); break;  // + the strip over blocks 0, 1, 2
     case 1: schur_macro_tile<0, 1, 0, 1>(c); break;
     case 2: schur_macro_tile<2, 3, 2, 3>(c); break;
-    default: schur_macro_tile<3, -1, 0, 1>(c); schur_strip4<2, 3, 4>(c); break;
+    default: schur_macro_tile<3, -1, 0, 1, 2>(c); break;  // + the strip over blocks 3, 4
   }
   AVM_PRIO_LIGHT();
   __syncthreads();
   return;
 #endif
+#ifdef AVM_X
   switch (t >> 6) {
     case 0: schur_macro_tile<2, 3, 0, 1>(c); break;  // 4 tiles
     case 1: schur_macro_tile<0, 1, 0, 1>(c); break;  // 3 tiles
@@ -2770,6 +2824,20 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
     case 5: schur_macro_tile<4, -1, 4, -1>(c); break;
     default: break;
   }
+#else
+  // latency build: the 10 lower tiles of the 4 x 4 grid + the three-row strip (schur_strip4) on eight wavefronts, at most three tiles' worth
+  // per SIMD (wavefronts w and w + 4 share one): 2 + strip | 2 + 1 | 2 + 1 | 2 + strip
+  switch (t >> 6) {
+    case 0: schur_macro_tile<1, -1, 0, 1>(c); break;
+    case 4: schur_strip4<0, 1, -1>(c); break;
+    case 1: schur_macro_tile<2, -1, 0, 1>(c); break;
+    case 5: schur_macro_tile<0, -1, 0, -1>(c); break;
+    case 2: schur_macro_tile<3, -1, 0, 1>(c); break;
+    case 6: schur_macro_tile<2, -1, 2, -1>(c); break;
+    case 3: schur_macro_tile<3, -1, 2, 3>(c); break;
+    default: schur_strip4<2, 3, 4>(c); break;
+  }
+#endif
   __syncthreads();
 }
 
