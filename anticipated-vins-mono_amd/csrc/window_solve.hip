@@ -1380,10 +1380,19 @@ AVM_DEV void imu_factor_load(int i, ImuOperands& o) {
   gcdouble* U = c.psqrt + i * 225;                 // upper triangular, zeros stored below the diagonal
   gcdouble* raw = c.sc + Scratch::IJRAW + i * 465; // [15][31]: column 0 = residual, 1..30 = Jacobian
   const int lic = min(li, 14);
+#if defined(AVM_TP) && !defined(AVM_IMU_GENERIC_SCATTER)
+  // Throughput build: the combined columns are taken in the order residual | pose i | pose i + 1 | speed-bias i | speed-bias i + 1, the
+  // order of the state columns themselves (12 consecutive pose columns, 18 consecutive speed-bias entries), so that the scatter of
+  // imu_factor_mfma needs no ordering of (row, column) and its offsets are linear in i.  raw's own order is pose i | sb i | pose i + 1 | sb i + 1.
+  auto rawcol = [](int cc) { return cc <= 6 ? cc : (cc <= 12 ? cc + 9 : (cc <= 21 ? cc - 6 : cc)); };
+  const int c0 = rawcol(li), c1 = rawcol(16 + lic);
+#else
+  const int c0 = li, c1 = 16 + lic;
+#endif
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     const int k = min(lk + 4 * m, 14);
-    o.ua[m] = U[lic * 15 + k], o.b0[m] = raw[k * 31 + li], o.b1[m] = raw[k * 31 + 16 + lic];
+    o.ua[m] = U[lic * 15 + k], o.b0[m] = raw[k * 31 + c0], o.b1[m] = raw[k * 31 + c1];
   }
 #pragma unroll
   for (int m = 0; m < 4; m++) {
@@ -1417,6 +1426,44 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
   // its (up to) 12 entries - or its private dump slot in the scratch tile - then all reads, all adds, all writes
   // (a predicated LDS read-modify-write is a branch with its own s_waitcnt; 16 of them in a row cost ~2K cycles).
   double half_rr = 0;
+#if defined(AVM_TP) && !defined(AVM_IMU_GENERIC_SCATTER)
+  // (round 5) combined index cc: 0 = residual, 1..12 = pose column 6 i + cc - 1, 13..30 = speed-bias entry 9 i + cc - 13 (rows of the compact
+  // speed-bias storage, s_off): rows and columns ascend together, and everything but the row term is a constant of the lane
+  {
+    const int psb = reinterpret_cast<const int*>(lds + L_INT)[I_PSB];
+    auto gcol = [&](int cc) { return cc <= 12 ? 6 * i + cc - 1 : SB0 + 9 * i + cc - 13; };  // state column of combined column cc >= 1
+    auto dest = [&](int R, int C) {  // R >= C >= 1
+      if (R <= 12) return L_S + roff(6 * i + R - 1) + 6 * i + C - 1;
+      const int qq = R - 13, second = qq >= 9 ? 1 : 0;
+      const int row = L_SBC + (9 * i + qq) * SBW;
+      if (C > 12) return row + 18 + (C - 13) + 9 - 9 * second;
+      return (i + second == psb) ? L_STRIP + (qq - 9 * second) * NPOSE + 6 * i + C - 1 : row + (C - 1) + 6 - 6 * second;
+    };
+    const int dump = L_DUMP + lane;
+    const double sc0 = li > 0 ? lds[L_SC + gcol(li)] : 1.0, sc1 = li < 15 ? lds[L_SC + gcol(16 + li)] : 1.0;
+    int off[12];
+    double val[12];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int R0 = lk + 4 * r, R1 = 16 + R0;  // combined rows in tile 0 / tile 1 (31 = padding)
+      const double sr0 = lds[L_SC + gcol(max(R0, 1))], sr1 = lds[L_SC + gcol(min(R1, 30))];
+      if (R0 == 0 && li == 0) half_rr = 0.5 * G00[r];
+      const bool v00 = R0 > 0 && li <= R0, v10 = R1 < 31, v11 = R1 < 31 && li < 15 && 16 + li <= R1;
+      off[3 * r] = !v00 ? dump : (li == 0 ? L_G + gcol(max(R0, 1)) : dest(max(R0, 1), max(li, 1)));
+      val[3 * r] = G00[r] * (li == 0 ? 1.0 : sr0 * sc0);
+      off[3 * r + 1] = !v10 ? dump : (li == 0 ? L_G + gcol(min(R1, 30)) : dest(min(R1, 30), max(li, 1)));
+      val[3 * r + 1] = G10[r] * (li == 0 ? 1.0 : sr1 * sc0);
+      off[3 * r + 2] = !v11 ? dump : dest(min(R1, 30), min(16 + li, min(R1, 30)));
+      val[3 * r + 2] = G11[r] * (sr1 * sc1);
+    }
+    double cur[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) cur[q] = lds[off[q]];
+#pragma unroll
+    for (int q = 0; q < 12; q++) lds[off[q]] = cur[q] + val[q];
+    return half_rr;
+  }
+#endif
   // entries of S are written Jacobi-scaled (see frame_task); the gradient is scaled afterwards, as a vector
 #ifdef AVM_X
 #define SCL(i) 1.0
@@ -1966,6 +2013,22 @@ AVM_DEV double tp_entry(int R, int C) {
   return hi > NF ? 0.0 : (hi == NF ? (lo < NF ? rhs : 0.0) : (o >= 0 ? v : 0.0));
 }
 
+// Can tile (k, i), k <= i, of the assembled system hold anything besides the right-hand side column and the prior's strip?  The compact
+// speed-bias rows couple block b to poses b - 1 .. b + 1 and speed-bias blocks b - 1, b only (s_off): 29 of the 66 tiles cannot - the load
+// of chol_regs leaves them out (round 5: 68 generic tp_entry() calls per lane and factorization were 2.6 % of the kernel).
+__host__ __device__ constexpr bool tp_tile_band(int k, int i) {
+  for (int R = 16 * k; R < 16 * k + 16; R++)
+    for (int C = 16 * i; C < 16 * i + 16; C++) {
+      const int hi = R > C ? R : C, lo = R > C ? C : R;
+      if (hi >= NF) continue;
+      if (hi < NPOSE) return true;
+      const int b = (hi - NPOSE) / 9;
+      const int p = lo < NPOSE ? lo - 6 * (b - 1) : lo - (NPOSE + 9 * (b - 1));
+      if (p >= 0 && p < 18) return true;
+    }
+  return false;
+}
+
 // 16-pivot chain on the diagonal block in the LDS patch ([row][16], symmetric): chol_diag_block with the patch as its source and
 // destination.  Leaves L~ (lower, unscaled: times sqrt(d_c) per column c, the pivot d_c on the diagonal) in the patch and
 // L~^-T in buffer `buf`.
@@ -2058,14 +2121,22 @@ AVM_NOINL bool chol_regs() {
   int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
   constexpr int NTL = tp_ntiles(WV);
   d4 T[NTL];
-  // ---- load (structural zeros included)
+  // ---- load (structural zeros included).  A tile outside the band (tp_tile_band) is zero but for the right-hand side column
+  //      (tile column 10, local column TP_NBL) and, where the prior's speed-bias block has columns in it, the strip's pose rows
+  const int psb0 = NPOSE + 9 * reinterpret_cast<const int*>(lds + L_INT)[I_PSB];  // first column of that block (uniform)
   tp_sfor<TPT>([&](auto I) {
     constexpr int i = I;
     if constexpr (tp_owner(i) == WV) {
       tp_sfor<i + 1>([&](auto K) {
         constexpr int k = K;
+        if (tp_tile_band(k, i) || (16 * k < NPOSE && psb0 <= 16 * i + 15 && psb0 + 8 >= 16 * i)) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) T[tp_base(WV, i) + k][r] = tp_entry(16 * k + lk + 4 * r, 16 * i + lr);
+          for (int r = 0; r < 4; r++) T[tp_base(WV, i) + k][r] = tp_entry(16 * k + lk + 4 * r, 16 * i + lr);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            T[tp_base(WV, i) + k][r] = (i == TPT - 1 && lr == TP_NBL) ? lds[L_RHS + min(16 * k + lk + 4 * r, NF - 1)] : 0.0;
+        }
       });
     }
   });
