@@ -1321,12 +1321,17 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
         const int j_end = (l_end - h0 + 3) >> 2;
 #pragma unroll 1
         for (int j0 = (l - h0) >> 2; j0 < j_end; j0 += 4) {
-          dv2 u0[4], u1[4];
+          // D10 / D11 have seven rows ([Jex Jtd]): two four-row strips on v_mfma_f64_4x4x4 each (18 cycles of the FP64 pipe an issue against
+          // 64; schur_strip4's operand layout: A = row li % 4 of the strip in every quad, B as the 16 x 16 tile takes it, D = register r of the
+          // tile's accumulator for strip r) - 128 + 8 x 18 = 272 instead of 384 cycles per step: 5.78 -> 5.60 ms per 1024 windows (round 5)
+          dv2 u0[4], u1[4], ua[4], ub[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int ro = 8 * min(j0 + u, 7) + 2 * drow;
             u0[u] = *reinterpret_cast<const dv2*>(stage + min(dcol, 12) * XRS_X + ro);
             u1[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(dcol, 6)) * XRS_X + ro);
+            ua[u] = *reinterpret_cast<const dv2*>(stage + (13 + (dcol & 3)) * XRS_X + ro);
+            ub[u] = *reinterpret_cast<const dv2*>(stage + (13 + min(4 + (dcol & 3), 6)) * XRS_X + ro);
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
@@ -1334,12 +1339,14 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
             const bool in = f >= l && f < l_end;
             const double a0 = (in && dcol < 13) ? u0[u][0] : 0.0, a1 = (in && dcol < 13) ? u0[u][1] : 0.0;
             const double x0 = (in && dcol < 7) ? u1[u][0] : 0.0, x1 = (in && dcol < 7) ? u1[u][1] : 0.0;
+            const double p0 = in ? ua[u][0] : 0.0, p1 = in ? ua[u][1] : 0.0;
+            const double q0 = (in && (dcol & 3) < 3) ? ub[u][0] : 0.0, q1 = (in && (dcol & 3) < 3) ? ub[u][1] : 0.0;
             D00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, D00, 0, 0, 0);
-            D10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, a0, D10, 0, 0, 0);
-            D11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, D11, 0, 0, 0);
+            D10[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(p0, a0, D10[0], 0, 0, 0), D10[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(q0, a0, D10[1], 0, 0, 0);
+            D11[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(p0, x0, D11[0], 0, 0, 0), D11[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(q0, x0, D11[1], 0, 0, 0);
             E00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, E00, 0, 0, 0);
-            E10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, a1, E10, 0, 0, 0);
-            E11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, E11, 0, 0, 0);
+            E10[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(p1, a1, E10[0], 0, 0, 0), E10[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(q1, a1, E10[1], 0, 0, 0);
+            E11[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(p1, x1, E11[0], 0, 0, 0), E11[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(q1, x1, E11[1], 0, 0, 0);
           }
         }
         l = l_end;
@@ -1380,15 +1387,11 @@ AVM_DEV void imu_factor_load(int i, ImuOperands& o) {
   gcdouble* U = c.psqrt + i * 225;                 // upper triangular, zeros stored below the diagonal
   gcdouble* raw = c.sc + Scratch::IJRAW + i * 465; // [15][31]: column 0 = residual, 1..30 = Jacobian
   const int lic = min(li, 14);
-#if defined(AVM_TP) && !defined(AVM_IMU_GENERIC_SCATTER)
-  // Throughput build: the combined columns are taken in the order residual | pose i | pose i + 1 | speed-bias i | speed-bias i + 1, the
+  // The combined columns are taken in the order residual | pose i | pose i + 1 | speed-bias i | speed-bias i + 1, the
   // order of the state columns themselves (12 consecutive pose columns, 18 consecutive speed-bias entries), so that the scatter of
   // imu_factor_mfma needs no ordering of (row, column) and its offsets are linear in i.  raw's own order is pose i | sb i | pose i + 1 | sb i + 1.
   auto rawcol = [](int cc) { return cc <= 6 ? cc : (cc <= 12 ? cc + 9 : (cc <= 21 ? cc - 6 : cc)); };
   const int c0 = rawcol(li), c1 = rawcol(16 + lic);
-#else
-  const int c0 = li, c1 = 16 + lic;
-#endif
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     const int k = min(lk + 4 * m, 14);
@@ -1426,12 +1429,12 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
   // its (up to) 12 entries - or its private dump slot in the scratch tile - then all reads, all adds, all writes
   // (a predicated LDS read-modify-write is a branch with its own s_waitcnt; 16 of them in a row cost ~2K cycles).
   double half_rr = 0;
-#if defined(AVM_TP) && !defined(AVM_IMU_GENERIC_SCATTER)
   // (round 5) combined index cc: 0 = residual, 1..12 = pose column 6 i + cc - 1, 13..30 = speed-bias entry 9 i + cc - 13 (rows of the compact
   // speed-bias storage, s_off): rows and columns ascend together, and everything but the row term is a constant of the lane
   {
-    const int psb = reinterpret_cast<const int*>(lds + L_INT)[I_PSB];
     auto gcol = [&](int cc) { return cc <= 12 ? 6 * i + cc - 1 : SB0 + 9 * i + cc - 13; };  // state column of combined column cc >= 1
+#ifdef AVM_TP
+    const int psb = reinterpret_cast<const int*>(lds + L_INT)[I_PSB];
     auto dest = [&](int R, int C) {  // R >= C >= 1
       if (R <= 12) return L_S + roff(6 * i + R - 1) + 6 * i + C - 1;
       const int qq = R - 13, second = qq >= 9 ? 1 : 0;
@@ -1439,14 +1442,23 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
       if (C > 12) return row + 18 + (C - 13) + 9 - 9 * second;
       return (i + second == psb) ? L_STRIP + (qq - 9 * second) * NPOSE + 6 * i + C - 1 : row + (C - 1) + 6 - 6 * second;
     };
+#else
+    auto dest = [&](int R, int C) { return L_S + roff(gcol(R)) + gcol(C); };  // R >= C >= 1: the packed triangle
+#endif
+    // entries of S are written Jacobi-scaled (see frame_task; not in the extended build); the gradient is scaled afterwards, as a vector
+#ifdef AVM_X
+    auto scl = [&](int) { return 1.0; };
+#else
+    auto scl = [&](int g) { return lds[L_SC + g]; };
+#endif
     const int dump = L_DUMP + lane;
-    const double sc0 = li > 0 ? lds[L_SC + gcol(li)] : 1.0, sc1 = li < 15 ? lds[L_SC + gcol(16 + li)] : 1.0;
+    const double sc0 = li > 0 ? scl(gcol(li)) : 1.0, sc1 = li < 15 ? scl(gcol(16 + li)) : 1.0;
     int off[12];
     double val[12];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int R0 = lk + 4 * r, R1 = 16 + R0;  // combined rows in tile 0 / tile 1 (31 = padding)
-      const double sr0 = lds[L_SC + gcol(max(R0, 1))], sr1 = lds[L_SC + gcol(min(R1, 30))];
+      const double sr0 = scl(gcol(max(R0, 1))), sr1 = scl(gcol(min(R1, 30)));
       if (R0 == 0 && li == 0) half_rr = 0.5 * G00[r];
       const bool v00 = R0 > 0 && li <= R0, v10 = R1 < 31, v11 = R1 < 31 && li < 15 && 16 + li <= R1;
       off[3 * r] = !v00 ? dump : (li == 0 ? L_G + gcol(max(R0, 1)) : dest(max(R0, 1), max(li, 1)));
@@ -1463,44 +1475,6 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
     for (int q = 0; q < 12; q++) lds[off[q]] = cur[q] + val[q];
     return half_rr;
   }
-#endif
-  // entries of S are written Jacobi-scaled (see frame_task); the gradient is scaled afterwards, as a vector
-#ifdef AVM_X
-#define SCL(i) 1.0
-#else
-#define SCL(i) lds[L_SC + max(i, 0)]
-#endif
-  const int ccol0 = li > 0 ? imu_col(i, li - 1) : -1;          // state column of combined column li
-  const int ccol1 = li < 15 ? imu_col(i, 15 + li) : -1;        // ... of combined column 16 + li
-  const int dump = L_DUMP + lane;
-  int off[12];
-  double val[12];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int R0 = lk + 4 * r;       // combined row in tile 0
-    const int R1 = 16 + R0;          // combined row in tile 1 (31 = padding)
-    const int sr0 = imu_col(i, max(R0 - 1, 0)), sr1 = imu_col(i, min(R1 - 1, 29));
-    // G00: rows / columns 0..15, lower part; row 0 is the residual row (its (0,0) entry is r^T r)
-    if (R0 == 0 && li == 0) half_rr = 0.5 * G00[r];
-    const bool v00 = R0 > 0 && li <= R0;
-    off[3 * r] = !v00 ? dump : (li == 0 ? L_G + sr0 : S_OFF(max(sr0, ccol0), min(sr0, ccol0)));
-    val[3 * r] = G00[r] * (li == 0 ? 1.0 : SCL(sr0) * SCL(ccol0));
-    // G10: rows 16..30, columns 0..15
-    const bool v10 = R1 < 31;
-    off[3 * r + 1] = !v10 ? dump : (li == 0 ? L_G + sr1 : S_OFF(max(sr1, ccol0), min(sr1, ccol0)));
-    val[3 * r + 1] = G10[r] * (li == 0 ? 1.0 : SCL(sr1) * SCL(ccol0));
-    // G11: rows / columns 16..30, lower part
-    const bool v11 = R1 < 31 && li < 15 && 16 + li <= R1;
-    off[3 * r + 2] = !v11 ? dump : S_OFF(max(sr1, ccol1), min(sr1, ccol1));
-    val[3 * r + 2] = G11[r] * (SCL(sr1) * SCL(ccol1));
-  }
-#undef SCL
-  double cur[12];
-#pragma unroll
-  for (int q = 0; q < 12; q++) cur[q] = lds[off[q]];
-#pragma unroll
-  for (int q = 0; q < 12; q++) lds[off[q]] = cur[q] + val[q];
-  return half_rr;
 }
 
 // Full evaluation at lds[L_X]: fills S (unscaled H_ff), W, hee, g (unscaled) and returns the cost.
