@@ -673,9 +673,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     int* pe_done = static_cast<int*>(pool_get(c, "pe_done", sizeof(int) * B));
     if (!pe_done) return fail(c, AVM_ERR_HIP, "hipMalloc failed (prior flags)");
-    double noise_rel = (opt->marg_noise_rel > 0.0 && opt->marg_noise_rel < 1.0) ? opt->marg_noise_rel : 0.0;
-    if (const char* e = getenv("AVM_MARG_NOISE_REL"))  // (development: another value for callers that pass the default, tests/tools/dev_noise_rel.sh)
-      if (opt->marg_noise_rel == 1e-18) noise_rel = atof(e);
+    const double noise_rel = (opt->marg_noise_rel > 0.0 && opt->marg_noise_rel < 1.0) ? opt->marg_noise_rel : 0.0;
     HIPCHK(c, launch_prior_eig(dpo, B, opt->marg_eps, noise_rel, marg_scale, c->prof, pe_done, c->stream));
     c->last_marg_windows = (int)B;
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
@@ -788,6 +786,9 @@ int avm_debug_solve_tp_occupancy(int* out) {
   out[0] = window_solve_tp_occupancy(), out[1] = window_solve_tp_lds_bytes();
   return 2;
 }
+
+// test hook (not in avm.h): the compile-time tables of the throughput solve's sparse factorization (window_solve.hip, chol_regs); out: >= 512 ints
+int avm_debug_solve_tp_pattern(int* out) { return window_solve_tp_pattern(out); }
 
 // test / bench hook (not in avm.h): out[0] = device / pinned (re)allocations of this ctx so far, out[1] = windows of the last
 // marginalization whose square root the one-wavefront kernel (prior_chol_kernel) finished, out[2] = windows of that marginalization

@@ -149,11 +149,16 @@ __host__ __device__ inline int check_fsel_tables(const avm_fsel_batch& b, int p)
 // Returns a bit mask of what window w's prior does NOT fit: bit 0 the throughput solve, bit 1 the throughput marginalization.
 __host__ __device__ inline int window_prior_tp_misfit(const avm_window_batch& B, int w) {
   if (!B.prior_n || B.prior_n[w] <= 0) return 0;
-  int nsb = 0, late = 0;
+  int nsb = 0, late = 0, later = 0;
   const int nb = B.prior_nblk[w];
   for (int k = 0; k < nb && k < B.max_pblk; k++)
-    if (B.prior_blk_kind[(size_t)w * B.max_pblk + k] == AVM_BLK_SPEEDBIAS) nsb++, late |= B.prior_blk_frame[(size_t)w * B.max_pblk + k] > 1;
-  return (nsb > 1 ? 1 : 0) | (late ? 2 : 0);
+    if (B.prior_blk_kind[(size_t)w * B.max_pblk + k] == AVM_BLK_SPEEDBIAS) {
+      const int fr = B.prior_blk_frame[(size_t)w * B.max_pblk + k];
+      nsb++, late |= fr > 1, later |= fr > 0;
+    }
+  // (the throughput solve eliminates the speed-bias blocks last frame first, so that the one block the prior couples to every pose comes
+  //  last of them: window_solve.hip, chol_regs - a prior whose block is not frame 0's would fill the factor in)
+  return (nsb > 1 || later ? 1 : 0) | (late ? 2 : 0);
 }
 
 // first_bad: TWO ints.  [0]: INT_MAX when every window / problem passes, else (index * 8 + rule) of the lowest failing index;
@@ -180,6 +185,7 @@ int window_solve_x_lds_bytes();
 hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream);  // window_solve_tp.o: two 256-thread workgroups per CU (large batches)
 int window_solve_tp_lds_bytes();
 int window_solve_tp_occupancy();
+int window_solve_tp_pattern(int* out);  // the throughput factorization's tile pattern / ownership / elimination order (tests)
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 // scale: [n_windows][po.max_prior] device array: the magnitude every diagonal entry of A' was formed at (for launch_prior_eig's noise test)
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, double* scale, hipStream_t stream);

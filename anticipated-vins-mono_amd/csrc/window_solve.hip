@@ -119,9 +119,11 @@ constexpr int USZ = 99 * SBW + 9 * NPOSE + 2; // 4160
 static_assert(ASM_WAVES * XSTG <= USZ, "staging fits the union region");
 constexpr int L_PATCH = L_U;                  // factorization: [16][16] diagonal block in lane = row form
 constexpr int L_LINV = L_PATCH + 256;         // [2][256 + 16]: L_kk^-T (unscaled, see chol_diag_block) and the pivots
-constexpr int L_WROW = L_LINV + 2 * 272;      // [10][256]: row k of W, tile column i at index i - 1, in the accumulator layout [r][lane]
-constexpr int L_PARTV = L_WROW + 10 * 256;    // back substitution: [4][176] partial sums of the four wavefronts
-static_assert(L_PARTV + 4 * 176 <= L_U + USZ, "factorization scratch fits the union region");
+constexpr int TP_WSLOTS = 7;                  // tiles of a row of W that exist beside the diagonal (tp_wslot: the factor is sparse in the order chol_regs eliminates in)
+constexpr int L_WROW = L_LINV + 2 * 272;      // [TP_WSLOTS][256]: row k of W, the tiles that exist in column order, in the accumulator layout [r][lane]
+constexpr int L_PARTV = L_WROW + TP_WSLOTS * 256;  // back substitution: [4][176] partial sums of the four wavefronts
+constexpr int L_ZV = L_PARTV + 4 * 176;       // [176] z = L^-1 b, then x, in elimination order (lds[L_Y] keeps the right-hand side until x replaces it, in the system's order)
+static_assert(L_ZV + 176 <= L_U + USZ, "factorization scratch fits the union region");
 constexpr int L_Y = L_U + USZ;                // Gauss-Newton solution y; until the solve writes it: the right-hand side (row NF of the other builds)
 constexpr int L_RHS = L_Y;
 constexpr int WCH_TP = 224;                   // doubles: ys of back_substitute / rvb of jac_times_vec_sq (<= 150), then 64 dump slots
@@ -1947,15 +1949,26 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
 
 #ifdef AVM_TP
 // =====================================================================================================================
-// Throughput build: the factorization on REGISTER tiles, distributed over the workgroup's four wavefronts.
+// Throughput build: the factorization on REGISTER tiles, distributed over the workgroup's four wavefronts, in an elimination
+// order that keeps the factor SPARSE (round 6).
 //
-// The augmented (NF + 1) x (NF + 1) system [H' + mu D^2, g'; g'^T, .] is cut into 11 x 11 tiles of 16 x 16 and held as its UPPER
-// tiles U(k, i), k <= i (U(k, i) = L(i, k)^T once factored), in the accumulator layout of v_mfma_f64_16x16x4: register r of lane
-// (lk = lane / 16, lr = lane % 16) is entry (lk + 4 r, lr).  With the k index of a product running as lk + 4 r such a tile IS a B
+// Order of elimination: the speed-bias blocks last frame first (10, 9, .. 0), then the poses, then the right-hand side.  Speed-bias
+// block b couples to blocks b - 1 / b + 1 and to the poses b - 1 .. b + 1 (one IMU factor each side); eliminated from the window's
+// end it hands the next block the poses b .. 10 as fill and nothing else, and the prior's speed-bias block (frame 0: the one block
+// the prior couples to EVERY pose - the strip) is eliminated last of them, so its dense row fills nothing.  Of the 66 upper tiles of
+// the 11 x 11 grid 51 can be nonzero and a factorization takes 115 tile updates (460 MFMAs) where the order poses | speed-biases
+// takes 220 (880): with the poses first every speed-bias row fills in completely.  The rest of the kernel keeps its layout; the
+// permutation happens when the tiles are loaded (tp_perm) and when the solution is written back.
+//
+// The augmented (NF + 1) x (NF + 1) system [H' + mu D^2, g'; g'^T, .] in that order is cut into 11 x 11 tiles of 16 x 16 and held as
+// its UPPER tiles U(k, i), k <= i (U(k, i) = L(i, k)^T once factored), in the accumulator layout of v_mfma_f64_16x16x4: register r of
+// lane (lk = lane / 16, lr = lane % 16) is entry (lk + 4 r, lr).  With the k index of a product running as lk + 4 r such a tile IS a B
 // operand and, read as an A operand, its transpose (the scheme of prior_chol_kernel, prior_eig.hip), so nothing is transposed or
-// moved between lanes.  The right-hand side is column NF (tile column 10, local column 5): the forward substitution rides along.
-//   * ownership by tile COLUMN: wavefront tp_owner(i) holds U(0..i, i) - column sizes {11 5} {10 6} {9 7 1} {8 4 3 2}: at most 17
-//     tiles = 136 registers per lane, and the trailing updates of every step are spread almost evenly;
+// moved between lanes.  The right-hand side is position NF (tile column 10, local column 5): the forward substitution rides along.
+//   * which tiles exist is a compile-time table (TPP: the system's tile pattern closed under the elimination's fill); a tile outside
+//     it is never loaded, solved, published or updated;
+//   * ownership by tile COLUMN (tp_owner): one wavefront holds the speed-bias columns 1..5, whose tiles only ever meet each other - the
+//     chain of chains runs on it -, the pose columns are spread over the other three: at most 14 tiles = 112 registers per lane;
 //   * step k:  [owner of column k] 16-pivot chain on the diagonal tile (through a 2 KB LDS patch into lane = row form: the
 //     square-root-free chain of chol_diag_block, L_kk^-T riding along in lanes 16..31) ............................. barrier
 //              [every wavefront] W(k, i) = L_kk^-1 U(k, i) for its columns i > k, published to LDS ................. barrier
@@ -1963,45 +1976,133 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
 //              first and running the next chain while the others still update (look-ahead): two barriers per step.
 //   * backward substitution L^T x = z by tile columns, last to first: the owner of column i solves x_i from z_i minus the four
 //     wavefronts' partial sums, folds x_i into element-wise accumulators E_k += U(k, i) .* x_i (k < i, no reduction), and every
-//     wavefront reduces its E_{i-1} over the 16-lane rows (DPP) into its partial vector: one barrier per column.
-// Nothing of the factor ever goes to memory; the LDS traffic is the published row of W (<= 20 KB per step).
+//     wavefront that holds a tile of row i - 1 reduces its E_{i-1} over the 16-lane rows (DPP) into its partial vector: one barrier per column.
+// Nothing of the factor ever goes to memory; the LDS traffic is the published row of W (<= 14 KB per step).
 constexpr int TPT = 11;
 constexpr int TP_NBL = NF - 16 * (TPT - 1);  // state columns in the last tile column: 5 (+ the right-hand side at local column 5)
 static_assert(TP_NBL >= 1 && TP_NBL < 16, "the right-hand side fits the last tile column");
-__host__ __device__ constexpr int tp_owner(int i) {
-  return i == 10 || i == 4 ? 0 : (i == 9 || i == 5 ? 1 : (i == 8 || i == 6 || i == 0 ? 2 : 3));
+constexpr int NSBV = NF - NPOSE;             // 99 speed-bias columns = positions 0 .. 98 of the elimination order
+static_assert(NSBV == 9 * NFR, "speed-bias blocks of nine");
+// position n of the elimination order -> column of the assembled system (poses | speed-biases | right-hand side)
+__host__ __device__ constexpr int tp_perm(int n) { return n < NSBV ? NPOSE + 9 * (NFR - 1 - n / 9) + n % 9 : (n < NF ? n - NSBV : n); }
+
+// Tile pattern of the system in elimination order, [k][i] with k <= i: h = the assembled system can be nonzero there (s_off: a speed-bias
+// block reaches its neighbours and three poses; the prior's block - frame 0, the host sends every other prior to the latency form - every
+// pose; the right-hand side is dense), nz = h closed under the fill of the tile-level elimination (which is what the scalar elimination
+// fills, aggregated: tests/test_tp_pattern.py states both in numpy).
+struct TpPattern {
+  bool h[TPT][TPT], nz[TPT][TPT];
+};
+constexpr TpPattern tp_make_pattern() {
+  TpPattern P{};
+  bool s[TPT][TPT] = {};
+  auto mark = [&](int r0, int r1, int c0, int c1) {  // positions [r0, r1] x [c0, c1]
+    for (int a = r0 / 16; a <= r1 / 16; a++)
+      for (int b = c0 / 16; b <= c1 / 16; b++) s[a][b] = s[b][a] = true;
+  };
+  mark(NSBV, NF - 1, NSBV, NF - 1);  // poses x poses
+  mark(0, NF, NF, NF);               // the right-hand side
+  for (int bb = 0; bb < NFR; bb++) {
+    const int b = NFR - 1 - bb, r0 = 9 * bb, r1 = 9 * bb + 8;
+    mark(r0, r1, r0, r1);
+    if (bb + 1 < NFR) mark(r0, r1, r0 + 9, r1 + 9);
+    for (int f = (b > 0 ? b - 1 : 0); f <= (b + 1 < NFR ? b + 1 : NFR - 1); f++) mark(r0, r1, NSBV + 6 * f, NSBV + 6 * f + 5);
+    if (b == 0) mark(r0, r1, NSBV, NF - 1);  // the strip
+  }
+  for (int k = 0; k < TPT; k++)
+    for (int i = 0; i < TPT; i++) P.h[k][i] = P.nz[k][i] = k <= i && s[k][i];
+  for (int k = 0; k < TPT; k++)
+    for (int j = k + 1; j < TPT; j++)
+      if (P.nz[k][j])
+        for (int i = j; i < TPT; i++)
+          if (P.nz[k][i]) P.nz[j][i] = true;
+  return P;
 }
-__host__ __device__ constexpr int tp_base(int wv, int i) {  // index of tile (0, i) in wavefront wv's array
+constexpr TpPattern TPP = tp_make_pattern();
+__host__ __device__ constexpr bool tp_nz(int k, int i) { return k <= i && TPP.nz[k][i]; }
+__host__ __device__ constexpr int tp_owner(int i) {
+  // (scripts/tp_ownership.py: the assignment that leaves the owner of column k + 1 nothing but its diagonal tile to update at step k)
+  return i == 0 || i == 10 ? 0 : (i <= 5 ? 3 : (i == 6 || i == 9 ? 1 : 2));
+}
+__host__ __device__ constexpr int tp_ncol(int i) {  // tiles of column i
   int n = 0;
-  for (int c = 0; c < i; c++) n += tp_owner(c) == wv ? c + 1 : 0;
+  for (int k = 0; k <= i; k++) n += tp_nz(k, i) ? 1 : 0;
   return n;
 }
-__host__ __device__ constexpr int tp_ntiles(int wv) { return tp_base(wv, TPT); }
-
-// entry (R, C) of the augmented symmetric system as the evaluation + schur_reduce left it (structural zeros included)
-AVM_DEV double tp_entry(int R, int C) {
-  double* lds = LDS();
-  const int hi = max(R, C), lo = min(R, C);
-  const int o = s_off(min(hi, NF - 1), min(lo, NF - 1));
-  const double v = lds[max(o, 0)], rhs = lds[L_RHS + min(lo, NF - 1)];
-  return hi > NF ? 0.0 : (hi == NF ? (lo < NF ? rhs : 0.0) : (o >= 0 ? v : 0.0));
+__host__ __device__ constexpr int tp_idx(int wv, int k, int i) {  // index of tile (k, i) in wavefront wv's array
+  int n = 0;
+  for (int c = 0; c < i; c++) n += tp_owner(c) == wv ? tp_ncol(c) : 0;
+  for (int q = 0; q < k; q++) n += tp_nz(q, i) ? 1 : 0;
+  return n;
 }
-
-// Can tile (k, i), k <= i, of the assembled system hold anything besides the right-hand side column and the prior's strip?  The compact
-// speed-bias rows couple block b to poses b - 1 .. b + 1 and speed-bias blocks b - 1, b only (s_off): 29 of the 66 tiles cannot - the load
-// of chol_regs leaves them out (round 5: 68 generic tp_entry() calls per lane and factorization were 2.6 % of the kernel).
-__host__ __device__ constexpr bool tp_tile_band(int k, int i) {
-  for (int R = 16 * k; R < 16 * k + 16; R++)
-    for (int C = 16 * i; C < 16 * i + 16; C++) {
-      const int hi = R > C ? R : C, lo = R > C ? C : R;
-      if (hi >= NF) continue;
-      if (hi < NPOSE) return true;
-      const int b = (hi - NPOSE) / 9;
-      const int p = lo < NPOSE ? lo - 6 * (b - 1) : lo - (NPOSE + 9 * (b - 1));
-      if (p >= 0 && p < 18) return true;
-    }
+__host__ __device__ constexpr int tp_ntiles(int wv) { return tp_idx(wv, 0, TPT); }
+__host__ __device__ constexpr int tp_wslot(int k, int i) {  // slot of W(k, i) in the published row k
+  int n = 0;
+  for (int c = k + 1; c < i; c++) n += tp_nz(k, c) ? 1 : 0;
+  return n;
+}
+__host__ __device__ constexpr int tp_max_wslots() {
+  int m = 0;
+  for (int k = 0; k < TPT; k++) m = tp_wslot(k, TPT) > m ? tp_wslot(k, TPT) : m;
+  return m;
+}
+static_assert(tp_max_wslots() <= TP_WSLOTS, "the published row of W fits its LDS slots");
+__host__ __device__ constexpr bool tp_row_held(int wv, int k) {  // does wavefront wv hold a tile (k, i), i > k ?
+  for (int i = k + 1; i < TPT; i++)
+    if (tp_owner(i) == wv && tp_nz(k, i)) return true;
   return false;
 }
+__host__ __device__ constexpr bool tp_chain_ok() {  // every column's diagonal tile and the tile above it exist (the look-ahead relies on it)
+  for (int k = 0; k + 1 < TPT; k++)
+    if (!tp_nz(k, k + 1) || !tp_nz(k, k)) return false;
+  return tp_nz(TPT - 1, TPT - 1);
+}
+static_assert(tp_chain_ok(), "tile pattern");
+
+AVM_DEV int tp_perm_dev(int n) { return n < NSBV ? NPOSE + 9 * (NFR - 1) - 9 * (n / 9) + n % 9 : (n < NF ? n - NSBV : n); }
+
+// Where the tiles are loaded from: for every tile the assembled system can reach (TPP.h) and every (lane, register) of it the LDS offset (in doubles)
+// of the entry - s_off() of the two columns with the prior's speed-bias block at frame 0, the right-hand side for position NF - or TP_NONE for a
+// structural zero; a table in the code object's constant data, evaluated at compile time ([tile][lane][register]: one 8-byte load per lane and
+// tile).  The generic form - position -> column, s_off with its division and branches, an LDS read behind each - was 28 K cycles per factorization.
+constexpr int TP_NONE = 0xffff;
+constexpr int tp_off_c(int Rn, int Cn) {
+  if (Rn > NF || Cn > NF) return TP_NONE;
+  const int R = tp_perm(Rn), C = tp_perm(Cn), hi = R > C ? R : C, lo = R > C ? C : R;
+  if (hi == NF) return lo < NF ? L_RHS + lo : TP_NONE;
+  if (hi < NPOSE) return L_S + croff(hi) + lo;
+  const int q = hi - NPOSE, b = q / 9;
+  if (lo < NPOSE) {
+    if (b == 0) return L_STRIP + (q - 9 * b) * NPOSE + lo;
+    const int p = lo - 6 * (b - 1);
+    return p >= 0 && p < 18 ? L_SBC + q * SBW + p : TP_NONE;
+  }
+  const int p = lo - (NPOSE + 9 * (b - 1));
+  return p >= 0 && p < 18 ? L_SBC + q * SBW + 18 + p : TP_NONE;
+}
+__host__ __device__ constexpr int tp_h_ord(int k, int i) {  // ordinal of tile (k, i) among the tiles with TPP.h, column by column
+  int n = 0;
+  for (int c = 0; c < TPT; c++)
+    for (int q = 0; q <= c; q++) {
+      if (c == i && q == k) return n;
+      n += TPP.h[q][c] ? 1 : 0;
+    }
+  return n;
+}
+constexpr int TP_NH = tp_h_ord(TPT, TPT);
+struct TpOffsets {
+  unsigned short o[TP_NH][64][4];
+};
+constexpr TpOffsets tp_make_offsets() {
+  TpOffsets t{};
+  for (int i = 0; i < TPT; i++)
+    for (int k = 0; k <= i; k++)
+      if (TPP.h[k][i])
+        for (int lane = 0; lane < 64; lane++)
+          for (int r = 0; r < 4; r++) t.o[tp_h_ord(k, i)][lane][r] = (unsigned short)tp_off_c(16 * k + (lane >> 4) + 4 * r, 16 * i + (lane & 15));
+  return t;
+}
+__device__ const TpOffsets tp_offsets = tp_make_offsets();
 
 // 16-pivot chain on the diagonal block in the LDS patch ([row][16], symmetric): chol_diag_block with the patch as its source and
 // destination.  Leaves L~ (lower, unscaled: times sqrt(d_c) per column c, the pivot d_c on the diagonal) in the patch and
@@ -2088,6 +2189,16 @@ AVM_DEV void tp_sfor(F&& f) {
 
 // Factor the assembled system and solve it: (H' + mu D^2) y = g', y -> lds[L_Y .. L_Y + NF).  Returns false on a non-positive pivot
 // (uniform over the workgroup).  Called by all four wavefronts, WV = the caller's wavefront.
+// (tile indices and LDS slots as constants of the instantiation: left to the optimizer, one of the four wavefronts' tile arrays ended up in scratch memory)
+#ifdef AVM_PROF_CHOL  // (development: where a factorization's time goes, per wavefront; slots 56.. of the profile: chain, wait b, solve, wait d, update, rest)
+#define CPROF_T0() long long cp__ = clock64()
+#define CPROF(slot) do { if (c.prof && lane == 0 && WV == AVM_PROF_CHOL) { long long n__ = clock64(); c.prof[56 + (slot)] += n__ - cp__; cp__ = n__; } } while (0)
+#else
+#define CPROF_T0() ((void)0)
+#define CPROF(slot) ((void)0)
+#endif
+#define TPI(k, i) (std::integral_constant<int, tp_idx(WV, k, i)>::value)
+#define TPW(k, i) (std::integral_constant<int, tp_wslot(k, i)>::value)
 template <int WV>
 AVM_NOINL bool chol_regs() {
   double* lds = LDS();
@@ -2095,21 +2206,26 @@ AVM_NOINL bool chol_regs() {
   int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
   constexpr int NTL = tp_ntiles(WV);
   d4 T[NTL];
-  // ---- load (structural zeros included).  A tile outside the band (tp_tile_band) is zero but for the right-hand side column
-  //      (tile column 10, local column TP_NBL) and, where the prior's speed-bias block has columns in it, the strip's pose rows
-  const int psb0 = NPOSE + 9 * reinterpret_cast<const int*>(lds + L_INT)[I_PSB];  // first column of that block (uniform)
+  // ---- load, in elimination order (structural zeros included; a tile of the pattern the assembled system cannot reach starts as zero: it is fill)
   tp_sfor<TPT>([&](auto I) {
     constexpr int i = I;
     if constexpr (tp_owner(i) == WV) {
       tp_sfor<i + 1>([&](auto K) {
         constexpr int k = K;
-        if (tp_tile_band(k, i) || (16 * k < NPOSE && psb0 <= 16 * i + 15 && psb0 + 8 >= 16 * i)) {
+        if constexpr (tp_nz(k, i)) {
+          d4& t = T[TPI(k, i)];
+          if constexpr (TPP.h[k][i]) {
+            typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+            const us4 o = *reinterpret_cast<const __attribute__((address_space(1))) us4*>(
+                (const __attribute__((address_space(1))) unsigned short*)&tp_offsets.o[tp_h_ord(k, i)][0][0] + 4 * lane);
 #pragma unroll
-          for (int r = 0; r < 4; r++) T[tp_base(WV, i) + k][r] = tp_entry(16 * k + lk + 4 * r, 16 * i + lr);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            T[tp_base(WV, i) + k][r] = (i == TPT - 1 && lr == TP_NBL) ? lds[L_RHS + min(16 * k + lk + 4 * r, NF - 1)] : 0.0;
+            for (int r = 0; r < 4; r++) {
+              const double v = lds[min((int)o[r], L_END - 1)];
+              t[r] = o[r] == TP_NONE ? 0.0 : v;
+            }
+          } else {
+            t = d4{0, 0, 0, 0};
+          }
         }
       });
     }
@@ -2120,15 +2236,18 @@ AVM_NOINL bool chol_regs() {
   __syncthreads();  // every tile is in registers: the union region becomes the factorization's scratch
   PROF(c, 4);
   for (int q = threadIdx.x; q < 4 * 176; q += NT) lds[L_PARTV + q] = 0.0;
+  CPROF_T0();
   // by the owner of column k: diagonal tile -> patch -> chain (L~_kk in the patch, L~_kk^-T in buffer k & 1)
   auto run_chain = [&](auto K) {
     constexpr int k = K;
-    const d4& D = T[tp_base(WV, k) + k];
+    CPROF(4);
+    const d4& D = T[TPI(k, k)];
 #pragma unroll
     for (int r = 0; r < 4; r++) lds[L_PATCH + (lk + 4 * r) * 16 + lr] = D[r];
     wave_lds_sync();
     tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, k & 1);
     wave_lds_sync();
+    CPROF(0);
   };
   d4 Dlast = {0, 0, 0, 0};  // the last diagonal tile as it was before its chain (its column TP_NBL is the right-hand side)
   if constexpr (tp_owner(0) == WV) run_chain(std::integral_constant<int, 0>{});
@@ -2137,23 +2256,25 @@ AVM_NOINL bool chol_regs() {
     constexpr int k = K;
     constexpr int nb = k == TPT - 1 ? TP_NBL : 16;
     if (failed) return;  // (uniform)
+    CPROF(4);
     __syncthreads();  // (b) L~_kk and L~_kk^-T are published; every wavefront is done with step k - 1
+    CPROF(1);
     // A operand of the solves: L_kk^-1[i' = lr][k' = lk + 4 m] = L~^-T[k'][i'] / sqrt(d_i'); the row scaling is applied to the product
     double aop[4], isq4[4];
-    {
+    if constexpr (tp_row_held(WV, k) || tp_owner(k) == WV) {
       const double* LT = lds + L_LINV + (k & 1) * 272;
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const double v = LT[(lk + 4 * m) * 16 + lr];
         aop[m] = (lk + 4 * m < nb && lr < nb) ? v : 0.0;
         const double dc = lds[L_PATCH + min(lk + 4 * m, nb - 1) * 17];
-        if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront sees the same values
+        if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront that looks sees the same values
         isq4[m] = fast_rsqrt_pe(dc);
       }
     }
     if constexpr (tp_owner(k) == WV) {
       // the diagonal tile becomes L~_kk^T (entry (a, b) = L~[b][a]); the last one first gives up the right-hand side: z_10 = L^-1 b
-      d4& D = T[tp_base(WV, k) + k];
+      d4& D = T[TPI(k, k)];
       if constexpr (k == TPT - 1) {
         d4 Za = {0, 0, 0, 0}, Zb = {0, 0, 0, 0};
         Za = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], Dlast[0], Za, 0, 0, 0);
@@ -2162,7 +2283,7 @@ AVM_NOINL bool chol_regs() {
         Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], Dlast[3], Zb, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; r++)
-          if (lr == TP_NBL && lk + 4 * r < TP_NBL) lds[L_Y + 16 * k + lk + 4 * r] = (Za[r] + Zb[r]) * isq4[r];
+          if (lr == TP_NBL && lk + 4 * r < TP_NBL) lds[L_ZV + 16 * k + lk + 4 * r] = (Za[r] + Zb[r]) * isq4[r];
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + lr * 16 + lk + 4 * r];
@@ -2170,8 +2291,8 @@ AVM_NOINL bool chol_regs() {
     // (c) W(k, i) = L_kk^-1 U(k, i) for this wavefront's columns i > k: the final factor tiles, published for the others' updates
     tp_sfor<TPT - 1 - k>([&](auto II) {
       constexpr int i = k + 1 + II;
-      if constexpr (tp_owner(i) == WV) {
-        d4& U = T[tp_base(WV, i) + k];
+      if constexpr (tp_owner(i) == WV && tp_nz(k, i)) {
+        d4& U = T[TPI(k, i)];
         d4 Wa = {0, 0, 0, 0}, Wb = {0, 0, 0, 0};
         Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], U[0], Wa, 0, 0, 0);
         Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], U[1], Wb, 0, 0, 0);
@@ -2180,43 +2301,50 @@ AVM_NOINL bool chol_regs() {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           U[r] = (Wa[r] + Wb[r]) * isq4[r];
-          lds[L_WROW + (i - 1) * 256 + r * 64 + lane] = U[r];
+          lds[L_WROW + TPW(k, i) * 256 + r * 64 + lane] = U[r];
         }
         if constexpr (i == TPT - 1) {  // the right-hand side column of tile column 10 is z_k
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            if (lr == TP_NBL) lds[L_Y + 16 * k + lk + 4 * r] = U[r];
+            if (lr == TP_NBL) lds[L_ZV + 16 * k + lk + 4 * r] = U[r];
         }
       }
     });
     if constexpr (k < TPT - 1) {
+      CPROF(2);
       __syncthreads();  // (d) row k of W is published
+      CPROF(3);
       if (*s_fail) {
         failed = true;
         return;
       }
-      // (e) trailing update U(j, i) -= W(k, j)^T W(k, i), k < j <= i.  The owner of column k + 1 starts with tile (k + 1, k + 1) and
-      // runs the next chain right away: the other wavefronts update meanwhile (look-ahead).
+      // (e) trailing update U(j, i) -= W(k, j)^T W(k, i), k < j <= i, over the tiles of row k that exist.  The owner of column k + 1 starts
+      // with tile (k + 1, k + 1) and runs the next chain right away: the other wavefronts update meanwhile (look-ahead).
       auto update_col = [&](auto II, auto J0) {
         constexpr int i = II, j0 = J0;
-        const d4& Wi = T[tp_base(WV, i) + k];
-        tp_sfor<i - j0 + 1>([&](auto JJ) {
-          constexpr int j = j0 + JJ;
-          d4 Wj;
-          if constexpr (tp_owner(j) == WV) {
-            Wj = T[tp_base(WV, j) + k];
-          } else {
+        if constexpr (tp_nz(k, i)) {
+          const d4& Wi = T[TPI(k, i)];
+          tp_sfor<i - j0 + 1>([&](auto JJ) {
+            constexpr int j = j0 + JJ;
+            if constexpr (tp_nz(k, j)) {
+              static_assert(tp_nz(j, i), "the pattern is closed under the elimination's fill");
+              d4 Wj;
+              if constexpr (tp_owner(j) == WV) {
+                Wj = T[TPI(k, j)];
+              } else {
 #pragma unroll
-            for (int r = 0; r < 4; r++) Wj[r] = lds[L_WROW + (j - 1) * 256 + r * 64 + lane];
-          }
-          d4& U = T[tp_base(WV, i) + j];
+                for (int r = 0; r < 4; r++) Wj[r] = lds[L_WROW + TPW(k, j) * 256 + r * 64 + lane];
+              }
+              d4& U = T[TPI(j, i)];
 #pragma unroll
-          for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wj[r], Wi[r], U, 0, 0, 0);
-        });
+              for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wj[r], Wi[r], U, 0, 0, 0);
+            }
+          });
+        }
       };
       if constexpr (tp_owner(k + 1) == WV) {
         update_col(std::integral_constant<int, k + 1>{}, std::integral_constant<int, k + 1>{});  // one tile: (k + 1, k + 1)
-        if constexpr (k + 1 == TPT - 1) Dlast = T[tp_base(WV, k + 1) + k + 1];
+        if constexpr (k + 1 == TPT - 1) Dlast = T[TPI(k + 1, k + 1)];
         run_chain(std::integral_constant<int, k + 1>{});
       }
       tp_sfor<TPT - 2 - k>([&](auto II) {
@@ -2226,10 +2354,10 @@ AVM_NOINL bool chol_regs() {
     }
   });
   if (failed) return false;
-  __syncthreads();  // z is complete in lds[L_Y]
+  __syncthreads();  // z is complete in lds[L_ZV]
   PROF(c, 5);
   if (*s_fail) return false;
-  // ---- backward substitution L^T x = z by tile columns, last to first
+  // ---- backward substitution L^T x = z by tile columns, last to first; x_i replaces z_i (elimination order) and goes to lds[L_Y] (the system's order)
   d4 E[TPT - 1];  // E[k] += U(k, i) .* x_i over this wavefront's columns i > k (element-wise: reduced once, when block k is due)
 #pragma unroll
   for (int k = 0; k < TPT - 1; k++) E[k] = d4{0, 0, 0, 0};
@@ -2238,11 +2366,11 @@ AVM_NOINL bool chol_regs() {
     constexpr int nb = i == TPT - 1 ? TP_NBL : 16;
     if constexpr (tp_owner(i) == WV) {
       // v = z_i - the four partial sums; L~_ii back into the patch in [row][column] form; the 16-step chain of chol_solve_block
-      const d4& D = T[tp_base(WV, i) + i];
+      const d4& D = T[TPI(i, i)];
 #pragma unroll
       for (int r = 0; r < 4; r++) lds[L_PATCH + lr * 16 + lk + 4 * r] = D[r];
       const int rr = min(lr, nb - 1);
-      double bv = lds[L_Y + 16 * i + rr];
+      double bv = lds[L_ZV + 16 * i + rr];
 #pragma unroll
       for (int w = 0; w < 4; w++) bv -= lds[L_PARTV + w * 176 + 16 * i + rr];
       wave_lds_sync();
@@ -2260,23 +2388,28 @@ AVM_NOINL bool chol_regs() {
         bv = fma(-colv[jj], xj, bv);
         xout = lane == jj ? xj : xout;
       }
-      if (lane < nb) lds[L_Y + 16 * i + lane] = xout;
+      if (lane < nb) lds[L_ZV + 16 * i + lane] = xout, lds[L_Y + tp_perm_dev(16 * i + lane)] = xout;
       wave_lds_sync();
       // fold x_i into the element-wise accumulators of the blocks above (lane (lk, lr): column lr of every tile)
-      const double xl = lr < nb ? lds[L_Y + 16 * i + min(lr, nb - 1)] : 0.0;
+      const double xl = lr < nb ? lds[L_ZV + 16 * i + min(lr, nb - 1)] : 0.0;
       tp_sfor<i>([&](auto K) {
         constexpr int k = K;
-        const d4& U = T[tp_base(WV, i) + k];
+        if constexpr (tp_nz(k, i)) {
+          const d4& U = T[TPI(k, i)];
 #pragma unroll
-        for (int r = 0; r < 4; r++) E[k][r] = fma(U[r], xl, E[k][r]);
+          for (int r = 0; r < 4; r++) E[k][r] = fma(U[r], xl, E[k][r]);
+        }
       });
     }
     if constexpr (i > 0) {
-      // every wavefront: its share of block i - 1 is complete (all its columns > i - 1 have been folded in)
+      // every wavefront that holds a tile of row i - 1: its share of block i - 1 is complete (all its columns > i - 1 have been folded in);
+      // the others' partial sums stay the zeros they were set to
+      if constexpr (tp_row_held(WV, i - 1)) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const double sacc = tp_row_sum(E[i - 1][r]);
-        if (lr == 15) lds[L_PARTV + WV * 176 + 16 * (i - 1) + lk + 4 * r] = sacc;
+        for (int r = 0; r < 4; r++) {
+          const double sacc = tp_row_sum(E[i - 1][r]);
+          if (lr == 15) lds[L_PARTV + WV * 176 + 16 * (i - 1) + lk + 4 * r] = sacc;
+        }
       }
       __syncthreads();
     }
@@ -2285,6 +2418,8 @@ AVM_NOINL bool chol_regs() {
   PROF(c, 6);
   return true;
 }
+#undef TPI
+#undef TPW
 #else  // the other builds: left-looking factorization of the packed system in LDS
 // Scratch of the factorization inside the tile at L_WCH (dead while S is being factored): L^-T of the current and of the
 // next diagonal block, and a per-lane dump slot for the masked-out stores.
@@ -5033,6 +5168,15 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
 
 #ifdef AVM_TP
 int window_solve_tp_lds_bytes() { return L_END * 8; }
+// the factorization's compile-time tables for the tests (tests/test_tp_pattern.py states them in numpy): out[0..120] = TPP.h, [121..241] = TPP.nz
+// (both [k][i]), [242..252] = tp_owner, [253 ..] = tp_perm of the NF + 1 positions
+int window_solve_tp_pattern(int* out) {
+  for (int k = 0; k < TPT; k++)
+    for (int i = 0; i < TPT; i++) out[k * TPT + i] = TPP.h[k][i], out[TPT * TPT + k * TPT + i] = TPP.nz[k][i];
+  for (int i = 0; i < TPT; i++) out[2 * TPT * TPT + i] = tp_owner(i);
+  for (int n = 0; n <= NF; n++) out[2 * TPT * TPT + TPT + n] = tp_perm(n);
+  return 2 * TPT * TPT + TPT + NF + 1;
+}
 // workgroups of the throughput kernel the runtime says a CU can hold (2 is what the kernel is built for)
 int window_solve_tp_occupancy() {
   int n = 0;

@@ -8,7 +8,7 @@ name=$1; extra=$2; shift 2
 which=${@:-base x tp}
 out=../../build/variants; mkdir -p $out/$name
 make -s -j4 >/dev/null
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -mllvm -sink-insts-to-avoid-spills"
+FLAGS="-O3 -std=c++17 -fconstexpr-steps=16000000 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -mllvm -sink-insts-to-avoid-spills"
 IPRA=${IPRA--mllvm -enable-ipra -fno-optimize-sibling-calls}   # (as csrc/Makefile: base and tp builds; IPRA= switches it off)
 cp window_solve.o window_solve_x.o window_solve_tp.o $out/$name/
 for w in $which; do

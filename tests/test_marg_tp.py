@@ -109,8 +109,8 @@ def test_which_form_a_marginalization_takes(ctx, monkeypatch):
 @pytest.mark.parametrize("where", ["host", "device"])
 def test_a_prior_with_a_later_speed_bias_block_takes_the_latency_marginalization(ctx, oracle, where):
     """The compact joint system holds speed-biases 0 and 1 only (all the reference ever keeps).  A prior on ONE speed-bias block of a
-    later frame fits the throughput solve but not the throughput marginalization: that window batch is marginalized by the other
-    kernel - and the result is the oracle's."""
+    later frame does not fit it - nor, since round 6, the throughput solve, whose elimination order puts frame 0's block last (chol_regs):
+    that window batch is solved and marginalized by the latency kernels - and the result is the oracle's."""
     o = abi.default_options()
     # (MARGIN_SECOND_NEW: under MARGIN_OLD a second kept speed-bias block would not fit the 76 rows a prior may have)
     o.marginalization_flag = abi.MARGIN_SECOND_NEW
@@ -126,7 +126,7 @@ def test_a_prior_with_a_later_speed_bias_block_takes_the_latency_marginalization
     oracle.window_solve(o, wo, po, buffers.summary_alloc(w.n_windows))
     g = w.to_device("cuda:0") if where == "device" else w.copy()
     E.optimization(g)
-    assert (ctx.last_solve_form(), ctx.last_marg_form()) == ("throughput", "latency")
+    assert (ctx.last_solve_form(), ctx.last_marg_form()) == ("latency", "latency")
     pg = E.last_marginalization_info
     pg = pg.to_host() if hasattr(pg, "to_host") and where == "device" else pg
     assert np.array_equal(pg.a["n"], po.a["n"]) and np.array_equal(pg.a["nblk"], po.a["nblk"])
