@@ -117,8 +117,8 @@ constexpr int L_SBC = L_U;                    // [99][SBW]
 constexpr int L_STRIP = L_SBC + 99 * SBW;     // [9][66]: rows of the prior's speed-bias block x every pose column
 constexpr int USZ = 99 * SBW + 9 * NPOSE + 2; // 4160
 static_assert(ASM_WAVES * XSTG <= USZ, "staging fits the union region");
-constexpr int L_PATCH = L_U;                  // factorization: [16][16] diagonal block in lane = row form
-constexpr int L_LINV = L_PATCH + 256;         // [2][256 + 16]: L_kk^-T (unscaled, see chol_diag_block) and the pivots
+constexpr int L_PATCH = L_U;                  // factorization: [2][16][16] diagonal block k in lane = row form, in patch k & 1
+constexpr int L_LINV = L_PATCH + 512;         // [2][256 + 16]: L_kk^-T (unscaled, see chol_diag_block) and 1 / sqrt(pivot) of the block's columns
 constexpr int TP_WSLOTS = 7;                  // tiles of a row of W that exist beside the diagonal (tp_wslot: the factor is sparse in the order chol_regs eliminates in)
 constexpr int L_WROW = L_LINV + 2 * 272;      // [TP_WSLOTS][256]: row k of W, the tiles that exist in column order, in the accumulator layout [r][lane]
 constexpr int L_PARTV = L_WROW + TP_WSLOTS * 256;  // back substitution: [4][176] partial sums of the four wavefronts
@@ -2115,7 +2115,7 @@ AVM_DEV void tp_diag_chain(int nb, int buf) {
   double a[NB];
   const bool idl = (r & 48) == 16;
   const int rc = min(r, nb - 1);
-  double* row = lds + L_PATCH + (rc & 15) * NB;
+  double* row = lds + L_PATCH + buf * 256 + (rc & 15) * NB;
   {
 #pragma unroll
     for (int k = 0; k < NB; k++) a[k] = row[k];
@@ -2157,6 +2157,14 @@ AVM_DEV void tp_diag_chain(int nb, int buf) {
     const int kmax = idl ? NB - 1 : (r < nb ? r : -1);
 #pragma unroll
     for (int k = 0; k < NB; k++) *(k <= kmax ? dst + k : dump) = a[k];
+  }
+  // 1 / sqrt(d_c) of the block's columns beside L~^-T (every wavefront's solves scale their rows with it: computed here once, not four times
+  // behind the barrier), and the verdict on the pivots
+  wave_lds_sync();
+  if (r < NB) {
+    const double dc = lds[L_PATCH + buf * 256 + min(r, nb - 1) * 17];
+    if (!(dc > 0.0)) reinterpret_cast<int*>(lds + L_INT)[I_FAIL] = 1;  // non-positive (or NaN) pivot
+    lds[L_LINV + buf * 272 + 256 + r] = fast_rsqrt_pe(dc);
   }
   AVM_PRIO_BULK_CHOL();
 }
@@ -2241,9 +2249,11 @@ AVM_NOINL bool chol_regs() {
   auto run_chain = [&](auto K) {
     constexpr int k = K;
     CPROF(4);
-    const d4& D = T[TPI(k, k)];
+    if constexpr (k == 0) {
+      const d4& D = T[TPI(k, k)];
 #pragma unroll
-    for (int r = 0; r < 4; r++) lds[L_PATCH + (lk + 4 * r) * 16 + lr] = D[r];
+      for (int r = 0; r < 4; r++) lds[L_PATCH + (k & 1) * 256 + (lk + 4 * r) * 16 + lr] = D[r];
+    }
     wave_lds_sync();
     tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, k & 1);
     wave_lds_sync();
@@ -2267,9 +2277,7 @@ AVM_NOINL bool chol_regs() {
       for (int m = 0; m < 4; m++) {
         const double v = LT[(lk + 4 * m) * 16 + lr];
         aop[m] = (lk + 4 * m < nb && lr < nb) ? v : 0.0;
-        const double dc = lds[L_PATCH + min(lk + 4 * m, nb - 1) * 17];
-        if (!(dc > 0.0)) *s_fail = 1;  // non-positive (or NaN) pivot: every wavefront that looks sees the same values
-        isq4[m] = fast_rsqrt_pe(dc);
+        isq4[m] = LT[256 + min(lk + 4 * m, nb - 1)];
       }
     }
     if constexpr (tp_owner(k) == WV) {
@@ -2286,7 +2294,7 @@ AVM_NOINL bool chol_regs() {
           if (lr == TP_NBL && lk + 4 * r < TP_NBL) lds[L_ZV + 16 * k + lk + 4 * r] = (Za[r] + Zb[r]) * isq4[r];
       }
 #pragma unroll
-      for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + lr * 16 + lk + 4 * r];
+      for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + (k & 1) * 256 + lr * 16 + lk + 4 * r];
     }
     // (c) W(k, i) = L_kk^-1 U(k, i) for this wavefront's columns i > k: the final factor tiles, published for the others' updates
     tp_sfor<TPT - 1 - k>([&](auto II) {
@@ -2311,6 +2319,17 @@ AVM_NOINL bool chol_regs() {
       }
     });
     if constexpr (k < TPT - 1) {
+      // the owner of column k + 1 needs nothing but its own W(k, k + 1) for tile (k + 1, k + 1): it is updated and put into the other patch
+      // before the barrier, while the wavefronts with more tiles in row k still solve; the chain starts right behind the barrier
+      if constexpr (tp_owner(k + 1) == WV) {
+        const d4& Wd = T[TPI(k, k + 1)];
+        d4& U = T[TPI(k + 1, k + 1)];
+#pragma unroll
+        for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[r], Wd[r], U, 0, 0, 0);
+        if constexpr (k + 1 == TPT - 1) Dlast = U;
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds[L_PATCH + ((k + 1) & 1) * 256 + (lk + 4 * r) * 16 + lr] = U[r];
+      }
       CPROF(2);
       __syncthreads();  // (d) row k of W is published
       CPROF(3);
@@ -2342,11 +2361,7 @@ AVM_NOINL bool chol_regs() {
           });
         }
       };
-      if constexpr (tp_owner(k + 1) == WV) {
-        update_col(std::integral_constant<int, k + 1>{}, std::integral_constant<int, k + 1>{});  // one tile: (k + 1, k + 1)
-        if constexpr (k + 1 == TPT - 1) Dlast = T[TPI(k + 1, k + 1)];
-        run_chain(std::integral_constant<int, k + 1>{});
-      }
+      if constexpr (tp_owner(k + 1) == WV) run_chain(std::integral_constant<int, k + 1>{});  // (its tile went to the patch before the barrier)
       tp_sfor<TPT - 2 - k>([&](auto II) {
         constexpr int i = k + 2 + II;
         if constexpr (tp_owner(i) == WV) update_col(std::integral_constant<int, i>{}, std::integral_constant<int, k + 1>{});
