@@ -191,7 +191,8 @@ constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 54
               I_NCOV = 624 /* [12] factors observed in frame b */, I_FRW = 636 /* [12] assembling wave of frame b */,
               I_PMASK = 648 /* [12] start frames flushed by frame b */, I_TIMEUP = 660 /* max_solver_time reached (set by thread 0) */,
               I_NRUN = 661 /* [12] distinct start frames among the factors observed in frame b */,
-              I_PSB = 673 /* throughput build: frame of the prior's speed-bias block (its rows x every pose column: the strip) */, I_END = 674;
+              I_PSB = 673 /* throughput build: frame of the prior's speed-bias block (its rows x every pose column: the strip) */,
+              I_CNT = 674 /* throughput build: wavefronts x rows of W published so far in this factorization (chol_regs) */, I_END = 675;
 static_assert(I_END <= 720, "int carve");
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -2107,7 +2108,7 @@ __device__ const TpOffsets tp_offsets = tp_make_offsets();
 // 16-pivot chain on the diagonal block in the LDS patch ([row][16], symmetric): chol_diag_block with the patch as its source and
 // destination.  Leaves L~ (lower, unscaled: times sqrt(d_c) per column c, the pivot d_c on the diagonal) in the patch and
 // L~^-T in buffer `buf`.
-AVM_DEV void tp_diag_chain(int nb, int buf) {
+AVM_DEV void tp_diag_chain(int nb, int buf, int stamp) {
   constexpr int NB = 16;
   double* lds = LDS();
   const int r = threadIdx.x & 63;
@@ -2163,7 +2164,7 @@ AVM_DEV void tp_diag_chain(int nb, int buf) {
   wave_lds_sync();
   if (r < NB) {
     const double dc = lds[L_PATCH + buf * 256 + min(r, nb - 1) * 17];
-    if (!(dc > 0.0)) reinterpret_cast<int*>(lds + L_INT)[I_FAIL] = 1;  // non-positive (or NaN) pivot
+    if (!(dc > 0.0)) reinterpret_cast<int*>(lds + L_INT)[I_FAIL] = stamp;  // non-positive (or NaN) pivot in block column stamp - 1
     lds[L_LINV + buf * 272 + 256 + r] = fast_rsqrt_pe(dc);
   }
   AVM_PRIO_BULK_CHOL();
@@ -2238,7 +2239,9 @@ AVM_NOINL bool chol_regs() {
       });
     }
   });
-  if (threadIdx.x == 0) *s_fail = 0;
+  typedef __attribute__((address_space(3))) int lds_int_t;
+  lds_int_t* s_cnt = reinterpret_cast<lds_int_t*>((uintptr_t)(L_INT * 8 + I_CNT * 4));
+  if (threadIdx.x == 0) *s_fail = 0, *s_cnt = 0;
   const WinCtx& c = lds_ctx();
   PROF_T0();
   __syncthreads();  // every tile is in registers: the union region becomes the factorization's scratch
@@ -2255,7 +2258,7 @@ AVM_NOINL bool chol_regs() {
       for (int r = 0; r < 4; r++) lds[L_PATCH + (k & 1) * 256 + (lk + 4 * r) * 16 + lr] = D[r];
     }
     wave_lds_sync();
-    tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, k & 1);
+    tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, k & 1, k + 1);
     wave_lds_sync();
     CPROF(0);
   };
@@ -2269,6 +2272,15 @@ AVM_NOINL bool chol_regs() {
     CPROF(4);
     __syncthreads();  // (b) L~_kk and L~_kk^-T are published; every wavefront is done with step k - 1
     CPROF(1);
+    // (a chain stamps a non-positive pivot with its block column + 1: the next chain may already run while a slow wavefront reads this, and
+    //  all four have to take the same way out)
+    {
+      const int f = *s_fail;
+      if (f != 0 && f <= k + 1) {
+        failed = true;
+        return;
+      }
+    }
     // A operand of the solves: L_kk^-1[i' = lr][k' = lk + 4 m] = L~^-T[k'][i'] / sqrt(d_i'); the row scaling is applied to the product
     double aop[4], isq4[4];
     if constexpr (tp_row_held(WV, k) || tp_owner(k) == WV) {
@@ -2331,12 +2343,16 @@ AVM_NOINL bool chol_regs() {
         for (int r = 0; r < 4; r++) lds[L_PATCH + ((k + 1) & 1) * 256 + (lk + 4 * r) * 16 + lr] = U[r];
       }
       CPROF(2);
-      __syncthreads();  // (d) row k of W is published
+      // (d) row k of W is published - counted, not a barrier: the owner of column k + 1 needs nobody's tiles for its chain and does not wait
+      // (1 K cycles per step it spent at a barrier for the wavefronts with more tiles to solve); everybody else waits for all four counts
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      auto wait_row = [&]() {
+        while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (k + 1)) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      };
+      if constexpr (tp_owner(k + 1) != WV) wait_row();
       CPROF(3);
-      if (*s_fail) {
-        failed = true;
-        return;
-      }
       // (e) trailing update U(j, i) -= W(k, j)^T W(k, i), k < j <= i, over the tiles of row k that exist.  The owner of column k + 1 starts
       // with tile (k + 1, k + 1) and runs the next chain right away: the other wavefronts update meanwhile (look-ahead).
       auto update_col = [&](auto II, auto J0) {
@@ -2361,7 +2377,10 @@ AVM_NOINL bool chol_regs() {
           });
         }
       };
-      if constexpr (tp_owner(k + 1) == WV) run_chain(std::integral_constant<int, k + 1>{});  // (its tile went to the patch before the barrier)
+      if constexpr (tp_owner(k + 1) == WV) {
+        run_chain(std::integral_constant<int, k + 1>{});  // (its tile went to the patch above)
+        wait_row();
+      }
       tp_sfor<TPT - 2 - k>([&](auto II) {
         constexpr int i = k + 2 + II;
         if constexpr (tp_owner(i) == WV) update_col(std::integral_constant<int, i>{}, std::integral_constant<int, k + 1>{});
