@@ -115,15 +115,17 @@ constexpr int SBW = 36;                       // compact speed-bias row: 18 pose
 constexpr int L_U = L_S + SPP;
 constexpr int L_SBC = L_U;                    // [99][SBW]
 constexpr int L_STRIP = L_SBC + 99 * SBW;     // [9][66]: rows of the prior's speed-bias block x every pose column
-constexpr int USZ = 99 * SBW + 9 * NPOSE + 2; // 4160
+constexpr int USZ = 99 * SBW + 9 * NPOSE + 2; // 4160; its last two doubles hold the constants 0.0 and 1.0 for chol_regs' tile load (set by schur_reduce)
+constexpr int L_ZERO = L_U + USZ - 2, L_ONE = L_U + USZ - 1;
 static_assert(ASM_WAVES * XSTG <= USZ, "staging fits the union region");
-constexpr int L_PATCH = L_U;                  // factorization: [2][16][16] diagonal block k in lane = row form, in patch k & 1
-constexpr int L_LINV = L_PATCH + 512;         // [2][256 + 16]: L_kk^-T (unscaled, see chol_diag_block) and 1 / sqrt(pivot) of the block's columns
-constexpr int TP_WSLOTS = 7;                  // tiles of a row of W that exist beside the diagonal (tp_wslot: the factor is sparse in the order chol_regs eliminates in)
-constexpr int L_WROW = L_LINV + 2 * 272;      // [TP_WSLOTS][256]: row k of W, the tiles that exist in column order, in the accumulator layout [r][lane]
-constexpr int L_PARTV = L_WROW + TP_WSLOTS * 256;  // back substitution: [4][176] partial sums of the four wavefronts
-constexpr int L_ZV = L_PARTV + 4 * 176;       // [176] z = L^-1 b, then x, in elimination order (lds[L_Y] keeps the right-hand side until x replaces it, in the system's order)
-static_assert(L_ZV + 176 <= L_U + USZ, "factorization scratch fits the union region");
+constexpr int L_PATCH = L_U;                  // factorization: [2][16][16] diagonal blocks of the (up to two) pivot columns of a step in lane = row form
+constexpr int L_LINV = L_PATCH + 512;         // [4][256 + 16]: L_kk^-T (unscaled, see chol_diag_block) and 1 / sqrt(pivot) of the block's columns (tp_buf)
+constexpr int TP_WSLOTS = 9;                  // tiles of a step's rows of W that exist beside the diagonal (tp_wslot: the factor is sparse in the order chol_regs eliminates in)
+constexpr int L_WROW = L_LINV + 4 * 272;      // [TP_WSLOTS][256]: the step's rows of W, the tiles that exist in column order, in the accumulator layout [r][lane]
+constexpr int L_PARTV = L_WROW;               // back substitution (the rows of W are dead by then): [4][176] partial sums of the four wavefronts
+constexpr int L_ZV = L_WROW + TP_WSLOTS * 256;  // [176] z = L^-1 b, then x, in elimination order (lds[L_Y] keeps the right-hand side until x replaces it, in the system's order)
+static_assert(L_ZV + 176 <= L_ZERO && 4 * 176 <= TP_WSLOTS * 256, "factorization scratch fits the union region");
+static_assert(ASM_WAVES * XSTG <= USZ - 2, "staging leaves the two constants alone");
 constexpr int L_Y = L_U + USZ;                // Gauss-Newton solution y; until the solve writes it: the right-hand side (row NF of the other builds)
 constexpr int L_RHS = L_Y;
 constexpr int WCH_TP = 224;                   // doubles: ys of back_substitute / rvb of jac_times_vec_sq (<= 150), then 64 dump slots
@@ -1951,67 +1953,95 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
 #ifdef AVM_TP
 // =====================================================================================================================
 // Throughput build: the factorization on REGISTER tiles, distributed over the workgroup's four wavefronts, in an elimination
-// order that keeps the factor SPARSE (round 6).
+// order that keeps the factor SPARSE and lets TWO pivot chains run at a time (round 6).
 //
-// Order of elimination: the speed-bias blocks last frame first (10, 9, .. 0), then the poses, then the right-hand side.  Speed-bias
-// block b couples to blocks b - 1 / b + 1 and to the poses b - 1 .. b + 1 (one IMU factor each side); eliminated from the window's
-// end it hands the next block the poses b .. 10 as fill and nothing else, and the prior's speed-bias block (frame 0: the one block
-// the prior couples to EVERY pose - the strip) is eliminated last of them, so its dense row fills nothing.  Of the 66 upper tiles of
-// the 11 x 11 grid 51 can be nonzero and a factorization takes 115 tile updates (460 MFMAs) where the order poses | speed-biases
-// takes 220 (880): with the poses first every speed-bias row fills in completely.  The rest of the kernel keeps its layout; the
-// permutation happens when the tiles are loaded (tp_perm) and when the solution is written back.
+// Order of elimination - a nested dissection of the speed-bias chain with frame 5's block as the separator:
+//     B: the speed-bias blocks of frames 10, 9, .. 6   (45 columns + 3 of padding = tile columns 0, 1, 2)
+//     F: the speed-bias blocks of frames 4, 3, .. 0    (45 columns + 3 of padding = tile columns 3, 4, 5)
+//     then frame 5's block, the poses and the right-hand side (9 + 66 + 1 = 76 positions = tile columns 6 .. 10).
+// Speed-bias block b couples to blocks b - 1 / b + 1 and to the poses b - 1 .. b + 1 (one IMU factor each side).  Eliminated from the
+// window's end, B hands each next block the poses b .. 10 as fill and nothing else; F is eliminated from the separator outwards, so
+// that the prior's speed-bias block (frame 0: the one block the prior couples to EVERY pose - the strip) comes last of it and its
+// dense row fills nothing.  B and F never meet (no factor joins them, and neither does the fill: what joins them is eliminated
+// later), so the 16-pivot chains of tile columns t and 3 + t, t = 0, 1, 2, run at the same time on two wavefronts: a factorization is
+// EIGHT chain times long (3 + 5) instead of eleven, and the chain - one wavefront, 4.5 K cycles - is what a step lasts.  Of the 66
+// upper tiles of the 11 x 11 grid 47 can be nonzero and a factorization takes 91 tile updates (364 MFMAs) where the order poses |
+// speed-biases takes 220 (880): with the poses first every speed-bias row fills in completely.  The padding positions are rows of the
+// identity.  The rest of the kernel keeps its layout; the permutation happens when the tiles are loaded (tp_offsets) and when the
+// solution is written back.
 //
-// The augmented (NF + 1) x (NF + 1) system [H' + mu D^2, g'; g'^T, .] in that order is cut into 11 x 11 tiles of 16 x 16 and held as
-// its UPPER tiles U(k, i), k <= i (U(k, i) = L(i, k)^T once factored), in the accumulator layout of v_mfma_f64_16x16x4: register r of
-// lane (lk = lane / 16, lr = lane % 16) is entry (lk + 4 r, lr).  With the k index of a product running as lk + 4 r such a tile IS a B
+// The augmented system [H' + mu D^2, g'; g'^T, .] in that order is cut into 11 x 11 tiles of 16 x 16 and held as its UPPER tiles
+// U(k, i), k <= i (U(k, i) = L(i, k)^T once factored), in the accumulator layout of v_mfma_f64_16x16x4: register r of lane
+// (lk = lane / 16, lr = lane % 16) is entry (lk + 4 r, lr).  With the k index of a product running as lk + 4 r such a tile IS a B
 // operand and, read as an A operand, its transpose (the scheme of prior_chol_kernel, prior_eig.hip), so nothing is transposed or
-// moved between lanes.  The right-hand side is position NF (tile column 10, local column 5): the forward substitution rides along.
+// moved between lanes.  The right-hand side is position TP_RHS (tile column 10, local column 11): the forward substitution rides along.
 //   * which tiles exist is a compile-time table (TPP: the system's tile pattern closed under the elimination's fill); a tile outside
 //     it is never loaded, solved, published or updated;
-//   * ownership by tile COLUMN (tp_owner): one wavefront holds the speed-bias columns 1..5, whose tiles only ever meet each other - the
-//     chain of chains runs on it -, the pose columns are spread over the other three: at most 14 tiles = 112 registers per lane;
-//   * step k:  [owner of column k] 16-pivot chain on the diagonal tile (through a 2 KB LDS patch into lane = row form: the
-//     square-root-free chain of chol_diag_block, L_kk^-T riding along in lanes 16..31) ............................. barrier
-//              [every wavefront] W(k, i) = L_kk^-1 U(k, i) for its columns i > k, published to LDS ................. barrier
-//              [every wavefront] U(j, i) -= W(k, j)^T W(k, i) for its columns, the owner of column k + 1 taking tile (k + 1, k + 1)
-//              first and running the next chain while the others still update (look-ahead): two barriers per step.
-//   * backward substitution L^T x = z by tile columns, last to first: the owner of column i solves x_i from z_i minus the four
+//   * ownership by tile COLUMN (tp_owner): wavefront 3 holds B's columns, wavefront 2 F's - their tiles only ever meet each other, the two
+//     chains of chains run there -, the other columns are spread so that a chain's owner has little else to do: at most 13 tiles;
+//   * step t (tp_step_piv: the pivot columns {t, 3 + t} for t < 3, then {t + 3}):
+//              [owner of a pivot column k] 16-pivot chain on the diagonal tile (through a 2 KB LDS patch into lane = row form: the
+//              square-root-free chain of chol_diag_block, L_kk^-T riding along in lanes 16..31) ...................... barrier
+//              [every wavefront] W(k, i) = L_kk^-1 U(k, i) for its columns i > k, published to LDS; the owner of a pivot column q of
+//              step t + 1 then updates tile (q, q) - it needs its own W(k, q) only -, stages it and starts the chain ... counted
+//              [every other wavefront] waits for the four counts, then U(j, i) -= W(k, j)^T W(k, i) for its columns while the chains run
+//   * backward substitution L^T x = z by the same steps, last to first: the owner of column i solves x_i from z_i minus the four
 //     wavefronts' partial sums, folds x_i into element-wise accumulators E_k += U(k, i) .* x_i (k < i, no reduction), and every
-//     wavefront that holds a tile of row i - 1 reduces its E_{i-1} over the 16-lane rows (DPP) into its partial vector: one barrier per column.
-// Nothing of the factor ever goes to memory; the LDS traffic is the published row of W (<= 14 KB per step).
+//     wavefront that holds a tile of the next step's rows reduces its E over the 16-lane rows (DPP) into its partial vector: one barrier per step.
+// Nothing of the factor ever goes to memory; the LDS traffic is the published rows of W (<= 18 KB per step).
 constexpr int TPT = 11;
-constexpr int TP_NBL = NF - 16 * (TPT - 1);  // state columns in the last tile column: 5 (+ the right-hand side at local column 5)
+static_assert(NFR == 11 && NF == 165 && NPOSE == 66, "the elimination order below is written for eleven frames");
+constexpr int TP_PAD = -1;
+constexpr int TP_M0 = 96, TP_P0 = 105, TP_RHS = 171;  // first position of frame 5's block / of the poses / the right-hand side
+constexpr int TP_NBL = TP_RHS - 16 * (TPT - 1);       // state columns in the last tile column: 11 (+ the right-hand side at local column 11)
 static_assert(TP_NBL >= 1 && TP_NBL < 16, "the right-hand side fits the last tile column");
-constexpr int NSBV = NF - NPOSE;             // 99 speed-bias columns = positions 0 .. 98 of the elimination order
-static_assert(NSBV == 9 * NFR, "speed-bias blocks of nine");
-// position n of the elimination order -> column of the assembled system (poses | speed-biases | right-hand side)
-__host__ __device__ constexpr int tp_perm(int n) { return n < NSBV ? NPOSE + 9 * (NFR - 1 - n / 9) + n % 9 : (n < NF ? n - NSBV : n); }
+// position n of the elimination order -> column of the assembled system (poses | speed-biases; NF = the right-hand side), TP_PAD for padding
+__host__ __device__ constexpr int tp_perm(int n) {
+  if (n < 45) return NPOSE + 9 * (10 - n / 9) + n % 9;             // B: frames 10 .. 6
+  if (n < 48) return TP_PAD;
+  if (n < 93) return NPOSE + 9 * (4 - (n - 48) / 9) + (n - 48) % 9;  // F: frames 4 .. 0
+  if (n < TP_M0) return TP_PAD;
+  if (n < TP_P0) return NPOSE + 45 + (n - TP_M0);                   // frame 5's block
+  if (n < TP_RHS) return n - TP_P0;                                 // poses
+  return n == TP_RHS ? NF : TP_PAD;
+}
 
-// Tile pattern of the system in elimination order, [k][i] with k <= i: h = the assembled system can be nonzero there (s_off: a speed-bias
-// block reaches its neighbours and three poses; the prior's block - frame 0, the host sends every other prior to the latency form - every
-// pose; the right-hand side is dense), nz = h closed under the fill of the tile-level elimination (which is what the scalar elimination
-// fills, aggregated: tests/test_tp_pattern.py states both in numpy).
+// Where the tiles are loaded from: for a pair of positions the LDS offset (in doubles) of the entry - s_off() of the two columns with the
+// prior's speed-bias block at frame 0 (the host sends every other prior to the latency form), the right-hand side for position TP_RHS -,
+// TP_NONE for a structural zero, TP_ONE for the diagonal of a padding position: the places of the constants 0.0 and 1.0 (with codes to be masked
+// the compiler built a branch per entry: 10 K cycles per factorization).
+constexpr int TP_NONE = L_ZERO, TP_ONE = L_ONE;
+constexpr int tp_off_c(int Rn, int Cn) {
+  const int R = tp_perm(Rn), C = tp_perm(Cn);
+  if (R == TP_PAD || C == TP_PAD) return Rn == Cn ? TP_ONE : TP_NONE;
+  const int hi = R > C ? R : C, lo = R > C ? C : R;
+  if (hi == NF) return lo < NF ? L_RHS + lo : TP_NONE;
+  if (hi < NPOSE) return L_S + croff(hi) + lo;
+  const int q = hi - NPOSE, b = q / 9;
+  if (lo < NPOSE) {
+    if (b == 0) return L_STRIP + (q - 9 * b) * NPOSE + lo;
+    const int p = lo - 6 * (b - 1);
+    return p >= 0 && p < 18 ? L_SBC + q * SBW + p : TP_NONE;
+  }
+  const int p = lo - (NPOSE + 9 * (b - 1));
+  return p >= 0 && p < 18 ? L_SBC + q * SBW + 18 + p : TP_NONE;
+}
+
+// Tile pattern of the system in elimination order, [k][i] with k <= i: h = the assembled system can be nonzero there (tp_off_c names a place),
+// nz = h closed under the fill of the tile-level elimination (which is what the scalar elimination fills, aggregated:
+// tests/test_tp_pattern.py states both in numpy).
 struct TpPattern {
   bool h[TPT][TPT], nz[TPT][TPT];
 };
 constexpr TpPattern tp_make_pattern() {
   TpPattern P{};
-  bool s[TPT][TPT] = {};
-  auto mark = [&](int r0, int r1, int c0, int c1) {  // positions [r0, r1] x [c0, c1]
-    for (int a = r0 / 16; a <= r1 / 16; a++)
-      for (int b = c0 / 16; b <= c1 / 16; b++) s[a][b] = s[b][a] = true;
-  };
-  mark(NSBV, NF - 1, NSBV, NF - 1);  // poses x poses
-  mark(0, NF, NF, NF);               // the right-hand side
-  for (int bb = 0; bb < NFR; bb++) {
-    const int b = NFR - 1 - bb, r0 = 9 * bb, r1 = 9 * bb + 8;
-    mark(r0, r1, r0, r1);
-    if (bb + 1 < NFR) mark(r0, r1, r0 + 9, r1 + 9);
-    for (int f = (b > 0 ? b - 1 : 0); f <= (b + 1 < NFR ? b + 1 : NFR - 1); f++) mark(r0, r1, NSBV + 6 * f, NSBV + 6 * f + 5);
-    if (b == 0) mark(r0, r1, NSBV, NF - 1);  // the strip
-  }
   for (int k = 0; k < TPT; k++)
-    for (int i = 0; i < TPT; i++) P.h[k][i] = P.nz[k][i] = k <= i && s[k][i];
+    for (int i = k; i < TPT; i++) {
+      bool any = false;
+      for (int a = 0; a < 16 && !any; a++)
+        for (int b = 0; b < 16 && !any; b++) any = tp_off_c(16 * k + a, 16 * i + b) != TP_NONE;
+      P.h[k][i] = P.nz[k][i] = any;
+    }
   for (int k = 0; k < TPT; k++)
     for (int j = k + 1; j < TPT; j++)
       if (P.nz[k][j])
@@ -2021,9 +2051,28 @@ constexpr TpPattern tp_make_pattern() {
 }
 constexpr TpPattern TPP = tp_make_pattern();
 __host__ __device__ constexpr bool tp_nz(int k, int i) { return k <= i && TPP.nz[k][i]; }
+// the steps of the factorization: pivot columns {t, 3 + t} for t < 3 (B and F side by side), then one column per step
+constexpr int TP_NSTEP = 8;
+__host__ __device__ constexpr int tp_step_np(int t) { return t < 3 ? 2 : 1; }
+__host__ __device__ constexpr int tp_step_piv(int t, int a) { return t < 3 ? (a == 0 ? t : t + 3) : t + 3; }
+__host__ __device__ constexpr int tp_step_of(int k) { return k < 3 ? k : k - 3; }
+__host__ __device__ constexpr int tp_slot_of(int k) { return k >= 3 && k < 6 ? 1 : 0; }           // which of its step's pivot columns (the patch it uses)
+__host__ __device__ constexpr int tp_buf(int k) { return 2 * (tp_step_of(k) & 1) + tp_slot_of(k); }  // its L^-T buffer: the next step's chains write the other pair
+__host__ __device__ constexpr bool tp_is_piv(int t, int q) {  // is q a pivot column of step t ?
+  return t >= 0 && t < TP_NSTEP && (tp_step_piv(t, 0) == q || (tp_step_np(t) == 2 && tp_step_piv(t, 1) == q));
+}
+__host__ __device__ constexpr bool tp_steps_ok() {  // the two pivot columns of a step share no tile, and a column's rows all belong to earlier steps
+  for (int t = 0; t < 3; t++)
+    if (tp_nz(t, t + 3)) return false;
+  for (int i = 0; i < TPT; i++)
+    for (int k = 0; k < i; k++)
+      if (tp_nz(k, i) && tp_step_of(k) >= tp_step_of(i)) return false;
+  return true;
+}
+static_assert(tp_steps_ok(), "B and F must not meet");
 __host__ __device__ constexpr int tp_owner(int i) {
-  // (scripts/tp_ownership.py: the assignment that leaves the owner of column k + 1 nothing but its diagonal tile to update at step k)
-  return i == 0 || i == 10 ? 0 : (i <= 5 ? 3 : (i == 6 || i == 9 ? 1 : 2));
+  // (build/dev: the assignment that leaves the owner of a step's pivot columns the least other work in the step before)
+  return i < 3 ? 3 : (i < 7 ? 2 : (i < 9 ? 0 : (i == 9 ? 3 : 1)));
 }
 __host__ __device__ constexpr int tp_ncol(int i) {  // tiles of column i
   int n = 0;
@@ -2037,50 +2086,51 @@ __host__ __device__ constexpr int tp_idx(int wv, int k, int i) {  // index of ti
   return n;
 }
 __host__ __device__ constexpr int tp_ntiles(int wv) { return tp_idx(wv, 0, TPT); }
-__host__ __device__ constexpr int tp_wslot(int k, int i) {  // slot of W(k, i) in the published row k
+__host__ __device__ constexpr int tp_nrow(int k) {  // tiles of row k beside the diagonal
   int n = 0;
+  for (int c = k + 1; c < TPT; c++) n += tp_nz(k, c) ? 1 : 0;
+  return n;
+}
+__host__ __device__ constexpr int tp_wslot(int k, int i) {  // slot of W(k, i) among its step's published tiles
+  int n = tp_slot_of(k) == 1 ? tp_nrow(tp_step_piv(tp_step_of(k), 0)) : 0;
   for (int c = k + 1; c < i; c++) n += tp_nz(k, c) ? 1 : 0;
   return n;
 }
 __host__ __device__ constexpr int tp_max_wslots() {
   int m = 0;
-  for (int k = 0; k < TPT; k++) m = tp_wslot(k, TPT) > m ? tp_wslot(k, TPT) : m;
+  for (int t = 0; t < TP_NSTEP; t++) {
+    int n = 0;
+    for (int a = 0; a < tp_step_np(t); a++) n += tp_nrow(tp_step_piv(t, a));
+    m = n > m ? n : m;
+  }
   return m;
 }
-static_assert(tp_max_wslots() <= TP_WSLOTS, "the published row of W fits its LDS slots");
+static_assert(tp_max_wslots() <= TP_WSLOTS, "the published rows of W fit their LDS slots");
 __host__ __device__ constexpr bool tp_row_held(int wv, int k) {  // does wavefront wv hold a tile (k, i), i > k ?
   for (int i = k + 1; i < TPT; i++)
     if (tp_owner(i) == wv && tp_nz(k, i)) return true;
   return false;
 }
-__host__ __device__ constexpr bool tp_chain_ok() {  // every column's diagonal tile and the tile above it exist (the look-ahead relies on it)
-  for (int k = 0; k + 1 < TPT; k++)
-    if (!tp_nz(k, k + 1) || !tp_nz(k, k)) return false;
-  return tp_nz(TPT - 1, TPT - 1);
+__host__ __device__ constexpr bool tp_owns_piv(int wv, int t) {  // does wavefront wv own a pivot column of step t ?
+  for (int a = 0; t >= 0 && t < TP_NSTEP && a < tp_step_np(t); a++)
+    if (tp_owner(tp_step_piv(t, a)) == wv) return true;
+  return false;
 }
-static_assert(tp_chain_ok(), "tile pattern");
+__host__ __device__ constexpr bool tp_owners_ok() {  // a wavefront runs one chain at a time
+  for (int t = 0; t < 3; t++)
+    if (tp_owner(tp_step_piv(t, 0)) == tp_owner(tp_step_piv(t, 1))) return false;
+  return true;
+}
+static_assert(tp_owners_ok(), "the two chains of a step run on two wavefronts");
 
-AVM_DEV int tp_perm_dev(int n) { return n < NSBV ? NPOSE + 9 * (NFR - 1) - 9 * (n / 9) + n % 9 : (n < NF ? n - NSBV : n); }
+AVM_DEV int tp_perm_dev(int n) {
+  const int m = n - 48;
+  const int b = NPOSE + 9 * 10 - 9 * (n / 9) + n % 9, f = NPOSE + 9 * 4 - 9 * (m / 9) + m % 9;
+  return n < 45 ? b : (n < 48 ? TP_PAD : (n < 93 ? f : (n < TP_M0 ? TP_PAD : (n < TP_P0 ? NPOSE + 45 + (n - TP_M0) : (n < TP_RHS ? n - TP_P0 : (n == TP_RHS ? NF : TP_PAD))))));
+}
 
-// Where the tiles are loaded from: for every tile the assembled system can reach (TPP.h) and every (lane, register) of it the LDS offset (in doubles)
-// of the entry - s_off() of the two columns with the prior's speed-bias block at frame 0, the right-hand side for position NF - or TP_NONE for a
-// structural zero; a table in the code object's constant data, evaluated at compile time ([tile][lane][register]: one 8-byte load per lane and
+// The offsets as a table in the code object's constant data, evaluated at compile time ([tile][lane][register]: one 8-byte load per lane and
 // tile).  The generic form - position -> column, s_off with its division and branches, an LDS read behind each - was 28 K cycles per factorization.
-constexpr int TP_NONE = 0xffff;
-constexpr int tp_off_c(int Rn, int Cn) {
-  if (Rn > NF || Cn > NF) return TP_NONE;
-  const int R = tp_perm(Rn), C = tp_perm(Cn), hi = R > C ? R : C, lo = R > C ? C : R;
-  if (hi == NF) return lo < NF ? L_RHS + lo : TP_NONE;
-  if (hi < NPOSE) return L_S + croff(hi) + lo;
-  const int q = hi - NPOSE, b = q / 9;
-  if (lo < NPOSE) {
-    if (b == 0) return L_STRIP + (q - 9 * b) * NPOSE + lo;
-    const int p = lo - 6 * (b - 1);
-    return p >= 0 && p < 18 ? L_SBC + q * SBW + p : TP_NONE;
-  }
-  const int p = lo - (NPOSE + 9 * (b - 1));
-  return p >= 0 && p < 18 ? L_SBC + q * SBW + 18 + p : TP_NONE;
-}
 __host__ __device__ constexpr int tp_h_ord(int k, int i) {  // ordinal of tile (k, i) among the tiles with TPP.h, column by column
   int n = 0;
   for (int c = 0; c < TPT; c++)
@@ -2105,10 +2155,10 @@ constexpr TpOffsets tp_make_offsets() {
 }
 __device__ const TpOffsets tp_offsets = tp_make_offsets();
 
-// 16-pivot chain on the diagonal block in the LDS patch ([row][16], symmetric): chol_diag_block with the patch as its source and
+// 16-pivot chain on the diagonal block in LDS patch `patch` ([row][16], symmetric): chol_diag_block with the patch as its source and
 // destination.  Leaves L~ (lower, unscaled: times sqrt(d_c) per column c, the pivot d_c on the diagonal) in the patch and
-// L~^-T in buffer `buf`.
-AVM_DEV void tp_diag_chain(int nb, int buf, int stamp) {
+// L~^-T with 1 / sqrt(d_c) behind it in buffer `buf`.
+AVM_DEV void tp_diag_chain(int nb, int patch, int buf, int stamp) {
   constexpr int NB = 16;
   double* lds = LDS();
   const int r = threadIdx.x & 63;
@@ -2116,7 +2166,7 @@ AVM_DEV void tp_diag_chain(int nb, int buf, int stamp) {
   double a[NB];
   const bool idl = (r & 48) == 16;
   const int rc = min(r, nb - 1);
-  double* row = lds + L_PATCH + buf * 256 + (rc & 15) * NB;
+  double* row = lds + L_PATCH + patch * 256 + (rc & 15) * NB;
   {
 #pragma unroll
     for (int k = 0; k < NB; k++) a[k] = row[k];
@@ -2163,8 +2213,8 @@ AVM_DEV void tp_diag_chain(int nb, int buf, int stamp) {
   // behind the barrier), and the verdict on the pivots
   wave_lds_sync();
   if (r < NB) {
-    const double dc = lds[L_PATCH + buf * 256 + min(r, nb - 1) * 17];
-    if (!(dc > 0.0)) reinterpret_cast<int*>(lds + L_INT)[I_FAIL] = stamp;  // non-positive (or NaN) pivot in block column stamp - 1
+    const double dc = lds[L_PATCH + patch * 256 + min(r, nb - 1) * 17];
+    if (!(dc > 0.0)) reinterpret_cast<int*>(lds + L_INT)[I_FAIL] = stamp;  // non-positive (or NaN) pivot in a pivot column of step stamp - 1
     lds[L_LINV + buf * 272 + 256 + r] = fast_rsqrt_pe(dc);
   }
   AVM_PRIO_BULK_CHOL();
@@ -2215,7 +2265,26 @@ AVM_NOINL bool chol_regs() {
   int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
   constexpr int NTL = tp_ntiles(WV);
   d4 T[NTL];
-  // ---- load, in elimination order (structural zeros included; a tile of the pattern the assembled system cannot reach starts as zero: it is fill)
+#ifdef AVM_PROF_CHOL
+  const long long cp_in__ = clock64();
+#endif
+  // ---- load, in elimination order (structural zeros included; a tile of the pattern the assembled system cannot reach starts as zero: it is fill).
+  // Two passes, each with all its memory operations in flight: the offsets of every tile (left alone the compiler waited for one 8-byte load
+  // per tile before the next: 13 trips to the L2 in a row), then the entries.
+  typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+  us4 off[NTL];
+  tp_sfor<TPT>([&](auto I) {
+    constexpr int i = I;
+    if constexpr (tp_owner(i) == WV) {
+      tp_sfor<i + 1>([&](auto K) {
+        constexpr int k = K;
+        if constexpr (tp_nz(k, i) && TPP.h[k][i])
+          off[TPI(k, i)] = *reinterpret_cast<const __attribute__((address_space(1))) us4*>(
+              (const __attribute__((address_space(1))) unsigned short*)&tp_offsets.o[tp_h_ord(k, i)][0][0] + 4 * lane);
+      });
+    }
+  });
+  __builtin_amdgcn_sched_barrier(0);
   tp_sfor<TPT>([&](auto I) {
     constexpr int i = I;
     if constexpr (tp_owner(i) == WV) {
@@ -2224,14 +2293,8 @@ AVM_NOINL bool chol_regs() {
         if constexpr (tp_nz(k, i)) {
           d4& t = T[TPI(k, i)];
           if constexpr (TPP.h[k][i]) {
-            typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-            const us4 o = *reinterpret_cast<const __attribute__((address_space(1))) us4*>(
-                (const __attribute__((address_space(1))) unsigned short*)&tp_offsets.o[tp_h_ord(k, i)][0][0] + 4 * lane);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const double v = lds[min((int)o[r], L_END - 1)];
-              t[r] = o[r] == TP_NONE ? 0.0 : v;
-            }
+            for (int r = 0; r < 4; r++) t[r] = lds[off[TPI(k, i)][r]];
           } else {
             t = d4{0, 0, 0, 0};
           }
@@ -2243,208 +2306,235 @@ AVM_NOINL bool chol_regs() {
   lds_int_t* s_cnt = reinterpret_cast<lds_int_t*>((uintptr_t)(L_INT * 8 + I_CNT * 4));
   if (threadIdx.x == 0) *s_fail = 0, *s_cnt = 0;
   const WinCtx& c = lds_ctx();
+#ifdef AVM_PROF_CHOL
+  if (c.prof && lane == 0 && WV == AVM_PROF_CHOL) c.prof[61] += clock64() - cp_in__;  // the load
+#endif
   PROF_T0();
   __syncthreads();  // every tile is in registers: the union region becomes the factorization's scratch
   PROF(c, 4);
-  for (int q = threadIdx.x; q < 4 * 176; q += NT) lds[L_PARTV + q] = 0.0;
   CPROF_T0();
-  // by the owner of column k: diagonal tile -> patch -> chain (L~_kk in the patch, L~_kk^-T in buffer k & 1)
+  // by the owner of pivot column k: diagonal tile (staged in its step's patch) -> chain -> L~_kk^T back into the tile, L~_kk^-T in buffer tp_buf(k)
+  d4 Dlast = {0, 0, 0, 0};  // the last diagonal tile as it was before its chain (its column TP_NBL is the right-hand side)
   auto run_chain = [&](auto K) {
     constexpr int k = K;
     CPROF(4);
-    if constexpr (k == 0) {
-      const d4& D = T[TPI(k, k)];
+    d4& D = T[TPI(k, k)];
+    if constexpr (tp_step_of(k) == 0) {  // (the later ones were staged by the step before)
 #pragma unroll
-      for (int r = 0; r < 4; r++) lds[L_PATCH + (k & 1) * 256 + (lk + 4 * r) * 16 + lr] = D[r];
+      for (int r = 0; r < 4; r++) lds[L_PATCH + tp_slot_of(k) * 256 + (lk + 4 * r) * 16 + lr] = D[r];
     }
     wave_lds_sync();
-    tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, k & 1, k + 1);
+    tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, tp_slot_of(k), tp_buf(k), tp_step_of(k) + 1);
     wave_lds_sync();
+    // the diagonal tile becomes L~_kk^T (entry (a, b) = L~[b][a]); the patch is free for the next step's chain
+#pragma unroll
+    for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + tp_slot_of(k) * 256 + lr * 16 + lk + 4 * r];
     CPROF(0);
   };
-  d4 Dlast = {0, 0, 0, 0};  // the last diagonal tile as it was before its chain (its column TP_NBL is the right-hand side)
-  if constexpr (tp_owner(0) == WV) run_chain(std::integral_constant<int, 0>{});
+  tp_sfor<2>([&](auto A) {
+    constexpr int k = tp_step_piv(0, A);
+    if constexpr (tp_owner(k) == WV) run_chain(std::integral_constant<int, k>{});
+  });
   bool failed = false;
-  tp_sfor<TPT>([&](auto K) {
-    constexpr int k = K;
-    constexpr int nb = k == TPT - 1 ? TP_NBL : 16;
+  tp_sfor<TP_NSTEP>([&](auto TT) {
+    constexpr int t = TT;
     if (failed) return;  // (uniform)
     CPROF(4);
-    __syncthreads();  // (b) L~_kk and L~_kk^-T are published; every wavefront is done with step k - 1
+    __syncthreads();  // (b) L~_kk^-T of this step's pivot columns are published; every wavefront is done with step t - 1
     CPROF(1);
-    // (a chain stamps a non-positive pivot with its block column + 1: the next chain may already run while a slow wavefront reads this, and
+    // (a chain stamps a non-positive pivot with its step + 1: the next chains may already run while a slow wavefront reads this, and
     //  all four have to take the same way out)
     {
       const int f = *s_fail;
-      if (f != 0 && f <= k + 1) {
+      if (f != 0 && f <= t + 1) {
         failed = true;
         return;
       }
     }
-    // A operand of the solves: L_kk^-1[i' = lr][k' = lk + 4 m] = L~^-T[k'][i'] / sqrt(d_i'); the row scaling is applied to the product
-    double aop[4], isq4[4];
-    if constexpr (tp_row_held(WV, k) || tp_owner(k) == WV) {
-      const double* LT = lds + L_LINV + (k & 1) * 272;
-#pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const double v = LT[(lk + 4 * m) * 16 + lr];
-        aop[m] = (lk + 4 * m < nb && lr < nb) ? v : 0.0;
-        isq4[m] = LT[256 + min(lk + 4 * m, nb - 1)];
-      }
-    }
-    if constexpr (tp_owner(k) == WV) {
-      // the diagonal tile becomes L~_kk^T (entry (a, b) = L~[b][a]); the last one first gives up the right-hand side: z_10 = L^-1 b
-      d4& D = T[TPI(k, k)];
-      if constexpr (k == TPT - 1) {
-        d4 Za = {0, 0, 0, 0}, Zb = {0, 0, 0, 0};
-        Za = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], Dlast[0], Za, 0, 0, 0);
-        Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], Dlast[1], Zb, 0, 0, 0);
-        Za = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], Dlast[2], Za, 0, 0, 0);
-        Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], Dlast[3], Zb, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (lr == TP_NBL && lk + 4 * r < TP_NBL) lds[L_ZV + 16 * k + lk + 4 * r] = (Za[r] + Zb[r]) * isq4[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + (k & 1) * 256 + lr * 16 + lk + 4 * r];
-    }
     // (c) W(k, i) = L_kk^-1 U(k, i) for this wavefront's columns i > k: the final factor tiles, published for the others' updates
-    tp_sfor<TPT - 1 - k>([&](auto II) {
-      constexpr int i = k + 1 + II;
-      if constexpr (tp_owner(i) == WV && tp_nz(k, i)) {
-        d4& U = T[TPI(k, i)];
-        d4 Wa = {0, 0, 0, 0}, Wb = {0, 0, 0, 0};
-        Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], U[0], Wa, 0, 0, 0);
-        Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], U[1], Wb, 0, 0, 0);
-        Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], U[2], Wa, 0, 0, 0);
-        Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], U[3], Wb, 0, 0, 0);
+    tp_sfor<tp_step_np(t)>([&](auto A) {
+      constexpr int k = tp_step_piv(t, A);
+      constexpr int nb = k == TPT - 1 ? TP_NBL : 16;
+      if constexpr (tp_row_held(WV, k) || (k == TPT - 1 && tp_owner(k) == WV)) {
+        // A operand of the solves: L_kk^-1[i' = lr][k' = lk + 4 m] = L~^-T[k'][i'] / sqrt(d_i'); the row scaling is applied to the product
+        double aop[4], isq4[4];
+        const double* LT = lds + L_LINV + tp_buf(k) * 272;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          U[r] = (Wa[r] + Wb[r]) * isq4[r];
-          lds[L_WROW + TPW(k, i) * 256 + r * 64 + lane] = U[r];
+        for (int m = 0; m < 4; m++) {
+          const double v = LT[(lk + 4 * m) * 16 + lr];
+          aop[m] = (lk + 4 * m < nb && lr < nb) ? v : 0.0;
+          isq4[m] = LT[256 + min(lk + 4 * m, nb - 1)];
         }
-        if constexpr (i == TPT - 1) {  // the right-hand side column of tile column 10 is z_k
+        if constexpr (k == TPT - 1 && tp_owner(k) == WV) {  // the last diagonal tile gives up the right-hand side: z_10 = L^-1 b
+          d4 Za = {0, 0, 0, 0}, Zb = {0, 0, 0, 0};
+          Za = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], Dlast[0], Za, 0, 0, 0);
+          Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], Dlast[1], Zb, 0, 0, 0);
+          Za = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], Dlast[2], Za, 0, 0, 0);
+          Zb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], Dlast[3], Zb, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 4; r++)
-            if (lr == TP_NBL) lds[L_ZV + 16 * k + lk + 4 * r] = U[r];
+            if (lr == TP_NBL && lk + 4 * r < TP_NBL) lds[L_ZV + 16 * k + lk + 4 * r] = (Za[r] + Zb[r]) * isq4[r];
         }
+        tp_sfor<TPT - 1 - k>([&](auto II) {
+          constexpr int i = k + 1 + II;
+          if constexpr (tp_owner(i) == WV && tp_nz(k, i)) {
+            d4& U = T[TPI(k, i)];
+            d4 Wa = {0, 0, 0, 0}, Wb = {0, 0, 0, 0};
+            Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[0], U[0], Wa, 0, 0, 0);
+            Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[1], U[1], Wb, 0, 0, 0);
+            Wa = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[2], U[2], Wa, 0, 0, 0);
+            Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[3], U[3], Wb, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              U[r] = (Wa[r] + Wb[r]) * isq4[r];
+              lds[L_WROW + TPW(k, i) * 256 + r * 64 + lane] = U[r];
+            }
+            if constexpr (i == TPT - 1) {  // the right-hand side column of tile column 10 is z_k
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (lr == TP_NBL) lds[L_ZV + 16 * k + lk + 4 * r] = U[r];
+            }
+          }
+        });
       }
     });
-    if constexpr (k < TPT - 1) {
-      // the owner of column k + 1 needs nothing but its own W(k, k + 1) for tile (k + 1, k + 1): it is updated and put into the other patch
-      // before the barrier, while the wavefronts with more tiles in row k still solve; the chain starts right behind the barrier
-      if constexpr (tp_owner(k + 1) == WV) {
-        const d4& Wd = T[TPI(k, k + 1)];
-        d4& U = T[TPI(k + 1, k + 1)];
+    if constexpr (t < TP_NSTEP - 1) {
+      // the owner of a pivot column q of the next step needs nothing but its own W(k, q) for tile (q, q): it is updated and staged in the
+      // patch before the count, while the wavefronts with more tiles in this step's rows still solve; the chain starts right behind it
+      tp_sfor<tp_step_np(t + 1)>([&](auto B) {
+        constexpr int q = tp_step_piv(t + 1, B);
+        if constexpr (tp_owner(q) == WV) {
+          d4& U = T[TPI(q, q)];
+          tp_sfor<tp_step_np(t)>([&](auto A) {
+            constexpr int k = tp_step_piv(t, A);
+            if constexpr (tp_nz(k, q)) {
+              const d4& Wd = T[TPI(k, q)];
 #pragma unroll
-        for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[r], Wd[r], U, 0, 0, 0);
-        if constexpr (k + 1 == TPT - 1) Dlast = U;
-#pragma unroll
-        for (int r = 0; r < 4; r++) lds[L_PATCH + ((k + 1) & 1) * 256 + (lk + 4 * r) * 16 + lr] = U[r];
-      }
-      CPROF(2);
-      // (d) row k of W is published - counted, not a barrier: the owner of column k + 1 needs nobody's tiles for its chain and does not wait
-      // (1 K cycles per step it spent at a barrier for the wavefronts with more tiles to solve); everybody else waits for all four counts
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      auto wait_row = [&]() {
-        while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (k + 1)) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      };
-      if constexpr (tp_owner(k + 1) != WV) wait_row();
-      CPROF(3);
-      // (e) trailing update U(j, i) -= W(k, j)^T W(k, i), k < j <= i, over the tiles of row k that exist.  The owner of column k + 1 starts
-      // with tile (k + 1, k + 1) and runs the next chain right away: the other wavefronts update meanwhile (look-ahead).
-      auto update_col = [&](auto II, auto J0) {
-        constexpr int i = II, j0 = J0;
-        if constexpr (tp_nz(k, i)) {
-          const d4& Wi = T[TPI(k, i)];
-          tp_sfor<i - j0 + 1>([&](auto JJ) {
-            constexpr int j = j0 + JJ;
-            if constexpr (tp_nz(k, j)) {
-              static_assert(tp_nz(j, i), "the pattern is closed under the elimination's fill");
-              d4 Wj;
-              if constexpr (tp_owner(j) == WV) {
-                Wj = T[TPI(k, j)];
-              } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) Wj[r] = lds[L_WROW + TPW(k, j) * 256 + r * 64 + lane];
-              }
-              d4& U = T[TPI(j, i)];
-#pragma unroll
-              for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wj[r], Wi[r], U, 0, 0, 0);
+              for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[r], Wd[r], U, 0, 0, 0);
             }
           });
+          if constexpr (q == TPT - 1) Dlast = U;
+#pragma unroll
+          for (int r = 0; r < 4; r++) lds[L_PATCH + tp_slot_of(q) * 256 + (lk + 4 * r) * 16 + lr] = U[r];
         }
+      });
+      CPROF(2);
+      // (d) this step's rows of W are published - counted, not a barrier: the owner of a next pivot column needs nobody's tiles for its chain
+      // and does not wait (1 K cycles per step it spent at a barrier for the wavefronts with more tiles to solve); everybody else waits for all four counts
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      auto wait_rows = [&]() {
+        while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (t + 1)) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       };
-      if constexpr (tp_owner(k + 1) == WV) {
-        run_chain(std::integral_constant<int, k + 1>{});  // (its tile went to the patch above)
-        wait_row();
+      if constexpr (tp_owns_piv(WV, t + 1)) {
+        tp_sfor<tp_step_np(t + 1)>([&](auto B) {
+          constexpr int q = tp_step_piv(t + 1, B);
+          if constexpr (tp_owner(q) == WV) run_chain(std::integral_constant<int, q>{});
+        });
       }
-      tp_sfor<TPT - 2 - k>([&](auto II) {
-        constexpr int i = k + 2 + II;
-        if constexpr (tp_owner(i) == WV) update_col(std::integral_constant<int, i>{}, std::integral_constant<int, k + 1>{});
+      wait_rows();
+      CPROF(3);
+      // (e) trailing update U(j, i) -= W(k, j)^T W(k, i), k < j <= i, over the tiles of this step's rows that exist (the next step's diagonal
+      // tiles have theirs already), while the next chains run on their owners
+      tp_sfor<tp_step_np(t)>([&](auto A) {
+        constexpr int k = tp_step_piv(t, A);
+        tp_sfor<TPT - 1 - k>([&](auto II) {
+          constexpr int i = k + 1 + II;
+          if constexpr (tp_owner(i) == WV && tp_nz(k, i)) {
+            const d4& Wi = T[TPI(k, i)];
+            tp_sfor<i - k>([&](auto JJ) {
+              constexpr int j = k + 1 + JJ;
+              if constexpr (tp_nz(k, j) && !(j == i && tp_is_piv(t + 1, i))) {
+                static_assert(tp_nz(j, i), "the pattern is closed under the elimination's fill");
+                d4 Wj;
+                if constexpr (tp_owner(j) == WV) {
+                  Wj = T[TPI(k, j)];
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 4; r++) Wj[r] = lds[L_WROW + TPW(k, j) * 256 + r * 64 + lane];
+                }
+                d4& U = T[TPI(j, i)];
+#pragma unroll
+                for (int r = 0; r < 4; r++) U = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wj[r], Wi[r], U, 0, 0, 0);
+              }
+            });
+          }
+        });
       });
     }
   });
   if (failed) return false;
+  // (every wavefront is past the last step's barrier: nobody reads a row of W any more, and the partial sums of the back substitution live there)
+  for (int q = lane; q < 176; q += 64) lds[L_PARTV + WV * 176 + q] = 0.0;
   __syncthreads();  // z is complete in lds[L_ZV]
   PROF(c, 5);
   if (*s_fail) return false;
-  // ---- backward substitution L^T x = z by tile columns, last to first; x_i replaces z_i (elimination order) and goes to lds[L_Y] (the system's order)
+  // ---- backward substitution L^T x = z by the same steps, last to first; x_i replaces z_i (elimination order) and goes to lds[L_Y] (the system's order)
   d4 E[TPT - 1];  // E[k] += U(k, i) .* x_i over this wavefront's columns i > k (element-wise: reduced once, when block k is due)
 #pragma unroll
   for (int k = 0; k < TPT - 1; k++) E[k] = d4{0, 0, 0, 0};
-  tp_sfor<TPT>([&](auto IR) {
-    constexpr int i = TPT - 1 - IR;
-    constexpr int nb = i == TPT - 1 ? TP_NBL : 16;
-    if constexpr (tp_owner(i) == WV) {
-      // v = z_i - the four partial sums; L~_ii back into the patch in [row][column] form; the 16-step chain of chol_solve_block
-      const d4& D = T[TPI(i, i)];
+  tp_sfor<TP_NSTEP>([&](auto TR) {
+    constexpr int t = TP_NSTEP - 1 - TR;
+    tp_sfor<tp_step_np(t)>([&](auto A) {
+      constexpr int i = tp_step_piv(t, A);
+      constexpr int nb = i == TPT - 1 ? TP_NBL : 16;
+      constexpr int PB = L_PATCH + tp_slot_of(i) * 256;
+      if constexpr (tp_owner(i) == WV) {
+        // v = z_i - the four partial sums; L~_ii back into the patch in [row][column] form; the 16-step chain of chol_solve_block
+        const d4& D = T[TPI(i, i)];
 #pragma unroll
-      for (int r = 0; r < 4; r++) lds[L_PATCH + lr * 16 + lk + 4 * r] = D[r];
-      const int rr = min(lr, nb - 1);
-      double bv = lds[L_ZV + 16 * i + rr];
+        for (int r = 0; r < 4; r++) lds[PB + lr * 16 + lk + 4 * r] = D[r];
+        const int rr = min(lr, nb - 1);
+        double bv = lds[L_ZV + 16 * i + rr];
 #pragma unroll
-      for (int w = 0; w < 4; w++) bv -= lds[L_PARTV + w * 176 + 16 * i + rr];
-      wave_lds_sync();
-      double colv[16];
+        for (int w = 0; w < 4; w++) bv -= lds[L_PARTV + w * 176 + 16 * i + rr];
+        wave_lds_sync();
+        double colv[16];
 #pragma unroll
-      for (int q = 0; q < 16; q++) colv[q] = lds[L_PATCH + q * 16 + rr];
-      const double isq = fast_rsqrt_pe(lds[L_PATCH + rr * 17]), di2 = isq * isq;
-      bv *= isq;
+        for (int q = 0; q < 16; q++) colv[q] = lds[PB + q * 16 + rr];
+        const double isq = fast_rsqrt_pe(lds[PB + rr * 17]), di2 = isq * isq;
+        bv *= isq;
 #pragma unroll
-      for (int q = 0; q < 16; q++) colv[q] *= di2;
-      double xout = 0.0;
+        for (int q = 0; q < 16; q++) colv[q] *= di2;
+        double xout = 0.0;
 #pragma unroll
-      for (int jj = nb - 1; jj >= 0; jj--) {
-        const double xj = readlane_d(bv, jj);
-        bv = fma(-colv[jj], xj, bv);
-        xout = lane == jj ? xj : xout;
+        for (int jj = nb - 1; jj >= 0; jj--) {
+          const double xj = readlane_d(bv, jj);
+          bv = fma(-colv[jj], xj, bv);
+          xout = lane == jj ? xj : xout;
+        }
+        if (lane < nb) {
+          lds[L_ZV + 16 * i + lane] = xout;
+          const int col = tp_perm_dev(16 * i + lane);
+          if (col != TP_PAD) lds[L_Y + col] = xout;
+        }
+        wave_lds_sync();
+        // fold x_i into the element-wise accumulators of the blocks above (lane (lk, lr): column lr of every tile)
+        const double xl = lr < nb ? lds[L_ZV + 16 * i + min(lr, nb - 1)] : 0.0;
+        tp_sfor<i>([&](auto K) {
+          constexpr int k = K;
+          if constexpr (tp_nz(k, i)) {
+            const d4& U = T[TPI(k, i)];
+#pragma unroll
+            for (int r = 0; r < 4; r++) E[k][r] = fma(U[r], xl, E[k][r]);
+          }
+        });
       }
-      if (lane < nb) lds[L_ZV + 16 * i + lane] = xout, lds[L_Y + tp_perm_dev(16 * i + lane)] = xout;
-      wave_lds_sync();
-      // fold x_i into the element-wise accumulators of the blocks above (lane (lk, lr): column lr of every tile)
-      const double xl = lr < nb ? lds[L_ZV + 16 * i + min(lr, nb - 1)] : 0.0;
-      tp_sfor<i>([&](auto K) {
-        constexpr int k = K;
-        if constexpr (tp_nz(k, i)) {
-          const d4& U = T[TPI(k, i)];
+    });
+    if constexpr (t > 0) {
+      // every wavefront that holds a tile of a row the next step solves: its share of that block is complete (all its columns beyond it have been
+      // folded in); the others' partial sums stay the zeros they were set to
+      tp_sfor<tp_step_np(t - 1)>([&](auto B) {
+        constexpr int p = tp_step_piv(t - 1, B);
+        if constexpr (tp_row_held(WV, p)) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) E[k][r] = fma(U[r], xl, E[k][r]);
+          for (int r = 0; r < 4; r++) {
+            const double sacc = tp_row_sum(E[p][r]);
+            if (lr == 15) lds[L_PARTV + WV * 176 + 16 * p + lk + 4 * r] = sacc;
+          }
         }
       });
-    }
-    if constexpr (i > 0) {
-      // every wavefront that holds a tile of row i - 1: its share of block i - 1 is complete (all its columns > i - 1 have been folded in);
-      // the others' partial sums stay the zeros they were set to
-      if constexpr (tp_row_held(WV, i - 1)) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const double sacc = tp_row_sum(E[i - 1][r]);
-          if (lr == 15) lds[L_PARTV + WV * 176 + 16 * (i - 1) + lk + 4 * r] = sacc;
-        }
-      }
       __syncthreads();
     }
   });
@@ -3001,6 +3091,7 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
 #ifdef AVM_TP
   if (t < NF) lds[s_off(t, t)] += mu * lds[L_DD + t] * lds[L_DD + t];
   for (int i = t; i < NF; i += NT) lds[L_RHS + i] = lds[L_G + i];  // the right-hand side (column NF of the register tiles; L_Y is free until the solve)
+  if (t == NT - 1) lds[L_ZERO] = 0.0, lds[L_ONE] = 1.0;             // what chol_regs' tile load reads for structural zeros / the padding's diagonal
 #else
   if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
   for (int i = t; i < NF; i += NT) lds[L_S + roff(NF) + i] = lds[L_G + i];  // RHS rides along as row NF
@@ -5203,13 +5294,13 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
 #ifdef AVM_TP
 int window_solve_tp_lds_bytes() { return L_END * 8; }
 // the factorization's compile-time tables for the tests (tests/test_tp_pattern.py states them in numpy): out[0..120] = TPP.h, [121..241] = TPP.nz
-// (both [k][i]), [242..252] = tp_owner, [253 ..] = tp_perm of the NF + 1 positions
+// (both [k][i]), [242..252] = tp_owner, [253 ..] = tp_perm of the 176 positions (-1: padding)
 int window_solve_tp_pattern(int* out) {
   for (int k = 0; k < TPT; k++)
     for (int i = 0; i < TPT; i++) out[k * TPT + i] = TPP.h[k][i], out[TPT * TPT + k * TPT + i] = TPP.nz[k][i];
   for (int i = 0; i < TPT; i++) out[2 * TPT * TPT + i] = tp_owner(i);
-  for (int n = 0; n <= NF; n++) out[2 * TPT * TPT + TPT + n] = tp_perm(n);
-  return 2 * TPT * TPT + TPT + NF + 1;
+  for (int n = 0; n < 16 * TPT; n++) out[2 * TPT * TPT + TPT + n] = tp_perm(n);
+  return 2 * TPT * TPT + TPT + 16 * TPT;
 }
 // workgroups of the throughput kernel the runtime says a CU can hold (2 is what the kernel is built for)
 int window_solve_tp_occupancy() {

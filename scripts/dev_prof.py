@@ -37,5 +37,5 @@ if prof[30]:
     mt = sum(prof[16:27]); print(f"preint {E.ctx.kernel_ms('preint'):.3f} ms; marginalize: kernel {E.ctx.kernel_ms('marginalize'):.3f} ms + prior_eig {E.ctx.kernel_ms('prior_eig'):.3f} ms; per-window cycles {mt/prof[30]:.0f}")
     print('  jacobi sweeps per window', prof[29]/prof[30])
     for k, nm in enumerate(MN): print(f"  {nm:22s} {prof[16+k]/prof[30]:12.0f} cyc/window  {100*prof[16+k]/mt:5.1f}%")
-if any(prof[56:61]):  # a -DAVM_PROF_CHOL=<wavefront> build: that wavefront's time inside the factorization (chol_regs), cycles per window
-    print("  factorization, one wavefront: " + " | ".join(f"{nm} {prof[56+k]/n:.0f}" for k, nm in enumerate(["chain", "wait (b)", "solve", "wait (d)", "update + rest"])))
+if any(prof[56:62]):  # a -DAVM_PROF_CHOL=<wavefront> build: that wavefront's time inside the factorization (chol_regs), cycles per window
+    print("  factorization, one wavefront: " + " | ".join(f"{nm} {prof[56+k]/n:.0f}" for k, nm in enumerate(["chain", "wait (b)", "solve", "wait (d)", "update + rest", "tile load"])))

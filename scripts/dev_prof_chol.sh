@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 P=anticipated-vins-mono_amd
 cp $P/libavm_hip.so /tmp/libavm_hip_shipped.so
 for g in 256 512; do
-  for w in 0 1 2 3; do
+  for w in ${WAVES:-0 1 2 3}; do
     cp build/variants/libavm_hip_pc$w.so $P/libavm_hip.so
     echo "grid $g wavefront $w: $(AVM_SOLVE_TP=1 AVM_TP_GRID=$g python scripts/dev_prof.py 4096 dense nomarg 2>&1 | grep -E "factorization, one|tp: factorization" | tr '\n' ' ')"
   done

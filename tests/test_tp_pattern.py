@@ -1,7 +1,7 @@
 """The compile-time tables of the throughput solve's sparse factorization (window_solve.hip, chol_regs; round 6) against a numpy statement.
 
-The kernel eliminates the speed-bias blocks last frame first, then the poses, then the right-hand side, and only ever touches the 16 x 16 tiles
-its table TPP.nz names.  A tile missing from that table would be a silently dropped part of the factor, so the table is stated a second time
+The kernel eliminates the speed-bias blocks of frames 10 .. 6 and, beside them, those of frames 4 .. 0 (two pivot chains at a time; each set padded to
+three 16-column tiles), then frame 5's block, the poses and the right-hand side, and only ever touches the 16 x 16 tiles its table TPP.nz names.  A tile missing from that table would be a silently dropped part of the factor, so the table is stated a second time
 here: the assembled system's SCALAR pattern (estimator.cpp:663-755: an IMU factor couples pose / speed-bias i to pose / speed-bias i + 1; the
 prior, marginalization_factor.cpp:333-381, couples speed-bias 0 to every pose; the poses are dense after the Schur complement on the depths), its
 scalar symbolic Cholesky factor in the kernel's order, aggregated to tiles.  CPU tier: the library's tables are constants of the build."""
@@ -43,31 +43,46 @@ def symbolic_cholesky(H):
     return Lp
 
 
-def test_elimination_order_is_a_permutation_speed_biases_last_frame_first():
+def expected_order():
+    """positions of the elimination order -> columns of the assembled system (poses | speed-biases), -1 for padding, NF for the right-hand side"""
+    sb = lambda f: list(range(NP_ + 9 * f, NP_ + 9 * f + 9))
+    order = sum((sb(f) for f in (10, 9, 8, 7, 6)), []) + [-1] * 3
+    order += sum((sb(f) for f in (4, 3, 2, 1, 0)), []) + [-1] * 3
+    order += sb(5) + list(range(NP_)) + [NF] + [-1] * 4
+    return np.array(order)
+
+
+def test_elimination_order_two_chains_then_the_separator_and_the_poses():
     _, _, _, perm = tables()
-    assert sorted(perm[:NF]) == list(range(NF)) and perm[NF] == NF
-    assert list(perm[:9]) == list(range(NP_ + 90, NP_ + 99)) and list(perm[90:99]) == list(range(NP_, NP_ + 9))
-    assert list(perm[99:NF]) == list(range(NP_))
+    assert np.array_equal(perm, expected_order())
+    assert sorted(perm[perm >= 0]) == list(range(NF + 1))
 
 
 def test_tile_tables_cover_the_scalar_factor():
     h, nz, owner, perm = tables()
-    H = scalar_pattern()[np.ix_(perm[:NF], perm[:NF])]
-    Lp = symbolic_cholesky(H)
-    Ha = np.zeros((16 * T, 16 * T), bool)
-    La = np.zeros((16 * T, 16 * T), bool)
-    Ha[:NF, :NF], La[:NF, :NF] = H, Lp
-    Ha[NF, : NF + 1] = Ha[: NF + 1, NF] = True  # the right-hand side rides along as position NF
-    La[NF, : NF + 1] = True
+    N = 16 * T
+    Ha = np.zeros((N, N), bool)
+    H = np.zeros((NF + 1, NF + 1), bool)
+    H[:NF, :NF] = scalar_pattern()
+    H[NF, :] = H[:, NF] = True  # the right-hand side rides along
+    H[NF, NF] = False
+    real = perm >= 0
+    Ha[np.ix_(real, real)] = H[np.ix_(perm[real], perm[real])]
+    Ha[np.arange(N)[~real], np.arange(N)[~real]] = True  # padding positions: rows of the identity
+    La = symbolic_cholesky(Ha)
     ht = np.array([[Ha[16 * i : 16 * i + 16, 16 * k : 16 * k + 16].any() for i in range(T)] for k in range(T)])
     lt = np.array([[La[16 * i : 16 * i + 16, 16 * k : 16 * k + 16].any() for i in range(T)] for k in range(T)])
     up = np.triu(np.ones((T, T), bool))
     assert np.array_equal(h, ht & up), "tiles the assembled system reaches"
     assert np.array_equal(nz, lt & up), "tiles of the factor (upper tile (k, i) = L(i, k)^T)"
+    # the two chains never meet: tile columns 0..2 (frames 10..6) and 3..5 (frames 4..0) share no tile, so chains t and 3 + t run side by side
+    assert not nz[:3, 3:6].any()
     # what the order buys: tile updates U(j, i) -= W(k, j)^T W(k, i) per factorization, against the dense grid's
     upd = sum(n * (n + 1) // 2 for n in (int(nz[k, k + 1 :].sum()) for k in range(T)))
-    assert upd == 115 and sum(n * (n + 1) // 2 for n in range(T)) == 220
-    assert int(nz.sum()) == 51
+    assert upd == 91 and sum(n * (n + 1) // 2 for n in range(T)) == 220
+    assert int(nz.sum()) == 47
     # every wavefront's tiles fit its registers (8 VGPRs per tile, the accumulators of the back substitution beside them)
     per_wave = [int(sum(nz[: i + 1, i].sum() for i in range(T) if owner[i] == w)) for w in range(4)]
-    assert max(per_wave) <= 15 and sum(per_wave) == 51
+    assert max(per_wave) <= 15 and sum(per_wave) == 47
+    # the two chains of a step run on two wavefronts
+    assert all(owner[t] != owner[t + 3] for t in range(3))
