@@ -232,12 +232,16 @@ class FselOut(C.Structure):
     _fields_ = [("n_selected", c_ip), ("selected_ids", c_ip), ("fvalues", c_dp), ("min_gap", c_dp)]
 
 
+AVM_ABI_VERSION = 6  # include/avm.h: avm_create() refuses a caller built against another header
+
+
 class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32),
         ("max_windows", C.c_int32),
         ("max_problems", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("abi_version", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

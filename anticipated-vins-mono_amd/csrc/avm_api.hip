@@ -395,6 +395,7 @@ int run_preint(avm_ctx* c, const avm_options* opt, const avm_window_batch* d) {
 extern "C" {
 
 const char* avm_version(void) { return "avm-mi355x 0.1 (gfx950, fp64)"; }
+int avm_abi_version(void) { return AVM_ABI_VERSION; }
 
 int avm_default_options(avm_options* o) {
   if (!o) return AVM_ERR_INVALID;
@@ -430,6 +431,7 @@ int avm_default_options(avm_options* o) {
 int avm_create(const avm_config* cfg, avm_ctx** out) {
   if (!out) return AVM_ERR_INVALID;
   *out = nullptr;
+  if (cfg && cfg->abi_version != AVM_ABI_VERSION) return AVM_ERR_INVALID;  // a caller compiled against another avm.h: before anything reads its structs
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AVM_ERR_NO_DEVICE;
   const int dev = cfg ? cfg->device : 0;

@@ -91,7 +91,7 @@ def lib():
 
 
 EXPORTS = [
-    "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version",
+    "avm_default_options", "avm_create", "avm_destroy", "avm_last_error", "avm_version", "avm_abi_version",
     "avm_window_solve_batch", "avm_window_solve", "avm_fsel_select", "avm_fsel_fallback_stats", "avm_imu_preintegrate_batch", "avm_window_eval_factors",
     "avm_fsel_select_batch", "avm_fsel_information", "avm_fsel_nn_depth", "avm_last_kernel_ms", "avm_triangulate_batch", "avm_imu_propagate_batch", "avm_fsel_horizon_imu", "avm_projection_td_eval", "avm_fsel_build_cloud",
     "avm_ctx_stream", "avm_comm_unique_id", "avm_comm_init", "avm_gather_states", "avm_comm_destroy", "avm_gt_load_csv", "avm_gt_from_rows", "avm_gt_free", "avm_gt_size", "avm_gt_seek", "avm_fsel_horizon_ground_truth", "avm_image_from_pointcloud", "avm_slide_window",
@@ -105,6 +105,7 @@ class Context:
         self._L = lib()
         cfg = abi.Config()
         cfg.device = device
+        cfg.abi_version = abi.AVM_ABI_VERSION
         h = C.c_void_p()
         rc = self._L.avm_create(C.byref(cfg), C.byref(h))
         if rc != abi.AVM_OK:

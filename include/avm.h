@@ -318,8 +318,12 @@ typedef struct avm_config {
   int32_t device;       /* HIP device ordinal */
   int32_t max_windows;  /* capacity of one avm_window_solve_batch call */
   int32_t max_problems; /* capacity of one avm_fsel_select_batch call */
-  int32_t reserved[5];
+  int32_t abi_version;  /* AVM_ABI_VERSION of the header the caller was compiled against.  avm_create() refuses any other value
+                         * (AVM_ERR_INVALID): the structs of this header carry no size fields, so a host built against an older
+                         * header - avm_fsel_out had three members before min_gap - must not get as far as a call that reads them. */
+  int32_t reserved[4];
 } avm_config;
+#define AVM_ABI_VERSION 6 /* bumped whenever a struct of this header changes its layout or an entry point its meaning */
 
 typedef struct avm_ctx avm_ctx;
 
@@ -329,6 +333,7 @@ int avm_create(const avm_config* cfg, avm_ctx** out);
 void avm_destroy(avm_ctx* ctx);
 const char* avm_last_error(const avm_ctx* ctx);
 const char* avm_version(void);
+int avm_abi_version(void); /* AVM_ABI_VERSION the library was built with */
 
 /* ---- HP-A: Estimator::optimization() for a batch of independent windows ------ */
 /* solve in place (states updated like double2vector+vector2double leave them),

@@ -79,7 +79,7 @@ struct Error : std::runtime_error {
 class Context {
  public:
   explicit Context(int device = 0, int max_windows = 1, int max_problems = 1) {
-    cfg_.device = device, cfg_.max_windows = max_windows, cfg_.max_problems = max_problems;
+    cfg_.device = device, cfg_.max_windows = max_windows, cfg_.max_problems = max_problems, cfg_.abi_version = AVM_ABI_VERSION;
   }
   ~Context() {
     if (h_) avm_destroy(h_);

@@ -1,6 +1,7 @@
 // Test hooks around include/avm_host.hpp: lets pytest drive the C++ host objects (avm_host::Estimator,
 // avm_host::FeatureSelector) through ctypes.  Test infrastructure only - the product is the header.
 // Built by __graft_entry__.build() into tests/host_cpp/libavm_host_shim.so (links libavm_hip.so).
+#include <chrono>
 #include <cstring>
 #include <memory>
 
@@ -11,6 +12,11 @@ using namespace avm_host;
 namespace {
 thread_local std::string g_err;
 thread_local int g_status = 0;
+thread_local double g_call_ms = 0.0;  // wall time of the last optimization() / select() call itself (bench.py: latency_host_call_ms)
+struct Stopwatch {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~Stopwatch() { g_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 struct Host {
   Context ctx;
@@ -38,6 +44,7 @@ int guarded(F f) {
 extern "C" {
 
 const char* hs_last_error() { return g_err.c_str(); }
+double hs_last_call_ms() { return g_call_ms; }
 
 void* hs_create(int device) { return new Host(device); }
 void hs_destroy(void* h) { delete static_cast<Host*>(h); }
@@ -171,7 +178,10 @@ int hs_set_options(void* hp, const avm_options* o) {
 
 int hs_optimization(void* hp) {
   Host& H = *static_cast<Host*>(hp);
-  return guarded([&] { H.est.optimization(); });
+  return guarded([&] {
+    Stopwatch sw;
+    H.est.optimization();
+  });
 }
 
 int hs_triangulate(void* hp, double init_depth) {
@@ -306,7 +316,11 @@ int hs_sel_select(void* hp, int n, const int32_t* ids, const double* rows8, doub
       std::copy(rows8 + 8 * i, rows8 + 8 * i + 8, v.begin());
       image[ids[i]].emplace_back(0, v);
     }
-    auto ret = H.sel->select(image, stamp, nrImu);
+    std::pair<std::vector<int>, std::vector<int>> ret;
+    {
+      Stopwatch sw;
+      ret = H.sel->select(image, stamp, nrImu);
+    }
     if ((int)image.size() > cap || (int)ret.first.size() > cap || (int)ret.second.size() > cap) throw Error(AVM_ERR_CAPACITY, "shim output capacity");
     int k = 0;
     for (const auto& f : image) image_out[k++] = f.first;

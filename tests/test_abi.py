@@ -58,3 +58,17 @@ def test_product_package_never_touches_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".sh", "Makefile")):
                     txt = open(os.path.join(dirpath, f)).read()
                     assert not banned.search(txt), (dirpath, f, banned.search(txt).group(0))
+
+
+def test_avm_create_refuses_a_caller_built_against_another_header(abi):
+    """avm_config::abi_version (ADVICE r5): the structs carry no size fields, so a host compiled against an older avm.h - avm_fsel_out had three
+    members before min_gap - is stopped at avm_create(), before any call reads its structs.  Checked first: no device needed."""
+    import ctypes as C
+
+    L = __import__("importlib").import_module("anticipated-vins-mono_amd.lib").lib()
+    assert L.avm_abi_version() == abi.AVM_ABI_VERSION
+    for stale in (0, abi.AVM_ABI_VERSION - 1, abi.AVM_ABI_VERSION + 1):
+        cfg = abi.Config()
+        cfg.abi_version = stale
+        h = C.c_void_p()
+        assert L.avm_create(C.byref(cfg), C.byref(h)) == abi.AVM_ERR_INVALID and not h.value

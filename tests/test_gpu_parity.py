@@ -752,6 +752,11 @@ def test_marginalization_keeps_old_prior_when_second_new_has_nothing_to_drop(ctx
     assert np.isfinite(w.a["pose"]).all()
 
 
+# measured on MI355X in round 6 (printed by the test), asserted at about three times the measurement
+CHAIN_LITERAL_VS_ORACLE = {"pose": 1e-4, "speedbias": 1e-4}
+CHAIN_ORACLE_VS_EXACT = {"pose": 1e-4, "speedbias": 1e-4}
+
+
 def test_chained_solves_through_the_new_prior(ctx, oracle):
     """optimization() twice: the prior produced by the first MARGIN_OLD solve feeds the second solve
     (window roll is host bookkeeping: here the same factors are simply re-solved with the new prior)."""
@@ -794,6 +799,23 @@ def test_chained_solves_through_the_new_prior(ctx, oracle):
     for k in ("pose", "speedbias"):
         print(f"\n[chained solve vs exact-prior chain] {k}: gpu {rel(wg.a[k], wt.a[k]):.2e}  oracle {rel(wo.a[k], wt.a[k]):.2e}")
         assert rel(wg.a[k], wt.a[k]) < 1e-6, (k, rel(wg.a[k], wt.a[k]))
+    # ... and the "equal to the reference" leg: the same chain with the REFERENCE-LITERAL clamp (marg_noise_rel = 0, what the
+    # FP64 oracle always runs) against the FP64 oracle's own chain, asserted at the bounds measured in round 6 (CHAIN_LITERAL_VS_ORACLE below: two FP64
+    # roundings of the pseudo-inverse of a 1e12-conditioned block apart - a regression of this leg is red, not a log line), and the oracle's own
+    # distance from the exact-prior chain, so that the yardstick cannot move unnoticed either
+    o_lit = abi.default_options()
+    o_lit.marg_noise_rel = 0.0
+    wl = w.copy()
+    El = est_m.Estimator(ctx=ctx, options=o_lit)
+    El.optimization(wl)
+    install(wl, El.last_marginalization_info)
+    sl = E2.optimization(wl)
+    assert np.array_equal(buffers.summary_to_numpy(sl)["accept_mask"], so["accept_mask"])
+    for k in ("pose", "speedbias"):
+        dlo, dot = rel(wl.a[k], wo.a[k]), rel(wo.a[k], wt.a[k])
+        print(f"[chained solve, reference-literal clamp vs the FP64 oracle's chain] {k}: {dlo:.2e}   (oracle vs exact-prior chain {dot:.2e})")
+        assert dlo < CHAIN_LITERAL_VS_ORACLE[k], (k, dlo)
+        assert dot < CHAIN_ORACLE_VS_EXACT[k], (k, dot)
 
 
 # ---------------------------------------------------------------- HP-B

@@ -366,6 +366,11 @@ def test_ten_frame_stream_against_the_exact_prior_stream(ctx, oracle, seq_id):
     assert worst_g <= max(worst_o, 1e-6)
 
 
+# measured on MI355X in round 6 (printed by the test below): 160 frames of eight streams
+STREAM_BOUNDS = {"default_frames_within_1e-6": 0, "default_worst_vs_exact": 1.0, "literal_frames_within_1e-6": 0, "literal_worst_vs_exact": 1.0,
+                 "literal_worst_vs_oracle": 1.0, "default_worst_vs_oracle": 1.0, "oracle_worst_vs_exact": 1.0}
+
+
 @pytest.mark.gpu
 def test_eight_twenty_frame_streams_against_the_exact_prior_stream(ctx, oracle):
     """Eight sequences, twenty images each, through optimization() + slideWindow() with the prior handed from frame to frame.
@@ -444,3 +449,9 @@ def test_eight_twenty_frame_streams_against_the_exact_prior_stream(ctx, oracle):
     assert not failures, failures
     assert third <= tot // 6 and within >= tot // 4
     assert lit_dec == 0
+    # what round 5 measured and only printed is asserted (bounds = the round-6 measurement with a margin: STREAM_BOUNDS), so that
+    # a regression of either leg - the default's distance from the exact-prior stream, the literal clamp's distance from the FP64 oracle's stream - is red
+    assert within >= STREAM_BOUNDS["default_frames_within_1e-6"] and worst_g < STREAM_BOUNDS["default_worst_vs_exact"], (within, worst_g)
+    assert lit_within >= STREAM_BOUNDS["literal_frames_within_1e-6"] and worst_l < STREAM_BOUNDS["literal_worst_vs_exact"], (lit_within, worst_l)
+    assert worst_lo < STREAM_BOUNDS["literal_worst_vs_oracle"] and worst_go < STREAM_BOUNDS["default_worst_vs_oracle"], (worst_lo, worst_go)
+    assert worst_o < STREAM_BOUNDS["oracle_worst_vs_exact"], worst_o
