@@ -185,10 +185,10 @@ def host_call_latency(abi, synth, reps=50):
             rc = L.hs_load_window(h, C.byref(ws), 0, abi.iptr(fid), abi.iptr(sf), 0, abi.iptr(z), abi.iptr(z), abi.iptr(z))
             if rc != 0:
                 raise RuntimeError(L.hs_last_error().decode())
+            L.hs_set_flags(h, 1, 0, 0)  # (the load clears the state: solver_flag = NON_LINEAR, marginalization_flag = MARGIN_OLD again)
 
         o = abi.default_options()
         L.hs_set_options(h, C.byref(o))
-        L.hs_set_flags(h, 1, int(o.marginalization_flag), 0)
         ms = []
         for _ in range(reps + 5):
             load()  # (the members as the front end leaves them; not timed)

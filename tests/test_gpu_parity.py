@@ -752,9 +752,10 @@ def test_marginalization_keeps_old_prior_when_second_new_has_nothing_to_drop(ctx
     assert np.isfinite(w.a["pose"]).all()
 
 
-# measured on MI355X in round 6 (printed by the test), asserted at about three times the measurement
-CHAIN_LITERAL_VS_ORACLE = {"pose": 1e-4, "speedbias": 1e-4}
-CHAIN_ORACLE_VS_EXACT = {"pose": 1e-4, "speedbias": 1e-4}
+# measured on MI355X in round 6 (printed by the test: pose 3.08e-6, speed-bias 5.68e-6 for both - the literal GPU chain sits on the exact-prior chain to
+# 1e-10, so its distance from the FP64 oracle's chain IS the oracle's distance from the exact one), asserted at about three times the measurement
+CHAIN_LITERAL_VS_ORACLE = {"pose": 1e-5, "speedbias": 2e-5}
+CHAIN_ORACLE_VS_EXACT = {"pose": 1e-5, "speedbias": 2e-5}
 
 
 def test_chained_solves_through_the_new_prior(ctx, oracle):

@@ -366,9 +366,11 @@ def test_ten_frame_stream_against_the_exact_prior_stream(ctx, oracle, seq_id):
     assert worst_g <= max(worst_o, 1e-6)
 
 
-# measured on MI355X in round 6 (printed by the test below): 160 frames of eight streams
-STREAM_BOUNDS = {"default_frames_within_1e-6": 0, "default_worst_vs_exact": 1.0, "literal_frames_within_1e-6": 0, "literal_worst_vs_exact": 1.0,
-                 "literal_worst_vs_oracle": 1.0, "default_worst_vs_oracle": 1.0, "oracle_worst_vs_exact": 1.0}
+# measured on MI355X in round 6 (printed by the test below), 160 frames of eight streams: default clamp 120 frames within 1e-6 of the exact-prior stream,
+# worst 1.6e-5; reference-literal clamp 112 frames, worst 1.6e-5; either GPU stream 4.4e-4 from the FP64 oracle's stream at worst, which is the oracle's
+# own worst distance from the exact-prior stream (4.4e-4).  Frame counts asserted with a margin of eight frames, distances at three times the measurement.
+STREAM_BOUNDS = {"default_frames_within_1e-6": 112, "default_worst_vs_exact": 5e-5, "literal_frames_within_1e-6": 104, "literal_worst_vs_exact": 5e-5,
+                 "literal_worst_vs_oracle": 1.5e-3, "default_worst_vs_oracle": 1.5e-3, "oracle_worst_vs_exact": 1.5e-3}
 
 
 @pytest.mark.gpu
