@@ -163,6 +163,14 @@ __device__ __forceinline__ void pc_sync() {
 // the noise of a pivot that follows a small genuine pivot is amplified by their ratio - measured: 5e-6 at s = 3e4 behind a pivot of 0.05)
 // (noise_rel = avm_options::marg_noise_rel: the constants were measured at 1e-16 and scale with its square root - a tenth of them at the
 //  default of round 5, 1e-18; 0 switches the test off)
+// The level the two Cholesky forms of the square root (prior_chol_kernel, the rank-r form of prior_eig_kernel) certify the noise test at.  The
+// eigen form tests S^2 > noise_rel v^T diag(s) v with the caller's constant (default 1e-18 since round 5: never drop a genuine direction).  A
+// direction between that and the level rounding noise was MEASURED at (1e-16: the constants of pc_zero) may be formation noise that happens to
+// pass; kept, it puts v (v^T b') into J^T r0 with a v that is itself noise, and two forms that see different roundings of the same zeros would hand
+// out priors with different gradients (g_scaled 5e-3 between the forms on windows without a prior).  So a Cholesky form is only handed
+// out when every kept direction clears the MEASURED noise level; a window with a direction in the band between the two goes to the eigen form, which
+// alone decides about it - which form finishes a window no longer changes the prior beyond rounding.
+__device__ __forceinline__ double pc_cert_noise(double noise_rel) { return noise_rel > 0.0 ? fmax(noise_rel, 1e-16) : 0.0; }
 __device__ __forceinline__ double pc_zero(double si, double sj, double noise_rel) {
   const double g = sqrt(si * sj), f = sqrt(noise_rel * 1e16);
   return f * fmax(1e-12 * g, 1e-7 * sqrt(g));
@@ -365,7 +373,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
   }
   f2 = wave_sum(f2), fs2 = wave_sum(fs2);
   const int ndel = __popcll(dm0) + __popcll(dm1);
-  bool ok = !__any(bad) && ndel <= PC_MAXDEL && f2 * (1000.0 * eps) < 1.0 && fs2 * (4.0 * noise_rel) < 1.0;  // (NaN compares false)
+  // (the noise test is certified at PC_CERT_NOISE, not at noise_rel: see pc_cert_noise)
+  bool ok = !__any(bad) && ndel <= PC_MAXDEL && f2 * (1000.0 * eps) < 1.0 && fs2 * (4.0 * pc_cert_noise(noise_rel)) < 1.0;  // (NaN compares false)
   if (!ok) return;
   // ---- the deleted pivots: row d of A' - J^T J has to be formation noise
   for (int q = 0; q < ndel; q++) {
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // S / v^T diag(s) v >= lambda_min(B): the noise test of the eigen path (S > 1e-16 v^T diag(s) v) passes for all of them.  The
     // comparison-matrix bound is rigorous but 40 - 3400 x pessimistic, and the variables formed by cancellation (gyroscope bias:
     // 1e2 left of 5e14) put lambda_min(B) at 1e-13 .. 1e-10, so this test gets a factor 4, not 1000.
-    if (verdict[0] * verdict[1] * (1000.0 * eps) < 1.0 && verdict[2] * verdict[3] * (4.0 * noise_rel) < 1.0) {  // (NaN compares false)
+    if (verdict[0] * verdict[1] * (1000.0 * eps) < 1.0 && verdict[2] * verdict[3] * (4.0 * pc_cert_noise(noise_rel)) < 1.0) {  // (NaN compares false; pc_cert_noise: below)
       // linearized_jacobians: row j = g_{p_j}^T, zero rows beyond the rank
       for (int e = t; e < n * n; e += NT) {
         const int j = e / n, c = e - j * n;

@@ -809,12 +809,14 @@ def main():
                 # larger batches (eight GPUs' worth of frames on one): from 33 frames on a batch takes the SOLO form of the selector on its own (one
                 # workgroup per frame, lazy evaluation: csrc/fsel.hip, fsel_solo_kernel); the teams' time for the same batch is measured beside it
                 big_b, big_form, big_teams, big_evals, big_kms = {}, {}, {}, {}, {}
-                for Pb in (64, 128, 256):
+                for Pb in (64, 128, 256, 512, 1024):  # (512 / 1024: two and four frames per CU's worth - where the solo form saturates: VERDICT r5 item 4)
                     fb = synth.make_fsel(min(Pb, 64), first_id=rank * P)
                     if Pb > 64:  # (tiled: the generator is the slow part)
                         fb = type(fb)(dict(fb.dims, n_problems=Pb), {k: np.ascontiguousarray(v[np.arange(Pb) % 64]) for k, v in fb.a.items()}, fb.scalars)
                     fbd = fb.to_device(dev)
                     for forced, store in ((None, big_b), ("0", big_teams)):
+                        if forced is not None and Pb > 256:
+                            continue
                         if forced is None:
                             os.environ.pop("AVM_FSEL_SOLO", None)
                         else:
