@@ -50,15 +50,12 @@ def test_cholesky_square_root_is_the_same_prior_as_the_eigen_square_root(ctx, or
         assert n_fast >= (2 if tracks == "dense" else 0) and (with_prior or n_fast == 0)
         m = prior_metrics(pb, pa)
         print("\n[cholesky vs eigen prior]", tracks, nf, with_prior, m, "full-rank Cholesky form:", n_fast, "rank-r Cholesky form:", n_rank_r)
-        if with_prior:
-            assert m["H_rel"] < 1e-9 and m["g_scaled"] < 1e-7 and m["cost_rel"] < 1e-6, m
-        else:
-            # No prior yet: 16 .. 30 EXACT zeros in A'.  With the default of round 5 (marg_noise_rel = 1e-18: never drop a genuine
-            # direction) a few of them survive the clamp as rounding noise, and a direction v that survives with a noise eigenvalue S
-            # carries v (v^T b') in J^T r0 whatever S is - noise of the order of 1e-4 of the scaled gradient that the two forms of the
-            # square root, which see different roundings of the same zeros, do not share.  J^T J agrees to 1e-9 all the same, and
-            # the next solve (below) moves by less than 1e-6.
-            assert m["H_rel"] < 1e-9 and m["g_scaled"] < 5e-3 and m["cost_rel"] < 1e-3, m
+        # Round 6: the tolerances are the same with and without a prior.  Without one A' has 16 .. 30 EXACT zeros, and with the default
+        # marg_noise_rel = 1e-18 (never drop a genuine direction) a few survive the clamp as rounding noise; a direction v that survives carries
+        # v (v^T b') in J^T r0 with a v that is itself noise.  A Cholesky form is therefore only handed out when every kept direction clears the
+        # MEASURED noise level (pc_cert_noise, prior_eig.hip); a window with a direction in the band between goes to the eigen form in either run -
+        # which form finishes a window does not change the prior beyond rounding (round 5 tolerated g_scaled 5e-3 here).
+        assert m["H_rel"] < 1e-9 and m["g_scaled"] < 1e-7 and m["cost_rel"] < 1e-6, m
         # and the next solve cannot tell them apart
         o2 = abi.default_options()
         o2.marginalization_flag = abi.MARGIN_NONE
@@ -69,7 +66,7 @@ def test_cholesky_square_root_is_the_same_prior_as_the_eigen_square_root(ctx, or
         sb = buffers.summary_to_numpy(E2.optimization(cb))
         assert np.array_equal(sa["accept_mask"], sb["accept_mask"])
         for k in ("pose", "speedbias", "inv_depth"):
-            assert rel(ca.a[k], cb.a[k]) < (1e-8 if with_prior else 1e-6), (k, rel(ca.a[k], cb.a[k]))
+            assert rel(ca.a[k], cb.a[k]) < 1e-8, (k, rel(ca.a[k], cb.a[k]))
 
 
 def test_one_wavefront_factorization_with_deleted_pivots_is_the_pivoted_path_s_prior(ctx, monkeypatch):
