@@ -39,3 +39,5 @@ if prof[30]:
     for k, nm in enumerate(MN): print(f"  {nm:22s} {prof[16+k]/prof[30]:12.0f} cyc/window  {100*prof[16+k]/mt:5.1f}%")
 if any(prof[56:62]):  # a -DAVM_PROF_CHOL=<wavefront> build: that wavefront's time inside the factorization (chol_regs), cycles per window
     print("  factorization, one wavefront: " + " | ".join(f"{nm} {prof[56+k]/n:.0f}" for k, nm in enumerate(["chain", "wait (b)", "solve", "wait (d)", "update + rest", "tile load"])))
+if os.environ.get("AVM_PROF_FT_PRINT") and prof[60]:  # a -DAVM_PROF_FT=<wavefront> build: that wavefront's frame task, cycles per 64-factor chunk
+    print("  frame task, one wavefront, per chunk (%d chunks per window): " % (prof[60] / n) + " | ".join(f"{nm} {prof[56+k]/prof[60]:.0f}" for k, nm in enumerate(["inputs' wait", "evaluation + stores", "E^T E", "staging + MFMAs"])))

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 P=anticipated-vins-mono_amd
 cp $P/libavm_hip.so /tmp/libavm_hip_shipped.so
-run() { python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fsel --distinct 256 2>/dev/null | python -c "
+run() { python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fsel --no-host-latency --distinct 256 2>/dev/null | python -c "
 import sys,json
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$1', {k: round(v,3) for k,v in j['kernel_ms'].items()}, 'ragged', round(j['sparse_tracks']['kernel_ms']['window_solve'],3), 'x1024', round(j['extended_problem']['kernel_ms']['window_solve'],3), 'single', round(j['latency_single_window_ms']['kernel_ms']['window_solve'],3))"; }
