@@ -118,10 +118,11 @@ constexpr int L_STRIP = L_SBC + 99 * SBW;     // [9][66]: rows of the prior's sp
 constexpr int USZ = 99 * SBW + 9 * NPOSE + 2; // 4160; its last two doubles hold the constants 0.0 and 1.0 for chol_regs' tile load (set by schur_reduce)
 constexpr int L_ZERO = L_U + USZ - 2, L_ONE = L_U + USZ - 1;
 static_assert(ASM_WAVES * XSTG <= USZ, "staging fits the union region");
-constexpr int L_PATCH = L_U;                  // factorization: [2][16][16] diagonal blocks of the (up to two) pivot columns of a step in lane = row form
-constexpr int L_LINV = L_PATCH + 512;         // [4][256 + 16]: L_kk^-T (unscaled, see chol_diag_block) and 1 / sqrt(pivot) of the block's columns (tp_buf)
+constexpr int TP_PS = 17;                     // row stride of the 16 x 16 blocks below: lane = row accesses of a stride-16 block put sixteen lanes on two LDS banks
+constexpr int L_PATCH = L_U;                  // factorization: [2][16][TP_PS] diagonal blocks of the (up to two) pivot columns of a step in lane = row form
+constexpr int L_LINV = L_PATCH + 2 * 16 * TP_PS;  // [4][16][TP_PS]: L_kk^-T (unscaled, see chol_diag_block), 1 / sqrt(pivot) of column r in the padding word of row r (tp_buf)
 constexpr int TP_WSLOTS = 9;                  // tiles of a step's rows of W that exist beside the diagonal (tp_wslot: the factor is sparse in the order chol_regs eliminates in)
-constexpr int L_WROW = L_LINV + 4 * 272;      // [TP_WSLOTS][256]: the step's rows of W, the tiles that exist in column order, in the accumulator layout [r][lane]
+constexpr int L_WROW = L_LINV + 4 * 16 * TP_PS;      // [TP_WSLOTS][256]: the step's rows of W, the tiles that exist in column order, in the accumulator layout [r][lane]
 constexpr int L_PARTV = L_WROW;               // back substitution (the rows of W are dead by then): [4][176] partial sums of the four wavefronts
 constexpr int L_ZV = L_WROW + TP_WSLOTS * 256;  // [176] z = L^-1 b, then x, in elimination order (lds[L_Y] keeps the right-hand side until x replaces it, in the system's order)
 static_assert(L_ZV + 176 <= L_ZERO && 4 * 176 <= TP_WSLOTS * 256, "factorization scratch fits the union region");
@@ -2166,7 +2167,7 @@ AVM_DEV void tp_diag_chain(int nb, int patch, int buf, int stamp) {
   double a[NB];
   const bool idl = (r & 48) == 16;
   const int rc = min(r, nb - 1);
-  double* row = lds + L_PATCH + patch * 256 + (rc & 15) * NB;
+  double* row = lds + L_PATCH + patch * (16 * TP_PS) + (rc & 15) * TP_PS;
   {
 #pragma unroll
     for (int k = 0; k < NB; k++) a[k] = row[k];
@@ -2203,7 +2204,7 @@ AVM_DEV void tp_diag_chain(int nb, int patch, int buf, int stamp) {
     uprev = a[j] * y;
   }
   {
-    double* dst = idl ? lds + L_LINV + buf * 272 + (r & 15) * NB : row;
+    double* dst = idl ? lds + L_LINV + buf * (16 * TP_PS) + (r & 15) * TP_PS : row;
     double* dump = lds + L_DUMP + r;
     const int kmax = idl ? NB - 1 : (r < nb ? r : -1);
 #pragma unroll
@@ -2213,9 +2214,9 @@ AVM_DEV void tp_diag_chain(int nb, int patch, int buf, int stamp) {
   // behind the barrier), and the verdict on the pivots
   wave_lds_sync();
   if (r < NB) {
-    const double dc = lds[L_PATCH + patch * 256 + min(r, nb - 1) * 17];
+    const double dc = lds[L_PATCH + patch * (16 * TP_PS) + min(r, nb - 1) * (TP_PS + 1)];
     if (!(dc > 0.0)) reinterpret_cast<int*>(lds + L_INT)[I_FAIL] = stamp;  // non-positive (or NaN) pivot in a pivot column of step stamp - 1
-    lds[L_LINV + buf * 272 + 256 + r] = fast_rsqrt_pe(dc);
+    lds[L_LINV + buf * (16 * TP_PS) + r * TP_PS + 16] = fast_rsqrt_pe(dc);
   }
   AVM_PRIO_BULK_CHOL();
 }
@@ -2321,14 +2322,14 @@ AVM_NOINL bool chol_regs() {
     d4& D = T[TPI(k, k)];
     if constexpr (tp_step_of(k) == 0) {  // (the later ones were staged by the step before)
 #pragma unroll
-      for (int r = 0; r < 4; r++) lds[L_PATCH + tp_slot_of(k) * 256 + (lk + 4 * r) * 16 + lr] = D[r];
+      for (int r = 0; r < 4; r++) lds[L_PATCH + tp_slot_of(k) * (16 * TP_PS) + (lk + 4 * r) * TP_PS + lr] = D[r];
     }
     wave_lds_sync();
     tp_diag_chain(k == TPT - 1 ? TP_NBL : 16, tp_slot_of(k), tp_buf(k), tp_step_of(k) + 1);
     wave_lds_sync();
     // the diagonal tile becomes L~_kk^T (entry (a, b) = L~[b][a]); the patch is free for the next step's chain
 #pragma unroll
-    for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + tp_slot_of(k) * 256 + lr * 16 + lk + 4 * r];
+    for (int r = 0; r < 4; r++) D[r] = lds[L_PATCH + tp_slot_of(k) * (16 * TP_PS) + lr * TP_PS + lk + 4 * r];
     CPROF(0);
   };
   tp_sfor<2>([&](auto A) {
@@ -2358,12 +2359,12 @@ AVM_NOINL bool chol_regs() {
       if constexpr (tp_row_held(WV, k) || (k == TPT - 1 && tp_owner(k) == WV)) {
         // A operand of the solves: L_kk^-1[i' = lr][k' = lk + 4 m] = L~^-T[k'][i'] / sqrt(d_i'); the row scaling is applied to the product
         double aop[4], isq4[4];
-        const double* LT = lds + L_LINV + tp_buf(k) * 272;
+        const double* LT = lds + L_LINV + tp_buf(k) * (16 * TP_PS);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-          const double v = LT[(lk + 4 * m) * 16 + lr];
+          const double v = LT[(lk + 4 * m) * TP_PS + lr];
           aop[m] = (lk + 4 * m < nb && lr < nb) ? v : 0.0;
-          isq4[m] = LT[256 + min(lk + 4 * m, nb - 1)];
+          isq4[m] = LT[min(lk + 4 * m, nb - 1) * TP_PS + 16];
         }
         if constexpr (k == TPT - 1 && tp_owner(k) == WV) {  // the last diagonal tile gives up the right-hand side: z_10 = L^-1 b
           d4 Za = {0, 0, 0, 0}, Zb = {0, 0, 0, 0};
@@ -2415,7 +2416,7 @@ AVM_NOINL bool chol_regs() {
           });
           if constexpr (q == TPT - 1) Dlast = U;
 #pragma unroll
-          for (int r = 0; r < 4; r++) lds[L_PATCH + tp_slot_of(q) * 256 + (lk + 4 * r) * 16 + lr] = U[r];
+          for (int r = 0; r < 4; r++) lds[L_PATCH + tp_slot_of(q) * (16 * TP_PS) + (lk + 4 * r) * TP_PS + lr] = U[r];
         }
       });
       CPROF(2);
@@ -2479,12 +2480,12 @@ AVM_NOINL bool chol_regs() {
     tp_sfor<tp_step_np(t)>([&](auto A) {
       constexpr int i = tp_step_piv(t, A);
       constexpr int nb = i == TPT - 1 ? TP_NBL : 16;
-      constexpr int PB = L_PATCH + tp_slot_of(i) * 256;
+      constexpr int PB = L_PATCH + tp_slot_of(i) * (16 * TP_PS);
       if constexpr (tp_owner(i) == WV) {
         // v = z_i - the four partial sums; L~_ii back into the patch in [row][column] form; the 16-step chain of chol_solve_block
         const d4& D = T[TPI(i, i)];
 #pragma unroll
-        for (int r = 0; r < 4; r++) lds[PB + lr * 16 + lk + 4 * r] = D[r];
+        for (int r = 0; r < 4; r++) lds[PB + lr * TP_PS + lk + 4 * r] = D[r];
         const int rr = min(lr, nb - 1);
         double bv = lds[L_ZV + 16 * i + rr];
 #pragma unroll
@@ -2492,8 +2493,8 @@ AVM_NOINL bool chol_regs() {
         wave_lds_sync();
         double colv[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) colv[q] = lds[PB + q * 16 + rr];
-        const double isq = fast_rsqrt_pe(lds[PB + rr * 17]), di2 = isq * isq;
+        for (int q = 0; q < 16; q++) colv[q] = lds[PB + q * TP_PS + rr];
+        const double isq = fast_rsqrt_pe(lds[PB + rr * (TP_PS + 1)]), di2 = isq * isq;
         bv *= isq;
 #pragma unroll
         for (int q = 0; q < 16; q++) colv[q] *= di2;
