@@ -145,7 +145,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // that is not noise, a bound that does not clear the thresholds - is left untouched (done[w] = 0) and taken by prior_eig_kernel.
 constexpr int PC_T = 5;                                 // tiles per dimension: n <= 80
 constexpr int PC_NT = PC_T * (PC_T + 1) / 2;            // 15 upper tiles
-constexpr int PC_LDS = 256 + PC_T * 256 + 6 * 80 + 256; // doubles: the diagonal patch | L_kk^-1 of every block | b', y, s, a 16-vector, a column of J, the pivots' thresholds | a 16 x 16 identity
+constexpr int PC_S = 17, PC_B = 16 * PC_S;                // row stride / size of a 16 x 16 block in LDS (round 6: at stride 16 the lane = row accesses put sixteen lanes on two banks -
+                                                          // SQ_LDS_BANK_CONFLICT was 11 cycles per LDS instruction of this kernel)
+constexpr int PC_LDS = PC_B + PC_T * PC_B + 6 * 80 + PC_B; // doubles: the diagonal patch | L_kk^-1 of every block | b', y, s, a 16-vector, a column of J, the pivots' thresholds | a 16 x 16 identity
 constexpr int PC_MAXDEL = 8;                            // deleted pivots per window
 typedef double pd4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ constexpr int pc_ti(int k, int i) { return k * PC_T - k * (k - 1) / 2 + (i - k); }
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
   double* gr = PO.r + (size_t)w * PO.max_prior;
   const int ldj = PO.max_prior;
   double* blk = pc_lds;                 // [16][16]
-  double* Linv = pc_lds + 256;          // [PC_T][16][16]: L_kk^-1, row-major
-  double* vb = Linv + PC_T * 256;       // b' (80)
+  double* Linv = pc_lds + PC_B;         // [PC_T][16][PC_S]: L_kk^-1, row-major
+  double* vb = Linv + PC_T * PC_B;      // b' (80)
   double* vy = vb + 80;                 // y = L^-1 b' (80)
   double* vs = vy + 80;                 // s: the magnitude every diagonal entry was formed at (marginalize_kernel), 0 on the pad
   double* vt = vs + 80;                 // a 16-vector in transit
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
     vb[c0] = c0 < n ? b0 : 0.0, vs[c0] = s0, vthr[c0] = pc_zero(s0, s0, noise_rel);
     if (c1 < 80) vb[c1] = c1 < n ? b1 : 0.0, vs[c1] = s1, vthr[c1] = pc_zero(s1, s1, noise_rel);
 #pragma unroll
-    for (int q = 0; q < 4; q++) ident[lane + 64 * q] = ((lane + 64 * q) >> 4) == ((lane + 64 * q) & 15) ? 1.0 : 0.0;
+    for (int q = 0; q < 4; q++) ident[((lane + 64 * q) >> 4) * PC_S + ((lane + 64 * q) & 15)] = ((lane + 64 * q) >> 4) == ((lane + 64 * q) & 15) ? 1.0 : 0.0;
   }
   pc_sync();
   bool bad = false;
@@ -259,14 +261,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
 #pragma unroll
   for (int k = 0; k < PC_T; k++) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) blk[(lk + 4 * r) * 16 + lr] = U[pc_ti(k, k)][r];
+    for (int r = 0; r < 4; r++) blk[(lk + 4 * r) * PC_S + lr] = U[pc_ti(k, k)][r];
     pc_sync();
     {
       // lane = row (lanes 0..15), lanes 16..31: the rows of the identity (they end as the rows of L_kk^-T); the others carry junk
       // (lanes 32..63 repeat lanes 0..31 - same loads, same arithmetic, same stores -, so that no store below is conditional)
       double a[16];
       const bool idl = (lane & 16) != 0;
-      const double* src = idl ? ident + lr * 16 : blk + lr * 16;  // (the diagonal tile is symmetric: its row lr)
+      const double* src = idl ? ident + lr * PC_S : blk + lr * PC_S;  // (the diagonal tile is symmetric: its row lr)
 #pragma unroll
       for (int c = 0; c < 16; c++) a[c] = src[c];
       const double thr_l = vthr[16 * k + lr];  // (off the pivot chain: lane j holds pivot j's threshold)
@@ -283,16 +285,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
       // Row lr of L_kk goes back into the patch as COLUMN lr (the patch then holds L_kk^T = J_kk), row i of L_kk^-T (lane 16 + i) as column
       // i of L_kk^-1: both with stride 16, sixteen unconditional stores at constant offsets.  The entries c > lr of a matrix lane are
       // leftovers of the elimination, masked where the patch is read; those c < i of an identity lane are exact zeros already.
-      double* dst = idl ? Linv + k * 256 + lr : blk + lr;
+      double* dst = idl ? Linv + k * PC_B + lr : blk + lr;
 #pragma unroll
-      for (int c = 0; c < 16; c++) dst[c * 16] = a[c];
+      for (int c = 0; c < 16; c++) dst[c * PC_S] = a[c];
     }
     pc_sync();
     {
       // What became of the sixteen pivots, read off L_kk's diagonal (in the chain this bookkeeping was twelve scalar instructions per pivot
       // on values the compiler then kept in spilled SGPRs: 2 K of the kernel's 12.8 K instructions): a deleted pivot left an exact zero
       // (a[j] *= 0), a negative or non-finite one a NaN (rsqrt), one beyond 1e300 a diagonal beyond 1e150
-      const double dj = blk[lr * 17];  // L_kk[lr][lr]
+      const double dj = blk[lr * (PC_S + 1)];  // L_kk[lr][lr]
       bad |= !(dj == 0.0 || (dj > 0.0 && dj < 1e150));
       const unsigned long long delm = __ballot(dj == 0.0) & 0xffffull;
       if (k < 4) dm0 |= delm << (16 * k);
@@ -300,11 +302,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
     }
     // J_kk = L_kk^T in the tile layout: entry (row, col) = L[col][row], zero below the diagonal
 #pragma unroll
-    for (int r = 0; r < 4; r++) U[pc_ti(k, k)][r] = lk + 4 * r <= lr ? blk[(lk + 4 * r) * 16 + lr] : 0.0;
+    for (int r = 0; r < 4; r++) U[pc_ti(k, k)][r] = lk + 4 * r <= lr ? blk[(lk + 4 * r) * PC_S + lr] : 0.0;
     if (k + 1 < PC_T) {
       double ao[4];  // A operand L_kk^-1[i' = lr][k' = lk + 4 r]
 #pragma unroll
-      for (int r = 0; r < 4; r++) ao[r] = Linv[k * 256 + lr * 16 + lk + 4 * r];
+      for (int r = 0; r < 4; r++) ao[r] = Linv[k * PC_B + lr * PC_S + lk + 4 * r];
 #pragma unroll
       for (int i = k + 1; i < PC_T; i++) {
         pd4 W = {0, 0, 0, 0};
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
     pc_sync();
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc = fma(Linv[k * 256 + lr * 16 + q], vt[q], acc);
+    for (int q = 0; q < 16; q++) acc = fma(Linv[k * PC_B + lr * PC_S + q], vt[q], acc);
     if (lk == 0) vy[16 * k + lr] = acc;
     pc_sync();
   }
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
     const bool cin = 16 * kk + lr < n;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      X[kk][r] = Linv[kk * 256 + (lk + 4 * r) * 16 + lr];
+      X[kk][r] = Linv[kk * PC_B + (lk + 4 * r) * PC_S + lr];
       const double e2 = (cin && 16 * kk + lk + 4 * r < n) ? X[kk][r] * X[kk][r] : 0.0;
       f2 += e2, fs2 = fma(e2, sc, fs2);
     }
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVM_PC_WAVES
         for (int r = 0; r < 4; r++) Sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[pc_ti(j, i)][r], X[j][r], Sacc, 0, 0, 0);  // L_ij X_j
       pd4 Xi = {0, 0, 0, 0};
 #pragma unroll
-      for (int r = 0; r < 4; r++) Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-Linv[i * 256 + lr * 16 + lk + 4 * r], Sacc[r], Xi, 0, 0, 0);
+      for (int r = 0; r < 4; r++) Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-Linv[i * PC_B + lr * PC_S + lk + 4 * r], Sacc[r], Xi, 0, 0, 0);
       X[i] = Xi;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
