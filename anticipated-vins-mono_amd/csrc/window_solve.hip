@@ -4268,6 +4268,92 @@ AVM_DEV void marg_schur_macro_tile(int nf0) {
     }
 }
 
+// Phase B of the marginalization (the per-feature sums) as a function of its own, like marg_schur_phase: its ten-deep load arrays are 140 registers
+AVM_NOINL void marg_feature_sums(int nf0) {
+  const WinCtx& c = lds_ctx();
+  using namespace mg;
+  double* lds = LDS();
+  int* ids = reinterpret_cast<int*>(lds + L_INT);
+  const int t = threadIdx.x;
+  double* W = c.sc + Scratch::W;
+  const double* PF = c.sc + Scratch::PF;
+  const double* PF2 = c.sc + Scratch::PF + 8 * (size_t)NFR * WLE;
+  // (the factor of feature e observed in frame k - these features start in frame 0 - sits at [quantity][k][e])
+  // the two heavy items of a feature (f == 0: its own pose block, hee, g_e;  f == 11: the ex_pose / td columns) are dealt
+  // densely to the threads; the structural zeros of the frames that do not observe it follow in a loop of their own
+  for (int idx = t; idx < nf0 * 2; idx += NT) {
+    const int e = idx >> 1, f = (idx & 1) ? 11 : 0;
+    const int no = ids[I_FNOBS + e], s0 = ids[I_FOBS + e];
+    {
+      const double* P = f == 0 ? PF : PF2;
+      // all loads of the feature's (<= 10) factors in flight at once, clamped to its last observation and masked
+      // (f == 11: the six ex_pose columns and the td column, W columns 66..72)
+      double pv[7][NFR - 1];
+#pragma unroll
+      for (int k = 1; k < NFR; k++)
+#pragma unroll
+        for (int q = 0; q < 7; q++) {  // (f == 0, q < 3: Ji_t^T Je is minus the observing frame's W entry - marg_frame_task does not store it twice)
+          const int kk = min(k, max(no - 1, 0));
+          pv[q][k - 1] = (f == 0 && q < 3) ? W[(size_t)(6 * kk + q) * WLE + e] : P[(size_t)(min(q, (f == 0 || !c.est_td) ? 5 : 6) * NFR + kk) * WLE + e];
+        }
+      double sacc[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 1; k < NFR; k++)
+#pragma unroll
+        for (int q = 0; q < 7; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = (f == 0 && q < 3) ? -sacc[q] : sacc[q];
+      if (f == 11) W[(size_t)72 * WLE + e] = c.est_td ? sacc[6] : 0.0;
+      if (f == 0) {
+        double hv[2][NFR - 1];
+#pragma unroll
+        for (int k = 1; k < NFR; k++) {
+          const int kk = min(k, max(no - 1, 0));
+          hv[0][k - 1] = PF[(size_t)(6 * NFR + kk) * WLE + e], hv[1][k - 1] = PF[(size_t)(7 * NFR + kk) * WLE + e];
+        }
+        double he = 0, ge = 0;
+#pragma unroll
+        for (int k = 1; k < NFR; k++) he += k < no ? hv[0][k - 1] : 0.0, ge += k < no ? hv[1][k - 1] : 0.0;
+        lds[L_HEE + e] = he;
+        lds[M_GE + e] = ge;
+      }
+    }
+  }
+  for (int idx = t; idx < nf0 * (NFR - 1); idx += NT) {
+    const int e = idx / (NFR - 1), f = 1 + idx % (NFR - 1);
+    if (f >= ids[I_FNOBS + e]) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = 0.0;
+    }
+  }
+}
+
+// Phase F of the marginalization as a function of its own (round 6): inlined, its accumulators and operands pushed the kernel body's
+// allocation so far that the registers holding SPILLED SGPRs were spilled themselves - every thread-range predicate of the kernel then began
+// with a trip to scratch memory (106 sites, 32 of them in this phase's scatter).
+AVM_NOINL void marg_schur_phase(int nf0) {
+#ifdef AVM_TP
+  AVM_PRIO_BULK();
+  switch (threadIdx.x >> 6) {  // four wavefronts, one per SIMD: 4 | 3 + 1 | 3 | 2 + 2 tiles (as schur_reduce)
+    case 0: marg_schur_macro_tile<2, 3, 0, 1>(nf0); break;
+    case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0), marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
+    case 2: marg_schur_macro_tile<2, 3, 2, 3>(nf0); break;
+    default: marg_schur_macro_tile<4, -1, 0, 1>(nf0), marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
+  }
+  AVM_PRIO_LIGHT();
+#else
+  switch (threadIdx.x >> 6) {
+    case 0: marg_schur_macro_tile<2, 3, 0, 1>(nf0); break;
+    case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0); break;
+    case 2: marg_schur_macro_tile<2, 3, 2, 3>(nf0); break;
+    case 3: marg_schur_macro_tile<4, -1, 0, 1>(nf0); break;
+    case 7: marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
+    case 5: marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
+    default: break;
+  }
+#endif
+}
+
 AVM_NOINL void marg_frame_task(const WinCtx&, const avm_options&, int b0, int b1, int stage_off) {
   // The wavefront's (at most two) frames b0 < b1 as ONE list of factors, 64 at a time: a chunk may straddle the two frames (5
   // chunks for two frames of 150 factors instead of 3 + 3), the MFMA accumulation is cut at the frame boundary.
@@ -4863,59 +4949,7 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
     __syncthreads();
     PROF(c, 17);
     // ---- phase B: per-feature sums, PART gather
-    {
-      double* W = c.sc + Scratch::W;
-      const double* PF = c.sc + Scratch::PF;
-      const double* PF2 = c.sc + Scratch::PF + 8 * (size_t)NFR * WLE;
-      // (the factor of feature e observed in frame k - these features start in frame 0 - sits at [quantity][k][e])
-      // the two heavy items of a feature (f == 0: its own pose block, hee, g_e;  f == 11: the ex_pose / td columns) are dealt
-      // densely to the threads; the structural zeros of the frames that do not observe it follow in a loop of their own
-      for (int idx = t; idx < nf0 * 2; idx += NT) {
-        const int e = idx >> 1, f = (idx & 1) ? 11 : 0;
-        const int no = ids[I_FNOBS + e], s0 = ids[I_FOBS + e];
-        {
-          const double* P = f == 0 ? PF : PF2;
-          // all loads of the feature's (<= 10) factors in flight at once, clamped to its last observation and masked
-          // (f == 11: the six ex_pose columns and the td column, W columns 66..72)
-          double pv[7][NFR - 1];
-#pragma unroll
-          for (int k = 1; k < NFR; k++)
-#pragma unroll
-            for (int q = 0; q < 7; q++) {  // (f == 0, q < 3: Ji_t^T Je is minus the observing frame's W entry - marg_frame_task does not store it twice)
-              const int kk = min(k, max(no - 1, 0));
-              pv[q][k - 1] = (f == 0 && q < 3) ? W[(size_t)(6 * kk + q) * WLE + e] : P[(size_t)(min(q, (f == 0 || !c.est_td) ? 5 : 6) * NFR + kk) * WLE + e];
-            }
-          double sacc[7] = {0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-          for (int k = 1; k < NFR; k++)
-#pragma unroll
-            for (int q = 0; q < 7; q++) sacc[q] += k < no ? pv[q][k - 1] : 0.0;
-#pragma unroll
-          for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = (f == 0 && q < 3) ? -sacc[q] : sacc[q];
-          if (f == 11) W[(size_t)72 * WLE + e] = c.est_td ? sacc[6] : 0.0;
-          if (f == 0) {
-            double hv[2][NFR - 1];
-#pragma unroll
-            for (int k = 1; k < NFR; k++) {
-              const int kk = min(k, max(no - 1, 0));
-              hv[0][k - 1] = PF[(size_t)(6 * NFR + kk) * WLE + e], hv[1][k - 1] = PF[(size_t)(7 * NFR + kk) * WLE + e];
-            }
-            double he = 0, ge = 0;
-#pragma unroll
-            for (int k = 1; k < NFR; k++) he += k < no ? hv[0][k - 1] : 0.0, ge += k < no ? hv[1][k - 1] : 0.0;
-            lds[L_HEE + e] = he;
-            lds[M_GE + e] = ge;
-          }
-        }
-      }
-      for (int idx = t; idx < nf0 * (NFR - 1); idx += NT) {
-        const int e = idx / (NFR - 1), f = 1 + idx % (NFR - 1);
-        if (f >= ids[I_FNOBS + e]) {
-#pragma unroll
-          for (int q = 0; q < 6; q++) W[(size_t)(6 * f + q) * WLE + e] = 0.0;
-        }
-      }
-    }
+    marg_feature_sums(nf0);
     __syncthreads();  // staging dead: rows >= 66 can be cleared, then the PART sums land (incl. the ex_pose rows)
     for (int i = SPP + t; i < MROWS; i += NT) lds[L_S + i] = 0.0;
     __syncthreads();
@@ -5007,26 +5041,7 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
     if (flag == AVM_MARGIN_OLD && nf0 > 0) {
       if (t < MAXE) lds[L_HEE + t] = (t < nf0 && lds[L_HEE + t] > o.marg_eps) ? 1.0 / lds[L_HEE + t] : 0.0;  // 1 / E^T E in place
       __syncthreads();
-#ifdef AVM_TP
-      AVM_PRIO_BULK();
-      switch (t >> 6) {  // four wavefronts, one per SIMD: 4 | 3 + 1 | 3 | 2 + 2 tiles (as schur_reduce)
-        case 0: marg_schur_macro_tile<2, 3, 0, 1>(nf0); break;
-        case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0), marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
-        case 2: marg_schur_macro_tile<2, 3, 2, 3>(nf0); break;
-        default: marg_schur_macro_tile<4, -1, 0, 1>(nf0), marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
-      }
-      AVM_PRIO_LIGHT();
-#else
-      switch (t >> 6) {
-        case 0: marg_schur_macro_tile<2, 3, 0, 1>(nf0); break;
-        case 1: marg_schur_macro_tile<0, 1, 0, 1>(nf0); break;
-        case 2: marg_schur_macro_tile<2, 3, 2, 3>(nf0); break;
-        case 3: marg_schur_macro_tile<4, -1, 0, 1>(nf0); break;
-        case 7: marg_schur_macro_tile<4, -1, 2, 3>(nf0); break;
-        case 5: marg_schur_macro_tile<4, -1, 4, -1>(nf0); break;
-        default: break;
-      }
-#endif
+      marg_schur_phase(nf0);
     }
     __syncthreads();
     PROF(c, 21);
