@@ -4715,7 +4715,7 @@ AVM_NOINL int jacobi_eig_lds(int A_off, int V_off, int n, int ld, int rot_off) {
 // pivots) proves that every eigenvalue is above eps; otherwise the caller falls back to the eigen-decomposition.
 // On success the result is handed over in the eigen-solver's output format: EV[i][c] = (L D^1/2)^-T rows, diag(EA) = the
 // pivots d_c, so that EV diag(1 / d) EV^T = Amm^-1.  EA is left untouched on failure.  Call with one full wavefront.
-AVM_DEV bool pinv16_cholesky(double* EA, double* EV, int m, double eps) {
+AVM_NOINL bool pinv16_cholesky(double* EA, double* EV, int m, double eps) {  // (outlined: its sixteen-register row was spilled inside the kernel body)
   constexpr int NB = 16;
   const int r = threadIdx.x & 63;
   const bool idl = (r & 48) == 16;
@@ -5118,8 +5118,9 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
     PROF(c, 23);
     // Amm^+ = V diag(1/lambda > eps) V^T  -> EA (reuse) ; T = Arm Amm^+ ; A' = Arr - T Amr ; b' = br - T bm
     {
-      double lam_inv[16];
-      for (int k = 0; k < 16; k++) lam_inv[k] = (k < m && EA[k * 16 + k] > o.marg_eps) ? 1.0 / EA[k * 16 + k] : 0.0;
+      // (1 / lambda once, by sixteen threads, through LDS - g_e's array is dead since phase F: every thread used to divide sixteen times)
+      double* lam_inv = lds + M_GE;
+      if (t < 16) lam_inv[t] = (t < m && EA[t * 16 + t] > o.marg_eps) ? 1.0 / EA[t * 16 + t] : 0.0;
       __syncthreads();
       if (t < 256) {
         const int i = t / 16, j = t % 16;
