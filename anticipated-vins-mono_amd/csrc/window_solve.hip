@@ -4268,6 +4268,13 @@ AVM_DEV void marg_schur_macro_tile(int nf0) {
     }
 }
 
+// ... and the two single-wavefront jobs beside the frame tasks (IMU factor 0's raw Jacobians on one lane, the old prior's residual and gradient)
+AVM_NOINL void marg_imu0_raw() {
+  const WinCtx& c = lds_ctx();
+  double* lds = LDS();
+  imu_raw<true>(lds + L_X, lds + L_FR, lds_opt(), c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, c.sc + Scratch::IJRAW);
+}
+AVM_NOINL void marg_prior_wave(int rb, int re, int buf_off) { (void)prior_wave<true>(L_X, rb, re, buf_off); }
 // Phase B of the marginalization (the per-feature sums) as a function of its own, like marg_schur_phase: its ten-deep load arrays are 140 registers
 AVM_NOINL void marg_feature_sums(int nf0) {
   const WinCtx& c = lds_ctx();
@@ -4927,13 +4934,13 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
         default: marg_frame_task(c, o, 4, 5, stage); break;
       }
       AVM_PRIO_LIGHT();
-      if (wv == 2 && lane == 0 && imu0) imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
+      if (wv == 2 && lane == 0 && imu0) marg_imu0_raw();
       if (wv >= 2 && use_prior) {
         const int h = (3 * c.pn + 2) / 5;
         if (wv == 2)
-          prior_wave<true>(L_X, h, c.pn, L_DX2);
+          marg_prior_wave(h, c.pn, L_DX2);
         else
-          prior_wave<true>(L_X, 0, h, L_DXP);
+          marg_prior_wave(0, h, L_DXP);
       }
     }
 #else
@@ -4941,9 +4948,9 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
       marg_frame_task(c, o, 1 + wv, 1 + wv + MASM, L_S + SPP + wv * MXSTG);  // this wavefront's (at most two) frames
       static_assert(1 + 2 * MASM >= NFR, "two frames per wavefront cover all frames");
     } else if (wv == 7) {
-      if (lane == 0 && imu0) imu_raw<true>(lds + L_X, lds + L_FR, o, c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, IJR);
+      if (lane == 0 && imu0) marg_imu0_raw();
       // ... and the old prior's residual and gradient (MarginalizationFactor at the current state): dx, r_p, J0^T r_p
-      if (use_prior) prior_wave<true>(L_X, 0, c.pn, L_DXP);
+      if (use_prior) marg_prior_wave(0, c.pn, L_DXP);
     }
 #endif
     __syncthreads();
