@@ -3334,6 +3334,45 @@ AVM_DEV void state_plus() {
 #define AVM_SOLVE_KERNEL window_solve_kernel
 #define AVM_SOLVE_OCC
 #endif
+// rot_diff and origin_P0 of double2vector (estimator.cpp:521-546): the yaw of frame 0 before and after the solve -> lds[gf .. gf + 9) = rot_diff,
+// [gf + 9 .. gf + 12) = origin_P0 (last_P0 under failure_occur, estimator.cpp:526-531: pl = last_pose0), [gf + 12 .. gf + 15) = the solved P[0].
+// Called by every thread before a workgroup barrier.  A function of its own since round 6: inlined, its nine atan2 and twelve sin / cos - full
+// library functions on ONE lane - sat in the kernel body with 114 scratch instructions of their own; the three Euler-angle conversions are
+// independent and run on three lanes side by side, each with one sincos of its yaw.
+AVM_NOINL void gauge_rot_diff(const double* p0, const double* pl, int gf) {
+  double* lds = LDS();
+  const int t = threadIdx.x;
+  if (t >= 64) return;
+  double* ang = lds + gf + 16;  // [3][3] yaw pitch roll (degrees) of: frame 0 before | the anchor (last_R0, or frame 0 before) | frame 0 after
+  if (t < 3) {
+    const double* src = t == 2 ? lds + L_X : (t == 1 && pl ? pl : p0);
+    double R[9];
+    q2R(quat{src[6], src[3], src[4], src[5]}, R);
+    const double y = atan2(R[3], R[0]), sy = sin(y), cy = cos(y);
+    const double p = atan2(-R[6], R[0] * cy + R[3] * sy);
+    const double r = atan2(R[2] * sy - R[5] * cy, -R[1] * sy + R[4] * cy);
+    ang[3 * t] = y / M_PI * 180.0, ang[3 * t + 1] = p / M_PI * 180.0, ang[3 * t + 2] = r / M_PI * 180.0;
+  }
+  wave_lds_sync();
+  if (t == 0) {
+    const double* a0 = ang + 3;  // (the anchor: what the reference's origin_R0 holds)
+    const double* a1 = ang + 6;
+    const double yd = (a0[0] - a1[0]) / 180.0 * M_PI;
+    double rd[9] = {cos(yd), -sin(yd), 0, sin(yd), cos(yd), 0, 0, 0, 1};
+    if (fabs(fabs(a0[1]) - 90) < 1.0 || fabs(fabs(a1[1]) - 90) < 1.0) {
+      // (pitch-singular branch: rot_diff = Rs[0] * R(para_Pose[0])^T with Rs[0] itself - failure_occur does not change it)
+      double Rs0[9], R00[9];
+      q2R(quat{p0[6], p0[3], p0[4], p0[5]}, Rs0);
+      q2R(quat{lds[L_X + 6], lds[L_X + 3], lds[L_X + 4], lds[L_X + 5]}, R00);
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) rd[a * 3 + b] = Rs0[a * 3] * R00[b * 3] + Rs0[a * 3 + 1] * R00[b * 3 + 1] + Rs0[a * 3 + 2] * R00[b * 3 + 2];
+    }
+    const double* P0 = pl ? pl : p0;
+    for (int k = 0; k < 9; k++) lds[gf + k] = rd[k];
+    for (int k = 0; k < 3; k++) lds[gf + 9 + k] = P0[k], lds[gf + 12 + k] = lds[L_X + k];
+  }
+}
+
 __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A) {
   lds_base_check();
   red_init();
@@ -4021,38 +4060,7 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
 #else
       constexpr int L_GF = L_DG;
 #endif
-      if (t == 0) {
-        const double* p0 = B.pose + (size_t)w * 77;
-        double Rs0[9], R00[9];
-        q2R(quat{p0[6], p0[3], p0[4], p0[5]}, Rs0);
-        q2R(quat{lds[L_X + 6], lds[L_X + 3], lds[L_X + 4], lds[L_X + 5]}, R00);
-        auto ypr = [](const double* R, double* out) {
-          const double y = atan2(R[3], R[0]);
-          const double p = atan2(-R[6], R[0] * cos(y) + R[3] * sin(y));
-          const double r = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
-          out[0] = y / M_PI * 180.0, out[1] = p / M_PI * 180.0, out[2] = r / M_PI * 180.0;
-        };
-        double a0[3], a1[3], P0[3] = {p0[0], p0[1], p0[2]};
-        ypr(Rs0, a0);
-        if (B.failure_occur && B.last_pose0 && B.failure_occur[w]) {
-          // failure_occur (estimator.cpp:526-531): the yaw / position anchor is last_R0 / last_P0; Rs[0] itself (the
-          // pitch-singular branch below) stays what it was
-          const double* lp = B.last_pose0 + (size_t)w * 7;
-          double Rl[9];
-          q2R(quat{lp[6], lp[3], lp[4], lp[5]}, Rl);
-          ypr(Rl, a0);
-          P0[0] = lp[0], P0[1] = lp[1], P0[2] = lp[2];
-        }
-        ypr(R00, a1);
-        const double yd = (a0[0] - a1[0]) / 180.0 * M_PI;
-        double rd[9] = {cos(yd), -sin(yd), 0, sin(yd), cos(yd), 0, 0, 0, 1};
-        if (fabs(fabs(a0[1]) - 90) < 1.0 || fabs(fabs(a1[1]) - 90) < 1.0) {
-          for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) rd[a * 3 + b] = Rs0[a * 3] * R00[b * 3] + Rs0[a * 3 + 1] * R00[b * 3 + 1] + Rs0[a * 3 + 2] * R00[b * 3 + 2];
-        }
-        for (int k = 0; k < 9; k++) lds[L_GF + k] = rd[k];
-        for (int k = 0; k < 3; k++) lds[L_GF + 9 + k] = P0[k], lds[L_GF + 12 + k] = lds[L_X + k];
-      }
+      gauge_rot_diff(B.pose + (size_t)w * 77, (B.failure_occur && B.last_pose0 && B.failure_occur[w]) ? B.last_pose0 + (size_t)w * 7 : nullptr, L_GF);
       __syncthreads();
       if (t < NFRP) {
         const double* rd = lds + L_GF;
