@@ -3539,17 +3539,23 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
     if (t == 0) {  // longest-processing-time assignment of the frames to the assembling wavefronts
       int done = 0;
       ids[I_FRW] = -1;
+      // (the loads in registers - constant indices only: indexed by a run-time value the array lived in private memory, 53 scratch instructions
+      //  in a one-thread loop of 130 steps per window)
       int load[ASM_WAVES];
+#pragma unroll
       for (int k = 0; k < ASM_WAVES; k++) load[k] = 0;
       for (int k = 1; k < NFRP; k++) {
         int bb = -1, bn = -1;
         for (int f = 1; f < NFRP; f++)
           if (!(done & (1 << f)) && ids[I_NCOV + f] > bn) bn = ids[I_NCOV + f], bb = f;
-        int bw = 0;
+        int bw = 0, lb = load[0];
+#pragma unroll
         for (int q = 1; q < ASM_WAVES; q++)
-          if (load[q] < load[bw]) bw = q;
+          if (load[q] < lb) lb = load[q], bw = q;
         ids[I_FRW + bb] = bw;
-        load[bw] += ((bn + 63) / 64) * 64 + 8;
+        const int inc = ((bn + 63) / 64) * 64 + 8;
+#pragma unroll
+        for (int q = 0; q < ASM_WAVES; q++) load[q] += q == bw ? inc : 0;
         done |= 1 << bb;
       }
     }

@@ -14,7 +14,7 @@ cp window_solve.o window_solve_x.o window_solve_tp.o $out/$name/
 for w in $which; do
   case $w in
     base) /opt/rocm/bin/hipcc $FLAGS $IPRA $extra -c window_solve.hip -o $out/$name/window_solve.o & ;;
-    x) /opt/rocm/bin/hipcc $FLAGS $extra -DAVM_X=1 -c window_solve.hip -o $out/$name/window_solve_x.o & ;;
+    x) /opt/rocm/bin/hipcc $FLAGS -mllvm -amdgpu-prealloc-sgpr-spill-vgprs $extra -DAVM_X=1 -c window_solve.hip -o $out/$name/window_solve_x.o & ;;
     tp) /opt/rocm/bin/hipcc $FLAGS $IPRA $extra -DAVM_TP=1 -c window_solve.hip -o $out/$name/window_solve_tp.o & ;;
   esac
 done

@@ -12,6 +12,8 @@ def build(src, defs):
         flags += ["-mllvm", "-sink-insts-to-avoid-spills"]
         if not any(d.startswith("-DAVM_X") for d in defs):
             flags += ["-mllvm", "-enable-ipra", "-fno-optimize-sibling-calls"]
+        else:
+            flags += ["-mllvm", "-amdgpu-prealloc-sgpr-spill-vgprs"]
     b, co = tmp + "/k.bundle", tmp + "/k.co"
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + defs + ["--cuda-device-only", "-c", src, "-o", b], cwd=CSRC)
     subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + b, "--output=" + co])
