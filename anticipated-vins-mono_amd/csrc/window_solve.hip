@@ -4289,6 +4289,45 @@ AVM_NOINL void marg_imu0_raw() {
   imu_raw<true>(lds + L_X, lds + L_FR, lds_opt(), c.pdelta, c.pjac, c.psum[0], c.lba, c.lbg, 0, c.sc + Scratch::IJRAW);
 }
 AVM_NOINL void marg_prior_wave(int rb, int re, int buf_off) { (void)prior_wave<true>(L_X, rb, re, buf_off); }
+// Phase D of the marginalization (IMU factor 0: J = sqrt_info [r | J_raw], then J^T J and J^T r into the system) as a function of its own
+AVM_NOINL void marg_imu0_gram() {
+  const WinCtx& c = lds_ctx();
+  using namespace mg;
+  double* lds = LDS();
+  const int t = threadIdx.x;
+  const double* IJR = c.sc + Scratch::IJRAW;
+  double* IJ = lds + M_WCH;
+  for (int idx = t; idx < 465; idx += NT) {
+    const int r = idx / 31, cc = idx % 31;
+    // (sqrt_info is stored with zeros below its diagonal: all fifteen products, their thirty loads in flight at once - as a loop
+    //  from k = r every step was a trip to the slot of its own)
+    double ps[15], ij[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) ps[k] = c.psqrt[r * 15 + k], ij[k] = IJR[k * 31 + cc];
+    double sacc = 0;
+#pragma unroll
+    for (int k = 0; k < 15; k++) sacc += k >= r ? ps[k] * ij[k] : 0.0;
+    IJ[idx] = sacc;
+  }
+  __syncthreads();
+  for (int q = t; q < 495; q += NT) {
+    if (q < 465) {
+      int p = 0;
+      while ((p + 1) * (p + 2) / 2 <= q) p++;
+      const int qq = q - p * (p + 1) / 2;
+      double sacc = 0;
+      for (int r = 0; r < 15; r++) sacc += IJ[r * 31 + 1 + p] * IJ[r * 31 + 1 + qq];
+      const int ip = imu_col(0, p), iq = imu_col(0, qq);
+      lds[L_S + roff(max(ip, iq)) + min(ip, iq)] += sacc;
+    } else {
+      const int p = q - 465;
+      double sacc = 0;
+      for (int r = 0; r < 15; r++) sacc += IJ[r * 31 + 1 + p] * IJ[r * 31];
+      lds[M_G + imu_col(0, p)] += sacc;
+    }
+  }
+  __syncthreads();
+}
 // Phase B of the marginalization (the per-feature sums) as a function of its own, like marg_schur_phase: its ten-deep load arrays are 140 registers
 AVM_NOINL void marg_feature_sums(int nf0) {
   const WinCtx& c = lds_ctx();
@@ -5012,39 +5051,7 @@ __global__ __launch_bounds__(NT) AVM_MARG_OCC void AVM_MARG_KERNEL(SolveArgs A, 
     __syncthreads();
     PROF(c, 18);
     // ---- phase D: IMU factor 0
-    if (imu0) {
-      double* IJ = lds + M_WCH;
-      for (int idx = t; idx < 465; idx += NT) {
-        const int r = idx / 31, cc = idx % 31;
-        // (sqrt_info is stored with zeros below its diagonal: all fifteen products, their thirty loads in flight at once - as a loop
-        //  from k = r every step was a trip to the slot of its own)
-        double ps[15], ij[15];
-#pragma unroll
-        for (int k = 0; k < 15; k++) ps[k] = c.psqrt[r * 15 + k], ij[k] = IJR[k * 31 + cc];
-        double sacc = 0;
-#pragma unroll
-        for (int k = 0; k < 15; k++) sacc += k >= r ? ps[k] * ij[k] : 0.0;
-        IJ[idx] = sacc;
-      }
-      __syncthreads();
-      for (int q = t; q < 495; q += NT) {
-        if (q < 465) {
-          int p = 0;
-          while ((p + 1) * (p + 2) / 2 <= q) p++;
-          const int qq = q - p * (p + 1) / 2;
-          double sacc = 0;
-          for (int r = 0; r < 15; r++) sacc += IJ[r * 31 + 1 + p] * IJ[r * 31 + 1 + qq];
-          const int ip = imu_col(0, p), iq = imu_col(0, qq);
-          lds[L_S + roff(max(ip, iq)) + min(ip, iq)] += sacc;
-        } else {
-          const int p = q - 465;
-          double sacc = 0;
-          for (int r = 0; r < 15; r++) sacc += IJ[r * 31 + 1 + p] * IJ[r * 31];
-          lds[M_G + imu_col(0, p)] += sacc;
-        }
-      }
-      __syncthreads();
-    }
+    if (imu0) marg_imu0_gram();
     PROF(c, 19);
     // ---- phase E: old prior (MarginalizationFactor at the current state)
     if (use_prior) {
