@@ -606,7 +606,10 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     d_sum = summary;
   }
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if ((rc = run_preint(c, opt, &d)) != AVM_OK) return rc;
+  if ((rc = run_preint(c, opt, &d)) != AVM_OK) {
+    if (vflag_host) (void)hipStreamSynchronize(c->stream);  // (the table check of a device-resident batch is still in flight: drain it before the caller may free its tables)
+    return rc;
+  }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   if (vflag_host && (rc = validate_windows_end(c, vflag_host, &tp_misfit)) != AVM_OK) return rc;
   use_tp = use_tp && (tp_misfit & 1) == 0;
