@@ -210,7 +210,7 @@ def host_call_latency(abi, synth, reps=50):
         cap = 8192
         io, tr, se = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
         ni, nt = C.c_int32(0), C.c_int32(0)
-        ms, nsel, next_id, stamp = [], [], 1, 10.0
+        ms, nsel, next_id, stamp, parts = [], [], 1, 10.0, []
         for _ in range(reps + 5):
             ids = np.arange(next_id, next_id + 500, dtype=np.int32)
             next_id += 500
@@ -227,8 +227,12 @@ def host_call_latency(abi, synth, reps=50):
                 raise RuntimeError(L.hs_last_error().decode())
             ms.append(L.hs_last_call_ms())
             nsel.append(rc)
+            pt = (C.c_double * 3)()
+            L.hs_sel_last_parts_ms(h, pt)
+            parts.append((pt[0], pt[1], pt[2]))
             stamp += 0.1
         out["select"] = {"value": statistics.median(ms[5:]), "min": min(ms[5:]), "max": max(ms[5:]), "reps": reps, "selected_per_call": int(statistics.median(nsel[5:])),
+                         "device_calls_ms": {k: statistics.median(p[i] for p in parts[5:]) for i, k in enumerate(("horizon_imu", "depth_cloud_incl_marshal", "select_batch"))},
                          "what": "avm_host::FeatureSelector::select() on an image of 500 new features, maxFeatures 150, horizon 10, IMU horizon, the window's "
                                  "depth cloud: split + horizon + marshal + H2D + greedy kernels + D2H", "reference_cpu_ms": 9.0,
                          "reference_source": "support_files/paper results.tex:72-85 (the reference's lazy greedy on its own machine)"}

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <iterator>
@@ -654,7 +655,9 @@ class FeatureSelector {
     // The reference builds the horizon and the information matrices on every call (:131-143) and reads them only when it
     // selects; here the device is asked only then.  The ground-truth cursor moves on every call, as it does there.
     std::vector<double> hor_pos, hor_quat;
+    const auto tm0 = std::chrono::steady_clock::now();
     if (useGT_ || initialized) generateFutureHorizon(nrImuMeasurements, deltaImu, deltaF, hor_pos, hor_quat);
+    lastHorizonMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
     if (initialized) {
       selectedIds = selectInformativeFeatures(subset, image_new, nrImuMeasurements, deltaImu, hor_pos, hor_quat);
       for (int id : selectedIds) subset[id] = image_new.at(id);  // :677
@@ -696,6 +699,7 @@ class FeatureSelector {
   std::vector<int> trackedFeatures_;  // feature_selector.h:93 (never pruned, :196)
   int lastFeatureId_ = 0;
   std::vector<double> lastF_;         // f value of each greedy round of the last select()
+  double lastHorizonMs_ = 0, lastCloudMs_ = 0, lastSelectMs_ = 0;  // wall time of the three device calls of the last select() (diagnostics: bench.py)
 
  private:
   // :139-171 + :613-686 behind one ABI call: information of the horizon, of every candidate and tracked feature, and the
@@ -712,8 +716,10 @@ class FeatureSelector {
     int32_t n_cloud = 0;
     std::vector<double> cloud_xy((size_t)max_cloud * 2, 0.0), cloud_depth(max_cloud, 0.0);
     const double k1q[4] = {state_k1_.q.x, state_k1_.q.y, state_k1_.q.z, state_k1_.q.w};
+    const auto tm0 = std::chrono::steady_clock::now();
     c.check(avm_fsel_build_cloud(c.get(), AVM_MEM_HOST, &wb, state_k1_.pos.data(), k1q, max_cloud, &n_cloud, cloud_xy.data(), cloud_depth.data()),
             "avm_fsel_build_cloud");
+    lastCloudMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
 
     const int32_t n_cand = (int32_t)image_new.size(), n_used = (int32_t)subset.size();
     std::vector<int32_t> cand_id, used_id;
@@ -748,7 +754,9 @@ class FeatureSelector {
     std::vector<int32_t> ids(std::max(1, maxFeatures_), 0);
     lastF_.assign(std::max(1, maxFeatures_), 0.0);
     avm_fsel_out out{&n_sel, ids.data(), lastF_.data(), nullptr};
+    const auto tm1 = std::chrono::steady_clock::now();
     c.check(avm_fsel_select_batch(c.get(), AVM_MEM_HOST, &p, &out), "avm_fsel_select_batch");
+    lastSelectMs_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm1).count();
     lastF_.resize(n_sel);
     return std::vector<int>(ids.begin(), ids.begin() + n_sel);
   }

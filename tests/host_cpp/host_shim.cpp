@@ -333,6 +333,13 @@ int hs_sel_select(void* hp, int n, const int32_t* ids, const double* rows8, doub
   return rc < 0 ? rc : n_sel;
 }
 
+// wall time of the three device calls inside the last select(): horizon, depth cloud (incl. the marshal of the window), the greedy selection
+int hs_sel_last_parts_ms(void* hp, double* out3) {
+  const auto& s = *static_cast<Host*>(hp)->sel;
+  out3[0] = s.lastHorizonMs_, out3[1] = s.lastCloudMs_, out3[2] = s.lastSelectMs_;
+  return 0;
+}
+
 int hs_sel_gt_seek(void* hp) { return static_cast<Host*>(hp)->sel->groundTruthSeek(); }
 
 int hs_sel_last_feature_id(void* hp) { return static_cast<Host*>(hp)->sel->lastFeatureId_; }
