@@ -151,6 +151,19 @@ constexpr int L_WCH = L_XC + XN;   // [WCH][80] scratch tile
 constexpr int L_DUMP = L_WCH + 512;     // per-lane dump slots of the masked-out stores
 constexpr int L_G = L_WCH + WCH * WLD;  // scaled gradient g (f | e)
 #endif
+#if !defined(AVM_TP) && !defined(AVM_X)
+// Latency build: the factorization on register tiles (chol_regs, the throughput build's, on wavefronts 0..3) reads the packed system once;
+// from then on the range of S is its scratch - same carve as the throughput build's union region, and the right-hand side is row NF of S.
+constexpr int L_RHS = L_S + croff(NF);
+constexpr int TP_PS = 17;
+constexpr int L_PATCH = L_S;
+constexpr int L_LINV = L_PATCH + 2 * 16 * TP_PS;
+constexpr int TP_WSLOTS = 9;
+constexpr int L_WROW = L_LINV + 4 * 16 * TP_PS;
+constexpr int L_PARTV = L_WROW;
+constexpr int L_ZV = L_WROW + TP_WSLOTS * 256;
+static_assert(L_ZV + 176 <= L_S + SROWS && 4 * 176 <= TP_WSLOTS * 256, "factorization scratch fits the range of S");
+#endif
 #ifdef AVM_TP
 #elif defined(AVM_X)
 constexpr int L_DD = L_G + VEC;    // D   (g / D is recomputed where it is needed: no room for a fourth vector next to the 178 x 178 system)
@@ -195,8 +208,13 @@ constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 54
               I_PMASK = 648 /* [12] start frames flushed by frame b */, I_TIMEUP = 660 /* max_solver_time reached (set by thread 0) */,
               I_NRUN = 661 /* [12] distinct start frames among the factors observed in frame b */,
               I_PSB = 673 /* throughput build: frame of the prior's speed-bias block (its rows x every pose column: the strip) */,
-              I_CNT = 674 /* throughput build: wavefronts x rows of W published so far in this factorization (chol_regs) */, I_END = 675;
+              I_CNT = 674 /* wavefronts x rows of W published so far in this factorization (chol_regs) */,
+              I_CRFIT = 675 /* latency build: the window's prior fits the sparse factorization (chol_regs), else cholesky_lds */, I_END = 676;
 static_assert(I_END <= 720, "int carve");
+#if !defined(AVM_TP) && !defined(AVM_X)
+constexpr int L_ZERO = L_INT + 340, L_ONE = L_INT + 341;  // the constants 0.0 and 1.0 of chol_regs' tile load, in the unused tail of the int carve (set by schur_reduce)
+static_assert(2 * 340 >= I_END, "the constants sit behind the int carve");
+#endif
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // Issue priority of the calling wavefront (throughput build only).  Two windows share every SIMD there, one wavefront each: while one
@@ -1951,9 +1969,10 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
-#ifdef AVM_TP
+#ifndef AVM_X
 // =====================================================================================================================
-// Throughput build: the factorization on REGISTER tiles, distributed over the workgroup's four wavefronts, in an elimination
+// Throughput build, and the latency build for every window whose prior fits (I_CRFIT): the factorization on REGISTER tiles, distributed over
+// four wavefronts (the latency build's other four only keep the barriers company), in an elimination
 // order that keeps the factor SPARSE and lets TWO pivot chains run at a time (round 6).
 //
 // Order of elimination - a nested dissection of the speed-bias chain with frame 5's block as the separator:
@@ -2019,6 +2038,7 @@ constexpr int tp_off_c(int Rn, int Cn) {
   if (hi == NF) return lo < NF ? L_RHS + lo : TP_NONE;
   if (hi < NPOSE) return L_S + croff(hi) + lo;
   const int q = hi - NPOSE, b = q / 9;
+#ifdef AVM_TP
   if (lo < NPOSE) {
     if (b == 0) return L_STRIP + (q - 9 * b) * NPOSE + lo;
     const int p = lo - 6 * (b - 1);
@@ -2026,6 +2046,11 @@ constexpr int tp_off_c(int Rn, int Cn) {
   }
   const int p = lo - (NPOSE + 9 * (b - 1));
   return p >= 0 && p < 18 ? L_SBC + q * SBW + 18 + p : TP_NONE;
+#else
+  // (latency build: the same structure, the places are those of the packed triangle)
+  const int p = lo < NPOSE ? lo - 6 * (b - 1) : lo - (NPOSE + 9 * (b - 1));
+  return (lo < NPOSE && b == 0) || (p >= 0 && p < 18) ? L_S + croff(hi) + lo : TP_NONE;
+#endif
 }
 
 // Tile pattern of the system in elimination order, [k][i] with k <= i: h = the assembled system can be nonzero there (tp_off_c names a place),
@@ -2218,7 +2243,11 @@ AVM_DEV void tp_diag_chain(int nb, int patch, int buf, int stamp) {
     if (!(dc > 0.0)) reinterpret_cast<int*>(lds + L_INT)[I_FAIL] = stamp;  // non-positive (or NaN) pivot in a pivot column of step stamp - 1
     lds[L_LINV + buf * (16 * TP_PS) + r * TP_PS + 16] = fast_rsqrt_pe(dc);
   }
+#ifdef AVM_TP
   AVM_PRIO_BULK_CHOL();
+#else
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // sum over the 16 lanes of a DPP row; the result is valid in lane 15 of every row (row_shr with bound_ctrl: a lane without a source adds 0)
@@ -2248,7 +2277,8 @@ AVM_DEV void tp_sfor(F&& f) {
 }
 
 // Factor the assembled system and solve it: (H' + mu D^2) y = g', y -> lds[L_Y .. L_Y + NF).  Returns false on a non-positive pivot
-// (uniform over the workgroup).  Called by all four wavefronts, WV = the caller's wavefront.
+// (uniform over the workgroup).  Called by every wavefront of the workgroup, WV = the caller's wavefront; the tiles live on wavefronts 0..3
+// (tp_owner) - the latency build's wavefronts 4..7 hold none and only take part in the barriers and the count.
 // (tile indices and LDS slots as constants of the instantiation: left to the optimizer, one of the four wavefronts' tile arrays ended up in scratch memory)
 #ifdef AVM_PROF_CHOL  // (development: where a factorization's time goes, per wavefront; slots 56.. of the profile: chain, wait b, solve, wait d, update, rest)
 #define CPROF_T0() long long cp__ = clock64()
@@ -2264,7 +2294,7 @@ AVM_NOINL bool chol_regs() {
   double* lds = LDS();
   const int lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
   int* s_fail = reinterpret_cast<int*>(lds + L_INT) + I_FAIL;
-  constexpr int NTL = tp_ntiles(WV);
+  constexpr int NTL = tp_ntiles(WV) > 0 ? tp_ntiles(WV) : 1;
   d4 T[NTL];
 #ifdef AVM_PROF_CHOL
   const long long cp_in__ = clock64();
@@ -2425,7 +2455,7 @@ AVM_NOINL bool chol_regs() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       auto wait_rows = [&]() {
-        while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (t + 1)) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (NT / 64) * (t + 1)) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       };
       if constexpr (tp_owns_piv(WV, t + 1)) {
@@ -2434,7 +2464,7 @@ AVM_NOINL bool chol_regs() {
           if constexpr (tp_owner(q) == WV) run_chain(std::integral_constant<int, q>{});
         });
       }
-      wait_rows();
+      if constexpr (tp_ntiles(WV) > 0) wait_rows();
       CPROF(3);
       // (e) trailing update U(j, i) -= W(k, j)^T W(k, i), k < j <= i, over the tiles of this step's rows that exist (the next step's diagonal
       // tiles have theirs already), while the next chains run on their owners
@@ -2467,7 +2497,8 @@ AVM_NOINL bool chol_regs() {
   });
   if (failed) return false;
   // (every wavefront is past the last step's barrier: nobody reads a row of W any more, and the partial sums of the back substitution live there)
-  for (int q = lane; q < 176; q += 64) lds[L_PARTV + WV * 176 + q] = 0.0;
+  if constexpr (WV < 4)
+    for (int q = lane; q < 176; q += 64) lds[L_PARTV + WV * 176 + q] = 0.0;
   __syncthreads();  // z is complete in lds[L_ZV]
   PROF(c, 5);
   if (*s_fail) return false;
@@ -2545,7 +2576,8 @@ AVM_NOINL bool chol_regs() {
 }
 #undef TPI
 #undef TPW
-#else  // the other builds: left-looking factorization of the packed system in LDS
+#endif  // !AVM_X: chol_regs
+#ifndef AVM_TP  // the other builds (the latency build: for a prior chol_regs' pattern does not hold): left-looking factorization of the packed system in LDS
 // Scratch of the factorization inside the tile at L_WCH (dead while S is being factored): L^-T of the current and of the
 // next diagonal block, and a per-lane dump slot for the masked-out stores.
 constexpr int L_CLT = L_WCH /* two buffers of 256: block j's L^-T in buffer j & 1 */, L_CDUMP = L_WCH + 512;
@@ -3096,6 +3128,9 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
 #else
   if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
   for (int i = t; i < NF; i += NT) lds[L_S + roff(NF) + i] = lds[L_G + i];  // RHS rides along as row NF
+#ifndef AVM_X
+  if (t == NT - 1) lds[L_ZERO] = 0.0, lds[L_ONE] = 1.0;  // (chol_regs' tile load, as above)
+#endif
 #endif
   // per feature: f_e = s_e^2 / (hee' + mu D_e^2) and x_e = s_e g'_e / (hee' + mu D_e^2)   (L_ST is dead here)
   if (t < MAXE + 2) {
@@ -3490,6 +3525,8 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
       int off = 0;
 #ifdef AVM_TP
       int psb_ = 0;
+#elif !defined(AVM_X)
+      int nsb_ = 0, sbfr_ = 0;
 #endif
       for (int k = 0; k < c.pnblk; k++) {
         const int kind = ids[I_PBLK + k * 3], fr = ids[I_PBLK + k * 3 + 1];  // (loaded by 16 lanes at once above)
@@ -3505,11 +3542,20 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
 #endif
 #ifdef AVM_TP
         if (kind == AVM_BLK_SPEEDBIAS) psb_ = fr;  // (at most one such block: the host checks it before it chooses this kernel)
+#elif !defined(AVM_X)
+        if (kind == AVM_BLK_SPEEDBIAS) nsb_++, sbfr_ |= fr;
 #endif
         off += n;
       }
 #ifdef AVM_TP
       ids[I_PSB] = psb_;
+#elif !defined(AVM_X)
+      // the rule of window_prior_tp_misfit (kernels.hpp): chol_regs' elimination order takes a prior whose only speed-bias block is frame 0's
+#ifdef AVM_NO_CR
+      ids[I_CRFIT] = 0;
+#else
+      ids[I_CRFIT] = (nsb_ <= 1 && sbfr_ == 0) ? 1 : 0;
+#endif
 #endif
     }
     for (int f = 1 + (t >> 6); f < NFR; f += NT / 64) {  // features observed in frame f (as imu_j), in feature order
@@ -3879,15 +3925,30 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
             continue;
           }
 #else
-          const bool ok = cholesky_lds(c.prof);
-          PROF(c, 12);
+          bool ok;
+#ifndef AVM_X
+          if (ids[I_CRFIT]) {  // (uniform: the window's prior has the structure chol_regs' pattern is closed for)
+            switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
+              case 0: ok = chol_regs<0>(); break;
+              case 1: ok = chol_regs<1>(); break;
+              case 2: ok = chol_regs<2>(); break;
+              case 3: ok = chol_regs<3>(); break;
+              default: ok = chol_regs<4>(); break;  // (wavefronts 4..7: no tiles)
+            }
+            PROF(c, 12);
+          } else
+#endif
+          {
+            ok = cholesky_lds(c.prof);
+            PROF(c, 12);
+            if (ok) chol_solve_lds(L_Y);
+            PROF(c, 13);
+          }
           if (!ok) {
             mu *= mu_inc;
             rebuilt = false;
             continue;
           }
-          chol_solve_lds(L_Y);
-          PROF(c, 13);
 #endif
           const double bad_y = back_substitute(c, mu);
           PROF(c, 14);
