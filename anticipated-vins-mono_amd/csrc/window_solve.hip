@@ -104,6 +104,15 @@ constexpr int ASM_WAVES = 6;       // wavefronts assembling projection factors (
 #ifndef AVM_LPT_RUNW
 #define AVM_LPT_RUNW 16
 #endif
+// positions of chol_regs' elimination order (see there): [0, 48) B, [48, 96) F, frame 5's speed-bias block, the dense columns, the right-hand side
+constexpr int TP_M0 = 96, TP_P0 = 105, TP_RHS = TP_P0 + NPOSE;  // 171 (184)
+constexpr int TPT = TP_RHS / 16 + 1;                            // tile columns: 11 (12)
+constexpr int TP_NPOS = 16 * TPT;                               // 176 (192)
+#ifdef AVM_X
+constexpr int TP_NWO = 8;          // wavefronts that hold tiles of the factorization
+#else
+constexpr int TP_NWO = 4;
+#endif
 constexpr int CNB = 16;            // Cholesky panel width (pivot chain per diagonal block); trailing tiles stay 16x16
 constexpr int TLAST = NF / 16;     // last 16-row tile of the packed matrix incl. the augmented row NF: 10 (11)
 constexpr int FRS = 18 * NFRP;     // one frames slot: R (NFRP x 9) then A = ric^T R^T (NFRP x 9)
@@ -125,7 +134,7 @@ constexpr int TP_WSLOTS = 9;                  // tiles of a step's rows of W tha
 constexpr int L_WROW = L_LINV + 4 * 16 * TP_PS;      // [TP_WSLOTS][256]: the step's rows of W, the tiles that exist in column order, in the accumulator layout [r][lane]
 constexpr int L_PARTV = L_WROW;               // back substitution (the rows of W are dead by then): [4][176] partial sums of the four wavefronts
 constexpr int L_ZV = L_WROW + TP_WSLOTS * 256;  // [176] z = L^-1 b, then x, in elimination order (lds[L_Y] keeps the right-hand side until x replaces it, in the system's order)
-static_assert(L_ZV + 176 <= L_ZERO && 4 * 176 <= TP_WSLOTS * 256, "factorization scratch fits the union region");
+static_assert(L_ZV + TP_NPOS <= L_ZERO && TP_NWO * TP_NPOS <= TP_WSLOTS * 256, "factorization scratch fits the union region");
 static_assert(ASM_WAVES * XSTG <= USZ - 2, "staging leaves the two constants alone");
 constexpr int L_Y = L_U + USZ;                // Gauss-Newton solution y; until the solve writes it: the right-hand side (row NF of the other builds)
 constexpr int L_RHS = L_Y;
@@ -151,18 +160,23 @@ constexpr int L_WCH = L_XC + XN;   // [WCH][80] scratch tile
 constexpr int L_DUMP = L_WCH + 512;     // per-lane dump slots of the masked-out stores
 constexpr int L_G = L_WCH + WCH * WLD;  // scaled gradient g (f | e)
 #endif
-#if !defined(AVM_TP) && !defined(AVM_X)
-// Latency build: the factorization on register tiles (chol_regs, the throughput build's, on wavefronts 0..3) reads the packed system once;
-// from then on the range of S is its scratch - same carve as the throughput build's union region, and the right-hand side is row NF of S.
+#ifndef AVM_TP
+// Latency and extended builds: the factorization on register tiles (chol_regs, the throughput build's; latency: on wavefronts 0..3, extended: on all
+// eight) reads the packed system once; from then on the range of S is its scratch - same carve as the throughput build's union region, and the
+// right-hand side is row NF of S.
 constexpr int L_RHS = L_S + croff(NF);
 constexpr int TP_PS = 17;
 constexpr int L_PATCH = L_S;
 constexpr int L_LINV = L_PATCH + 2 * 16 * TP_PS;
+#ifdef AVM_X
+constexpr int TP_WSLOTS = 14;
+#else
 constexpr int TP_WSLOTS = 9;
+#endif
 constexpr int L_WROW = L_LINV + 4 * 16 * TP_PS;
 constexpr int L_PARTV = L_WROW;
 constexpr int L_ZV = L_WROW + TP_WSLOTS * 256;
-static_assert(L_ZV + 176 <= L_S + SROWS && 4 * 176 <= TP_WSLOTS * 256, "factorization scratch fits the range of S");
+static_assert(L_ZV + TP_NPOS <= L_S + SROWS && TP_NWO * TP_NPOS <= TP_WSLOTS * 256, "factorization scratch fits the range of S");
 #endif
 #ifdef AVM_TP
 #elif defined(AVM_X)
@@ -211,7 +225,7 @@ constexpr int I_FSTART = 0, I_FNOBS = 150, I_FOBS = 300, I_PIDX = 450, I_FS = 54
               I_CNT = 674 /* wavefronts x rows of W published so far in this factorization (chol_regs) */,
               I_CRFIT = 675 /* latency build: the window's prior fits the sparse factorization (chol_regs), else cholesky_lds */, I_END = 676;
 static_assert(I_END <= 720, "int carve");
-#if !defined(AVM_TP) && !defined(AVM_X)
+#ifndef AVM_TP
 constexpr int L_ZERO = L_INT + 340, L_ONE = L_INT + 341;  // the constants 0.0 and 1.0 of chol_regs' tile load, in the unused tail of the int carve (set by schur_reduce)
 static_assert(2 * 340 >= I_END, "the constants sit behind the int carve");
 #endif
@@ -1969,11 +1983,11 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
-#ifndef AVM_X
 // =====================================================================================================================
-// Throughput build, and the latency build for every window whose prior fits (I_CRFIT): the factorization on REGISTER tiles, distributed over
-// four wavefronts (the latency build's other four only keep the barriers company), in an elimination
-// order that keeps the factor SPARSE and lets TWO pivot chains run at a time (round 6).
+// Throughput build, and the latency / extended builds for every window whose prior fits (I_CRFIT): the factorization on REGISTER tiles,
+// distributed over four wavefronts (the latency build's other four only keep the barriers company; the extended build, with 13 more dense
+// columns = one more tile column, spreads them over all eight), in an elimination order that keeps the factor SPARSE and lets TWO pivot
+// chains run at a time (round 6).
 //
 // Order of elimination - a nested dissection of the speed-bias chain with frame 5's block as the separator:
 //     B: the speed-bias blocks of frames 10, 9, .. 6   (45 columns + 3 of padding = tile columns 0, 1, 2)
@@ -2009,10 +2023,9 @@ AVM_DEV double readlane_d(double v, int srclane) {  // srclane must be wave-unif
 //     wavefronts' partial sums, folds x_i into element-wise accumulators E_k += U(k, i) .* x_i (k < i, no reduction), and every
 //     wavefront that holds a tile of the next step's rows reduces its E over the 16-lane rows (DPP) into its partial vector: one barrier per step.
 // Nothing of the factor ever goes to memory; the LDS traffic is the published rows of W (<= 18 KB per step).
-constexpr int TPT = 11;
-static_assert(NFR == 11 && NF == 165 && NPOSE == 66, "the elimination order below is written for eleven frames");
+static_assert(NFR == 11 && NF == NPOSE + 99 && (TPT == 11 || TPT == 12), "the elimination order below is written for eleven frames");
 constexpr int TP_PAD = -1;
-constexpr int TP_M0 = 96, TP_P0 = 105, TP_RHS = 171;  // first position of frame 5's block / of the poses / the right-hand side
+// (TP_M0, TP_P0, TP_RHS - first position of frame 5's block / of the dense columns (poses [, relo_Pose, ex_pose, td]) / the right-hand side - and TPT: at the LDS carve)
 constexpr int TP_NBL = TP_RHS - 16 * (TPT - 1);       // state columns in the last tile column: 11 (+ the right-hand side at local column 11)
 static_assert(TP_NBL >= 1 && TP_NBL < 16, "the right-hand side fits the last tile column");
 // position n of the elimination order -> column of the assembled system (poses | speed-biases; NF = the right-hand side), TP_PAD for padding
@@ -2078,7 +2091,7 @@ constexpr TpPattern tp_make_pattern() {
 constexpr TpPattern TPP = tp_make_pattern();
 __host__ __device__ constexpr bool tp_nz(int k, int i) { return k <= i && TPP.nz[k][i]; }
 // the steps of the factorization: pivot columns {t, 3 + t} for t < 3 (B and F side by side), then one column per step
-constexpr int TP_NSTEP = 8;
+constexpr int TP_NSTEP = TPT - 3;  // 8 (9)
 __host__ __device__ constexpr int tp_step_np(int t) { return t < 3 ? 2 : 1; }
 __host__ __device__ constexpr int tp_step_piv(int t, int a) { return t < 3 ? (a == 0 ? t : t + 3) : t + 3; }
 __host__ __device__ constexpr int tp_step_of(int k) { return k < 3 ? k : k - 3; }
@@ -2097,8 +2110,13 @@ __host__ __device__ constexpr bool tp_steps_ok() {  // the two pivot columns of 
 }
 static_assert(tp_steps_ok(), "B and F must not meet");
 __host__ __device__ constexpr int tp_owner(int i) {
+#ifdef AVM_X
+  // eight wavefronts: B and F as below, every later column a wavefront of its own (a chain's owner has nothing else in the rows of the step before)
+  return i < 3 ? 3 : (i < 6 ? 2 : (i == 6 ? 0 : (i == 7 ? 1 : i - 4)));
+#else
   // (build/dev: the assignment that leaves the owner of a step's pivot columns the least other work in the step before)
   return i < 3 ? 3 : (i < 7 ? 2 : (i < 9 ? 0 : (i == 9 ? 3 : 1)));
+#endif
 }
 __host__ __device__ constexpr int tp_ncol(int i) {  // tiles of column i
   int n = 0;
@@ -2497,8 +2515,8 @@ AVM_NOINL bool chol_regs() {
   });
   if (failed) return false;
   // (every wavefront is past the last step's barrier: nobody reads a row of W any more, and the partial sums of the back substitution live there)
-  if constexpr (WV < 4)
-    for (int q = lane; q < 176; q += 64) lds[L_PARTV + WV * 176 + q] = 0.0;
+  if constexpr (WV < TP_NWO)
+    for (int q = lane; q < TP_NPOS; q += 64) lds[L_PARTV + WV * TP_NPOS + q] = 0.0;
   __syncthreads();  // z is complete in lds[L_ZV]
   PROF(c, 5);
   if (*s_fail) return false;
@@ -2520,7 +2538,7 @@ AVM_NOINL bool chol_regs() {
         const int rr = min(lr, nb - 1);
         double bv = lds[L_ZV + 16 * i + rr];
 #pragma unroll
-        for (int w = 0; w < 4; w++) bv -= lds[L_PARTV + w * 176 + 16 * i + rr];
+        for (int w = 0; w < TP_NWO; w++) bv -= lds[L_PARTV + w * TP_NPOS + 16 * i + rr];
         wave_lds_sync();
         double colv[16];
 #pragma unroll
@@ -2563,7 +2581,7 @@ AVM_NOINL bool chol_regs() {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const double sacc = tp_row_sum(E[p][r]);
-            if (lr == 15) lds[L_PARTV + WV * 176 + 16 * p + lk + 4 * r] = sacc;
+            if (lr == 15) lds[L_PARTV + WV * TP_NPOS + 16 * p + lk + 4 * r] = sacc;
           }
         }
       });
@@ -2576,7 +2594,7 @@ AVM_NOINL bool chol_regs() {
 }
 #undef TPI
 #undef TPW
-#endif  // !AVM_X: chol_regs
+// (end of chol_regs)
 #ifndef AVM_TP  // the other builds (the latency build: for a prior chol_regs' pattern does not hold): left-looking factorization of the packed system in LDS
 // Scratch of the factorization inside the tile at L_WCH (dead while S is being factored): L^-T of the current and of the
 // next diagonal block, and a per-lane dump slot for the masked-out stores.
@@ -3128,9 +3146,7 @@ AVM_NOINL void schur_reduce(const WinCtx&, double mu) {
 #else
   if (t < NF) lds[L_S + roff(t) + t] += mu * lds[L_DD + t] * lds[L_DD + t];
   for (int i = t; i < NF; i += NT) lds[L_S + roff(NF) + i] = lds[L_G + i];  // RHS rides along as row NF
-#ifndef AVM_X
   if (t == NT - 1) lds[L_ZERO] = 0.0, lds[L_ONE] = 1.0;  // (chol_regs' tile load, as above)
-#endif
 #endif
   // per feature: f_e = s_e^2 / (hee' + mu D_e^2) and x_e = s_e g'_e / (hee' + mu D_e^2)   (L_ST is dead here)
   if (t < MAXE + 2) {
@@ -3525,7 +3541,7 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
       int off = 0;
 #ifdef AVM_TP
       int psb_ = 0;
-#elif !defined(AVM_X)
+#else
       int nsb_ = 0, sbfr_ = 0;
 #endif
       for (int k = 0; k < c.pnblk; k++) {
@@ -3542,14 +3558,14 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
 #endif
 #ifdef AVM_TP
         if (kind == AVM_BLK_SPEEDBIAS) psb_ = fr;  // (at most one such block: the host checks it before it chooses this kernel)
-#elif !defined(AVM_X)
+#else
         if (kind == AVM_BLK_SPEEDBIAS) nsb_++, sbfr_ |= fr;
 #endif
         off += n;
       }
 #ifdef AVM_TP
       ids[I_PSB] = psb_;
-#elif !defined(AVM_X)
+#else
       // the rule of window_prior_tp_misfit (kernels.hpp): chol_regs' elimination order takes a prior whose only speed-bias block is frame 0's
 #ifdef AVM_NO_CR
       ids[I_CRFIT] = 0;
@@ -3926,19 +3942,23 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
           }
 #else
           bool ok;
-#ifndef AVM_X
           if (ids[I_CRFIT]) {  // (uniform: the window's prior has the structure chol_regs' pattern is closed for)
             switch (__builtin_amdgcn_readfirstlane(t >> 6)) {
               case 0: ok = chol_regs<0>(); break;
               case 1: ok = chol_regs<1>(); break;
               case 2: ok = chol_regs<2>(); break;
               case 3: ok = chol_regs<3>(); break;
+#ifdef AVM_X
+              case 4: ok = chol_regs<4>(); break;
+              case 5: ok = chol_regs<5>(); break;
+              case 6: ok = chol_regs<6>(); break;
+              default: ok = chol_regs<7>(); break;
+#else
               default: ok = chol_regs<4>(); break;  // (wavefronts 4..7: no tiles)
+#endif
             }
             PROF(c, 12);
-          } else
-#endif
-          {
+          } else {
             ok = cholesky_lds(c.prof);
             PROF(c, 12);
             if (ok) chol_solve_lds(L_Y);
