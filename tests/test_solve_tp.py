@@ -163,3 +163,35 @@ def test_failed_factorizations_retry_like_the_latency_form(estimator, monkeypatc
         assert np.array_equal(s0[k], s1[k]), k
     assert np.isfinite(g1.a["pose"]).all()
     assert rel(g1.a["pose"], g0.a["pose"]) < 1e-6
+
+
+@pytest.mark.parametrize("extended", [False, True])
+def test_a_batch_mixing_priors_that_fit_the_sparse_factorization_and_priors_that_do_not(ctx, oracle, monkeypatch, extended):
+    """The latency and extended kernels choose the factorization PER WINDOW (I_CRFIT, window_solve.hip: chol_regs where the prior's only speed-bias
+    block is frame 0's, the left-looking factorization in LDS otherwise).  One call with both kinds of window - window 1's speed-bias block moved to
+    frame 3 - gives the oracle's result for every window, and the windows that fit are bit-identical to a batch without the odd one."""
+    import importlib
+    monkeypatch.setenv("AVM_SOLVE_TP", "0")
+    opt = abi.default_options()
+    opt.marginalization_flag = abi.MARGIN_NONE
+    if extended:
+        opt.estimate_extrinsic = 1
+    E = importlib.import_module("anticipated-vins-mono_amd.estimator").Estimator(ctx=ctx, options=opt)
+    w = synth.make_windows(3, first_id=71, tracks="sparse", n_feat=60, max_feat=150)
+    plain = w.copy()
+    k = w.a["prior_blk_kind"][1]
+    sb = [q for q in range(int(w.a["prior_nblk"][1])) if k[q] == abi.BLK_SPEEDBIAS]
+    assert len(sb) == 1
+    w.a["prior_blk_frame"][1, sb[0]] = 3
+    w.a["prior_x0"][1, sb[0], :9] = w.a["speedbias"][1, 3]
+    wo, so = w.copy(), buffers.summary_alloc(3)
+    oracle.window_solve(opt, wo, None, so)
+    g = w.copy()
+    s = buffers.summary_to_numpy(E.optimization(g)).copy()
+    assert ctx.last_solve_form() == "latency"
+    assert np.array_equal(s["accept_mask"], so["accept_mask"]) and np.array_equal(s["termination"], so["termination"])
+    for key in ("pose", "speedbias", "inv_depth", "ex_pose"):
+        assert rel(g.a[key], wo.a[key]) < 1e-6, key
+    E.optimization(plain)
+    for b in (0, 2):
+        assert np.array_equal(plain.a["pose"][b], g.a["pose"][b]) and np.array_equal(plain.a["speedbias"][b], g.a["speedbias"][b])
