@@ -1266,6 +1266,7 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
   double* PF = c.sc + Scratch::PF;
   double* PART = c.sc + Scratch::PART + (size_t)b * NFR * SPARTW;
   double* PX = c.sc + Scratch::PART + PARTX0 + (size_t)b * PARTX;
+  const double* scl = lds + L_SC;
   d4 Dtot = {0, 0, 0, 0}, D00 = {0, 0, 0, 0}, E00 = {0, 0, 0, 0}, D10 = {0, 0, 0, 0}, E10 = {0, 0, 0, 0}, D10tot = {0, 0, 0, 0},
      D11 = {0, 0, 0, 0}, E11 = {0, 0, 0, 0};
   int a_run = -1, pmask = 0;
@@ -1279,7 +1280,7 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
     for (int r = 0; r < 4; r++) {
       const int row = drow + 4 * r;
       const double v = D00[r];
-      if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + 6 * a_run + (dcol - 6)] = v;  // Jj^T Ji
+      if (row < 6 && dcol >= 6 && dcol < 12) lds[L_S + roff(6 * b + row) + 6 * a_run + (dcol - 6)] = v * (scl[6 * b + row] * scl[6 * a_run + (dcol - 6)]);  // Jj^T Ji (S is written Jacobi-scaled, as in the other builds)
       if (row >= 6 && row < 12) {
         const int i = row - 6;
         if (dcol >= 6 && dcol < 12 && dcol - 6 <= i) PART[a_run * SPARTW + i * (i + 1) / 2 + (dcol - 6)] = v;  // Ji^T Ji (lower)
@@ -1397,10 +1398,10 @@ AVM_DEV double frame_task(const WinCtx&, const avm_options&, int b, int stage_of
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = drow + 4 * r;
-    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r];   // (b,b) lower
-    if (row < 6 && dcol == 12) lds[L_G + 6 * b + row] = Dtot[r];                         // g_b
+    if (row < 6 && dcol <= row) lds[L_S + roff(6 * b + row) + 6 * b + dcol] = Dtot[r] * (scl[6 * b + row] * scl[6 * b + dcol]);   // (b,b) lower
+    if (row < 6 && dcol == 12) lds[L_G + 6 * b + row] = Dtot[r];                         // g_b (the gradient is scaled afterwards, as a vector)
     if (row < 7) {
-      if (dcol < 6) lds[L_S + roff(XC_EX + row) + 6 * b + dcol] = D10tot[r];             // ([ex td], pose b)
+      if (dcol < 6) lds[L_S + roff(XC_EX + row) + 6 * b + dcol] = D10tot[r] * (scl[XC_EX + row] * scl[6 * b + dcol]);  // ([ex td], pose b)
       if (dcol == 12) PX[28 + row] = D10tot[r];                                          // [Jex Jtd]^T r
       if (dcol <= row) PX[row * (row + 1) / 2 + dcol] = D11[r];                          // ([ex td], [ex td]) lower
     }
@@ -1483,12 +1484,8 @@ AVM_DEV double imu_factor_mfma(const WinCtx&, int i, const ImuOperands& ops) {
 #else
     auto dest = [&](int R, int C) { return L_S + roff(gcol(R)) + gcol(C); };  // R >= C >= 1: the packed triangle
 #endif
-    // entries of S are written Jacobi-scaled (see frame_task; not in the extended build); the gradient is scaled afterwards, as a vector
-#ifdef AVM_X
-    auto scl = [&](int) { return 1.0; };
-#else
+    // entries of S are written Jacobi-scaled (see frame_task); the gradient is scaled afterwards, as a vector
     auto scl = [&](int g) { return lds[L_SC + g]; };
-#endif
     const int dump = L_DUMP + lane;
     const double sc0 = li > 0 ? scl(gcol(li)) : 1.0, sc1 = li < 15 ? scl(gcol(16 + li)) : 1.0;
     int off[12];
@@ -1695,11 +1692,11 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
           int i = 0;
           while ((i + 1) * (i + 2) / 2 <= q) i++;
           const int j = q - i * (i + 1) / 2;
-          lds[L_S + roff(6 * f + i) + 6 * f + j] += sacc;
+          lds[L_S + roff(6 * f + i) + 6 * f + j] += sacc * (lds[L_SC + 6 * f + i] * lds[L_SC + 6 * f + j]);
         } else if (q < 27) {
           lds[L_G + 6 * f + (q - 21)] += sacc;
         } else {
-          lds[L_S + roff(XC_EX + (q - 27) / 6) + 6 * f + (q - 27) % 6] += sacc;  // ([ex td], start pose f)
+          lds[L_S + roff(XC_EX + (q - 27) / 6) + 6 * f + (q - 27) % 6] += sacc * (lds[L_SC + XC_EX + (q - 27) / 6] * lds[L_SC + 6 * f + (q - 27) % 6]);  // ([ex td], start pose f)
         }
       } else {
         const int q = tt - NFR * SPARTW;
@@ -1708,7 +1705,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
         if (q < 28) {
           int i = 0;
           while ((i + 1) * (i + 2) / 2 <= q) i++;
-          lds[L_S + roff(XC_EX + i) + XC_EX + (q - i * (i + 1) / 2)] = sacc;
+          lds[L_S + roff(XC_EX + i) + XC_EX + (q - i * (i + 1) / 2)] = sacc * (lds[L_SC + XC_EX + i] * lds[L_SC + XC_EX + (q - i * (i + 1) / 2)]);
         } else {
           lds[L_G + XC_EX + (q - 28)] = sacc;
         }
@@ -1719,7 +1716,7 @@ AVM_NOINL double eval_jac(const WinCtx&, const avm_options&) {
     if (t < 13) {
       const int col = NFR * 6 + t;  // relo 66..71 | ex 72..77 | td 78
       const bool on = t < 6 ? c.relo_n > 0 : (t < 12 ? c.est_ex != 0 : c.est_td != 0);
-      if (!on) lds[L_S + roff(col) + col] = 1.0;
+      if (!on) lds[L_S + roff(col) + col] = lds[L_SC + col] * lds[L_SC + col];  // (1.0, Jacobi-scaled like every other entry)
     }
 #elif defined(AVM_TP)
 #pragma unroll
@@ -3249,7 +3246,6 @@ AVM_NOINL void scale_system(const WinCtx&, bool matrix) {
   double* lds = LDS();
   const int t = threadIdx.x;
   const double* scl = lds + L_SC;
-#ifndef AVM_X
   if (matrix && c.pn > 0) {
     const int* pidx = reinterpret_cast<const int*>(lds + L_INT) + I_PIDX;
     gdouble* HPk = c.sc + Scratch::HP;
@@ -3263,7 +3259,6 @@ AVM_NOINL void scale_system(const WinCtx&, bool matrix) {
       if (ip >= 0 && iq >= 0) HPk[idx] *= scl[ip] * scl[iq];
     }
   }
-#endif
 #ifdef AVM_TP
   if (matrix) {
     // once per solve: the pose rows of the packed triangle entry by entry, then the speed-bias rows in their structural form
@@ -3808,11 +3803,7 @@ __global__ __launch_bounds__(NT) AVM_SOLVE_OCC void AVM_SOLVE_KERNEL(SolveArgs A
       gradient_max_norm = block_max1(gm);
       __syncthreads();
       if (c.prof && t == 0) c.prof[43] += clock64() - pt__;
-#ifdef AVM_X
-      scale_system(c, true);
-#else
       scale_system(c, was_first);
-#endif
       PROF(c, 10);
     };
     auto evaluate_x = [&]() {
