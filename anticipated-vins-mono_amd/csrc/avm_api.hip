@@ -588,8 +588,10 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   bool use_tp = batch->n_windows > c->n_slots;
   if (const char* e = getenv("AVM_SOLVE_TP")) use_tp = e[0] == '1' ? true : (e[0] == '0' ? false : use_tp);
   use_tp = use_tp && !extended;
+  // (the marginalization is the same problem whatever the solve estimated: a large batch of the extended problem takes its throughput form too)
+  const bool big_x = extended && marg && batch->n_windows > c->n_slots;
   // (the slots for the throughput forms are sized before the priors' verdict is in: a batch that then takes the latency forms uses half of them)
-  if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp)) != AVM_OK) {
+  if ((rc = ensure_window_buffers(c, batch->n_windows, use_tp || big_x)) != AVM_OK) {
     if (vflag_host) (void)hipStreamSynchronize(c->stream);
     return rc;
   }
@@ -614,8 +616,9 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
   if (vflag_host && (rc = validate_windows_end(c, vflag_host, &tp_misfit)) != AVM_OK) return rc;
   use_tp = use_tp && (tp_misfit & 1) == 0;
   // ... and the marginalization follows the solve: its throughput form (two 256-thread workgroups per CU on the solve's 2 x CUs slots)
-  // for the batches that took the throughput solve, unless a prior keeps a speed-bias block beyond frame 1 (AVM_MARG_TP=0: never)
-  bool use_marg_tp = use_tp && (tp_misfit & 2) == 0;
+  // for the batches that took the throughput solve - and for a batch of the extended problem that is larger than the CU count: the marginalization
+  // does not depend on what the solve estimated -, unless a prior keeps a speed-bias block beyond frame 1 (AVM_MARG_TP=0: never)
+  bool use_marg_tp = (use_tp || big_x) && (tp_misfit & 2) == 0;
   if (const char* e = getenv("AVM_MARG_TP")) use_marg_tp = use_marg_tp && e[0] != '0';
   SolveArgs sa;
   sa.b = d, sa.opt = *opt;
@@ -637,6 +640,7 @@ int avm_window_solve_batch(avm_ctx* c, const avm_options* opt, avm_mem mem, cons
     sa.n_slots = use_marg_tp ? 2 * c->n_slots : c->n_slots;  // (the marginalization below: two workgroups per CU in its throughput form, else one)
   } else {
     HIPCHK(c, extended ? launch_window_solve_x(sa, c->stream) : launch_window_solve(sa, c->stream));
+    sa.n_slots = use_marg_tp ? 2 * c->n_slots : c->n_slots;
   }
   c->last_solve_tp = use_tp;
   c->last_marg_tp = false;

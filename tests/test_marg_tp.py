@@ -136,3 +136,37 @@ def test_a_prior_with_a_later_speed_bias_block_takes_the_latency_marginalization
         d = 1.0 / np.sqrt(np.diag(Ho))
         assert rel(Hg, Ho) < 1e-9
         assert rel(Hg * d[:, None] * d[None, :], Ho * d[:, None] * d[None, :]) < 1e-9
+
+
+def test_a_large_batch_of_the_extended_problem_takes_the_throughput_marginalization(ctx, monkeypatch):
+    """The extended problem (ex_pose / td as variables, a relocalization frame) is always solved by its own kernel, one workgroup per CU; the
+    marginalization that follows is the same problem whatever the solve estimated, so a batch beyond the CU count takes its throughput form (two
+    workgroups per CU).  Same solve, and the same prior as far as a consumer can see it, as with AVM_MARG_TP=0."""
+    monkeypatch.delenv("AVM_SOLVE_TP", raising=False)
+    o = abi.default_options()
+    o.estimate_extrinsic, o.estimate_td = 1, 1
+    E = est_m.Estimator(ctx=ctx, options=o)
+    base = synth.make_windows(6, first_id=5, tracks="sparse", n_feat=60, max_feat=150, td_true=0.004, relo=True)
+    small = base.copy()
+    E.optimization(small)
+    assert (ctx.last_solve_form(), ctx.last_marg_form()) == ("latency", "latency")
+    p_small = E.last_marginalization_info
+    out = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("AVM_MARG_TP", form)
+        g = synth.tile_windows(base, 300)
+        E.optimization(g)
+        assert (ctx.last_solve_form(), ctx.last_marg_form()) == ("latency", "throughput" if form == "1" else "latency")
+        out[form] = (g, E.last_marginalization_info)
+    (g0, p0), (g1, p1) = out["0"], out["1"]
+    assert np.array_equal(g0.a["pose"], g1.a["pose"]) and np.array_equal(g0.a["pose"][:6], small.a["pose"])
+    assert np.array_equal(p0.a["J"][:6], p_small.a["J"])  # (the latency form of a tiled batch: bit-identical to the six windows alone)
+    assert np.array_equal(p0.a["n"], p1.a["n"]) and np.array_equal(p0.a["blk_kind"], p1.a["blk_kind"]) and np.array_equal(p0.a["x0"], p1.a["x0"])
+    J1 = p1.a["J"].reshape(50, 6, 96, 96)
+    assert (J1 == J1[0]).all()
+    for i in range(6):
+        n, H0, b0, c0 = _quad(p0, i)
+        _, H1, b1, c1 = _quad(p1, i)
+        d = 1.0 / np.sqrt(np.maximum(np.diag(H0), 1e-300))
+        assert rel(H1, H0) < 1e-6 and rel(H1 * d[:, None] * d[None, :], H0 * d[:, None] * d[None, :]) < 1e-4
+        assert rel(b1 * d, b0 * d) < 1e-4 and abs(c1 - c0) <= 1e-4 * max(c0, 1e-300)
