@@ -798,6 +798,10 @@ int avm_debug_solve_tp_occupancy(int* out) {
 
 // test hook (not in avm.h): the compile-time tables of the throughput solve's sparse factorization (window_solve.hip, chol_regs); out: >= 512 ints
 int avm_debug_solve_tp_pattern(int* out) { return window_solve_tp_pattern(out); }
+// which = 0: throughput build, 1: latency build, 2: extended build
+int avm_debug_solve_pattern(int which, int* out) {
+  return which == 0 ? window_solve_tp_pattern(out) : (which == 1 ? window_solve_pattern(out) : window_solve_x_pattern(out));
+}
 
 // test / bench hook (not in avm.h): out[0] = device / pinned (re)allocations of this ctx so far, out[1] = windows of the last
 // marginalization whose square root the one-wavefront kernel (prior_chol_kernel) finished, out[2] = windows of that marginalization

@@ -186,6 +186,8 @@ hipError_t launch_window_solve_tp(const SolveArgs& a, hipStream_t stream);  // w
 int window_solve_tp_lds_bytes();
 int window_solve_tp_occupancy();
 int window_solve_tp_pattern(int* out);  // the throughput factorization's tile pattern / ownership / elimination order (tests)
+int window_solve_pattern(int* out);     // ... the latency build's (the same pattern from the packed triangle, same owners)
+int window_solve_x_pattern(int* out);   // ... the extended build's (twelve tile columns on eight wavefronts)
 hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream);
 // scale: [n_windows][po.max_prior] device array: the magnitude every diagonal entry of A' was formed at (for launch_prior_eig's noise test)
 hipError_t launch_marginalize(const SolveArgs& a, const avm_prior_out& po, int* err, double* scale, hipStream_t stream);

@@ -2591,6 +2591,15 @@ AVM_NOINL bool chol_regs() {
 }
 #undef TPI
 #undef TPW
+// the factorization's compile-time tables of this build for the tests (tests/test_tp_pattern.py states them in numpy): T = TPT tile columns,
+// out[0 .. T T) = TPP.h, [T T .. 2 T T) = TPP.nz (both [k][i]), then tp_owner [T], then tp_perm of the 16 T positions (-1: padding)
+int tp_pattern_export(int* out) {
+  for (int k = 0; k < TPT; k++)
+    for (int i = 0; i < TPT; i++) out[k * TPT + i] = TPP.h[k][i], out[TPT * TPT + k * TPT + i] = TPP.nz[k][i];
+  for (int i = 0; i < TPT; i++) out[2 * TPT * TPT + i] = tp_owner(i);
+  for (int n = 0; n < 16 * TPT; n++) out[2 * TPT * TPT + TPT + n] = tp_perm(n);
+  return 2 * TPT * TPT + TPT + 16 * TPT;
+}
 // (end of chol_regs)
 #ifndef AVM_TP  // the other builds (the latency build: for a prior chol_regs' pattern does not hold): left-looking factorization of the packed system in LDS
 // Scratch of the factorization inside the tile at L_WCH (dead while S is being factored): L^-T of the current and of the
@@ -5412,13 +5421,7 @@ __global__ __launch_bounds__(NT) void eval_factors_kernel(EvalArgs A) {
 int window_solve_tp_lds_bytes() { return L_END * 8; }
 // the factorization's compile-time tables for the tests (tests/test_tp_pattern.py states them in numpy): out[0..120] = TPP.h, [121..241] = TPP.nz
 // (both [k][i]), [242..252] = tp_owner, [253 ..] = tp_perm of the 176 positions (-1: padding)
-int window_solve_tp_pattern(int* out) {
-  for (int k = 0; k < TPT; k++)
-    for (int i = 0; i < TPT; i++) out[k * TPT + i] = TPP.h[k][i], out[TPT * TPT + k * TPT + i] = TPP.nz[k][i];
-  for (int i = 0; i < TPT; i++) out[2 * TPT * TPT + i] = tp_owner(i);
-  for (int n = 0; n < 16 * TPT; n++) out[2 * TPT * TPT + TPT + n] = tp_perm(n);
-  return 2 * TPT * TPT + TPT + 16 * TPT;
-}
+int window_solve_tp_pattern(int* out) { return tp_pattern_export(out); }
 // workgroups of the throughput kernel the runtime says a CU can hold (2 is what the kernel is built for)
 int window_solve_tp_occupancy() {
   int n = 0;
@@ -5454,6 +5457,7 @@ hipError_t launch_marginalize_tp(const SolveArgs& a, const avm_prior_out& po, in
 }
 #elif !defined(AVM_X)
 int window_solve_lds_bytes() { return L_END * 8; }
+int window_solve_pattern(int* out) { return tp_pattern_export(out); }
 
 hipError_t launch_window_solve(const SolveArgs& a, hipStream_t stream) {
   static bool attr_set = false;
@@ -5491,6 +5495,7 @@ hipError_t launch_eval_factors(const EvalArgs& a, hipStream_t stream) {
 }
 #else
 int window_solve_x_lds_bytes() { return L_END * 8; }
+int window_solve_x_pattern(int* out) { return tp_pattern_export(out); }
 
 // the solve with ex_pose / td / relo_Pose as (optional) variables: 178 x 178 reduced system
 hipError_t launch_window_solve_x(const SolveArgs& a, hipStream_t stream) {

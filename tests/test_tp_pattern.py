@@ -86,3 +86,56 @@ def test_tile_tables_cover_the_scalar_factor():
     assert max(per_wave) <= 15 and sum(per_wave) == 47
     # the two chains of a step run on two wavefronts
     assert all(owner[t] != owner[t + 3] for t in range(3))
+
+
+def tables_of(which, T_):
+    """avm_debug_solve_pattern: which = 0 throughput, 1 latency, 2 extended build"""
+    L = mod("lib").lib()
+    out = (C.c_int * 512)()
+    L.avm_debug_solve_pattern.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    n = L.avm_debug_solve_pattern(which, out)
+    a = np.array(out[:n])
+    assert n == 2 * T_ * T_ + T_ + 16 * T_
+    return a[: T_ * T_].reshape(T_, T_).astype(bool), a[T_ * T_ : 2 * T_ * T_].reshape(T_, T_).astype(bool), a[2 * T_ * T_ : 2 * T_ * T_ + T_], a[2 * T_ * T_ + T_ :]
+
+
+def test_the_latency_build_factors_with_the_same_tables():
+    """The latency form calls the same chol_regs: same order, same pattern (its offsets name places in the packed triangle), same owners."""
+    for a, b in zip(tables(), tables_of(1, T)):
+        assert np.array_equal(a, b)
+
+
+def test_the_extended_builds_tables_cover_its_scalar_factor():
+    """-DAVM_X: 79 dense columns (poses | relo_Pose | ex_pose | td) in front of the speed-biases, 178 columns, twelve tile columns, nine steps; every
+    dense tile column on a wavefront of its own.  Same statement as above: the scalar pattern (the prior couples speed-bias 0 to EVERY dense column,
+    ex_pose / td blocks included), its symbolic factor in the kernel's order, aggregated to tiles."""
+    NPX, NFX, TX = 79, 178, 12
+    h, nz, owner, perm = tables_of(2, TX)
+    sb = lambda f: list(range(NPX + 9 * f, NPX + 9 * f + 9))
+    order = sum((sb(f) for f in (10, 9, 8, 7, 6)), []) + [-1] * 3 + sum((sb(f) for f in (4, 3, 2, 1, 0)), []) + [-1] * 3
+    order += sb(5) + list(range(NPX)) + [NFX] + [-1] * 7
+    assert np.array_equal(perm, np.array(order)) and sorted(perm[perm >= 0]) == list(range(NFX + 1))
+    H = np.zeros((NFX + 1, NFX + 1), bool)
+    H[:NPX, :NPX] = True
+    for i in range(NFR - 1):
+        cols = list(range(6 * i, 6 * i + 12)) + list(range(NPX + 9 * i, NPX + 9 * i + 18))
+        H[np.ix_(cols, cols)] = True
+    H[NPX : NPX + 9, :NPX] = H[:NPX, NPX : NPX + 9] = True
+    H[NFX, :] = H[:, NFX] = True
+    H[NFX, NFX] = False
+    N = 16 * TX
+    Ha = np.zeros((N, N), bool)
+    real = perm >= 0
+    Ha[np.ix_(real, real)] = H[np.ix_(perm[real], perm[real])]
+    Ha[np.arange(N)[~real], np.arange(N)[~real]] = True
+    La = symbolic_cholesky(Ha)
+    ht = np.array([[Ha[16 * i : 16 * i + 16, 16 * k : 16 * k + 16].any() for i in range(TX)] for k in range(TX)])
+    lt = np.array([[La[16 * i : 16 * i + 16, 16 * k : 16 * k + 16].any() for i in range(TX)] for k in range(TX)])
+    up = np.triu(np.ones((TX, TX), bool))
+    # (the kernel's table may name a place the system never fills - it reads the packed triangle's zeros there -, never the other way round)
+    assert not ((ht & up) & ~h).any() and not ((lt & up) & ~nz).any()
+    assert np.array_equal(nz, lt & up), "tiles of the factor"
+    assert not nz[:3, 3:6].any()
+    per_wave = [int(sum(nz[: i + 1, i].sum() for i in range(TX) if owner[i] == w)) for w in range(8)]
+    assert max(per_wave) <= 13 and sum(per_wave) == int(nz.sum())
+    assert all(owner[t] != owner[t + 3] for t in range(3)) and len(set(owner[6:])) == 6
