@@ -906,6 +906,29 @@ AVM_DEV double fs_rowbcast(double v, int k) {  // k is a compile-time constant a
   }
 }
 
+// acc += (lane k of src's 16-lane row) * nmul in ONE instruction: v_fmac_f64_dpp with row_newbcast (the FP64 ALU of gfx90a+ takes a DPP operand
+// of that one kind).  Round 6, scripts/ubench/dpp2.hip: 5.8 cycles an issue against 4.8 for a plain v_fmac_f64 - and it does accumulate; the round-3
+// probe (scripts/ubench/dpp.hip: "assembles but does not accumulate") issued it right behind the VALU write of its source, and a DPP read needs two wait
+// states there which the compiler's hazard recognizer does not add inside inline assembly.  The caller keeps those two wait states (fs_dpp_fence) between the
+// last write of any operand and the first instruction of a run; inside a run of these nothing reads what a neighbour writes.
+#ifndef FS_NO_FMAC_DPP
+#define FS_FMAC_DPP 1
+#endif
+AVM_DEV void fs_dpp_fence() { asm volatile("s_nop 1"); }
+template <int K>
+AVM_DEV void fs_fmac_bcast(double& acc, double src, double nmul) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(nmul), "n"(K));
+}
+// compile-time loops (the lane index of a DPP operand is part of the instruction)
+template <class F, int... Is>
+AVM_DEV void fs_sfor_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+AVM_DEV void fs_sfor(F&& f) {
+  fs_sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 constexpr int FS_CPWG = (FS_NT / 64) * 4;  // candidates per workgroup of the round kernel
 
 // State that changes from round to round exists twice (C, dpp, the live list and its inverse, nlive, fval, ub: buffer `par` at
@@ -1281,6 +1304,39 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
   FS_TK(1)
   double dkeep[NB];  // lane j keeps the pivot of row bj BS + j
   bool bad = false;
+#ifdef FS_FMAC_DPP
+  // m[bi][gk] += A[gk][gj] * (-mult[bi]) with A[gk][gj] = lane k of m[bk][gj], taken by the multiply-add itself (fs_fmac_bcast): one instruction per
+  // (pivot, column, block row) where it was two 32-bit DPP moves per (pivot, column) and a multiply-add per block row - the same product, the same rounding
+  fs_sfor<NB>([&](auto BJ) {
+    constexpr int bj = BJ;
+    dkeep[bj] = 1.0;
+    fs_sfor<BS>([&](auto J) {
+      constexpr int j = J, gj = bj * BS + j;
+      const double djj = fs_rowbcast_k<j>(m[bj][gj]);
+      if (!(djj > 0.0)) bad = true;
+      dkeep[bj] = (lane & 15) == j ? djj : dkeep[bj];
+      double y = __builtin_amdgcn_rcp(djj), e = fma(-djj, y, 1.0);
+      y = fma(y, e, y);
+      e = fma(-djj, y, 1.0);
+      y = fma(y, e, y);
+      double nmult[NB];
+#pragma unroll
+      for (int bi = bj; bi < NB; bi++) nmult[bi] = -(m[bi][gj] * y);
+      fs_dpp_fence();
+      fs_sfor<NB - bj>([&](auto BKK) {
+        constexpr int bk = bj + BKK, k0 = bk == bj ? j + 1 : 0;
+        fs_sfor<BS - k0>([&](auto KK) {
+          constexpr int k = k0 + KK, gk = bk * BS + k;
+          fs_sfor<NB - bk>([&](auto BII) {
+            constexpr int bi = bk + BII;
+            fs_fmac_bcast<k>(m[bi][gk], m[bk][gj], nmult[bi]);
+          });
+        });
+      });
+      fs_dpp_fence();  // (the next pivot's broadcast reads an entry this run has written)
+    });
+  });
+#else
 #pragma unroll
   for (int bj = 0; bj < NB; bj++) {
     dkeep[bj] = 1.0;
@@ -1308,6 +1364,7 @@ AVM_DEV bool fsel_logdet4(const double* sC, const double* sdpp, const double* D,
         }
     }
   }
+#endif
   FS_TK(2)
   // log(sqrt(d)): per lane over its block rows, then across the candidate's lanes
   double ldl = 0;
