@@ -1703,7 +1703,13 @@ AVM_DEV void fsel_frame_body(const FselDev& A, int32_t* sync, int nslots, int te
   // wavefronts per SIMD, 3 H <= 32 - and the DPP form (fsel_logdet4) where a wavefront has its SIMD to itself and the evaluation's
   // dependent chain is what counts (a single frame: 1.38 ms against 1.46) or where the 55 tiles of 3 H = 39 do not fit the registers
   // next to everything else (90 spilled registers, 0.33 -> 0.37 ms per frame).  Measured: profiles/r03_experiments.md, 3.
+  // Round 6: with the broadcast folded into the multiply-add (fs_fmac_bcast) the DPP form issues 45 % fewer instructions and wins there too - 16 frames per
+  // call 0.140 -> 0.119 ms per frame, 32 frames 0.127 -> 0.104 - so the matrix-core form is only built on request (-DFS_MF).
+#ifdef FS_MF
   constexpr bool MF = TPX == 2 && T <= 32;
+#else
+  constexpr bool MF = false;
+#endif
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int g = MF ? (lane >> 2) & 3 : lane >> 4;  // this lane's candidate slot: its MFMA block (quad column) / its 16-lane DPP row
   const bool rec_lane = MF ? (lane & 0x33) == 0 : (lane & 15) == 0;  // one lane per candidate writes the records
