@@ -872,11 +872,11 @@ AVM_DEV double fs_readlane_d(double v, int srclane) {  // srclane must be wave-u
 // FOUR candidates per wavefront: candidate g lives in the 16-lane DPP row g of the wave.  The T x T matrix is cut into NB block
 // rows of BS <= 16 rows (T = 30: 2 x 15, T = 39: 3 x 13); lane r of the row holds row r of EVERY block row in registers
 // (block row bi: columns 0 .. (bi + 1) BS - 1), so an entry A[gk][gj] is broadcast to the whole candidate with a DPP
-// row_newbcast of lane gk % BS (two 32-bit DPP moves; the 64-bit DPP forms are ~50x slower on gfx950, scripts/ubench/dpp.hip)
-// and one broadcast feeds the updates of all block rows.  The factorization is the same right-looking, square-root-free
+// row_newbcast of lane gk % BS - since round 6 as the DPP operand of the multiply-add itself (fs_fmac_bcast below: v_fmac_f64_dpp, one instruction per
+// update; before: two 32-bit DPP moves feeding the updates of all block rows).  The factorization is the same right-looking, square-root-free
 // LDL^T as before (column j divided by its pivot with v_rcp_f64 + two Newton steps; junk above the diagonal of the diagonal
 // blocks is computed and never read), only the lanes are used four times as densely and there are no SGPR round trips:
-// 2 DPP moves + 1-3 FMAs per (pivot, column) pair for four candidates instead of 2 v_readlane + 1 FMA for one.
+// 1-3 DPP multiply-adds per (pivot, column) pair for four candidates instead of 2 v_readlane + 1 FMA for one.
 // logdet = sum_j log(d_j) and the Hadamard bound (sortedlogDetUB) are summed in one fixed association for every candidate, so
 // mirror-image candidates still get bit-identical bounds (the std::map rule of the pick depends on that).
 template <int K>

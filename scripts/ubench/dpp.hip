@@ -1,3 +1,6 @@
+// (ROUND 6: superseded by dpp2.hip.  This probe issued v_fmac_f64_dpp right behind the VALU write of its source - a DPP read needs two wait states there,
+//  and the hazard recognizer does not look into inline assembly -, read stale lanes and concluded "does not accumulate"; its v_mov_b64_dpp timing had the
+//  same flaw.  With the wait states v_fmac_f64_dpp accumulates and issues in 5.8 cycles.)
 // v_fmac_f64_dpp / v_mov_b64_dpp with row_newbcast on gfx950: semantics and cost (the selector's round kernel broadcasts a
 // lane's value to its 16-lane row with it: four 15-row matrices per wavefront).
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/ubench/dpp scripts/ubench/dpp.hip && gpurun -- scripts/ubench/dpp
