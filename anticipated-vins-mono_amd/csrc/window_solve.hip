@@ -2545,12 +2545,23 @@ AVM_NOINL bool chol_regs() {
 #pragma unroll
         for (int q = 0; q < 16; q++) colv[q] *= di2;
         double xout = 0.0;
+#ifndef AVM_BS_READLANE  // (round 6, last: 2 v_readlane_b32 + v_fma_f64 per step before - bit-identical, solve 9.29 -> 9.21 ms)
+        // x_jj is lane jj's bv; every lane subtracts colv[jj] x_jj - the broadcast as the multiply-add's own DPP operand (v_fmac_f64_dpp row_newbcast: no trip
+        // through the scalar registers; the s_nop is the two wait states a DPP read needs behind the VALU write of the same register)
+        tp_sfor<nb>([&](auto JR) {
+          constexpr int jj = nb - 1 - JR;
+          xout = lr == jj ? bv : xout;
+          const double nc = -colv[jj];
+          asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(bv) : "v"(nc), "n"(jj));
+        });
+#else
 #pragma unroll
         for (int jj = nb - 1; jj >= 0; jj--) {
           const double xj = readlane_d(bv, jj);
           bv = fma(-colv[jj], xj, bv);
           xout = lane == jj ? xj : xout;
         }
+#endif
         if (lane < nb) {
           lds[L_ZV + 16 * i + lane] = xout;
           const int col = tp_perm_dev(16 * i + lane);
